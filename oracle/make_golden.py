@@ -1,0 +1,348 @@
+"""Generate tests/golden/*.npz by IMPORTING the reference (build container only).
+
+TEST INFRASTRUCTURE.  Run from anywhere:  ``python oracle/make_golden.py``.
+Needs /root/reference (read-only, never shipped).  What it does:
+
+  1. builds the reference model through its own factory
+     (models.get_model(opt), models/__init__.py:64-94) for tiny and full-shape
+     configs, loads weights produced by ``nacf_oracle.init_state_dict`` (seeded,
+     regenerable anywhere), and runs the reference's forward / criterion /
+     backward / optimiser step / Translator.translate_batch on seeded inputs;
+  2. asserts the oracle restatement agrees with the reference (<=2e-6 on
+     floats, exact on token ids) -- this is the pin;
+  3. stores inputs + reference outputs as plain arrays (no pickled objects)
+     under tests/golden/.
+
+The fixtures are data (inputs, expected outputs); no reference source text is
+stored.  SURVEY.md section 8c lists the cases.
+"""
+import copy
+import io
+import os
+import sys
+import contextlib
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+REF = "/root/reference"
+sys.path.insert(0, ROOT)
+sys.dont_write_bytecode = True
+torch.set_num_threads(8)
+
+from oracle import nacf_oracle as O  # noqa: E402
+
+GOLD = os.path.join(ROOT, "tests", "golden")
+os.makedirs(GOLD, exist_ok=True)
+
+
+def ref_opt(method, dataset="MSRVTT", extra=()):
+    """Reference option dict via its own opts.parse_opt (opts.py:5-213)."""
+    cwd = os.getcwd()
+    os.chdir(REF)
+    if REF not in sys.path:
+        sys.path.insert(0, REF)
+    import opts  # noqa
+    argv = sys.argv
+    sys.argv = ["train.py", "--method", method, "--dataset", dataset, "--scope", "x"] + list(extra)
+    try:
+        with contextlib.redirect_stdout(io.StringIO()):
+            opt = vars(opts.parse_opt())
+    finally:
+        sys.argv = argv
+        os.chdir(cwd)
+    return opt
+
+
+def ref_model(opt, sd):
+    os.chdir(REF)
+    import models  # noqa
+    with contextlib.redirect_stdout(io.StringIO()):
+        m = models.get_model(opt)
+    os.chdir(ROOT)
+    missing = set(m.state_dict().keys()) ^ set(sd.keys())
+    assert not missing, missing
+    for k, v in m.state_dict().items():
+        assert tuple(v.shape) == tuple(sd[k].shape), (k, v.shape, sd[k].shape)
+    m.load_state_dict({k: v.clone() for k, v in sd.items()})
+    return m
+
+
+TINY = ["--dim_hidden", "64", "--num_attention_heads", "4", "--intermediate_size", "128",
+        "--dim_i", "32", "--dim_m", "32", "--max_len", "10",
+        "--hidden_dropout_prob", "0", "--encoder_dropout", "0", "--n_frames", "6"]
+
+
+def keep(opt):
+    ks = list(O.DEFAULT_OPT.keys()) + ["vocab_size", "grad_clip", "weight_decay", "learning_rate", "crit"]
+    return {k: opt[k] for k in ks if k in opt}
+
+
+def check(a, b, tol, what):
+    err = float((a - b).abs().max())
+    assert err <= tol, f"{what}: oracle vs reference {err:.3e} > {tol}"
+    return err
+
+
+def npz(d):
+    out = {}
+    for k, v in d.items():
+        if isinstance(v, torch.Tensor):
+            out[k] = v.detach().cpu().numpy()
+        else:
+            out[k] = np.asarray(v)
+    return out
+
+
+def opt_blob(opt):
+    import json
+    return np.frombuffer(json.dumps(keep(opt), sort_keys=True).encode(), dtype=np.uint8)
+
+
+def train_case(name, method, extra, V, B, F_, dataset="MSRVTT", beta=(0.35, 0.9)):
+    """forward + loss + backward + clip + Adam, reference vs oracle (dropout 0)."""
+    opt = ref_opt(method, dataset, TINY + list(extra))
+    opt["vocab_size"] = V
+    sd = O.init_state_dict(opt, seed=0)
+    model = ref_model(opt, sd)
+    model.train()
+    batch = O.synth_batch(opt, B, F_, seed=1, beta=beta)
+    os.chdir(REF)
+    from misc.crit import get_criterion
+    from misc.optim import get_optimizer
+    os.chdir(ROOT)
+    crit = get_criterion(opt)
+    crit.reset_loss_recorder()
+    optim = get_optimizer(opt, model)
+    vw = opt["visual_word_generation"]
+    tokens = [batch["tokens_1"], batch["tokens"]] if vw else batch["tokens"]
+    start = 0 if opt["decoding_type"] == "NARFormer" else 1
+    labels = [batch["labels_1"], batch["labels"]] if vw else batch["labels"]
+    # --- reference step (misc/run.py:254-261) ---
+    optim.zero_grad()
+    results = model(feats=[f.clone() for f in batch["feats"]], tgt_tokens=tokens, category=batch["category"])
+    if opt["decoding_type"] == "NARFormer":
+        results["tgt_length"] = batch["tgt_length"]
+    results["tgt_word_labels"] = labels
+    loss = crit.get_loss(results)
+    loss.backward()
+    torch.nn.utils.clip_grad_value_(model.parameters(), opt["grad_clip"])
+    ref_grads = {k: p.grad.clone() for k, p in model.named_parameters()}
+    optim.step()
+    ref_after = {k: v.clone() for k, v in model.state_dict().items()}
+    names, infos = crit.get_loss_info()
+    # --- oracle step ---
+    sd_o = {k: v.clone() for k, v in sd.items()}
+    st = {}
+    o_loss, o_info, o_grads = O.train_step(sd_o, opt, batch["feats"], tokens, batch["category"],
+                                           labels, batch.get("tgt_length"), st, lr=opt["learning_rate"])
+    errs = {"loss": check(o_loss, loss.detach(), 2e-5, "loss")}
+    for k in ref_grads:
+        g = o_grads[k].clamp(-opt["grad_clip"], opt["grad_clip"])
+        errs["g:" + k] = check(g, ref_grads[k], 5e-6, "grad " + k)
+    for k in ref_after:
+        if ref_after[k].is_floating_point():
+            errs["w:" + k] = check(sd_o[k], ref_after[k], 1e-4, "post-step " + k)  # Adam step 1 = lr*g/(|g|+eps): ill-conditioned where |g|~eps
+        else:
+            assert int(sd_o[k]) == int(ref_after[k]), k
+    # forward outputs (reference values stored)
+    model2 = ref_model(opt, sd); model2.train()
+    with torch.no_grad():
+        r2 = model2(feats=[f.clone() for f in batch["feats"]], tgt_tokens=tokens, category=batch["category"])
+    out = {"opt_json": opt_blob(opt), "B": B, "F": F_,
+           "loss": loss.detach(), "loss_names": np.array(names), "loss_info": np.array(infos, dtype=np.float64)}
+    for k, v in batch.items():
+        if k == "feats":
+            for i, f in enumerate(v):
+                out[f"in.feats{i}"] = f
+        else:
+            out["in." + k] = v
+    out["out.enc_output"] = r2["enc_output"]
+    if "pred_length" in r2:
+        out["out.pred_length"] = r2["pred_length"]
+    for i, lp in enumerate(r2["tgt_word_logprobs"]):
+        out[f"out.logprobs{i}"] = lp
+    for k, v in ref_grads.items():
+        out["grad." + k] = v
+    for k, v in ref_after.items():
+        out["after." + k] = v
+    np.savez_compressed(os.path.join(GOLD, name + ".npz"), **npz(out))
+    print(f"[{name}] ok  max err {max(errs.values()):.2e}  loss {float(loss):.6f}")
+    return opt, sd
+
+
+def decode_case(name, method, extra, V, B, F_, variants, teacher_method=None, dataset="MSRVTT"):
+    opt = ref_opt(method, dataset, TINY + list(extra))
+    opt["vocab_size"] = V
+    sd = O.init_state_dict(opt, seed=3)
+    # sharpen the distributions a little so decode is not dominated by ties
+    model = ref_model(opt, sd)
+    model.eval()
+    batch = O.synth_batch(opt, B, F_, seed=5)
+    os.chdir(REF)
+    from models.Translator import Translator
+    os.chdir(ROOT)
+    out = {"opt_json": opt_blob(opt), "B": B, "F": F_, "in.category": batch["category"]}
+    for i, f in enumerate(batch["feats"]):
+        out[f"in.feats{i}"] = f
+    teacher = None
+    t_model = None
+    if teacher_method is not None:
+        t_opt = ref_opt(teacher_method, dataset, TINY + list(extra))
+        t_opt["vocab_size"] = V
+        t_sd = O.init_state_dict(t_opt, seed=7)
+        t_model = ref_model(t_opt, t_sd); t_model.eval()
+        out["teacher_opt_json"] = opt_blob(t_opt)
+        with torch.no_grad():
+            t_enc = t_model.encode(feats=[f.clone() for f in batch["feats"]])
+        teacher = (t_sd, t_opt, t_enc["enc_output"])
+    with torch.no_grad():
+        enc = model.encode(feats=[f.clone() for f in batch["feats"]])
+    o_enc = O.encode(sd, opt, batch["feats"], training=False)
+    check(o_enc["enc_output"], enc["enc_output"], 2e-6, "enc_output")
+    check(o_enc["pred_length"], enc["pred_length"], 2e-6, "pred_length")
+    out["out.enc_output"] = enc["enc_output"]
+    out["out.pred_length"] = enc["pred_length"]
+    for vname, dec in variants.items():
+        dopt = dict(opt)
+        dopt.update(dec)
+        dopt.update(collect_best_candidate_iterative_results=True, not_only_best_candidate=True)
+        tr = Translator(model, dopt, device=torch.device("cpu"), teacher_model=t_model)
+        with torch.no_grad():
+            hyp, (it_tok, it_prob) = tr.translate_batch(
+                {k: (v.clone() if isinstance(v, torch.Tensor) else v) for k, v in enc.items()},
+                batch["category"], None, {i: str(i) for i in range(V)},
+                teacher_encoder_outputs=(t_enc if t_model is not None else None))
+        col = []
+        o_hyp, o_all, o_lp, o_beam = O.generate(sd, opt, dec, o_enc, batch["category"], teacher, col)
+        assert torch.equal(o_hyp, hyp), f"{name}/{vname}: hypotheses differ"
+        o_tok = torch.stack([c[0] for c in col], 1)
+        o_prob = torch.stack([c[1] for c in col], 1)
+        assert o_tok.shape == it_tok.shape, (o_tok.shape, it_tok.shape)
+        assert torch.equal(o_tok, it_tok), f"{name}/{vname}: per-iteration tokens differ"
+        check(o_prob, it_prob, 5e-6, f"{name}/{vname} probs")
+        out[f"{vname}.hyp"] = hyp
+        out[f"{vname}.iter_tokens"] = it_tok.to(torch.int16)
+        out[f"{vname}.iter_probs"] = it_prob
+        out[f"{vname}.beam"] = o_beam
+        out[f"{vname}.cand_lprobs"] = o_lp
+        import json
+        out[f"{vname}.dec_json"] = np.frombuffer(json.dumps(dec, sort_keys=True).encode(), dtype=np.uint8)
+        print(f"[{name}/{vname}] ok  iters {it_tok.shape[1]}  L' {it_tok.shape[2]}")
+    np.savez_compressed(os.path.join(GOLD, name + ".npz"), **npz(out))
+
+
+def ar_case(name, method, extra, V, B, F_, dataset="MSRVTT"):
+    opt = ref_opt(method, dataset, TINY + list(extra))
+    opt["vocab_size"] = V
+    opt["beam_size"] = 3
+    opt["beam_alpha"] = 1.0
+    opt["topk"] = 1
+    sd = O.init_state_dict(opt, seed=11)
+    model = ref_model(opt, sd); model.eval()
+    batch = O.synth_batch(opt, B, F_, seed=13)
+    os.chdir(REF)
+    from models.Translator import Translator
+    os.chdir(ROOT)
+    with torch.no_grad():
+        enc = model.encode(feats=[f.clone() for f in batch["feats"]])
+    tr = Translator(model, opt, device=torch.device("cpu"))
+    hyps, scores = tr.translate_batch({k: v for k, v in enc.items()}, batch["category"], None, None)
+    o_enc = O.encode(sd, opt, batch["feats"], training=False)
+    o_h, o_s = O.ar_beam_search(sd, opt, o_enc, batch["category"], beam_size=3, alpha=1.0, topk=1)
+    assert [h[0] for h in hyps] == [h[0] for h in o_h], (hyps, o_h)
+    for a, b in zip(scores, o_s):
+        assert abs(a[0] - b[0]) < 1e-5
+    Lm = max(len(h[0]) for h in hyps)
+    arr = np.zeros((B, Lm), dtype=np.int64)
+    for i, h in enumerate(hyps):
+        arr[i, :len(h[0])] = h[0]
+    out = {"opt_json": opt_blob(opt), "B": B, "F": F_, "in.category": batch["category"],
+           "hyp": arr, "hyp_len": np.array([len(h[0]) for h in hyps]), "score": np.array([s[0] for s in scores])}
+    for i, f in enumerate(batch["feats"]):
+        out[f"in.feats{i}"] = f
+    np.savez_compressed(os.path.join(GOLD, name + ".npz"), **npz(out))
+    print(f"[{name}] ok  lens {[len(h[0]) for h in hyps]}")
+
+
+def full_shape_case(name="full_nacf", B=4, V=10547, L=20, F_=60):
+    """d=512 / F=60 / V=10547: weights come from the seeded generator (only the
+    seed + checksums are stored), outputs are sampled."""
+    opt = ref_opt("NACF", "MSRVTT", ["-wc", "--max_len", str(L), "--n_frames", str(F_)])
+    opt["vocab_size"] = V
+    sd = O.init_state_dict(opt, seed=0)
+    model = ref_model(opt, sd); model.eval()
+    batch = O.synth_batch(opt, B, F_, seed=1)
+    os.chdir(REF)
+    from models.Translator import Translator
+    os.chdir(ROOT)
+    with torch.no_grad():
+        enc = model.encode(feats=[f.clone() for f in batch["feats"]])
+        hid, *_ = model.decoder(batch["tokens"], enc_output=enc["enc_output"], category=batch["category"])
+        logits = model.tgt_word_prj(hid)
+    o_enc = O.encode(sd, opt, batch["feats"], training=False)
+    check(o_enc["enc_output"], enc["enc_output"], 5e-6, "full enc_output")
+    o_h, _, _ = O.decoder_forward(sd, opt, batch["tokens"], o_enc["enc_output"], batch["category"])
+    check(O.vocab_logits(sd, opt, o_h), logits, 2e-5, "full logits")
+    dec = dict(paradigm="mp", use_ct=True, iterations=5, length_beam_size=6, beam_alpha=1.35)
+    dopt = dict(opt); dopt.update(dec)
+    dopt.update(collect_best_candidate_iterative_results=True, not_only_best_candidate=True)
+    tr = Translator(model, dopt, device=torch.device("cpu"))
+    with torch.no_grad():
+        hyp, (it_tok, it_prob) = tr.translate_batch({k: v.clone() for k, v in enc.items()}, batch["category"],
+                                                    None, {i: str(i) for i in range(V)})
+    col = []
+    o_hyp, _, o_lp, o_beam = O.generate(sd, opt, dec, o_enc, batch["category"], None, col)
+    assert torch.equal(o_hyp, hyp)
+    assert torch.equal(torch.stack([c[0] for c in col], 1), it_tok)
+    g = torch.Generator().manual_seed(99)
+    flat = logits.reshape(-1)
+    idx = torch.randint(0, flat.numel(), (4096,), generator=g)
+    top2 = logits.topk(2, dim=-1)[0]
+    out = {"opt_json": opt_blob(opt), "B": B, "F": F_, "seed_weights": 0, "seed_batch": 1,
+           "weight_checksums": np.array([float(v.double().sum()) for v in sd.values()]),
+           "weight_names": np.array(list(sd.keys())),
+           "logit_idx": idx, "logit_val": flat[idx], "logit_margin": (top2[..., 0] - top2[..., 1]),
+           "logit_argmax": logits.argmax(-1).to(torch.int16),
+           "enc_output_sample": enc["enc_output"][:, ::7, ::5].contiguous(),
+           "pred_length": enc["pred_length"],
+           "mp_ct.hyp": hyp, "mp_ct.iter_tokens": it_tok.to(torch.int16), "mp_ct.iter_probs": it_prob,
+           "mp_ct.beam": o_beam, "in.tokens": batch["tokens"], "in.category": batch["category"]}
+    np.savez_compressed(os.path.join(GOLD, name + ".npz"), **npz(out))
+    print(f"[{name}] ok  min top1-top2 margin {float(out['logit_margin'].min()):.3e}")
+
+
+def main():
+    torch.manual_seed(0)
+    # training: forward + loss + grads + Adam (tiny, dropout 0)
+    train_case("tiny_nacf_train", "NACF", ["-wc"], V=101, B=3, F_=6)
+    train_case("tiny_nab_train", "NAB", [], V=101, B=3, F_=6, dataset="Youtube2Text", beta=(0.0, 1.0))
+    train_case("tiny_arb2_train", "ARB2", ["-wc"], V=101, B=3, F_=6)
+    train_case("tiny_arb_train", "ARB", ["-wc"], V=101, B=3, F_=6)
+    # NA decode: all paradigms, +-ct, per-iteration tokens/probs
+    decode_case("tiny_nacf_decode", "NACF", ["-wc"], V=101, B=4, F_=6, variants={
+        "mp_ct": dict(paradigm="mp", use_ct=True, iterations=5, length_beam_size=6, beam_alpha=1.35),
+        "mp": dict(paradigm="mp", use_ct=False, iterations=5, length_beam_size=6, beam_alpha=1.0),
+        "mp_lbs3": dict(paradigm="mp", use_ct=True, iterations=3, length_beam_size=3, beam_alpha=1.35),
+        "ef_ct": dict(paradigm="ef", use_ct=True, q=1, q_iterations=1, length_beam_size=6, beam_alpha=1.35),
+        "l2r_ct": dict(paradigm="l2r", use_ct=True, q=1, q_iterations=1, length_beam_size=6, beam_alpha=1.35),
+        "ef_q2": dict(paradigm="ef", use_ct=False, q=2, q_iterations=2, length_beam_size=4, beam_alpha=1.0),
+        "l2r_q2": dict(paradigm="l2r", use_ct=False, q=2, q_iterations=2, length_beam_size=4, beam_alpha=1.0),
+    })
+    decode_case("tiny_nab_decode", "NAB", [], V=101, B=4, F_=6, dataset="Youtube2Text", variants={
+        "mp": dict(paradigm="mp", use_ct=False, iterations=5, length_beam_size=5, beam_alpha=1.0),
+    })
+    decode_case("tiny_nacf_teacher", "NACF", ["-wc"], V=101, B=3, F_=6, teacher_method="ARB", variants={
+        "mp_ct": dict(paradigm="mp", use_ct=True, iterations=5, length_beam_size=6, beam_alpha=1.35),
+        "mp_md": dict(paradigm="mp", use_ct=True, iterations=4, length_beam_size=4, beam_alpha=1.35,
+                      masking_decision=True),
+    })
+    ar_case("tiny_arb2_beam", "ARB2", ["-wc"], V=101, B=3, F_=6)
+    ar_case("tiny_arb_beam", "ARB", ["-wc"], V=101, B=3, F_=6)
+    full_shape_case()
+
+
+if __name__ == "__main__":
+    main()
