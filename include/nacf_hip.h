@@ -1,0 +1,315 @@
+/*
+ * nacf_hip.h -- C ABI of libnacf_hip.so, the MI355X (gfx950) implementation of
+ * the NACF video-captioning hot path.
+ *
+ * The reference (yangbang18/Non-Autoregressive-Video-Captioning) is pure
+ * Python/PyTorch: it has no FFI of its own, so there is no upstream binding to
+ * mirror symbol-for-symbol.  Each entry point below replaces the aten work
+ * issued by one reference call site (cited as file:line, relative to the
+ * upstream checkout); INTEGRATION.md shows the ctypes stub a maintainer of the
+ * reference would add to bind them.
+ *
+ * Conventions (all entry points):
+ *   - return 0 on success, a negative NACF_E* code on failure; the text of the
+ *     last failure on the calling thread is returned by nacf_last_error();
+ *   - never allocate, never synchronise, never throw: every launch is
+ *     asynchronous on `stream` (safe to capture in a hipGraph);
+ *   - pointers are DEVICE pointers into caller-owned, fp32 / int64 buffers on
+ *     the current device; `ld*` arguments are leading dimensions in ELEMENTS;
+ *   - results are deterministic for fixed inputs (no floating-point atomics);
+ *   - dropout masks are a pure function of (rng_state[0]=seed,
+ *     rng_state[1]=step, salt, element index), so backward regenerates them
+ *     instead of storing them, and graph replays see fresh masks once
+ *     nacf_rng_advance() has bumped the device-side step.
+ */
+#ifndef NACF_HIP_H
+#define NACF_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct ihipStream_t* nacf_stream_t; /* == hipStream_t */
+
+/* error codes */
+#define NACF_OK 0
+#define NACF_EINVAL (-1)   /* bad argument (shape, alignment, null pointer) */
+#define NACF_EWORKSPACE (-2) /* workspace too small */
+#define NACF_ELAUNCH (-3)  /* hipGetLastError() after launch */
+#define NACF_EUNSUPPORTED (-4)
+
+/* token ids, config/Constants.py:1-6 */
+#define NACF_PAD 0
+#define NACF_UNK 1
+#define NACF_BOS 2
+#define NACF_EOS 3
+#define NACF_MASK 4
+#define NACF_VIS 5
+
+/* activations, models/bert.py:9-19 (ACT2FN) + models/Encoder.py:20-22 */
+#define NACF_ACT_NONE 0
+#define NACF_ACT_RELU 1
+#define NACF_ACT_GELU_NEW 2   /* tanh form, models/bert.py:12-13 */
+#define NACF_ACT_TANH 3
+#define NACF_ACT_SIGMOID 4
+#define NACF_ACT_TANH_SIGMOID 5 /* cols < act_split: tanh, else sigmoid (packed HighWay w1|w2) */
+#define NACF_ACT_GELU_ERF 6   /* models/bert.py:9-10 */
+
+const char* nacf_last_error(void);
+int nacf_version(void);
+/* number of exported compute entry points (used by the loader self-check) */
+int nacf_abi_count(void);
+
+/* ------------------------------------------------------------------------
+ * RNG state: device uint64[2] = {seed, step}.
+ * ---------------------------------------------------------------------- */
+int nacf_rng_advance(uint64_t* rng_state, nacf_stream_t stream);
+
+/* ------------------------------------------------------------------------
+ * Linear layers (nn.Linear: y = x W^T + b, W is [N, K] row-major).
+ * Fused epilogue, applied in this order to z = x W^T + bias:
+ *   preact <- z (optional store) ; a = act(z) ; a = dropout(a, p_drop1) ;
+ *   a += residual ; a = dropout(a, p_drop2) ; a *= (row_tokens[m] != PAD) .
+ * Replaces: models/Encoder.py:19-25,65 ; models/bert.py:146-148 (q/k/v),
+ * :192-200 (BertSelfOutput), :227-230 (BertIntermediate), :240-247
+ * (BertOutput, which applies dropout twice), :271-299 (x non_pad_mask);
+ * models/Predictor.py:15-20 ; models/__init__.py:83 (tgt_word_prj).
+ * ---------------------------------------------------------------------- */
+typedef struct nacf_epilogue {
+  const float* bias;        /* [N] or NULL */
+  int32_t act;              /* NACF_ACT_* */
+  int32_t act_split;        /* NACF_ACT_TANH_SIGMOID only */
+  float* preact;            /* optional [M, ld_preact] store of z */
+  int64_t ld_preact;
+  float p_drop1;
+  uint32_t salt1;
+  const float* residual;    /* optional [M, ld_residual] */
+  int64_t ld_residual;
+  float p_drop2;
+  uint32_t salt2;
+  const int64_t* row_tokens; /* optional [M] */
+  const uint64_t* rng_state; /* required when a p_drop > 0 */
+} nacf_epilogue;
+
+int nacf_linear_fwd(const float* X, int64_t ldx, const float* W, int64_t ldw,
+                    float* Y, int64_t ldy, int M, int N, int K,
+                    const nacf_epilogue* ep, nacf_stream_t stream);
+
+/* dX[M,K] = beta*dX + dZ[M,N] W[N,K]   (autograd of nn.Linear wrt input) */
+int nacf_linear_bwd_data(const float* dZ, int64_t lddz, const float* W, int64_t ldw,
+                         float* dX, int64_t lddx, int M, int N, int K, float beta,
+                         nacf_stream_t stream);
+
+/* dW[N,K] = beta*dW + dZ^T X ; db[N] = beta*db + colsum(dZ) (db may be NULL).
+ * The M reduction is split over workgroups; partial slabs live in `ws`
+ * (nacf_linear_bwd_weight_workspace bytes) and are combined in a fixed order. */
+size_t nacf_linear_bwd_weight_workspace(int M, int N, int K);
+int nacf_linear_bwd_weight(const float* dZ, int64_t lddz, const float* X, int64_t ldx,
+                           float* dW, int64_t lddw, float* db, int M, int N, int K,
+                           float beta, void* ws, size_t ws_bytes, nacf_stream_t stream);
+
+/* Backward of the fused epilogue: from dY produce dZ (grad of the pre-bias
+ * GEMM output) and, when ep->residual != NULL, dR (+= when accumulate_dR).
+ * `ep` must be the struct used in forward (preact required when act != NONE).
+ * dZ may alias dY. */
+int nacf_epilogue_bwd(const float* dY, int64_t lddy, float* dZ, int64_t lddz,
+                      float* dR, int64_t lddr, int accumulate_dR,
+                      int M, int N, const nacf_epilogue* ep, nacf_stream_t stream);
+
+/* ------------------------------------------------------------------------
+ * Visual encoder tail + feature fusion  
+ * ---------------------------------------------------------------------- */
+/* HighWay gate mix + dropout, models/Encoder.py:19-25,65:
+ *   out = dropout(G*H + (1-G)*T),  TG = [T | G] packed [rows, 2D]. */
+int nacf_highway_mix_fwd(const float* H, const float* TG, float* out, int rows, int D,
+                         float p_drop, uint32_t salt, const uint64_t* rng_state,
+                         nacf_stream_t stream);
+/* given dOut: dH_direct = d*G ; dP = [ d*(1-G)*(1-T^2) | d*(H-T)*G*(1-G) ]  (pre-activation grads) */
+int nacf_highway_mix_bwd(const float* dOut, const float* H, const float* TG,
+                         float* dH, float* dP, int rows, int D,
+                         float p_drop, uint32_t salt, const uint64_t* rng_state,
+                         nacf_stream_t stream);
+
+/* BatchNorm1d over the flattened rows of one modality and temporal concat,
+ * models/joint_representation.py:40-51.  x is [B, F, D]; the result is written
+ * to out[b, f_off + f, :] of a [B, M_total, D] memory.
+ * training != 0: batch statistics (biased var), running stats updated with
+ * `momentum` (unbiased var), save_mean/save_invstd [D] kept for backward.
+ * training == 0: running statistics.  ws: nacf_bn_workspace(rows, D) bytes. */
+size_t nacf_bn_workspace(int rows, int D);
+int nacf_bn_concat_fwd(const float* x, float* out, int B, int F, int D, int M_total, int f_off,
+                       const float* weight, const float* bias,
+                       float* running_mean, float* running_var, int64_t* num_batches_tracked,
+                       float* save_mean, float* save_invstd,
+                       int training, float momentum, float eps,
+                       void* ws, size_t ws_bytes, nacf_stream_t stream);
+/* dOut is the gradient wrt the [B, M_total, D] memory; dx is [B, F, D]. */
+int nacf_bn_concat_bwd(const float* dOut, const float* x, float* dx, int B, int F, int D,
+                       int M_total, int f_off, const float* weight,
+                       const float* save_mean, const float* save_invstd,
+                       float* dweight, float* dbias, float beta,
+                       void* ws, size_t ws_bytes, nacf_stream_t stream);
+
+/* mean over the time axis: out[b, :] = mean_t x[b, t, :]   (x is [B, T, D]);
+ * models/Predictor.py:29, models/Decoder.py:137, models/Encoder.py:51 */
+int nacf_mean_time_fwd(const float* x, float* out, int B, int T, int D, nacf_stream_t stream);
+/* dx[b, t, :] (+)= dOut[b, :] / T */
+int nacf_mean_time_bwd(const float* dOut, float* dx, int B, int T, int D, int accumulate,
+                       nacf_stream_t stream);
+
+/* row-wise log_softmax for narrow rows (length head, N <= 1024),
+ * models/Predictor.py:30; in == out allowed. */
+int nacf_log_softmax_rows(const float* in, float* out, int rows, int N, nacf_stream_t stream);
+/* d(in) = dOut - exp(out) * rowsum(dOut) */
+int nacf_log_softmax_rows_bwd(const float* dOut, const float* out, float* dIn, int rows, int N,
+                              nacf_stream_t stream);
+/* nn.KLDivLoss() legacy 'mean': loss = sum(t*(log t - x))/numel, misc/crit.py:223.
+ * loss_out: device float[1]; dX = -t * scale / numel (written when dX != NULL). */
+int nacf_kldiv_mean(const float* x, const float* t, float* loss_out, float* dX, float scale,
+                    int rows, int N, nacf_stream_t stream);
+
+/* ------------------------------------------------------------------------
+ * Decoder  
+ * ---------------------------------------------------------------------- */
+/* BertEmbeddings, models/bert.py:70-96:
+ *   out[r,l,:] = dropout(LN(word[tok[r,l]] + pos[l] + cat[category[r/vdiv % vmod]] + add[r/vdiv % vmod]))
+ * category / cat_emb / additional may be NULL.  `additional` is [n_video, D]
+ * (the mean-pooled memory of enhance_input=2, models/Decoder.py:136-137).
+ * xhat (normalised, pre-affine) and rstd [R*L] are saved when non-NULL. */
+int nacf_embed_ln_fwd(const int64_t* tokens, const int64_t* category, const float* additional,
+                      const float* word_emb, const float* pos_emb, const float* cat_emb,
+                      const float* ln_w, const float* ln_b, float* out,
+                      float* xhat, float* rstd,
+                      int R, int L, int D, int vdiv, int vmod, float eps,
+                      float p_drop, uint32_t salt, const uint64_t* rng_state,
+                      nacf_stream_t stream);
+/* Backward: dE (grad of the pre-LN sum, [R*L, D]) plus LN weight/bias grads. */
+size_t nacf_embed_ln_bwd_workspace(int R, int L, int D);
+int nacf_embed_ln_bwd(const float* dOut, const float* xhat, const float* rstd,
+                      const float* ln_w, float* dE, float* dln_w, float* dln_b, float beta,
+                      int R, int L, int D, float p_drop, uint32_t salt, const uint64_t* rng_state,
+                      void* ws, size_t ws_bytes, nacf_stream_t stream);
+/* Deterministic scatter of dE into the embedding tables (fixed summation order):
+ *   dword[tok] += dE rows (PAD row left untouched: padding_idx, models/bert.py:55)
+ *   dpos[l]    += sum_r dE[r,l]
+ *   dcat[c]    += sum over rows of that category, dadd[v] (+)= sum over rows/positions of video v */
+int nacf_embed_scatter_bwd(const float* dE, const int64_t* tokens, const int64_t* category,
+                           float* dword, float* dpos, float* dcat, float* dadd,
+                           int R, int L, int D, int V, int n_cat, int n_video, int vdiv, int vmod,
+                           nacf_stream_t stream);
+
+/* Multi-head attention core, models/bert.py:150-179:
+ *   S = Q K^T / sqrt(dk) ; S[key masked] = -1e7 ; P = softmax(S) ; O = P V
+ * Q: [R, Lq, *] row stride ldq (head h at column h*dk); K, V: [n_kv, Lk, *];
+ * query row r reads kv row (r / kv_div) % kv_mod.
+ * key_tokens: optional [n_kv... R, Lk] int64 (self-attention: the decoder
+ * tokens; key masked when token == PAD, models/Decoder.py:13-22);
+ * causal != 0 adds the strict upper-triangular mask (models/Decoder.py:24-39).
+ * probs: optional [H, R, Lq, Lk] output (models/bert.py:179). */
+int nacf_attention_fwd(const float* Q, int64_t ldq, const float* K, int64_t ldk,
+                       const float* V, int64_t ldv, float* O, int64_t ldo,
+                       const int64_t* key_tokens, int causal, float* probs,
+                       int R, int H, int Lq, int Lk, int dk, int kv_div, int kv_mod,
+                       nacf_stream_t stream);
+/* dQ [R,Lq,*], dK/dV [n_kv, Lk, *]; each kv row sums, in a fixed order, the
+ * contributions of the query rows mapped to it. */
+int nacf_attention_bwd(const float* Q, int64_t ldq, const float* K, int64_t ldk,
+                       const float* V, int64_t ldv, const float* dO, int64_t lddo,
+                       float* dQ, int64_t lddq, float* dK, int64_t lddk, float* dV, int64_t lddv,
+                       const int64_t* key_tokens, int causal,
+                       int R, int n_kv, int H, int Lq, int Lk, int dk, int kv_div, int kv_mod,
+                       nacf_stream_t stream);
+
+/* masked row mean of the last layer (the `embs` output, models/bert.py:301):
+ * out[r,:] = sum_l y[r,l,:] / count(tokens[r,:] != PAD) */
+int nacf_masked_mean_fwd(const float* y, const int64_t* tokens, float* out, int R, int L, int D,
+                         nacf_stream_t stream);
+
+/* ------------------------------------------------------------------------
+ * Vocabulary projection + loss (training)  
+ * ---------------------------------------------------------------------- */
+/* In place: logits[rows, ld] -> log-probs (torch.log_softmax, models/seq2seq.py:103).
+ * Also emits, per row: lse, argmax (for Word Acc, misc/crit.py:86-98), and
+ * the log-prob of labels[row] (for the NLL / perplexity, misc/crit.py:62-114);
+ * labels may be NULL. */
+int nacf_vocab_logsoftmax_fwd(float* logits, int64_t ld, int rows, int V,
+                              const int64_t* labels, float* lse, int64_t* argmax,
+                              float* label_logp, nacf_stream_t stream);
+/* Reduce per-row results to the scalars the criterion reports:
+ * out[0] = -sum_{label!=PAD} logp[label]      (token-SUM NLL, misc/crit.py:82)
+ * out[1] = #(argmax == label) over the accuracy set, out[2] = |accuracy set|
+ *          (label != PAD, and != MASK when exclude_mask: misc/crit.py:88-90)
+ * out[3] = sum of gathered logp over label != PAD, out[4] = count (perplexity) */
+int nacf_nll_reduce(const float* label_logp, const int64_t* argmax, const int64_t* labels,
+                    int rows, int exclude_mask, float* out5, nacf_stream_t stream);
+/* dlogits = (exp(logp) - onehot(label)) * gscale[0]*scale for rows with label != PAD, else 0.
+ * gscale: optional device float[1] (upstream gradient of the loss). In place on logp allowed. */
+int nacf_xent_bwd(const float* logp, int64_t ld, float* dlogits, int64_t ldd, int rows, int V,
+                  const int64_t* labels, const float* gscale, float scale, nacf_stream_t stream);
+/* Generic log_softmax backward for wide rows (when the caller consumes the
+ * log-probs with its own criterion): dlogits = dlogp - exp(logp)*rowsum(dlogp) */
+int nacf_vocab_logsoftmax_bwd(const float* dlogp, int64_t ldg, const float* logp, int64_t ld,
+                              float* dlogits, int64_t ldd, int rows, int V, nacf_stream_t stream);
+
+/* ------------------------------------------------------------------------
+ * NA decoding  
+ * ---------------------------------------------------------------------- */
+/* One fused "project + softmax + max" step, decoding/algorithms.py:7-15,149:
+ * for every row of hidden [rows, K]: idx = argmax_v (h W^T), prob = max softmax.
+ * The [rows, V] logits are never materialised.  Then the bookkeeping of
+ * decoding/algorithms.py:154-155,140,262-265 is applied in the same pass:
+ *   pad_tokens[row] == PAD      -> (PAD, 1.0)
+ *   zero_mask_prob && idx==MASK -> prob = 0          (coarse-grained template pass)
+ *   update_mask != NULL         -> tokens/probs only overwritten where update_mask != 0
+ * ws: nacf_vocab_argmax_workspace(rows, V) bytes. */
+size_t nacf_vocab_argmax_workspace(int rows, int V);
+int nacf_vocab_argmax(const float* hidden, int64_t ldh, const float* W, int64_t ldw, const float* bias,
+                      int rows, int V, int K,
+                      const int64_t* pad_tokens, int zero_mask_prob, const uint8_t* update_mask,
+                      int64_t* tokens, float* probs, void* ws, size_t ws_bytes,
+                      nacf_stream_t stream);
+
+/* predict_length_beam + canvas, decoding/na_generate.py:35-50,116-135:
+ * beam[b,j] = clamp(top-k index of pred_length[b,:] (descending) + bias, 4, max_len-1);
+ * beam_max[0] = max over all (device int32, read back once by the host). */
+int nacf_length_beam(const float* pred_length, int B, int max_len, int lbs, int length_bias,
+                     int32_t* beam, int32_t* beam_max, nacf_stream_t stream);
+/* tokens[b*lbs+j, l] = l < beam[b,j] ? MASK : PAD ; width Lp */
+int nacf_canvas_init(const int32_t* beam, int rows, int Lp, int64_t* tokens, nacf_stream_t stream);
+
+/* select_worst + re-mask, decoding/algorithms.py:206-215,255-260: per row,
+ * n = max(1, num_mask_lut[seq_len(row)]) slots of lowest score = probs*teacher
+ * are flagged in mask_out and set to MASK in tokens.  seq_len = # non-PAD of
+ * pad_tokens (the initial canvas).  mode 1: mask = (tokens == MASK) instead
+ * (the counter==1 step with coarse templates, algorithms.py:250-253);
+ * mode 2: mask = tokens != MASK && pad_tokens != PAD  (visual_mask, :292). */
+int nacf_select_mask(const float* probs, const float* teacher_probs, const int64_t* pad_tokens,
+                     const int32_t* num_mask_lut, int mode, int rows, int Lp,
+                     int64_t* tokens, uint8_t* mask_out, nacf_stream_t stream);
+
+/* score = sum_l log(probs*teacher) / len^alpha ; best = argmax_j ; out[b,:] = tokens[b*lbs+best,:]
+ * decoding/na_generate.py:66-77.  cand_lprobs optional [rows, Lp] output. */
+int nacf_best_candidate(const int64_t* tokens, const float* probs, const float* teacher_probs,
+                        const int32_t* beam, float alpha, int B, int lbs, int Lp,
+                        int64_t* out_tokens, int32_t* best_idx, float* cand_lprobs,
+                        nacf_stream_t stream);
+
+/* ------------------------------------------------------------------------
+ * Optimiser  
+ * ---------------------------------------------------------------------- */
+/* clip_grad_value_(+-clip) (misc/run.py:260) then Adam with L2 weight decay
+ * (misc/optim.py:61-62) over flat buffers.  g is first multiplied by
+ * grad_scale (1/world_size after the RCCL all-reduce).  step_count: device
+ * int64[1], incremented by this call; lr: device float[1]. */
+int nacf_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq,
+                   int64_t n, const float* lr, int64_t* step_count,
+                   float beta1, float beta2, float eps, float weight_decay,
+                   float grad_clip, float grad_scale, nacf_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NACF_HIP_H */

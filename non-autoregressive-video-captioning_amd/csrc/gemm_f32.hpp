@@ -1,0 +1,392 @@
+// LDS-tiled fp32 GEMM on the CDNA4 matrix cores (v_mfma_f32_16x16x4_f32).
+//
+//   C[m][n] = sum_k Qop[m][k] * Pop[n][k]
+//
+// Exact fp32 (the MFMA is bitwise an fmaf chain), which is what the parity
+// bar needs: greedy NA-decode tokens must match the reference's fp32 CPU path.
+//
+// Operand layouts (per operand, compile time):
+//   KC ("reduce-dim contiguous"):  element (row, k) at base[row*ld + k]
+//   MC ("row-dim contiguous"):     element (row, k) at base[k*ld + row]
+// so  y = x W^T      is (Q=x  KC, P=W  KC)       [forward, nn.Linear]
+//     dx = dz W      is (Q=dz KC, P=W  MC)       [reduce over n]
+//     dW = dz^T x    is (Q=dz MC, P=x  MC)       [reduce over m; Q rows = n]
+//
+// Workgroup: 256 threads = 4 waves (WM x WN), block tile BM x BN, BK = 16,
+// double-buffered LDS with register prefetch of the next k-tile (one barrier
+// per k-tile).  Wave tile = (BM/WM) x (BN/WN) = TM x TN MFMA tiles of 16x16.
+//
+// LDS images and the k-permutation trick: the 16x16x4 MFMA wants, from lane
+// (i = lane&15, g = lane>>4), A[i][k=g].  Which physical k each (step, g)
+// pair uses is free as long as both operands agree, so step s of a 16-deep
+// k-tile uses k = 4g + s:
+//   KC tiles are stored [row][16] (64 B rows, as they arrive from HBM) and a
+//      lane fetches its 4 steps with ONE ds_read_b128 of columns 4g..4g+3; the
+//      16-B column slot is XOR-swizzled with sw(row) = (-(row>>2))&3, which
+//      makes every ds_read_b128 lane group {rows x g} hit 16 distinct slots
+//      and keeps the staging ds_write_b128 conflict-free as well;
+//   MC tiles are stored [16][rows+4] (row stride = 4 mod 8 dwords) and read
+//      with ds_read_b32 at [(4g+s)][row]: the two g's of a 32-lane group land
+//      16 banks apart.
+// The MFMA is issued "swapped" (a = P fragment, b = Q fragment) so each lane
+// ends up with 4 CONSECUTIVE n of one row m: epilogues store float4s.
+#pragma once
+#include "common.hpp"
+
+struct GemmShape {
+  const float* Q;
+  const float* P;
+  int64_t ldq, ldp;
+  int M, N, K;
+  int k_per_split;  // multiple of 16
+  int tiles_m, tiles_n;
+};
+
+__device__ __forceinline__ int lds_sw(int row) { return (-(row >> 2)) & 3; }
+
+template <int R, bool KC, bool VEC>
+__device__ __forceinline__ void tile_load(f32x4 (&reg)[R / 64], const float* __restrict__ base,
+                                          int64_t ld, int row0, int rows_total, int k0, int k_end,
+                                          int tid) {
+#pragma unroll
+  for (int u = 0; u < R / 64; ++u) {
+    const int q = tid + 256 * u;
+    const float* p;
+    int nv;      // valid elements along the vector
+    bool ok;     // the other coordinate in range
+    if (KC) {
+      const int rr = q >> 2, c = q & 3;
+      const int gr = row0 + rr, gk = k0 + c * 4;
+      p = base + (int64_t)gr * ld + gk;
+      nv = k_end - gk;
+      ok = gr < rows_total;
+    } else {
+      constexpr int RV = R / 4;
+      const int kk = q / RV, r4 = q % RV;
+      const int gk = k0 + kk, gr = row0 + r4 * 4;
+      p = base + (int64_t)gk * ld + gr;
+      nv = rows_total - gr;
+      ok = gk < k_end;
+    }
+    f32x4 t = {0.f, 0.f, 0.f, 0.f};
+    if (ok) {
+      if (nv >= 4) {
+        if (VEC) {
+          t = *reinterpret_cast<const f32x4*>(p);
+        } else {
+          t[0] = p[0]; t[1] = p[1]; t[2] = p[2]; t[3] = p[3];
+        }
+      } else {
+        if (nv > 0) t[0] = p[0];
+        if (nv > 1) t[1] = p[1];
+        if (nv > 2) t[2] = p[2];
+      }
+    }
+    reg[u] = t;
+  }
+}
+
+template <int R, bool KC>
+__device__ __forceinline__ void tile_store(float* lds, const f32x4 (&reg)[R / 64], int tid) {
+#pragma unroll
+  for (int u = 0; u < R / 64; ++u) {
+    const int q = tid + 256 * u;
+    if (KC) {
+      const int rr = q >> 2, c = q & 3;
+      *reinterpret_cast<f32x4*>(&lds[rr * 16 + ((c ^ lds_sw(rr)) << 2)]) = reg[u];
+    } else {
+      constexpr int RV = R / 4;
+      const int kk = q / RV, r4 = q % RV;
+      *reinterpret_cast<f32x4*>(&lds[kk * (R + 4) + r4 * 4]) = reg[u];
+    }
+  }
+}
+
+template <int R, bool KC>
+__device__ __forceinline__ f32x4 frag_load(const float* lds, int rb, int i, int g) {
+  if (KC) {
+    const int row = rb + i;
+    return *reinterpret_cast<const f32x4*>(&lds[row * 16 + ((g ^ lds_sw(row)) << 2)]);
+  } else {
+    f32x4 v;
+    const float* p = lds + (g * 4) * (R + 4) + rb + i;
+    v[0] = p[0];
+    v[1] = p[R + 4];
+    v[2] = p[2 * (R + 4)];
+    v[3] = p[3 * (R + 4)];
+    return v;
+  }
+}
+
+// ---------------------------------------------------------------- epilogues
+// plain / accumulate / split-K slab store
+struct EpiStore {
+  float* C;
+  int64_t ldc;
+  float beta;
+  int64_t slab_stride;  // elements between blockIdx.z slabs (0: none)
+  int vec_out;
+  static constexpr bool kArgmax = false;
+  __device__ __forceinline__ void operator()(int m, int n, f32x4 v, int M, int N, int z) const {
+    if (m >= M || n >= N) return;
+    float* p = C + (int64_t)z * slab_stride + (int64_t)m * ldc + n;
+    const int nv = N - n;
+    if (nv >= 4 && vec_out) {
+      if (beta != 0.f) {
+        f32x4 o = *reinterpret_cast<const f32x4*>(p);
+        v[0] += beta * o[0]; v[1] += beta * o[1]; v[2] += beta * o[2]; v[3] += beta * o[3];
+      }
+      *reinterpret_cast<f32x4*>(p) = v;
+    } else {
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        if (e < nv) p[e] = (beta != 0.f) ? v[e] + beta * p[e] : v[e];
+    }
+  }
+};
+
+// nn.Linear forward epilogue (see nacf_epilogue in nacf_hip.h)
+struct EpiLinear {
+  float* Y;
+  int64_t ldy;
+  nacf_epilogue ep;
+  int vec_out;  // Y / preact / residual all float4-addressable
+  static constexpr bool kArgmax = false;
+  __device__ __forceinline__ void operator()(int m, int n, f32x4 v, int M, int N, int /*z*/) const {
+    if (m >= M || n >= N) return;
+    const int nv = N - n;
+    if (ep.bias) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        if (e < nv) v[e] += ep.bias[n + e];
+    }
+    if (ep.preact) {
+      float* z = ep.preact + (int64_t)m * ep.ld_preact + n;
+      if (nv >= 4 && vec_out) *reinterpret_cast<f32x4*>(z) = v;
+      else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if (e < nv) z[e] = v[e];
+      }
+    }
+    if (ep.act != NACF_ACT_NONE) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = apply_act(ep.act, v[e], n + e, ep.act_split);
+    }
+    const bool any_drop = (ep.p_drop1 > 0.f) || (ep.p_drop2 > 0.f);
+    DropRng rng;
+    if (any_drop) rng.init(ep.rng_state);
+    const uint64_t e0 = (uint64_t)m * (uint64_t)N + (uint64_t)n;
+    const bool grp_ok = (N & 3) == 0;  // aligned groups of 4 share one Philox call
+    if (ep.p_drop1 > 0.f) {
+      if (grp_ok) {
+        f32x4 k = rng.keep4(e0 >> 2, ep.salt1, ep.p_drop1);
+        v[0] *= k[0]; v[1] *= k[1]; v[2] *= k[2]; v[3] *= k[3];
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] *= rng.keep1(e0 + e, ep.salt1, ep.p_drop1);
+      }
+    }
+    if (ep.residual) {
+      const float* r = ep.residual + (int64_t)m * ep.ld_residual + n;
+      if (nv >= 4 && vec_out) {
+        f32x4 o = *reinterpret_cast<const f32x4*>(r);
+        v[0] += o[0]; v[1] += o[1]; v[2] += o[2]; v[3] += o[3];
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if (e < nv) v[e] += r[e];
+      }
+    }
+    if (ep.p_drop2 > 0.f) {
+      if (grp_ok) {
+        f32x4 k = rng.keep4(e0 >> 2, ep.salt2, ep.p_drop2);
+        v[0] *= k[0]; v[1] *= k[1]; v[2] *= k[2]; v[3] *= k[3];
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] *= rng.keep1(e0 + e, ep.salt2, ep.p_drop2);
+      }
+    }
+    if (ep.row_tokens) {
+      if (ep.row_tokens[m] == NACF_PAD) { v[0] = 0.f; v[1] = 0.f; v[2] = 0.f; v[3] = 0.f; }
+    }
+    float* y = Y + (int64_t)m * ldy + n;
+    if (nv >= 4 && vec_out) *reinterpret_cast<f32x4*>(y) = v;
+    else {
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        if (e < nv) y[e] = v[e];
+    }
+  }
+};
+
+// fused "softmax-max" partials: per (n-tile, row): max logit, its index, sum exp(l - max)
+struct EpiArgmax {
+  const float* bias;
+  float* pmax;   // [tiles_n][M]
+  float* psum;   // [tiles_n][M]
+  int* pidx;     // [tiles_n][M]
+  static constexpr bool kArgmax = true;
+  __device__ __forceinline__ void operator()(int, int, f32x4, int, int, int) const {}
+};
+
+// ---------------------------------------------------------------- kernel
+template <int BM, int BN, int WM, int WN, bool QKC, bool PKC, bool VEC, class Epi>
+__global__ __launch_bounds__(256) void gemm_f32_kernel(GemmShape g, Epi epi) {
+  constexpr int BK = 16;
+  constexpr int WTM = BM / WM, WTN = BN / WN;
+  constexpr int TM = WTM / 16, TN = WTN / 16;
+  constexpr int QSZ = QKC ? BM * BK : BK * (BM + 4);
+  constexpr int PSZ = PKC ? BN * BK : BK * (BN + 4);
+  constexpr int BUF = QSZ + PSZ;
+  static_assert(WM * WN == 4, "4 waves");
+  static_assert(BM % 64 == 0 && BN % 64 == 0, "tile loader granularity");
+  constexpr int RED = Epi::kArgmax ? 3 * WN * BM : 0;
+  constexpr int SMEM = (2 * BUF > RED) ? 2 * BUF : RED;
+  __shared__ __attribute__((aligned(16))) float smem[SMEM];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+  const int li = lane & 15, lg = lane >> 4;
+
+  // XCD-aware tile order: workgroup b runs on XCD b%8; give every XCD a
+  // contiguous run of logical tiles (n fastest) so the tiles that share a
+  // Q row panel hit the same private L2 (bijective for any grid size).
+  const int nwg = g.tiles_m * g.tiles_n;
+  const int bid = blockIdx.x;
+  const int xq = nwg >> 3, xr = nwg & 7;
+  const int xcd = bid & 7, slot = bid >> 3;
+  const int logical = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + slot;
+  const int tile_m = logical / g.tiles_n, tile_n = logical % g.tiles_n;
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+
+  const int z = blockIdx.z;
+  const int kbeg = z * g.k_per_split;
+  const int kend = min(g.K, kbeg + g.k_per_split);
+  const int nk = (kend - kbeg + BK - 1) / BK;
+
+  f32x4 acc[TM][TN];
+#pragma unroll
+  for (int a = 0; a < TM; ++a)
+#pragma unroll
+    for (int b = 0; b < TN; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  f32x4 qreg[BM / 64], preg[BN / 64];
+  tile_load<BM, QKC, VEC>(qreg, g.Q, g.ldq, m0, g.M, kbeg, kend, tid);
+  tile_load<BN, PKC, VEC>(preg, g.P, g.ldp, n0, g.N, kbeg, kend, tid);
+  tile_store<BM, QKC>(smem, qreg, tid);
+  tile_store<BN, PKC>(smem + QSZ, preg, tid);
+  __syncthreads();
+
+  for (int kt = 0; kt < nk; ++kt) {
+    const float* qs = smem + (kt & 1) * BUF;
+    const float* ps = qs + QSZ;
+    const bool more = (kt + 1) < nk;
+    if (more) {
+      const int k0 = kbeg + (kt + 1) * BK;
+      tile_load<BM, QKC, VEC>(qreg, g.Q, g.ldq, m0, g.M, k0, kend, tid);
+      tile_load<BN, PKC, VEC>(preg, g.P, g.ldp, n0, g.N, k0, kend, tid);
+    }
+    f32x4 qf[TM], pf[TN];
+#pragma unroll
+    for (int a = 0; a < TM; ++a) qf[a] = frag_load<BM, QKC>(qs, wm * WTM + a * 16, li, lg);
+#pragma unroll
+    for (int b = 0; b < TN; ++b) pf[b] = frag_load<BN, PKC>(ps, wn * WTN + b * 16, li, lg);
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+#pragma unroll
+      for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int b = 0; b < TN; ++b)
+          acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(pf[b][s], qf[a][s], acc[a][b], 0, 0, 0);
+    if (more) {
+      float* qd = smem + ((kt + 1) & 1) * BUF;
+      tile_store<BM, QKC>(qd, qreg, tid);
+      tile_store<BN, PKC>(qd + QSZ, preg, tid);
+    }
+    __syncthreads();
+  }
+
+  if constexpr (!Epi::kArgmax) {
+#pragma unroll
+    for (int a = 0; a < TM; ++a)
+#pragma unroll
+      for (int b = 0; b < TN; ++b) {
+        const int m = m0 + wm * WTM + a * 16 + li;
+        const int n = n0 + wn * WTN + b * 16 + lg * 4;
+        epi(m, n, acc[a][b], g.M, g.N, z);
+      }
+  } else {
+    // per-row (max, argmax, sum-exp) over this tile's BN columns
+    float* redv = smem;                  // [WN][BM]
+    float* reds = smem + WN * BM;        // [WN][BM]
+    int* redi = reinterpret_cast<int*>(smem + 2 * WN * BM);
+    const float NEG = -3.0e38f;
+#pragma unroll
+    for (int a = 0; a < TM; ++a) {
+      float best = NEG;
+      int bidx = 0x7fffffff;
+#pragma unroll
+      for (int b = 0; b < TN; ++b)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int n = n0 + wn * WTN + b * 16 + lg * 4 + e;
+          float v = NEG;
+          if (n < g.N) {
+            v = acc[a][b][e] + (epi.bias ? epi.bias[n] : 0.f);
+            acc[a][b][e] = v;
+          } else {
+            acc[a][b][e] = NEG;
+          }
+          if (v > best) { best = v; bidx = n; }
+        }
+#pragma unroll
+      for (int o = 16; o <= 32; o <<= 1) {
+        float ov = __shfl_xor(best, o, 64);
+        int oi = __shfl_xor(bidx, o, 64);
+        if (ov > best || (ov == best && oi < bidx)) { best = ov; bidx = oi; }
+      }
+      const int row = wm * WTM + a * 16 + li;
+      if (lg == 0) { redv[wn * BM + row] = best; redi[wn * BM + row] = bidx; }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int a = 0; a < TM; ++a) {
+      const int row = wm * WTM + a * 16 + li;
+      float tmax = redv[row];
+#pragma unroll
+      for (int w = 1; w < WN; ++w) tmax = fmaxf(tmax, redv[w * BM + row]);
+      float s = 0.f;
+#pragma unroll
+      for (int b = 0; b < TN; ++b)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float v = acc[a][b][e];
+          s += (v > -1.0e38f) ? __expf(v - tmax) : 0.f;
+        }
+      s += __shfl_xor(s, 16, 64);
+      s += __shfl_xor(s, 32, 64);
+      if (lg == 0) reds[wn * BM + row] = s;
+    }
+    __syncthreads();
+    for (int row = tid; row < BM; row += 256) {
+      const int m = m0 + row;
+      if (m >= g.M) continue;
+      float best = redv[row];
+      int bidx = redi[row];
+      float s = reds[row];
+#pragma unroll
+      for (int w = 1; w < WN; ++w) {
+        float ov = redv[w * BM + row];
+        int oi = redi[w * BM + row];
+        if (ov > best || (ov == best && oi < bidx)) { best = ov; bidx = oi; }
+        s += reds[w * BM + row];
+      }
+      const int64_t o = (int64_t)tile_n * g.M + m;
+      epi.pmax[o] = best;
+      epi.psum[o] = s;
+      epi.pidx[o] = bidx;
+    }
+  }
+}

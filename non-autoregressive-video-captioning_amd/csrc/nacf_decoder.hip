@@ -1,0 +1,529 @@
+// Decoder-side kernels: BertEmbeddings (gather + LayerNorm), its backward and
+// the deterministic scatter into the embedding tables, the multi-head
+// attention core (forward + backward) and the masked row mean.
+//
+// Attention here is tiny (Lq <= 30, Lk <= 120, dk = 64: <1% of the step's
+// FLOPs) so it runs on the fp32 VALU out of LDS; one workgroup
+// per (sequence, head) keeps K/V/scores on chip for the whole softmax(QK^T)V.
+#include "common.hpp"
+
+namespace {
+
+constexpr int EMB_THREADS = 128;
+constexpr int EMB_MAXJ = 4;  // D <= 4 * 128 * 4 = 2048
+
+__global__ __launch_bounds__(EMB_THREADS) void embed_ln_fwd_kernel(
+    const int64_t* __restrict__ tokens, const int64_t* __restrict__ category, const float* __restrict__ additional,
+    const float* __restrict__ word, const float* __restrict__ pos, const float* __restrict__ cat,
+    const float* __restrict__ ln_w, const float* __restrict__ ln_b, float* __restrict__ out,
+    float* __restrict__ xhat, float* __restrict__ rstd_out, int L, int D, int vdiv, int vmod, float eps, float p,
+    uint32_t salt, const uint64_t* __restrict__ rng_state) {
+  __shared__ float red[16];
+  const int row = blockIdx.x;
+  const int r = row / L, l = row % L;
+  const int v = (r / vdiv) % vmod;
+  const int64_t tok = tokens[row];
+  const int64_t c = (cat && category) ? category[v] : 0;
+  f32x4 x[EMB_MAXJ];
+  float sum = 0.f;
+#pragma unroll
+  for (int j = 0; j < EMB_MAXJ; ++j) {
+    const int d = (threadIdx.x + EMB_THREADS * j) * 4;
+    x[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (d < D) {
+      f32x4 a = *reinterpret_cast<const f32x4*>(word + tok * D + d);
+      f32x4 b = *reinterpret_cast<const f32x4*>(pos + (int64_t)l * D + d);
+      a += b;
+      if (cat && category) a += *reinterpret_cast<const f32x4*>(cat + c * D + d);
+      if (additional) a += *reinterpret_cast<const f32x4*>(additional + (int64_t)v * D + d);
+      x[j] = a;
+      sum += a[0] + a[1] + a[2] + a[3];
+    }
+  }
+  const float mean = block_sum(sum, red) / (float)D;
+  float sq = 0.f;
+#pragma unroll
+  for (int j = 0; j < EMB_MAXJ; ++j) {
+    const int d = (threadIdx.x + EMB_THREADS * j) * 4;
+    if (d < D) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { const float dv = x[j][e] - mean; sq += dv * dv; }
+    }
+  }
+  const float var = block_sum(sq, red) / (float)D;
+  const float rstd = 1.0f / sqrtf(var + eps);
+  DropRng rng;
+  if (p > 0.f) rng.init(rng_state);
+#pragma unroll
+  for (int j = 0; j < EMB_MAXJ; ++j) {
+    const int d = (threadIdx.x + EMB_THREADS * j) * 4;
+    if (d < D) {
+      f32x4 xh;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) xh[e] = (x[j][e] - mean) * rstd;
+      if (xhat) *reinterpret_cast<f32x4*>(xhat + (int64_t)row * D + d) = xh;
+      const f32x4 w = *reinterpret_cast<const f32x4*>(ln_w + d);
+      const f32x4 b = *reinterpret_cast<const f32x4*>(ln_b + d);
+      f32x4 y = xh * w + b;
+      if (p > 0.f) y *= rng.keep4(((uint64_t)row * D + d) >> 2, salt, p);
+      *reinterpret_cast<f32x4*>(out + (int64_t)row * D + d) = y;
+    }
+  }
+  if (threadIdx.x == 0 && rstd_out) rstd_out[row] = rstd;
+}
+
+__global__ __launch_bounds__(EMB_THREADS) void embed_ln_bwd_kernel(
+    const float* __restrict__ dOut, const float* __restrict__ xhat, const float* __restrict__ rstd,
+    const float* __restrict__ ln_w, float* __restrict__ dE, float* __restrict__ part, int rows, int D, float p,
+    uint32_t salt, const uint64_t* __restrict__ rng_state) {
+  __shared__ float red[16];
+  f32x4 dw[EMB_MAXJ], db[EMB_MAXJ];
+#pragma unroll
+  for (int j = 0; j < EMB_MAXJ; ++j) { dw[j] = f32x4{0.f, 0.f, 0.f, 0.f}; db[j] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+  DropRng rng;
+  if (p > 0.f) rng.init(rng_state);
+  const float invD = 1.f / (float)D;
+  for (int row = blockIdx.x; row < rows; row += gridDim.x) {
+    f32x4 dxh[EMB_MAXJ], xh[EMB_MAXJ];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int j = 0; j < EMB_MAXJ; ++j) {
+      const int d = (threadIdx.x + EMB_THREADS * j) * 4;
+      dxh[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+      xh[j] = dxh[j];
+      if (d < D) {
+        f32x4 dy = *reinterpret_cast<const f32x4*>(dOut + (int64_t)row * D + d);
+        if (p > 0.f) dy *= rng.keep4(((uint64_t)row * D + d) >> 2, salt, p);
+        xh[j] = *reinterpret_cast<const f32x4*>(xhat + (int64_t)row * D + d);
+        const f32x4 w = *reinterpret_cast<const f32x4*>(ln_w + d);
+        dw[j] += dy * xh[j];
+        db[j] += dy;
+        dxh[j] = dy * w;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { s1 += dxh[j][e]; s2 += dxh[j][e] * xh[j][e]; }
+      }
+    }
+    s1 = block_sum(s1, red) * invD;
+    s2 = block_sum(s2, red) * invD;
+    const float rs = rstd[row];
+#pragma unroll
+    for (int j = 0; j < EMB_MAXJ; ++j) {
+      const int d = (threadIdx.x + EMB_THREADS * j) * 4;
+      if (d < D) {
+        f32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = rs * (dxh[j][e] - s1 - xh[j][e] * s2);
+        *reinterpret_cast<f32x4*>(dE + (int64_t)row * D + d) = o;
+      }
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < EMB_MAXJ; ++j) {
+    const int d = (threadIdx.x + EMB_THREADS * j) * 4;
+    if (d < D) {
+      *reinterpret_cast<f32x4*>(part + ((int64_t)blockIdx.x * 2 + 0) * D + d) = dw[j];
+      *reinterpret_cast<f32x4*>(part + ((int64_t)blockIdx.x * 2 + 1) * D + d) = db[j];
+    }
+  }
+}
+__global__ void embed_ln_bwd_final_kernel(const float* __restrict__ part, int nblk, int D, float* __restrict__ dln_w,
+                                          float* __restrict__ dln_b, float beta) {
+  const int d = blockIdx.x * blockDim.x + threadIdx.x;
+  if (d >= D) return;
+  float a = 0.f, b = 0.f;
+  for (int k = 0; k < nblk; ++k) { a += part[((int64_t)k * 2 + 0) * D + d]; b += part[((int64_t)k * 2 + 1) * D + d]; }
+  if (dln_w) dln_w[d] = (beta != 0.f) ? a + beta * dln_w[d] : a;
+  if (dln_b) dln_b[d] = (beta != 0.f) ? b + beta * dln_b[d] : b;
+}
+
+// dword[tok] += sum of the dE rows carrying `tok`, in ascending row order; the
+// workgroup of the FIRST occurrence of a token does the whole sum.
+__global__ __launch_bounds__(EMB_THREADS) void embed_scatter_word_kernel(const float* __restrict__ dE,
+                                                                          const int64_t* __restrict__ tokens,
+                                                                          float* __restrict__ dword, int n_rows,
+                                                                          int D) {
+  __shared__ int list[EMB_THREADS];
+  __shared__ int wcnt[2];
+  const int me = blockIdx.x;
+  const int64_t tok = tokens[me];
+  if (tok == NACF_PAD) return;
+  for (int base = 0; base < me; base += EMB_THREADS) {
+    const int idx = base + threadIdx.x;
+    const int found = (idx < me && tokens[idx] == tok) ? 1 : 0;
+    if (__syncthreads_or(found)) return;
+  }
+  f32x4 acc[EMB_MAXJ];
+#pragma unroll
+  for (int j = 0; j < EMB_MAXJ; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int base = me; base < n_rows; base += EMB_THREADS) {
+    const int idx = base + threadIdx.x;
+    const bool match = idx < n_rows && tokens[idx] == tok;
+    const unsigned long long bal = __ballot(match);
+    const int pre = __popcll(bal & ((1ull << lane) - 1ull));
+    if (lane == 0) wcnt[wave] = __popcll(bal);
+    __syncthreads();
+    const int off = (wave == 0) ? 0 : wcnt[0];
+    const int n = wcnt[0] + wcnt[1];
+    if (match) list[off + pre] = idx;
+    __syncthreads();
+    for (int i = 0; i < n; ++i) {
+      const int64_t src = (int64_t)list[i] * D;
+#pragma unroll
+      for (int j = 0; j < EMB_MAXJ; ++j) {
+        const int d = (threadIdx.x + EMB_THREADS * j) * 4;
+        if (d < D) acc[j] += *reinterpret_cast<const f32x4*>(dE + src + d);
+      }
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int j = 0; j < EMB_MAXJ; ++j) {
+    const int d = (threadIdx.x + EMB_THREADS * j) * 4;
+    if (d < D) {
+      float* o = dword + tok * D + d;
+      f32x4 cur = *reinterpret_cast<f32x4*>(o);
+      *reinterpret_cast<f32x4*>(o) = cur + acc[j];
+    }
+  }
+}
+
+// mode 0: dpos[l] += sum_r dE[r,l]          (grid = L)
+// mode 1: dcat[c] += sum over rows whose video has category c  (grid = n_cat)
+// mode 2: dadd[v]  = sum over rows of video v (all positions)  (grid = n_video)
+__global__ __launch_bounds__(EMB_THREADS) void embed_scatter_misc_kernel(const float* __restrict__ dE,
+                                                                          const int64_t* __restrict__ category,
+                                                                          float* __restrict__ dst, int mode, int R,
+                                                                          int L, int D, int vdiv, int vmod) {
+  f32x4 acc[EMB_MAXJ];
+#pragma unroll
+  for (int j = 0; j < EMB_MAXJ; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int me = blockIdx.x;
+  for (int r = 0; r < R; ++r) {
+    const int v = (r / vdiv) % vmod;
+    int l0 = 0, l1 = L;
+    if (mode == 0) { l0 = me; l1 = me + 1; }
+    else if (mode == 1) { if (category[v] != me) continue; }
+    else { if (v != me) continue; }
+    for (int l = l0; l < l1; ++l) {
+      const int64_t src = ((int64_t)r * L + l) * D;
+#pragma unroll
+      for (int j = 0; j < EMB_MAXJ; ++j) {
+        const int d = (threadIdx.x + EMB_THREADS * j) * 4;
+        if (d < D) acc[j] += *reinterpret_cast<const f32x4*>(dE + src + d);
+      }
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < EMB_MAXJ; ++j) {
+    const int d = (threadIdx.x + EMB_THREADS * j) * 4;
+    if (d < D) {
+      float* o = dst + (int64_t)me * D + d;
+      if (mode == 2) *reinterpret_cast<f32x4*>(o) = acc[j];
+      else {
+        f32x4 cur = *reinterpret_cast<f32x4*>(o);
+        *reinterpret_cast<f32x4*>(o) = cur + acc[j];
+      }
+    }
+  }
+}
+
+__global__ void masked_mean_fwd_kernel(const float* __restrict__ y, const int64_t* __restrict__ tokens,
+                                       float* __restrict__ out, int L, int D) {
+  const int r = blockIdx.x;
+  int cnt = 0;
+  for (int l = 0; l < L; ++l) cnt += tokens[(int64_t)r * L + l] != NACF_PAD ? 1 : 0;
+  for (int d = threadIdx.x; d < D; d += blockDim.x) {
+    float acc = 0.f;
+    for (int l = 0; l < L; ++l) acc += y[((int64_t)r * L + l) * D + d];
+    out[(int64_t)r * D + d] = acc / (float)cnt;
+  }
+}
+
+// ------------------------------------------------------------------ attention
+__global__ __launch_bounds__(256) void attention_fwd_kernel(const float* __restrict__ Q, int64_t ldq,
+                                                             const float* __restrict__ K, int64_t ldk,
+                                                             const float* __restrict__ V, int64_t ldv,
+                                                             float* __restrict__ O, int64_t ldo,
+                                                             const int64_t* __restrict__ key_tokens, int causal,
+                                                             float* __restrict__ probs, int R, int Lq, int Lk, int dk,
+                                                             int kv_div, int kv_mod) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  const int r = blockIdx.x, h = blockIdx.y;
+  const int kvr = (r / kv_div) % kv_mod;
+  const int ldd = dk + 1;
+  float* qs = sm;                // [Lq][dk+1]
+  float* ks = qs + Lq * ldd;     // [Lk][dk+1], later V as [Lk][dk]
+  float* ps = ks + Lk * ldd;     // [Lq][Lk]
+  const int tid = threadIdx.x;
+  for (int idx = tid; idx < Lq * dk; idx += 256) {
+    const int q = idx / dk, d = idx % dk;
+    qs[q * ldd + d] = Q[((int64_t)r * Lq + q) * ldq + h * dk + d];
+  }
+  for (int idx = tid; idx < Lk * dk; idx += 256) {
+    const int k = idx / dk, d = idx % dk;
+    ks[k * ldd + d] = K[((int64_t)kvr * Lk + k) * ldk + h * dk + d];
+  }
+  __syncthreads();
+  const float sq = sqrtf((float)dk);
+  for (int idx = tid; idx < Lq * Lk; idx += 256) {
+    const int q = idx / Lk, k = idx % Lk;
+    float dot = 0.f;
+    const float* a = qs + q * ldd;
+    const float* b = ks + k * ldd;
+    for (int d = 0; d < dk; ++d) dot += a[d] * b[d];
+    float s = dot / sq;
+    const bool masked = (key_tokens && key_tokens[(int64_t)r * Lk + k] == NACF_PAD) || (causal && k > q);
+    if (masked) s = -10e6f;  // models/bert.py:161: -10e6, not -inf
+    ps[idx] = s;
+  }
+  __syncthreads();
+  const int lane = tid & 63, wave = tid >> 6;
+  for (int q = wave; q < Lq; q += 4) {
+    float* row = ps + q * Lk;
+    float m = -3.0e38f;
+    for (int k = lane; k < Lk; k += 64) m = fmaxf(m, row[k]);
+    m = wave_max(m);
+    float s = 0.f;
+    for (int k = lane; k < Lk; k += 64) { const float e = expf(row[k] - m); row[k] = e; s += e; }
+    s = wave_sum(s);
+    for (int k = lane; k < Lk; k += 64) {
+      const float p = row[k] / s;
+      row[k] = p;
+      if (probs) probs[(((int64_t)h * R + r) * Lq + q) * Lk + k] = p;
+    }
+  }
+  __syncthreads();
+  float* vs = ks;  // [Lk][dk]
+  for (int idx = tid; idx < Lk * dk; idx += 256) {
+    const int k = idx / dk, d = idx % dk;
+    vs[k * dk + d] = V[((int64_t)kvr * Lk + k) * ldv + h * dk + d];
+  }
+  __syncthreads();
+  for (int idx = tid; idx < Lq * dk; idx += 256) {
+    const int q = idx / dk, d = idx % dk;
+    float acc = 0.f;
+    const float* prow = ps + q * Lk;
+    for (int k = 0; k < Lk; ++k) acc += prow[k] * vs[k * dk + d];
+    O[((int64_t)r * Lq + q) * ldo + h * dk + d] = acc;
+  }
+}
+
+constexpr int ATT_BWD_MAXJ = 32;  // Lk*dk <= 8192
+
+__global__ __launch_bounds__(256) void attention_bwd_kernel(
+    const float* __restrict__ Q, int64_t ldq, const float* __restrict__ K, int64_t ldk, const float* __restrict__ V,
+    int64_t ldv, const float* __restrict__ dO, int64_t lddo, float* __restrict__ dQ, int64_t lddq,
+    float* __restrict__ dK, int64_t lddk, float* __restrict__ dV, int64_t lddv,
+    const int64_t* __restrict__ key_tokens, int causal, int R, int Lq, int Lk, int dk, int kv_div, int kv_mod) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  const int kvr = blockIdx.x, h = blockIdx.y;
+  const int ldd = dk + 1;
+  float* qs = sm;                 // [Lq][dk+1]
+  float* dos = qs + Lq * ldd;     // [Lq][dk+1]
+  float* ks = dos + Lq * ldd;     // [Lk][dk+1]
+  float* vs = ks + Lk * ldd;      // [Lk][dk+1]
+  float* ps = vs + Lk * ldd;      // [Lq][Lk]
+  float* dps = ps + Lq * Lk;      // [Lq][Lk]
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  for (int idx = tid; idx < Lk * dk; idx += 256) {
+    const int k = idx / dk, d = idx % dk;
+    ks[k * ldd + d] = K[((int64_t)kvr * Lk + k) * ldk + h * dk + d];
+    vs[k * ldd + d] = V[((int64_t)kvr * Lk + k) * ldv + h * dk + d];
+  }
+  float dka[ATT_BWD_MAXJ], dva[ATT_BWD_MAXJ];
+#pragma unroll
+  for (int j = 0; j < ATT_BWD_MAXJ; ++j) { dka[j] = 0.f; dva[j] = 0.f; }
+  const float sq = sqrtf((float)dk);
+  for (int r = 0; r < R; ++r) {
+    if ((r / kv_div) % kv_mod != kvr) continue;
+    __syncthreads();
+    for (int idx = tid; idx < Lq * dk; idx += 256) {
+      const int q = idx / dk, d = idx % dk;
+      qs[q * ldd + d] = Q[((int64_t)r * Lq + q) * ldq + h * dk + d];
+      dos[q * ldd + d] = dO[((int64_t)r * Lq + q) * lddo + h * dk + d];
+    }
+    __syncthreads();
+    for (int idx = tid; idx < Lq * Lk; idx += 256) {
+      const int q = idx / Lk, k = idx % Lk;
+      float dot = 0.f, dp = 0.f;
+      const float* a = qs + q * ldd;
+      const float* b = ks + k * ldd;
+      const float* g = dos + q * ldd;
+      const float* vv = vs + k * ldd;
+      for (int d = 0; d < dk; ++d) { dot += a[d] * b[d]; dp += g[d] * vv[d]; }
+      float s = dot / sq;
+      const bool masked = (key_tokens && key_tokens[(int64_t)r * Lk + k] == NACF_PAD) || (causal && k > q);
+      if (masked) s = -10e6f;
+      ps[idx] = s;
+      dps[idx] = dp;
+    }
+    __syncthreads();
+    for (int q = wave; q < Lq; q += 4) {
+      float* row = ps + q * Lk;
+      float* drow = dps + q * Lk;
+      float m = -3.0e38f;
+      for (int k = lane; k < Lk; k += 64) m = fmaxf(m, row[k]);
+      m = wave_max(m);
+      float s = 0.f;
+      for (int k = lane; k < Lk; k += 64) { const float e = expf(row[k] - m); row[k] = e; s += e; }
+      s = wave_sum(s);
+      float dotp = 0.f;
+      for (int k = lane; k < Lk; k += 64) { const float p = row[k] / s; row[k] = p; dotp += p * drow[k]; }
+      dotp = wave_sum(dotp);
+      for (int k = lane; k < Lk; k += 64) drow[k] = row[k] * (drow[k] - dotp) / sq;  // grad wrt Q.K^T
+    }
+    __syncthreads();
+    for (int idx = tid; idx < Lq * dk; idx += 256) {
+      const int q = idx / dk, d = idx % dk;
+      float acc = 0.f;
+      const float* ds = dps + q * Lk;
+      for (int k = 0; k < Lk; ++k) acc += ds[k] * ks[k * ldd + d];
+      dQ[((int64_t)r * Lq + q) * lddq + h * dk + d] = acc;
+    }
+#pragma unroll
+    for (int j = 0; j < ATT_BWD_MAXJ; ++j) {
+      const int idx = tid + 256 * j;
+      if (idx < Lk * dk) {
+        const int k = idx / dk, d = idx % dk;
+        float a = 0.f, b = 0.f;
+        for (int q = 0; q < Lq; ++q) {
+          a += dps[q * Lk + k] * qs[q * ldd + d];
+          b += ps[q * Lk + k] * dos[q * ldd + d];
+        }
+        dka[j] += a;
+        dva[j] += b;
+      }
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < ATT_BWD_MAXJ; ++j) {
+    const int idx = tid + 256 * j;
+    if (idx < Lk * dk) {
+      const int k = idx / dk, d = idx % dk;
+      dK[((int64_t)kvr * Lk + k) * lddk + h * dk + d] = dka[j];
+      dV[((int64_t)kvr * Lk + k) * lddv + h * dk + d] = dva[j];
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+int nacf_embed_ln_fwd(const int64_t* tokens, const int64_t* category, const float* additional, const float* word_emb,
+                      const float* pos_emb, const float* cat_emb, const float* ln_w, const float* ln_b, float* out,
+                      float* xhat, float* rstd, int R, int L, int D, int vdiv, int vmod, float eps, float p_drop,
+                      uint32_t salt, const uint64_t* rng_state, nacf_stream_t stream) {
+  NACF_CHECK(tokens && word_emb && pos_emb && ln_w && ln_b && out, NACF_EINVAL, "nacf_embed_ln_fwd: null pointer");
+  NACF_CHECK(R > 0 && L > 0 && D > 0 && vdiv > 0 && vmod > 0, NACF_EINVAL, "nacf_embed_ln_fwd: bad shape");
+  NACF_CHECK(D % 4 == 0 && D <= EMB_MAXJ * EMB_THREADS * 4, NACF_EUNSUPPORTED,
+             "nacf_embed_ln_fwd: D must be a multiple of 4 and <= 2048 (got %d)", D);
+  NACF_CHECK(p_drop < 1.f && !(p_drop > 0.f && !rng_state), NACF_EINVAL, "nacf_embed_ln_fwd: dropout needs rng_state, p<1");
+  hipLaunchKernelGGL(embed_ln_fwd_kernel, dim3(R * L), dim3(EMB_THREADS), 0, as_hip(stream), tokens, category,
+                     additional, word_emb, pos_emb, cat_emb, ln_w, ln_b, out, xhat, rstd, L, D, vdiv, vmod, eps, p_drop,
+                     salt, rng_state);
+  NACF_LAUNCH_CHECK("nacf_embed_ln_fwd");
+  return NACF_OK;
+}
+
+static int embed_bwd_blocks(int rows) { return rows < 256 ? rows : 256; }
+
+size_t nacf_embed_ln_bwd_workspace(int R, int L, int D) {
+  return (size_t)embed_bwd_blocks(R * L) * 2 * D * sizeof(float) + 256;
+}
+
+int nacf_embed_ln_bwd(const float* dOut, const float* xhat, const float* rstd, const float* ln_w, float* dE,
+                      float* dln_w, float* dln_b, float beta, int R, int L, int D, float p_drop, uint32_t salt,
+                      const uint64_t* rng_state, void* ws, size_t ws_bytes, nacf_stream_t stream) {
+  NACF_CHECK(dOut && xhat && rstd && ln_w && dE, NACF_EINVAL, "nacf_embed_ln_bwd: null pointer");
+  NACF_CHECK(R > 0 && L > 0 && D > 0 && D % 4 == 0 && D <= EMB_MAXJ * EMB_THREADS * 4, NACF_EINVAL,
+             "nacf_embed_ln_bwd: bad shape");
+  NACF_CHECK(ws && ws_bytes >= nacf_embed_ln_bwd_workspace(R, L, D), NACF_EWORKSPACE, "nacf_embed_ln_bwd: workspace too small");
+  NACF_CHECK(p_drop < 1.f && !(p_drop > 0.f && !rng_state), NACF_EINVAL, "nacf_embed_ln_bwd: dropout needs rng_state, p<1");
+  const int rows = R * L, nblk = embed_bwd_blocks(rows);
+  float* part = reinterpret_cast<float*>(ws);
+  hipStream_t s = as_hip(stream);
+  hipLaunchKernelGGL(embed_ln_bwd_kernel, dim3(nblk), dim3(EMB_THREADS), 0, s, dOut, xhat, rstd, ln_w, dE, part, rows, D,
+                     p_drop, salt, rng_state);
+  hipLaunchKernelGGL(embed_ln_bwd_final_kernel, dim3(cdiv(D, 256)), dim3(256), 0, s, part, nblk, D, dln_w, dln_b, beta);
+  NACF_LAUNCH_CHECK("nacf_embed_ln_bwd");
+  return NACF_OK;
+}
+
+int nacf_embed_scatter_bwd(const float* dE, const int64_t* tokens, const int64_t* category, float* dword, float* dpos,
+                           float* dcat, float* dadd, int R, int L, int D, int V, int n_cat, int n_video, int vdiv,
+                           int vmod, nacf_stream_t stream) {
+  NACF_CHECK(dE && tokens, NACF_EINVAL, "nacf_embed_scatter_bwd: null pointer");
+  NACF_CHECK(R > 0 && L > 0 && D > 0 && D % 4 == 0 && D <= EMB_MAXJ * EMB_THREADS * 4 && vdiv > 0 && vmod > 0,
+             NACF_EINVAL, "nacf_embed_scatter_bwd: bad shape");
+  NACF_CHECK(!(dcat && !category), NACF_EINVAL, "nacf_embed_scatter_bwd: dcat needs category");
+  (void)V;
+  hipStream_t s = as_hip(stream);
+  if (dword)
+    hipLaunchKernelGGL(embed_scatter_word_kernel, dim3(R * L), dim3(EMB_THREADS), 0, s, dE, tokens, dword, R * L, D);
+  if (dpos)
+    hipLaunchKernelGGL(embed_scatter_misc_kernel, dim3(L), dim3(EMB_THREADS), 0, s, dE, category, dpos, 0, R, L, D, vdiv, vmod);
+  if (dcat)
+    hipLaunchKernelGGL(embed_scatter_misc_kernel, dim3(n_cat), dim3(EMB_THREADS), 0, s, dE, category, dcat, 1, R, L, D, vdiv, vmod);
+  if (dadd)
+    hipLaunchKernelGGL(embed_scatter_misc_kernel, dim3(n_video), dim3(EMB_THREADS), 0, s, dE, category, dadd, 2, R, L, D, vdiv, vmod);
+  NACF_LAUNCH_CHECK("nacf_embed_scatter_bwd");
+  return NACF_OK;
+}
+
+int nacf_masked_mean_fwd(const float* y, const int64_t* tokens, float* out, int R, int L, int D, nacf_stream_t stream) {
+  NACF_CHECK(y && tokens && out && R > 0 && L > 0 && D > 0, NACF_EINVAL, "nacf_masked_mean_fwd: bad argument");
+  hipLaunchKernelGGL(masked_mean_fwd_kernel, dim3(R), dim3(256), 0, as_hip(stream), y, tokens, out, L, D);
+  NACF_LAUNCH_CHECK("nacf_masked_mean_fwd");
+  return NACF_OK;
+}
+
+int nacf_attention_fwd(const float* Q, int64_t ldq, const float* K, int64_t ldk, const float* V, int64_t ldv, float* O,
+                       int64_t ldo, const int64_t* key_tokens, int causal, float* probs, int R, int H, int Lq, int Lk,
+                       int dk, int kv_div, int kv_mod, nacf_stream_t stream) {
+  NACF_CHECK(Q && K && V && O, NACF_EINVAL, "nacf_attention_fwd: null pointer");
+  NACF_CHECK(R > 0 && H > 0 && Lq > 0 && Lk > 0 && dk > 0 && kv_div > 0 && kv_mod > 0, NACF_EINVAL,
+             "nacf_attention_fwd: bad shape");
+  NACF_CHECK(!(causal && Lq != Lk), NACF_EINVAL, "nacf_attention_fwd: causal mask needs Lq == Lk");
+  const size_t lds = ((size_t)Lq * (dk + 1) + (size_t)Lk * (dk + 1) + (size_t)Lq * Lk) * sizeof(float);
+  NACF_CHECK(lds <= 160 * 1024, NACF_EUNSUPPORTED, "nacf_attention_fwd: tile does not fit LDS (%zu B)", lds);
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attention_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                        160 * 1024);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(attention_fwd_kernel, dim3(R, H), dim3(256), lds, as_hip(stream), Q, ldq, K, ldk, V, ldv, O, ldo,
+                     key_tokens, causal, probs, R, Lq, Lk, dk, kv_div, kv_mod);
+  NACF_LAUNCH_CHECK("nacf_attention_fwd");
+  return NACF_OK;
+}
+
+int nacf_attention_bwd(const float* Q, int64_t ldq, const float* K, int64_t ldk, const float* V, int64_t ldv,
+                       const float* dO, int64_t lddo, float* dQ, int64_t lddq, float* dK, int64_t lddk, float* dV,
+                       int64_t lddv, const int64_t* key_tokens, int causal, int R, int n_kv, int H, int Lq, int Lk,
+                       int dk, int kv_div, int kv_mod, nacf_stream_t stream) {
+  NACF_CHECK(Q && K && V && dO && dQ && dK && dV, NACF_EINVAL, "nacf_attention_bwd: null pointer");
+  NACF_CHECK(R > 0 && n_kv > 0 && H > 0 && Lq > 0 && Lk > 0 && dk > 0 && kv_div > 0 && kv_mod > 0, NACF_EINVAL,
+             "nacf_attention_bwd: bad shape");
+  NACF_CHECK(n_kv == kv_mod || (kv_div == 1 && kv_mod >= R && n_kv == R), NACF_EINVAL,
+             "nacf_attention_bwd: n_kv must equal kv_mod (or R for the identity map)");
+  NACF_CHECK(Lk * dk <= ATT_BWD_MAXJ * 256, NACF_EUNSUPPORTED, "nacf_attention_bwd: Lk*dk > %d", ATT_BWD_MAXJ * 256);
+  NACF_CHECK(!(causal && Lq != Lk), NACF_EINVAL, "nacf_attention_bwd: causal mask needs Lq == Lk");
+  const size_t lds = ((size_t)2 * Lq * (dk + 1) + (size_t)2 * Lk * (dk + 1) + (size_t)2 * Lq * Lk) * sizeof(float);
+  NACF_CHECK(lds <= 160 * 1024, NACF_EUNSUPPORTED, "nacf_attention_bwd: tile does not fit LDS (%zu B)", lds);
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attention_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                        160 * 1024);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(attention_bwd_kernel, dim3(n_kv, H), dim3(256), lds, as_hip(stream), Q, ldq, K, ldk, V, ldv, dO, lddo,
+                     dQ, lddq, dK, lddk, dV, lddv, key_tokens, causal, R, Lq, Lk, dk, kv_div, kv_mod);
+  NACF_LAUNCH_CHECK("nacf_attention_bwd");
+  return NACF_OK;
+}
+
+}  // extern "C"

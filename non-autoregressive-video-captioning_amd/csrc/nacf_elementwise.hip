@@ -1,0 +1,589 @@
+// HBM-bound kernels of the NACF path: HighWay mix, BatchNorm + temporal concat,
+// time mean, narrow log-softmax / KL, epilogue backward, wide (vocabulary)
+// log-softmax + NLL + cross-entropy backward, fused clip + Adam.
+// All reductions use a fixed summation order (no float atomics).
+#include "common.hpp"
+
+namespace {
+
+inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+// ------------------------------------------------------------------ HighWay
+__global__ void highway_mix_fwd_kernel(const float* __restrict__ H, const float* __restrict__ TG,
+                                       float* __restrict__ out, int rows, int D, float p, uint32_t salt,
+                                       const uint64_t* __restrict__ rng_state) {
+  const int64_t total = (int64_t)rows * D;
+  DropRng rng;
+  if (p > 0.f) rng.init(rng_state);
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+    const int r = (int)(e / D), d = (int)(e % D);
+    const float h = H[e];
+    const float t = TG[(int64_t)r * 2 * D + d];
+    const float g = TG[(int64_t)r * 2 * D + D + d];
+    float o = g * h + (1.f - g) * t;
+    if (p > 0.f) o *= rng.keep1((uint64_t)e, salt, p);
+    out[e] = o;
+  }
+}
+
+__global__ void highway_mix_bwd_kernel(const float* __restrict__ dOut, const float* __restrict__ H,
+                                       const float* __restrict__ TG, float* __restrict__ dH,
+                                       float* __restrict__ dP, int rows, int D, float p, uint32_t salt,
+                                       const uint64_t* __restrict__ rng_state) {
+  const int64_t total = (int64_t)rows * D;
+  DropRng rng;
+  if (p > 0.f) rng.init(rng_state);
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+    const int r = (int)(e / D), d = (int)(e % D);
+    float g0 = dOut[e];
+    if (p > 0.f) g0 *= rng.keep1((uint64_t)e, salt, p);
+    const float h = H[e];
+    const float t = TG[(int64_t)r * 2 * D + d];
+    const float g = TG[(int64_t)r * 2 * D + D + d];
+    dH[e] = g0 * g;
+    dP[(int64_t)r * 2 * D + d] = g0 * (1.f - g) * (1.f - t * t);
+    dP[(int64_t)r * 2 * D + D + d] = g0 * (h - t) * g * (1.f - g);
+  }
+}
+
+// ------------------------------------------------------------------ BatchNorm + concat
+// stage A: part_sum[s][d] over a slab of rows
+__global__ void bn_partial_sum_kernel(const float* __restrict__ x, int rows, int D, int rows_per,
+                                      float* __restrict__ part) {
+  __shared__ float red[4][64];
+  const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int rl = threadIdx.x >> 6;
+  const int r0 = blockIdx.y * rows_per, r1 = min(rows, r0 + rows_per);
+  float acc = 0.f;
+  if (c < D)
+    for (int r = r0 + rl; r < r1; r += 4) acc += x[(int64_t)r * D + c];
+  red[rl][threadIdx.x & 63] = acc;
+  __syncthreads();
+  if (rl == 0 && c < D)
+    part[(int64_t)blockIdx.y * D + c] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+}
+// stage B: mean from partials, then partial sum of squared deviations
+__global__ void bn_partial_sqdev_kernel(const float* __restrict__ x, int rows, int D, int rows_per, int S,
+                                        const float* __restrict__ part_sum, float* __restrict__ part_sq) {
+  __shared__ float red[4][64];
+  const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int rl = threadIdx.x >> 6;
+  const int r0 = blockIdx.y * rows_per, r1 = min(rows, r0 + rows_per);
+  float mean = 0.f;
+  if (c < D) {
+    for (int s = 0; s < S; ++s) mean += part_sum[(int64_t)s * D + c];
+    mean /= (float)rows;
+  }
+  float acc = 0.f;
+  if (c < D)
+    for (int r = r0 + rl; r < r1; r += 4) {
+      const float dv = x[(int64_t)r * D + c] - mean;
+      acc += dv * dv;
+    }
+  red[rl][threadIdx.x & 63] = acc;
+  __syncthreads();
+  if (rl == 0 && c < D)
+    part_sq[(int64_t)blockIdx.y * D + c] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+}
+// stage C: finalise statistics, normalise, write into the concatenated memory
+__global__ void bn_apply_kernel(const float* __restrict__ x, float* __restrict__ out, int B, int F, int D,
+                                int M_total, int f_off, const float* __restrict__ w, const float* __restrict__ b,
+                                float* __restrict__ running_mean, float* __restrict__ running_var,
+                                int64_t* __restrict__ nbt, float* __restrict__ save_mean,
+                                float* __restrict__ save_invstd, int training, float momentum, float eps, int S,
+                                const float* __restrict__ part_sum, const float* __restrict__ part_sq, int rows_per) {
+  const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int rl = threadIdx.x >> 6;
+  const int rows = B * F;
+  const int r0 = blockIdx.y * rows_per, r1 = min(rows, r0 + rows_per);
+  if (c >= D) return;
+  float mean, invstd;
+  if (training) {
+    float sm = 0.f, sq = 0.f;
+    for (int s = 0; s < S; ++s) { sm += part_sum[(int64_t)s * D + c]; sq += part_sq[(int64_t)s * D + c]; }
+    mean = sm / (float)rows;
+    const float var_b = sq / (float)rows;
+    invstd = 1.0f / sqrtf(var_b + eps);
+    if (blockIdx.y == 0 && rl == 0) {
+      const float var_u = sq / (float)(rows > 1 ? rows - 1 : 1);
+      if (running_mean) running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mean;
+      if (running_var) running_var[c] = (1.f - momentum) * running_var[c] + momentum * var_u;
+      if (save_mean) save_mean[c] = mean;
+      if (save_invstd) save_invstd[c] = invstd;
+      if (nbt && c == 0) nbt[0] += 1;
+    }
+  } else {
+    mean = running_mean[c];
+    invstd = 1.0f / sqrtf(running_var[c] + eps);
+  }
+  const float ww = w ? w[c] : 1.f, bb = b ? b[c] : 0.f;
+  for (int r = r0 + rl; r < r1; r += 4) {
+    const int bi = r / F, f = r % F;
+    out[((int64_t)bi * M_total + f_off + f) * D + c] = (x[(int64_t)r * D + c] - mean) * invstd * ww + bb;
+  }
+}
+
+// backward stage A: partial sums of dy and dy*xhat
+__global__ void bn_bwd_partial_kernel(const float* __restrict__ dOut, const float* __restrict__ x, int B, int F,
+                                      int D, int M_total, int f_off, const float* __restrict__ save_mean,
+                                      const float* __restrict__ save_invstd, int rows_per,
+                                      float* __restrict__ part_dy, float* __restrict__ part_dyx) {
+  __shared__ float red[2][4][64];
+  const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int rl = threadIdx.x >> 6;
+  const int rows = B * F;
+  const int r0 = blockIdx.y * rows_per, r1 = min(rows, r0 + rows_per);
+  float a0 = 0.f, a1 = 0.f;
+  if (c < D) {
+    const float mean = save_mean[c], invstd = save_invstd[c];
+    for (int r = r0 + rl; r < r1; r += 4) {
+      const int bi = r / F, f = r % F;
+      const float dy = dOut[((int64_t)bi * M_total + f_off + f) * D + c];
+      a0 += dy;
+      a1 += dy * (x[(int64_t)r * D + c] - mean) * invstd;
+    }
+  }
+  red[0][rl][threadIdx.x & 63] = a0;
+  red[1][rl][threadIdx.x & 63] = a1;
+  __syncthreads();
+  if (rl == 0 && c < D) {
+    const int t = threadIdx.x;
+    part_dy[(int64_t)blockIdx.y * D + c] = red[0][0][t] + red[0][1][t] + red[0][2][t] + red[0][3][t];
+    part_dyx[(int64_t)blockIdx.y * D + c] = red[1][0][t] + red[1][1][t] + red[1][2][t] + red[1][3][t];
+  }
+}
+__global__ void bn_bwd_apply_kernel(const float* __restrict__ dOut, const float* __restrict__ x,
+                                    float* __restrict__ dx, int B, int F, int D, int M_total, int f_off,
+                                    const float* __restrict__ w, const float* __restrict__ save_mean,
+                                    const float* __restrict__ save_invstd, float* __restrict__ dweight,
+                                    float* __restrict__ dbias, float beta, int S, int rows_per,
+                                    const float* __restrict__ part_dy, const float* __restrict__ part_dyx) {
+  const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int rl = threadIdx.x >> 6;
+  const int rows = B * F;
+  const int r0 = blockIdx.y * rows_per, r1 = min(rows, r0 + rows_per);
+  if (c >= D) return;
+  float sdy = 0.f, sdyx = 0.f;
+  for (int s = 0; s < S; ++s) { sdy += part_dy[(int64_t)s * D + c]; sdyx += part_dyx[(int64_t)s * D + c]; }
+  if (blockIdx.y == 0 && rl == 0) {
+    if (dweight) dweight[c] = (beta != 0.f) ? sdyx + beta * dweight[c] : sdyx;
+    if (dbias) dbias[c] = (beta != 0.f) ? sdy + beta * dbias[c] : sdy;
+  }
+  const float mean = save_mean[c], invstd = save_invstd[c];
+  const float ww = w ? w[c] : 1.f;
+  const float invn = 1.f / (float)rows;
+  for (int r = r0 + rl; r < r1; r += 4) {
+    const int bi = r / F, f = r % F;
+    const float dy = dOut[((int64_t)bi * M_total + f_off + f) * D + c];
+    const float xh = (x[(int64_t)r * D + c] - mean) * invstd;
+    dx[(int64_t)r * D + c] = ww * invstd * (dy - sdy * invn - xh * sdyx * invn);
+  }
+}
+
+// ------------------------------------------------------------------ time mean
+__global__ void mean_time_fwd_kernel(const float* __restrict__ x, float* __restrict__ out, int T, int D) {
+  const int b = blockIdx.x;
+  for (int d = blockIdx.y * blockDim.x + threadIdx.x; d < D; d += gridDim.y * blockDim.x) {
+    float acc = 0.f;
+    const float* p = x + (int64_t)b * T * D + d;
+    for (int t = 0; t < T; ++t) acc += p[(int64_t)t * D];
+    out[(int64_t)b * D + d] = acc / (float)T;
+  }
+}
+__global__ void mean_time_bwd_kernel(const float* __restrict__ dOut, float* __restrict__ dx, int B, int T, int D,
+                                     int accumulate) {
+  const int64_t total = (int64_t)B * T * D;
+  const float inv = 1.f / (float)T;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+    const int d = (int)(e % D);
+    const int b = (int)(e / ((int64_t)T * D));
+    const float g = dOut[(int64_t)b * D + d] * inv;
+    dx[e] = accumulate ? dx[e] + g : g;
+  }
+}
+
+// ------------------------------------------------------------------ narrow log-softmax / KL
+__global__ void log_softmax_rows_kernel(const float* __restrict__ in, float* __restrict__ out, int rows, int N) {
+  const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (row >= rows) return;
+  const float* p = in + (int64_t)row * N;
+  float m = -3.0e38f;
+  for (int i = lane; i < N; i += 64) m = fmaxf(m, p[i]);
+  m = wave_max(m);
+  float s = 0.f;
+  for (int i = lane; i < N; i += 64) s += expf(p[i] - m);
+  s = wave_sum(s);
+  const float lse = m + logf(s);
+  for (int i = lane; i < N; i += 64) out[(int64_t)row * N + i] = p[i] - lse;
+}
+__global__ void log_softmax_rows_bwd_kernel(const float* __restrict__ dOut, const float* __restrict__ out,
+                                            float* __restrict__ dIn, int rows, int N) {
+  const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (row >= rows) return;
+  float s = 0.f;
+  for (int i = lane; i < N; i += 64) s += dOut[(int64_t)row * N + i];
+  s = wave_sum(s);
+  for (int i = lane; i < N; i += 64) {
+    const int64_t o = (int64_t)row * N + i;
+    dIn[o] = dOut[o] - expf(out[o]) * s;
+  }
+}
+__global__ void kldiv_mean_kernel(const float* __restrict__ x, const float* __restrict__ t,
+                                  float* __restrict__ loss_out, float* __restrict__ dX, float scale, int total) {
+  __shared__ float red[16];
+  float acc = 0.f;
+  const float inv = 1.f / (float)total;
+  for (int e = threadIdx.x; e < total; e += blockDim.x) {
+    const float tt = t[e];
+    if (tt > 0.f) acc += tt * (logf(tt) - x[e]);
+    if (dX) dX[e] = -tt * scale * inv;
+  }
+  acc = block_sum(acc, red);
+  if (threadIdx.x == 0) loss_out[0] = acc * inv;
+}
+
+// ------------------------------------------------------------------ epilogue backward
+__global__ void epilogue_bwd_kernel(const float* __restrict__ dY, int64_t lddy, float* __restrict__ dZ, int64_t lddz,
+                                    float* __restrict__ dR, int64_t lddr, int accumulate_dR, int M, int N,
+                                    nacf_epilogue ep) {
+  const int64_t total = (int64_t)M * N;
+  const bool any_drop = ep.p_drop1 > 0.f || ep.p_drop2 > 0.f;
+  DropRng rng;
+  if (any_drop) rng.init(ep.rng_state);
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+    const int m = (int)(e / N), n = (int)(e % N);
+    float g = dY[(int64_t)m * lddy + n];
+    if (ep.row_tokens && ep.row_tokens[m] == NACF_PAD) g = 0.f;
+    if (ep.p_drop2 > 0.f) g *= rng.keep1((uint64_t)e, ep.salt2, ep.p_drop2);
+    if (dR) {
+      float* r = dR + (int64_t)m * lddr + n;
+      *r = accumulate_dR ? *r + g : g;
+    }
+    if (ep.p_drop1 > 0.f) g *= rng.keep1((uint64_t)e, ep.salt1, ep.p_drop1);
+    if (ep.act != NACF_ACT_NONE) g *= act_grad(ep.act, ep.preact[(int64_t)m * ep.ld_preact + n], n, ep.act_split);
+    dZ[(int64_t)m * lddz + n] = g;
+  }
+}
+
+// ------------------------------------------------------------------ vocabulary log-softmax / NLL
+__global__ __launch_bounds__(256) void vocab_logsoftmax_fwd_kernel(float* __restrict__ logits, int64_t ld, int V,
+                                                                    const int64_t* __restrict__ labels,
+                                                                    float* __restrict__ lse_out,
+                                                                    int64_t* __restrict__ argmax_out,
+                                                                    float* __restrict__ label_logp) {
+  __shared__ float redv[4];
+  __shared__ int redi[4];
+  __shared__ float reds[16];
+  const int row = blockIdx.x;
+  float* p = logits + (int64_t)row * ld;
+  float best = -3.0e38f;
+  int bidx = 0x7fffffff;
+  for (int i = threadIdx.x; i < V; i += 256) {
+    const float v = p[i];
+    if (v > best) { best = v; bidx = i; }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const float ov = __shfl_xor(best, o, 64);
+    const int oi = __shfl_xor(bidx, o, 64);
+    if (ov > best || (ov == best && oi < bidx)) { best = ov; bidx = oi; }
+  }
+  if ((threadIdx.x & 63) == 0) { redv[threadIdx.x >> 6] = best; redi[threadIdx.x >> 6] = bidx; }
+  __syncthreads();
+  best = redv[0]; bidx = redi[0];
+  for (int w = 1; w < 4; ++w)
+    if (redv[w] > best || (redv[w] == best && redi[w] < bidx)) { best = redv[w]; bidx = redi[w]; }
+  float s = 0.f;
+  for (int i = threadIdx.x; i < V; i += 256) s += expf(p[i] - best);
+  s = block_sum(s, reds);
+  const float lse = best + logf(s);
+  for (int i = threadIdx.x; i < V; i += 256) p[i] = p[i] - lse;
+  if (threadIdx.x == 0) {
+    if (lse_out) lse_out[row] = lse;
+    if (argmax_out) argmax_out[row] = bidx;
+  }
+  if (labels && label_logp) {
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      const int64_t lab = labels[row];
+      label_logp[row] = (lab >= 0 && lab < V) ? p[lab] : 0.f;
+    }
+  }
+}
+
+__global__ void nll_reduce_kernel(const float* __restrict__ label_logp, const int64_t* __restrict__ argmax,
+                                  const int64_t* __restrict__ labels, int rows, int exclude_mask,
+                                  float* __restrict__ out5) {
+  __shared__ float red[16];
+  float nll = 0.f, hit = 0.f, cnt = 0.f, sl = 0.f, sc = 0.f;
+  for (int r = threadIdx.x; r < rows; r += blockDim.x) {
+    const int64_t lab = labels[r];
+    if (lab != NACF_PAD) {
+      const float lp = label_logp[r];
+      nll -= lp; sl += lp; sc += 1.f;
+      if (!(exclude_mask && lab == NACF_MASK)) {
+        cnt += 1.f;
+        if (argmax[r] == lab) hit += 1.f;
+      }
+    }
+  }
+  nll = block_sum(nll, red);
+  hit = block_sum(hit, red);
+  cnt = block_sum(cnt, red);
+  sl = block_sum(sl, red);
+  sc = block_sum(sc, red);
+  if (threadIdx.x == 0) { out5[0] = nll; out5[1] = hit; out5[2] = cnt; out5[3] = sl; out5[4] = sc; }
+}
+
+__global__ __launch_bounds__(256) void xent_bwd_kernel(const float* __restrict__ logp, int64_t ld,
+                                                        float* __restrict__ dlogits, int64_t ldd, int V,
+                                                        const int64_t* __restrict__ labels,
+                                                        const float* __restrict__ gscale, float scale) {
+  const int row = blockIdx.x;
+  const int64_t lab = labels[row];
+  const float g = (gscale ? gscale[0] : 1.f) * scale;
+  const float* p = logp + (int64_t)row * ld;
+  float* d = dlogits + (int64_t)row * ldd;
+  if (lab == NACF_PAD) {
+    for (int i = threadIdx.x; i < V; i += 256) d[i] = 0.f;
+  } else {
+    for (int i = threadIdx.x; i < V; i += 256) {
+      const float sm = expf(p[i]);
+      d[i] = (sm - (i == lab ? 1.f : 0.f)) * g;
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void vocab_logsoftmax_bwd_kernel(const float* __restrict__ dlogp, int64_t ldg,
+                                                                    const float* __restrict__ logp, int64_t ld,
+                                                                    float* __restrict__ dlogits, int64_t ldd, int V) {
+  __shared__ float red[16];
+  const int row = blockIdx.x;
+  const float* g = dlogp + (int64_t)row * ldg;
+  const float* p = logp + (int64_t)row * ld;
+  float s = 0.f;
+  for (int i = threadIdx.x; i < V; i += 256) s += g[i];
+  s = block_sum(s, red);
+  float* d = dlogits + (int64_t)row * ldd;
+  for (int i = threadIdx.x; i < V; i += 256) d[i] = g[i] - expf(p[i]) * s;
+}
+
+// ------------------------------------------------------------------ Adam
+__global__ void adam_step_kernel(float* __restrict__ param, const float* __restrict__ grad, float* __restrict__ m,
+                                 float* __restrict__ v, int64_t n, const float* __restrict__ lr_p,
+                                 const int64_t* __restrict__ step_p, float b1, float b2, float eps, float wd,
+                                 float clip, float gscale) {
+  // step_p already holds the 1-based step of THIS update (bumped by adam_bump_kernel)
+  const float t = (float)step_p[0];
+  const float lr = lr_p[0];
+  const float bc1 = 1.f - powf(b1, t);
+  const float bc2 = 1.f - powf(b2, t);
+  const float step_size = lr / bc1;
+  const float inv_sqrt_bc2 = 1.f / sqrtf(bc2);
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    float g = grad[i] * gscale;
+    g = fminf(fmaxf(g, -clip), clip);
+    const float p = param[i];
+    g += wd * p;
+    const float mm = b1 * m[i] + (1.f - b1) * g;
+    const float vv = b2 * v[i] + (1.f - b2) * g * g;
+    m[i] = mm;
+    v[i] = vv;
+    const float denom = sqrtf(vv) * inv_sqrt_bc2 + eps;
+    param[i] = p - step_size * (mm / denom);
+  }
+}
+__global__ void adam_bump_kernel(int64_t* step_p) { step_p[0] += 1; }
+
+inline int grid_for(int64_t total, int block = 256, int cap = 8192) {
+  int64_t b = (total + block - 1) / block;
+  if (b > cap) b = cap;
+  if (b < 1) b = 1;
+  return (int)b;
+}
+
+inline void bn_split(int rows, int* S, int* rows_per) {
+  int s = cdiv(rows, 64);
+  if (s > 32) s = 32;
+  if (s < 1) s = 1;
+  *rows_per = cdiv(rows, s);
+  *S = cdiv(rows, *rows_per);
+}
+
+}  // namespace
+
+extern "C" {
+
+int nacf_highway_mix_fwd(const float* H, const float* TG, float* out, int rows, int D, float p_drop,
+                         uint32_t salt, const uint64_t* rng_state, nacf_stream_t stream) {
+  NACF_CHECK(H && TG && out && rows > 0 && D > 0, NACF_EINVAL, "nacf_highway_mix_fwd: bad argument");
+  NACF_CHECK(p_drop < 1.f && !(p_drop > 0.f && !rng_state), NACF_EINVAL, "nacf_highway_mix_fwd: dropout needs rng_state, p<1");
+  hipLaunchKernelGGL(highway_mix_fwd_kernel, dim3(grid_for((int64_t)rows * D)), dim3(256), 0, as_hip(stream), H, TG, out,
+                     rows, D, p_drop, salt, rng_state);
+  NACF_LAUNCH_CHECK("nacf_highway_mix_fwd");
+  return NACF_OK;
+}
+
+int nacf_highway_mix_bwd(const float* dOut, const float* H, const float* TG, float* dH, float* dP, int rows, int D,
+                         float p_drop, uint32_t salt, const uint64_t* rng_state, nacf_stream_t stream) {
+  NACF_CHECK(dOut && H && TG && dH && dP && rows > 0 && D > 0, NACF_EINVAL, "nacf_highway_mix_bwd: bad argument");
+  NACF_CHECK(p_drop < 1.f && !(p_drop > 0.f && !rng_state), NACF_EINVAL, "nacf_highway_mix_bwd: dropout needs rng_state, p<1");
+  hipLaunchKernelGGL(highway_mix_bwd_kernel, dim3(grid_for((int64_t)rows * D)), dim3(256), 0, as_hip(stream), dOut, H, TG,
+                     dH, dP, rows, D, p_drop, salt, rng_state);
+  NACF_LAUNCH_CHECK("nacf_highway_mix_bwd");
+  return NACF_OK;
+}
+
+size_t nacf_bn_workspace(int rows, int D) {
+  (void)rows;
+  return (size_t)2 * 32 * D * sizeof(float) + 256;
+}
+
+int nacf_bn_concat_fwd(const float* x, float* out, int B, int F, int D, int M_total, int f_off, const float* weight,
+                       const float* bias, float* running_mean, float* running_var, int64_t* num_batches_tracked,
+                       float* save_mean, float* save_invstd, int training, float momentum, float eps, void* ws,
+                       size_t ws_bytes, nacf_stream_t stream) {
+  NACF_CHECK(x && out && B > 0 && F > 0 && D > 0, NACF_EINVAL, "nacf_bn_concat_fwd: bad argument");
+  NACF_CHECK(f_off >= 0 && f_off + F <= M_total, NACF_EINVAL, "nacf_bn_concat_fwd: frame window outside the memory");
+  NACF_CHECK(training || (running_mean && running_var), NACF_EINVAL, "nacf_bn_concat_fwd: eval mode needs running stats");
+  NACF_CHECK(ws && ws_bytes >= nacf_bn_workspace(B * F, D), NACF_EWORKSPACE, "nacf_bn_concat_fwd: workspace too small");
+  const int rows = B * F;
+  int S, rows_per;
+  bn_split(rows, &S, &rows_per);
+  float* part_sum = reinterpret_cast<float*>(ws);
+  float* part_sq = part_sum + (size_t)32 * D;
+  hipStream_t s = as_hip(stream);
+  dim3 grid(cdiv(D, 64), S);
+  if (training) {
+    hipLaunchKernelGGL(bn_partial_sum_kernel, grid, dim3(256), 0, s, x, rows, D, rows_per, part_sum);
+    hipLaunchKernelGGL(bn_partial_sqdev_kernel, grid, dim3(256), 0, s, x, rows, D, rows_per, S, part_sum, part_sq);
+  }
+  hipLaunchKernelGGL(bn_apply_kernel, grid, dim3(256), 0, s, x, out, B, F, D, M_total, f_off, weight, bias, running_mean,
+                     running_var, num_batches_tracked, save_mean, save_invstd, training, momentum, eps, S, part_sum,
+                     part_sq, rows_per);
+  NACF_LAUNCH_CHECK("nacf_bn_concat_fwd");
+  return NACF_OK;
+}
+
+int nacf_bn_concat_bwd(const float* dOut, const float* x, float* dx, int B, int F, int D, int M_total, int f_off,
+                       const float* weight, const float* save_mean, const float* save_invstd, float* dweight,
+                       float* dbias, float beta, void* ws, size_t ws_bytes, nacf_stream_t stream) {
+  NACF_CHECK(dOut && x && dx && save_mean && save_invstd, NACF_EINVAL, "nacf_bn_concat_bwd: null pointer");
+  NACF_CHECK(B > 0 && F > 0 && D > 0 && f_off >= 0 && f_off + F <= M_total, NACF_EINVAL, "nacf_bn_concat_bwd: bad shape");
+  NACF_CHECK(ws && ws_bytes >= nacf_bn_workspace(B * F, D), NACF_EWORKSPACE, "nacf_bn_concat_bwd: workspace too small");
+  const int rows = B * F;
+  int S, rows_per;
+  bn_split(rows, &S, &rows_per);
+  float* part_dy = reinterpret_cast<float*>(ws);
+  float* part_dyx = part_dy + (size_t)32 * D;
+  hipStream_t s = as_hip(stream);
+  dim3 grid(cdiv(D, 64), S);
+  hipLaunchKernelGGL(bn_bwd_partial_kernel, grid, dim3(256), 0, s, dOut, x, B, F, D, M_total, f_off, save_mean,
+                     save_invstd, rows_per, part_dy, part_dyx);
+  hipLaunchKernelGGL(bn_bwd_apply_kernel, grid, dim3(256), 0, s, dOut, x, dx, B, F, D, M_total, f_off, weight, save_mean,
+                     save_invstd, dweight, dbias, beta, S, rows_per, part_dy, part_dyx);
+  NACF_LAUNCH_CHECK("nacf_bn_concat_bwd");
+  return NACF_OK;
+}
+
+int nacf_mean_time_fwd(const float* x, float* out, int B, int T, int D, nacf_stream_t stream) {
+  NACF_CHECK(x && out && B > 0 && T > 0 && D > 0, NACF_EINVAL, "nacf_mean_time_fwd: bad argument");
+  hipLaunchKernelGGL(mean_time_fwd_kernel, dim3(B, cdiv(D, 256)), dim3(256), 0, as_hip(stream), x, out, T, D);
+  NACF_LAUNCH_CHECK("nacf_mean_time_fwd");
+  return NACF_OK;
+}
+
+int nacf_mean_time_bwd(const float* dOut, float* dx, int B, int T, int D, int accumulate, nacf_stream_t stream) {
+  NACF_CHECK(dOut && dx && B > 0 && T > 0 && D > 0, NACF_EINVAL, "nacf_mean_time_bwd: bad argument");
+  hipLaunchKernelGGL(mean_time_bwd_kernel, dim3(grid_for((int64_t)B * T * D)), dim3(256), 0, as_hip(stream), dOut, dx, B,
+                     T, D, accumulate);
+  NACF_LAUNCH_CHECK("nacf_mean_time_bwd");
+  return NACF_OK;
+}
+
+int nacf_log_softmax_rows(const float* in, float* out, int rows, int N, nacf_stream_t stream) {
+  NACF_CHECK(in && out && rows > 0 && N > 0, NACF_EINVAL, "nacf_log_softmax_rows: bad argument");
+  hipLaunchKernelGGL(log_softmax_rows_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, as_hip(stream), in, out, rows, N);
+  NACF_LAUNCH_CHECK("nacf_log_softmax_rows");
+  return NACF_OK;
+}
+
+int nacf_log_softmax_rows_bwd(const float* dOut, const float* out, float* dIn, int rows, int N, nacf_stream_t stream) {
+  NACF_CHECK(dOut && out && dIn && rows > 0 && N > 0, NACF_EINVAL, "nacf_log_softmax_rows_bwd: bad argument");
+  hipLaunchKernelGGL(log_softmax_rows_bwd_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, as_hip(stream), dOut, out, dIn, rows, N);
+  NACF_LAUNCH_CHECK("nacf_log_softmax_rows_bwd");
+  return NACF_OK;
+}
+
+int nacf_kldiv_mean(const float* x, const float* t, float* loss_out, float* dX, float scale, int rows, int N,
+                    nacf_stream_t stream) {
+  NACF_CHECK(x && t && loss_out && rows > 0 && N > 0, NACF_EINVAL, "nacf_kldiv_mean: bad argument");
+  hipLaunchKernelGGL(kldiv_mean_kernel, dim3(1), dim3(256), 0, as_hip(stream), x, t, loss_out, dX, scale, rows * N);
+  NACF_LAUNCH_CHECK("nacf_kldiv_mean");
+  return NACF_OK;
+}
+
+int nacf_epilogue_bwd(const float* dY, int64_t lddy, float* dZ, int64_t lddz, float* dR, int64_t lddr,
+                      int accumulate_dR, int M, int N, const nacf_epilogue* ep, nacf_stream_t stream) {
+  NACF_CHECK(dY && dZ && ep && M > 0 && N > 0, NACF_EINVAL, "nacf_epilogue_bwd: bad argument");
+  NACF_CHECK(!(ep->act != NACF_ACT_NONE && !ep->preact), NACF_EINVAL, "nacf_epilogue_bwd: activation backward needs preact");
+  NACF_CHECK(!((ep->p_drop1 > 0.f || ep->p_drop2 > 0.f) && !ep->rng_state), NACF_EINVAL,
+             "nacf_epilogue_bwd: dropout needs rng_state");
+  hipLaunchKernelGGL(epilogue_bwd_kernel, dim3(grid_for((int64_t)M * N)), dim3(256), 0, as_hip(stream), dY, lddy, dZ, lddz,
+                     dR, lddr, accumulate_dR, M, N, *ep);
+  NACF_LAUNCH_CHECK("nacf_epilogue_bwd");
+  return NACF_OK;
+}
+
+int nacf_vocab_logsoftmax_fwd(float* logits, int64_t ld, int rows, int V, const int64_t* labels, float* lse,
+                              int64_t* argmax, float* label_logp, nacf_stream_t stream) {
+  NACF_CHECK(logits && rows > 0 && V > 0 && ld >= V, NACF_EINVAL, "nacf_vocab_logsoftmax_fwd: bad argument");
+  hipLaunchKernelGGL(vocab_logsoftmax_fwd_kernel, dim3(rows), dim3(256), 0, as_hip(stream), logits, ld, V, labels, lse,
+                     argmax, label_logp);
+  NACF_LAUNCH_CHECK("nacf_vocab_logsoftmax_fwd");
+  return NACF_OK;
+}
+
+int nacf_nll_reduce(const float* label_logp, const int64_t* argmax, const int64_t* labels, int rows, int exclude_mask,
+                    float* out5, nacf_stream_t stream) {
+  NACF_CHECK(label_logp && argmax && labels && out5 && rows > 0, NACF_EINVAL, "nacf_nll_reduce: bad argument");
+  hipLaunchKernelGGL(nll_reduce_kernel, dim3(1), dim3(1024), 0, as_hip(stream), label_logp, argmax, labels, rows,
+                     exclude_mask, out5);
+  NACF_LAUNCH_CHECK("nacf_nll_reduce");
+  return NACF_OK;
+}
+
+int nacf_xent_bwd(const float* logp, int64_t ld, float* dlogits, int64_t ldd, int rows, int V, const int64_t* labels,
+                  const float* gscale, float scale, nacf_stream_t stream) {
+  NACF_CHECK(logp && dlogits && labels && rows > 0 && V > 0, NACF_EINVAL, "nacf_xent_bwd: bad argument");
+  hipLaunchKernelGGL(xent_bwd_kernel, dim3(rows), dim3(256), 0, as_hip(stream), logp, ld, dlogits, ldd, V, labels, gscale,
+                     scale);
+  NACF_LAUNCH_CHECK("nacf_xent_bwd");
+  return NACF_OK;
+}
+
+int nacf_vocab_logsoftmax_bwd(const float* dlogp, int64_t ldg, const float* logp, int64_t ld, float* dlogits,
+                              int64_t ldd, int rows, int V, nacf_stream_t stream) {
+  NACF_CHECK(dlogp && logp && dlogits && rows > 0 && V > 0, NACF_EINVAL, "nacf_vocab_logsoftmax_bwd: bad argument");
+  hipLaunchKernelGGL(vocab_logsoftmax_bwd_kernel, dim3(rows), dim3(256), 0, as_hip(stream), dlogp, ldg, logp, ld, dlogits,
+                     ldd, V);
+  NACF_LAUNCH_CHECK("nacf_vocab_logsoftmax_bwd");
+  return NACF_OK;
+}
+
+int nacf_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, const float* lr,
+                   int64_t* step_count, float beta1, float beta2, float eps, float weight_decay, float grad_clip,
+                   float grad_scale, nacf_stream_t stream) {
+  NACF_CHECK(param && grad && exp_avg && exp_avg_sq && lr && step_count && n > 0, NACF_EINVAL,
+             "nacf_adam_step: bad argument");
+  hipStream_t s = as_hip(stream);
+  hipLaunchKernelGGL(adam_bump_kernel, dim3(1), dim3(1), 0, s, step_count);
+  hipLaunchKernelGGL(adam_step_kernel, dim3(grid_for(n, 256, 4096)), dim3(256), 0, s, param, grad, exp_avg, exp_avg_sq, n,
+                     lr, step_count, beta1, beta2, eps, weight_decay, grad_clip, grad_scale);
+  NACF_LAUNCH_CHECK("nacf_adam_step");
+  return NACF_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,273 @@
+// C entry points built on the fp32 MFMA GEMM: nn.Linear forward/backward and
+// the fused vocabulary projection + softmax-max used by NA decoding.
+#include "gemm_f32.hpp"
+#include <stdlib.h>
+#include <string.h>
+
+namespace {
+
+inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+// tile selection: 0 = 128x128, 1 = 64x64.  Override with NACF_GEMM_TILE=128|64.
+int pick_tile(int M, int N, int splits) {
+  static int forced = -2;
+  if (forced == -2) {
+    const char* e = getenv("NACF_GEMM_TILE");
+    forced = e ? (atoi(e) == 64 ? 1 : (atoi(e) == 128 ? 0 : -1)) : -1;
+  }
+  if (forced >= 0) return forced;
+  const long big = (long)cdiv(M, 128) * cdiv(N, 128) * splits;
+  return big >= 384 ? 0 : 1;  // >= 1.5 workgroups per CU with the big tile, else go small
+}
+
+template <bool QKC, bool PKC, class Epi>
+void launch_gemm(const GemmShape& g0, const Epi& epi, int splits, int tile, bool vec, hipStream_t s) {
+  GemmShape g = g0;
+  if (tile == 0) {
+    g.tiles_m = cdiv(g.M, 128);
+    g.tiles_n = cdiv(g.N, 128);
+    dim3 grid(g.tiles_m * g.tiles_n, 1, splits);
+    if (vec) hipLaunchKernelGGL((gemm_f32_kernel<128, 128, 2, 2, QKC, PKC, true, Epi>), grid, dim3(256), 0, s, g, epi);
+    else hipLaunchKernelGGL((gemm_f32_kernel<128, 128, 2, 2, QKC, PKC, false, Epi>), grid, dim3(256), 0, s, g, epi);
+  } else {
+    g.tiles_m = cdiv(g.M, 64);
+    g.tiles_n = cdiv(g.N, 64);
+    dim3 grid(g.tiles_m * g.tiles_n, 1, splits);
+    if (vec) hipLaunchKernelGGL((gemm_f32_kernel<64, 64, 2, 2, QKC, PKC, true, Epi>), grid, dim3(256), 0, s, g, epi);
+    else hipLaunchKernelGGL((gemm_f32_kernel<64, 64, 2, 2, QKC, PKC, false, Epi>), grid, dim3(256), 0, s, g, epi);
+  }
+}
+
+// dst[i] = beta*dst[i] + sum_z slab[z][i], fixed z order (deterministic split-K combine)
+__global__ void splitk_reduce_kernel(const float* __restrict__ slabs, int64_t slab_stride, int splits,
+                                     float* __restrict__ dst, int64_t ldd, int rows, int cols, float beta) {
+  const int64_t total = (int64_t)rows * cols;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (int64_t)gridDim.x * blockDim.x) {
+    const int r = (int)(idx / cols), c = (int)(idx % cols);
+    float acc = 0.f;
+    for (int zz = 0; zz < splits; ++zz) acc += slabs[(int64_t)zz * slab_stride + idx];
+    float* d = dst + (int64_t)r * ldd + c;
+    *d = (beta != 0.f) ? acc + beta * (*d) : acc;
+  }
+}
+
+// column sums of dZ[M,N]: stage 1 -> part[S][N], stage 2 -> db
+__global__ void colsum_partial_kernel(const float* __restrict__ dz, int64_t ld, int M, int N, int rows_per,
+                                      float* __restrict__ part) {
+  __shared__ float red[4][64];
+  const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int rl = threadIdx.x >> 6;
+  const int r0 = blockIdx.y * rows_per;
+  const int r1 = min(M, r0 + rows_per);
+  float acc = 0.f;
+  if (c < N)
+    for (int r = r0 + rl; r < r1; r += 4) acc += dz[(int64_t)r * ld + c];
+  red[rl][threadIdx.x & 63] = acc;
+  __syncthreads();
+  if (rl == 0 && c < N)
+    part[(int64_t)blockIdx.y * N + c] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+}
+__global__ void colsum_final_kernel(const float* __restrict__ part, int S, int N, float* __restrict__ db, float beta) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= N) return;
+  float acc = 0.f;
+  for (int s = 0; s < S; ++s) acc += part[(int64_t)s * N + c];
+  db[c] = (beta != 0.f) ? acc + beta * db[c] : acc;
+}
+
+// merge the per-tile (max, idx, sumexp) partials and apply the decode bookkeeping
+__global__ void argmax_merge_kernel(const float* __restrict__ pmax, const float* __restrict__ psum,
+                                    const int* __restrict__ pidx, int tiles_n, int rows,
+                                    const int64_t* __restrict__ pad_tokens, int zero_mask_prob,
+                                    const uint8_t* __restrict__ update_mask,
+                                    int64_t* __restrict__ tokens, float* __restrict__ probs) {
+  const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (row >= rows) return;
+  float best = -3.0e38f;
+  int bidx = 0x7fffffff;
+  for (int t = lane; t < tiles_n; t += 64) {
+    float v = pmax[(int64_t)t * rows + row];
+    int i = pidx[(int64_t)t * rows + row];
+    if (v > best || (v == best && i < bidx)) { best = v; bidx = i; }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    float ov = __shfl_xor(best, o, 64);
+    int oi = __shfl_xor(bidx, o, 64);
+    if (ov > best || (ov == best && oi < bidx)) { best = ov; bidx = oi; }
+  }
+  float s = 0.f;
+  for (int t = lane; t < tiles_n; t += 64)
+    s += psum[(int64_t)t * rows + row] * __expf(pmax[(int64_t)t * rows + row] - best);
+  s = wave_sum(s);
+  if (lane == 0) {
+    int64_t tok = bidx;
+    float p = 1.0f / s;
+    if (pad_tokens && pad_tokens[row] == NACF_PAD) { tok = NACF_PAD; p = 1.0f; }
+    if (zero_mask_prob && tok == NACF_MASK) p = 0.f;
+    if (!update_mask || update_mask[row]) { tokens[row] = tok; probs[row] = p; }
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+int nacf_linear_fwd(const float* X, int64_t ldx, const float* W, int64_t ldw, float* Y, int64_t ldy,
+                    int M, int N, int K, const nacf_epilogue* ep, nacf_stream_t stream) {
+  NACF_CHECK(X && W && Y, NACF_EINVAL, "nacf_linear_fwd: null pointer");
+  NACF_CHECK(M > 0 && N > 0 && K > 0, NACF_EINVAL, "nacf_linear_fwd: bad shape M=%d N=%d K=%d", M, N, K);
+  NACF_CHECK(ldx >= K && ldw >= K && ldy >= N, NACF_EINVAL, "nacf_linear_fwd: leading dimension too small");
+  EpiLinear epi;
+  memset(&epi, 0, sizeof(epi));
+  epi.Y = Y;
+  epi.ldy = ldy;
+  if (ep) epi.ep = *ep;
+  NACF_CHECK(!((epi.ep.p_drop1 > 0.f || epi.ep.p_drop2 > 0.f) && !epi.ep.rng_state), NACF_EINVAL,
+             "nacf_linear_fwd: dropout requested without rng_state");
+  NACF_CHECK(epi.ep.p_drop1 < 1.f && epi.ep.p_drop2 < 1.f, NACF_EINVAL, "nacf_linear_fwd: p_drop must be < 1");
+  bool vo = (ldy % 4 == 0) && aligned16(Y);
+  if (epi.ep.preact) vo = vo && (epi.ep.ld_preact % 4 == 0) && aligned16(epi.ep.preact);
+  if (epi.ep.residual) vo = vo && (epi.ep.ld_residual % 4 == 0) && aligned16(epi.ep.residual);
+  epi.vec_out = vo ? 1 : 0;
+  GemmShape g;
+  g.Q = X; g.P = W; g.ldq = ldx; g.ldp = ldw; g.M = M; g.N = N; g.K = K;
+  g.k_per_split = cdiv(K, 16) * 16;
+  const bool vec = (ldx % 4 == 0) && (ldw % 4 == 0) && aligned16(X) && aligned16(W);
+  launch_gemm<true, true, EpiLinear>(g, epi, 1, pick_tile(M, N, 1), vec, as_hip(stream));
+  NACF_LAUNCH_CHECK("nacf_linear_fwd");
+  return NACF_OK;
+}
+
+int nacf_linear_bwd_data(const float* dZ, int64_t lddz, const float* W, int64_t ldw, float* dX, int64_t lddx,
+                         int M, int N, int K, float beta, nacf_stream_t stream) {
+  NACF_CHECK(dZ && W && dX, NACF_EINVAL, "nacf_linear_bwd_data: null pointer");
+  NACF_CHECK(M > 0 && N > 0 && K > 0, NACF_EINVAL, "nacf_linear_bwd_data: bad shape");
+  NACF_CHECK(lddz >= N && ldw >= K && lddx >= K, NACF_EINVAL, "nacf_linear_bwd_data: leading dimension too small");
+  // dX[m][k] = sum_n dZ[m][n] W[n][k]: Q = dZ (KC, reduce = n), P rows = k, P element (k, n) at W[n*ldw + k] (MC)
+  EpiStore epi;
+  epi.C = dX; epi.ldc = lddx; epi.beta = beta; epi.slab_stride = 0;
+  epi.vec_out = ((lddx % 4 == 0) && aligned16(dX)) ? 1 : 0;
+  GemmShape g;
+  g.Q = dZ; g.P = W; g.ldq = lddz; g.ldp = ldw; g.M = M; g.N = K; g.K = N;
+  g.k_per_split = cdiv(N, 16) * 16;
+  const bool vec = (lddz % 4 == 0) && (ldw % 4 == 0) && aligned16(dZ) && aligned16(W);
+  launch_gemm<true, false, EpiStore>(g, epi, 1, pick_tile(M, K, 1), vec, as_hip(stream));
+  NACF_LAUNCH_CHECK("nacf_linear_bwd_data");
+  return NACF_OK;
+}
+
+static int bwd_weight_splits(int M, int N, int K, int* tile_out) {
+  // enough workgroups to fill 256 CUs, each split at least 256 reduce rows
+  int tile = ((long)cdiv(N, 128) * cdiv(K, 128) >= 192) ? 0 : 1;
+  static int forced = -2;
+  if (forced == -2) {
+    const char* e = getenv("NACF_GEMM_TILE");
+    forced = e ? (atoi(e) == 64 ? 1 : (atoi(e) == 128 ? 0 : -1)) : -1;
+  }
+  if (forced >= 0) tile = forced;
+  const int t = tile == 0 ? 128 : 64;
+  const long tiles = (long)cdiv(N, t) * cdiv(K, t);
+  int s = (int)((768 + tiles - 1) / tiles);
+  const int max_s = M / 256 > 0 ? M / 256 : 1;
+  if (s > max_s) s = max_s;
+  if (s < 1) s = 1;
+  if (s > 64) s = 64;
+  *tile_out = tile;
+  return s;
+}
+
+size_t nacf_linear_bwd_weight_workspace(int M, int N, int K) {
+  int tile;
+  const int s = bwd_weight_splits(M, N, K, &tile);
+  const size_t slabs = s > 1 ? (size_t)s * N * K * sizeof(float) : 0;
+  const size_t col = (size_t)64 * N * sizeof(float);
+  return slabs + col + 256;
+}
+
+int nacf_linear_bwd_weight(const float* dZ, int64_t lddz, const float* X, int64_t ldx, float* dW, int64_t lddw,
+                           float* db, int M, int N, int K, float beta, void* ws, size_t ws_bytes,
+                           nacf_stream_t stream) {
+  NACF_CHECK(dZ && X && dW, NACF_EINVAL, "nacf_linear_bwd_weight: null pointer");
+  NACF_CHECK(M > 0 && N > 0 && K > 0, NACF_EINVAL, "nacf_linear_bwd_weight: bad shape");
+  NACF_CHECK(lddz >= N && ldx >= K && lddw >= K, NACF_EINVAL, "nacf_linear_bwd_weight: leading dimension too small");
+  NACF_CHECK(ws && ws_bytes >= nacf_linear_bwd_weight_workspace(M, N, K), NACF_EWORKSPACE,
+             "nacf_linear_bwd_weight: workspace too small (%zu < %zu)", ws_bytes,
+             nacf_linear_bwd_weight_workspace(M, N, K));
+  NACF_CHECK(aligned16(ws), NACF_EINVAL, "nacf_linear_bwd_weight: workspace must be 16-byte aligned");
+  int tile;
+  const int splits = bwd_weight_splits(M, N, K, &tile);
+  hipStream_t s = as_hip(stream);
+  // dW[n][k] = sum_m dZ[m][n] X[m][k]: output rows = n (Q = dZ, MC: element (n, m) at dZ[m*lddz + n]),
+  // output cols = k (P = X, MC: element (k, m) at X[m*ldx + k]), reduce = m
+  GemmShape g;
+  g.Q = dZ; g.P = X; g.ldq = lddz; g.ldp = ldx; g.M = N; g.N = K; g.K = M;
+  g.k_per_split = cdiv(cdiv(M, splits), 16) * 16;
+  const int real_splits = cdiv(M, g.k_per_split);
+  const bool vec = (lddz % 4 == 0) && (ldx % 4 == 0) && aligned16(dZ) && aligned16(X);
+  float* slabs = reinterpret_cast<float*>(ws);
+  EpiStore epi;
+  if (real_splits > 1) {
+    epi.C = slabs; epi.ldc = K; epi.beta = 0.f; epi.slab_stride = (int64_t)N * K; epi.vec_out = (K % 4 == 0) ? 1 : 0;
+  } else {
+    epi.C = dW; epi.ldc = lddw; epi.beta = beta; epi.slab_stride = 0;
+    epi.vec_out = ((lddw % 4 == 0) && aligned16(dW)) ? 1 : 0;
+  }
+  launch_gemm<false, false, EpiStore>(g, epi, real_splits, tile, vec, s);
+  NACF_LAUNCH_CHECK("nacf_linear_bwd_weight(gemm)");
+  if (real_splits > 1) {
+    const int64_t total = (int64_t)N * K;
+    const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, s, slabs, (int64_t)N * K, real_splits, dW,
+                       lddw, N, K, beta);
+    NACF_LAUNCH_CHECK("nacf_linear_bwd_weight(reduce)");
+  }
+  if (db) {
+    float* part = slabs + (splits > 1 ? (size_t)splits * N * K : 0);
+    int S = cdiv(M, 128);
+    if (S > 64) S = 64;
+    const int rows_per = cdiv(M, S);
+    S = cdiv(M, rows_per);
+    hipLaunchKernelGGL(colsum_partial_kernel, dim3(cdiv(N, 64), S), dim3(256), 0, s, dZ, lddz, M, N, rows_per, part);
+    hipLaunchKernelGGL(colsum_final_kernel, dim3(cdiv(N, 256)), dim3(256), 0, s, part, S, N, db, beta);
+    NACF_LAUNCH_CHECK("nacf_linear_bwd_weight(bias)");
+  }
+  return NACF_OK;
+}
+
+size_t nacf_vocab_argmax_workspace(int rows, int V) {
+  const size_t tiles_n = (size_t)cdiv(V, 64);  // upper bound for either tile size
+  return tiles_n * (size_t)rows * 3 * sizeof(float) + 256;
+}
+
+int nacf_vocab_argmax(const float* hidden, int64_t ldh, const float* W, int64_t ldw, const float* bias,
+                      int rows, int V, int K, const int64_t* pad_tokens, int zero_mask_prob,
+                      const uint8_t* update_mask, int64_t* tokens, float* probs, void* ws, size_t ws_bytes,
+                      nacf_stream_t stream) {
+  NACF_CHECK(hidden && W && tokens && probs, NACF_EINVAL, "nacf_vocab_argmax: null pointer");
+  NACF_CHECK(rows > 0 && V > 0 && K > 0, NACF_EINVAL, "nacf_vocab_argmax: bad shape");
+  NACF_CHECK(ws && ws_bytes >= nacf_vocab_argmax_workspace(rows, V), NACF_EWORKSPACE,
+             "nacf_vocab_argmax: workspace too small");
+  const int tile = pick_tile(rows, V, 1);
+  const int tn = cdiv(V, tile == 0 ? 128 : 64);
+  EpiArgmax epi;
+  epi.bias = bias;
+  epi.pmax = reinterpret_cast<float*>(ws);
+  epi.psum = epi.pmax + (size_t)tn * rows;
+  epi.pidx = reinterpret_cast<int*>(epi.psum + (size_t)tn * rows);
+  GemmShape g;
+  g.Q = hidden; g.P = W; g.ldq = ldh; g.ldp = ldw; g.M = rows; g.N = V; g.K = K;
+  g.k_per_split = cdiv(K, 16) * 16;
+  const bool vec = (ldh % 4 == 0) && (ldw % 4 == 0) && aligned16(hidden) && aligned16(W);
+  hipStream_t s = as_hip(stream);
+  launch_gemm<true, true, EpiArgmax>(g, epi, 1, tile, vec, s);
+  NACF_LAUNCH_CHECK("nacf_vocab_argmax(gemm)");
+  hipLaunchKernelGGL(argmax_merge_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, s, epi.pmax, epi.psum, epi.pidx, tn, rows,
+                     pad_tokens, zero_mask_prob, update_mask, tokens, probs);
+  NACF_LAUNCH_CHECK("nacf_vocab_argmax(merge)");
+  return NACF_OK;
+}
+
+}  // extern "C"
