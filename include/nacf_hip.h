@@ -167,9 +167,10 @@ int nacf_log_softmax_rows(const float* in, float* out, int rows, int N, nacf_str
 int nacf_log_softmax_rows_bwd(const float* dOut, const float* out, float* dIn, int rows, int N,
                               nacf_stream_t stream);
 /* nn.KLDivLoss() legacy 'mean': loss = sum(t*(log t - x))/numel, misc/crit.py:223.
- * loss_out: device float[1]; dX = -t * scale / numel (written when dX != NULL). */
-int nacf_kldiv_mean(const float* x, const float* t, float* loss_out, float* dX, float scale,
-                    int rows, int N, nacf_stream_t stream);
+ * loss_out: optional device float[1]; dX (optional) = -t * gscale[0]*scale / numel,
+ * gscale: optional device float[1] (upstream gradient). */
+int nacf_kldiv_mean(const float* x, const float* t, float* loss_out, float* dX,
+                    const float* gscale, float scale, int rows, int N, nacf_stream_t stream);
 
 /* ------------------------------------------------------------------------
  * Decoder  
@@ -289,6 +290,29 @@ int nacf_canvas_init(const int32_t* beam, int rows, int Lp, int64_t* tokens, nac
 int nacf_select_mask(const float* probs, const float* teacher_probs, const int64_t* pad_tokens,
                      const int32_t* num_mask_lut, int mode, int rows, int Lp,
                      int64_t* tokens, uint8_t* mask_out, nacf_stream_t stream);
+
+/* small index helpers of the decode loop (flat arrays of n elements):
+ *   token_replace: tokens[i] == from -> to        (<mask> -> <vis>, algorithms.py:137-138)
+ *   teacher_probs: out[i] = pad_tokens[i] == PAD ? 1 : exp(label_logp[i])   (algorithms.py:197-203)
+ *   init_probs:    probs[i] = pad_tokens[i] == PAD ? 1 : 0                  (algorithms.py:294-295)
+ *   apply_mask:    tokens[i] = mask[i] ? value : tokens[i] */
+int nacf_token_replace(int64_t* tokens, int64_t n, int64_t from, int64_t to, nacf_stream_t stream);
+int nacf_teacher_probs(const float* label_logp, const int64_t* pad_tokens, float* out, int64_t n,
+                       nacf_stream_t stream);
+int nacf_init_probs(const int64_t* pad_tokens, float* probs, int64_t n, nacf_stream_t stream);
+int nacf_apply_mask(int64_t* tokens, const uint8_t* mask, int64_t value, int64_t n, nacf_stream_t stream);
+/* Left2Right / EasyFirst bookkeeping (algorithms.py:299-324,371-393):
+ * mask_rank:  rank[r,l] = index of slot l among the <mask> slots of row r, -1 elsewhere;
+ *             counts[0] = max <mask> count of a row, counts[1] = total count (device int32[2]);
+ * select_rank: mask = (cur <= rank < cur+q), tokens[mask] = MASK   (select_left);
+ * easy_first_update: per row, the min(q, remaining) <mask> slots with the largest
+ *             new_probs take (new_tokens, new_probs)   (select_most_confidence). */
+int nacf_mask_rank(const int64_t* tokens, int rows, int Lp, int32_t* rank, int32_t* counts,
+                   nacf_stream_t stream);
+int nacf_select_rank(const int32_t* rank, int cur, int q, int rows, int Lp, int64_t* tokens,
+                     uint8_t* mask_out, nacf_stream_t stream);
+int nacf_easy_first_update(int64_t* tokens, float* probs, const int64_t* new_tokens,
+                           const float* new_probs, int q, int rows, int Lp, nacf_stream_t stream);
 
 /* score = sum_l log(probs*teacher) / len^alpha ; best = argmax_j ; out[b,:] = tokens[b*lbs+best,:]
  * decoding/na_generate.py:66-77.  cand_lprobs optional [rows, Lp] output. */

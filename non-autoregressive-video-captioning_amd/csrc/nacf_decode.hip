@@ -106,9 +106,138 @@ __global__ void best_candidate_kernel(const int64_t* __restrict__ tokens, const 
   if (lane == 0 && best_idx) best_idx[b] = bj;
 }
 
+__global__ void token_replace_kernel(int64_t* __restrict__ tokens, int64_t n, int64_t from, int64_t to) {
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x)
+    if (tokens[e] == from) tokens[e] = to;
+}
+__global__ void teacher_probs_kernel(const float* __restrict__ label_logp, const int64_t* __restrict__ pad_tokens,
+                                     float* __restrict__ out, int64_t n) {
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x)
+    out[e] = pad_tokens[e] == NACF_PAD ? 1.0f : expf(label_logp[e]);
+}
+__global__ void init_probs_kernel(const int64_t* __restrict__ pad_tokens, float* __restrict__ probs, int64_t n) {
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x)
+    probs[e] = pad_tokens[e] == NACF_PAD ? 1.0f : 0.0f;
+}
+__global__ void apply_mask_kernel(int64_t* __restrict__ tokens, const uint8_t* __restrict__ mask, int64_t value,
+                                  int64_t n) {
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x)
+    if (mask[e]) tokens[e] = value;
+}
+
+// single workgroup: rank of each <mask> slot inside its row, max per-row count, total count
+__global__ void mask_rank_kernel(const int64_t* __restrict__ tokens, int rows, int Lp, int32_t* __restrict__ rank,
+                                 int32_t* __restrict__ counts) {
+  __shared__ int red_max[4];
+  __shared__ int red_tot[4];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  int lmax = 0, ltot = 0;
+  for (int row = wave; row < rows; row += 4) {
+    const bool in = lane < Lp;
+    const bool m = in && tokens[(int64_t)row * Lp + lane] == NACF_MASK;
+    const unsigned long long bal = __ballot(m);
+    if (in) rank[(int64_t)row * Lp + lane] = m ? __popcll(bal & ((1ull << lane) - 1ull)) : -1;
+    const int c = __popcll(bal);
+    lmax = max(lmax, c);
+    ltot += c;
+  }
+  if (lane == 0) { red_max[wave] = lmax; red_tot[wave] = ltot; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    counts[0] = max(max(red_max[0], red_max[1]), max(red_max[2], red_max[3]));
+    counts[1] = red_tot[0] + red_tot[1] + red_tot[2] + red_tot[3];
+  }
+}
+__global__ void select_rank_kernel(const int32_t* __restrict__ rank, int cur, int q, int64_t n,
+                                   int64_t* __restrict__ tokens, uint8_t* __restrict__ mask_out) {
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x) {
+    const int r = rank[e];
+    const bool sel = r >= cur && r < cur + q;
+    if (sel) tokens[e] = NACF_MASK;
+    mask_out[e] = sel ? 1 : 0;
+  }
+}
+// one wave per row: among <mask> slots take the min(q, remaining) most confident new predictions
+__global__ void easy_first_update_kernel(int64_t* __restrict__ tokens, float* __restrict__ probs,
+                                         const int64_t* __restrict__ new_tokens, const float* __restrict__ new_probs,
+                                         int q, int rows, int Lp) {
+  const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (row >= rows) return;
+  const bool in = lane < Lp;
+  const int64_t o = (int64_t)row * Lp + lane;
+  const bool m = in && tokens[o] == NACF_MASK;
+  const int remain = __popcll(__ballot(m));
+  if (remain == 0) return;
+  const int k = min(q, remain);
+  const float s = m ? new_probs[o] : 0.0f;          // token_probs[~mask_ind] = 0 (algorithms.py:373)
+  int rank = 0;
+  for (int j = 0; j < Lp; ++j) {
+    const float sj = __shfl(s, j, 64);
+    rank += (sj > s || (sj == s && j < lane)) ? 1 : 0;
+  }
+  if (in && rank < k) { tokens[o] = new_tokens[o]; probs[o] = s; }
+}
+
+inline int flat_grid(int64_t n) {
+  int64_t b = (n + 255) / 256;
+  return (int)(b > 4096 ? 4096 : (b < 1 ? 1 : b));
+}
+
 }  // namespace
 
 extern "C" {
+
+int nacf_token_replace(int64_t* tokens, int64_t n, int64_t from, int64_t to, nacf_stream_t stream) {
+  NACF_CHECK(tokens && n > 0, NACF_EINVAL, "nacf_token_replace: bad argument");
+  hipLaunchKernelGGL(token_replace_kernel, dim3(flat_grid(n)), dim3(256), 0, as_hip(stream), tokens, n, from, to);
+  NACF_LAUNCH_CHECK("nacf_token_replace");
+  return NACF_OK;
+}
+int nacf_teacher_probs(const float* label_logp, const int64_t* pad_tokens, float* out, int64_t n,
+                       nacf_stream_t stream) {
+  NACF_CHECK(label_logp && pad_tokens && out && n > 0, NACF_EINVAL, "nacf_teacher_probs: bad argument");
+  hipLaunchKernelGGL(teacher_probs_kernel, dim3(flat_grid(n)), dim3(256), 0, as_hip(stream), label_logp, pad_tokens, out, n);
+  NACF_LAUNCH_CHECK("nacf_teacher_probs");
+  return NACF_OK;
+}
+int nacf_init_probs(const int64_t* pad_tokens, float* probs, int64_t n, nacf_stream_t stream) {
+  NACF_CHECK(pad_tokens && probs && n > 0, NACF_EINVAL, "nacf_init_probs: bad argument");
+  hipLaunchKernelGGL(init_probs_kernel, dim3(flat_grid(n)), dim3(256), 0, as_hip(stream), pad_tokens, probs, n);
+  NACF_LAUNCH_CHECK("nacf_init_probs");
+  return NACF_OK;
+}
+int nacf_apply_mask(int64_t* tokens, const uint8_t* mask, int64_t value, int64_t n, nacf_stream_t stream) {
+  NACF_CHECK(tokens && mask && n > 0, NACF_EINVAL, "nacf_apply_mask: bad argument");
+  hipLaunchKernelGGL(apply_mask_kernel, dim3(flat_grid(n)), dim3(256), 0, as_hip(stream), tokens, mask, value, n);
+  NACF_LAUNCH_CHECK("nacf_apply_mask");
+  return NACF_OK;
+}
+int nacf_mask_rank(const int64_t* tokens, int rows, int Lp, int32_t* rank, int32_t* counts, nacf_stream_t stream) {
+  NACF_CHECK(tokens && rank && counts && rows > 0, NACF_EINVAL, "nacf_mask_rank: bad argument");
+  NACF_CHECK(Lp > 0 && Lp <= 64, NACF_EUNSUPPORTED, "nacf_mask_rank: Lp must be in 1..64");
+  hipLaunchKernelGGL(mask_rank_kernel, dim3(1), dim3(256), 0, as_hip(stream), tokens, rows, Lp, rank, counts);
+  NACF_LAUNCH_CHECK("nacf_mask_rank");
+  return NACF_OK;
+}
+int nacf_select_rank(const int32_t* rank, int cur, int q, int rows, int Lp, int64_t* tokens, uint8_t* mask_out,
+                     nacf_stream_t stream) {
+  NACF_CHECK(rank && tokens && mask_out && rows > 0 && Lp > 0 && q > 0, NACF_EINVAL, "nacf_select_rank: bad argument");
+  const int64_t n = (int64_t)rows * Lp;
+  hipLaunchKernelGGL(select_rank_kernel, dim3(flat_grid(n)), dim3(256), 0, as_hip(stream), rank, cur, q, n, tokens, mask_out);
+  NACF_LAUNCH_CHECK("nacf_select_rank");
+  return NACF_OK;
+}
+int nacf_easy_first_update(int64_t* tokens, float* probs, const int64_t* new_tokens, const float* new_probs, int q,
+                           int rows, int Lp, nacf_stream_t stream) {
+  NACF_CHECK(tokens && probs && new_tokens && new_probs && rows > 0 && q > 0, NACF_EINVAL,
+             "nacf_easy_first_update: bad argument");
+  NACF_CHECK(Lp > 0 && Lp <= 64, NACF_EUNSUPPORTED, "nacf_easy_first_update: Lp must be in 1..64");
+  hipLaunchKernelGGL(easy_first_update_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, as_hip(stream), tokens, probs,
+                     new_tokens, new_probs, q, rows, Lp);
+  NACF_LAUNCH_CHECK("nacf_easy_first_update");
+  return NACF_OK;
+}
 
 int nacf_length_beam(const float* pred_length, int B, int max_len, int lbs, int length_bias, int32_t* beam,
                      int32_t* beam_max, nacf_stream_t stream) {

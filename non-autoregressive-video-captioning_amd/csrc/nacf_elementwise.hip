@@ -231,17 +231,19 @@ __global__ void log_softmax_rows_bwd_kernel(const float* __restrict__ dOut, cons
   }
 }
 __global__ void kldiv_mean_kernel(const float* __restrict__ x, const float* __restrict__ t,
-                                  float* __restrict__ loss_out, float* __restrict__ dX, float scale, int total) {
+                                  float* __restrict__ loss_out, float* __restrict__ dX,
+                                  const float* __restrict__ gscale, float scale, int total) {
   __shared__ float red[16];
   float acc = 0.f;
   const float inv = 1.f / (float)total;
+  const float g = (gscale ? gscale[0] : 1.f) * scale;
   for (int e = threadIdx.x; e < total; e += blockDim.x) {
     const float tt = t[e];
     if (tt > 0.f) acc += tt * (logf(tt) - x[e]);
-    if (dX) dX[e] = -tt * scale * inv;
+    if (dX) dX[e] = -tt * g * inv;
   }
   acc = block_sum(acc, red);
-  if (threadIdx.x == 0) loss_out[0] = acc * inv;
+  if (threadIdx.x == 0 && loss_out) loss_out[0] = acc * inv;
 }
 
 // ------------------------------------------------------------------ epilogue backward
@@ -517,10 +519,11 @@ int nacf_log_softmax_rows_bwd(const float* dOut, const float* out, float* dIn, i
   return NACF_OK;
 }
 
-int nacf_kldiv_mean(const float* x, const float* t, float* loss_out, float* dX, float scale, int rows, int N,
-                    nacf_stream_t stream) {
-  NACF_CHECK(x && t && loss_out && rows > 0 && N > 0, NACF_EINVAL, "nacf_kldiv_mean: bad argument");
-  hipLaunchKernelGGL(kldiv_mean_kernel, dim3(1), dim3(256), 0, as_hip(stream), x, t, loss_out, dX, scale, rows * N);
+int nacf_kldiv_mean(const float* x, const float* t, float* loss_out, float* dX, const float* gscale, float scale,
+                    int rows, int N, nacf_stream_t stream) {
+  NACF_CHECK(x && t && (loss_out || dX) && rows > 0 && N > 0, NACF_EINVAL, "nacf_kldiv_mean: bad argument");
+  hipLaunchKernelGGL(kldiv_mean_kernel, dim3(1), dim3(256), 0, as_hip(stream), x, t, loss_out, dX, gscale, scale,
+                     rows * N);
   NACF_LAUNCH_CHECK("nacf_kldiv_mean");
   return NACF_OK;
 }

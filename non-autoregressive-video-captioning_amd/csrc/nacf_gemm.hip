@@ -9,12 +9,13 @@ namespace {
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 // tile selection: 0 = 128x128, 1 = 64x64.  Override with NACF_GEMM_TILE=128|64.
+int forced_tile() {
+  const char* e = getenv("NACF_GEMM_TILE");  // tuning / test knob, read per call
+  return e ? (atoi(e) == 64 ? 1 : (atoi(e) == 128 ? 0 : -1)) : -1;
+}
+
 int pick_tile(int M, int N, int splits) {
-  static int forced = -2;
-  if (forced == -2) {
-    const char* e = getenv("NACF_GEMM_TILE");
-    forced = e ? (atoi(e) == 64 ? 1 : (atoi(e) == 128 ? 0 : -1)) : -1;
-  }
+  const int forced = forced_tile();
   if (forced >= 0) return forced;
   const long big = (long)cdiv(M, 128) * cdiv(N, 128) * splits;
   return big >= 384 ? 0 : 1;  // >= 1.5 workgroups per CU with the big tile, else go small
@@ -162,11 +163,7 @@ int nacf_linear_bwd_data(const float* dZ, int64_t lddz, const float* W, int64_t 
 static int bwd_weight_splits(int M, int N, int K, int* tile_out) {
   // enough workgroups to fill 256 CUs, each split at least 256 reduce rows
   int tile = ((long)cdiv(N, 128) * cdiv(K, 128) >= 192) ? 0 : 1;
-  static int forced = -2;
-  if (forced == -2) {
-    const char* e = getenv("NACF_GEMM_TILE");
-    forced = e ? (atoi(e) == 64 ? 1 : (atoi(e) == 128 ? 0 : -1)) : -1;
-  }
+  const int forced = forced_tile();
   if (forced >= 0) tile = forced;
   const int t = tile == 0 ? 128 : 64;
   const long tiles = (long)cdiv(N, t) * cdiv(K, t);

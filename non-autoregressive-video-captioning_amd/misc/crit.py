@@ -1,0 +1,125 @@
+"""Criterion for the training step (reference: misc/crit.py:10-251).
+
+Same semantics: language loss = sum_i w_i * (token-SUM NLL of pass i) / B with
+weights `nv_weights` when visual_word_generation (crit.py:40-55,82); length
+loss = legacy nn.KLDivLoss() mean over B*max_len elements (crit.py:223); total
+= sum_i scale_i * loss_i.  Side meters: top-1 word accuracy per pass (pass 0
+excludes <mask> labels) and perplexity of the caption pass (crit.py:86-114).
+
+Two input forms:
+  * results['_nacf_hidden'] (model built with opt['fused_loss']=True): the
+    vocabulary projection, log-softmax, NLL, argmax-hit and gathered-logp
+    reductions run as ONE fused operator per pass; [B, L, V] log-probs are
+    never handed to Python.
+  * results['tgt_word_logprobs'] (reference form): consumed as tensors.
+Meters accumulate on the device; the host only syncs in get_loss_info().
+"""
+import math
+
+import torch
+
+from ..config import Constants
+from ..runtime.functional import FusedVocabXentFn, KLDivMeanFn
+
+
+class Criterion(object):
+    def __init__(self, opt):
+        self.opt = opt
+        self.crit = [c.lower() for c in opt['crit']]
+        self.names = list(opt.get('crit_name', ['Cap Loss', 'Length Loss'][:len(self.crit)]))
+        self.scales = list(opt.get('crit_scale', [1.0] * len(self.crit)))
+        self.vw = opt.get('visual_word_generation', False)
+        self.weights = list(opt.get('nv_weights', [0.8, 1.0])) if self.vw else None
+        self.reset_loss_recorder()
+
+    def reset_loss_recorder(self):
+        self._loss_sum = [None] * len(self.crit)
+        self._loss_cnt = [0] * len(self.crit)
+        self._acc = None      # device [n_pass, 2] (hits, count)
+        self._ppl = None      # device [2] (sum logp, count)
+
+    @staticmethod
+    def _acc_add(cur, new):
+        return new if cur is None else cur + new
+
+    def _lang(self, results, labels):
+        if '_nacf_hidden' in results:
+            hidden = results['_nacf_hidden']
+            pack, params = results['_nacf_vocab']
+        else:
+            hidden = None
+            logps = results[Constants.mapping['lang'][0]]
+            if not isinstance(logps, (list, tuple)):
+                logps = [logps]
+        n = len(hidden) if hidden is not None else len(logps)
+        if not isinstance(labels, (list, tuple)):
+            labels = [labels] * n
+        weights = self.weights if self.weights is not None else [1.0] * n
+        assert len(labels) == n == len(weights)
+        B = (hidden[0] if hidden is not None else logps[0]).shape[0]
+        loss = None
+        acc_rows, ppl = [], None
+        for i in range(n):
+            exclude = (i == 0 and self.vw)
+            lab = labels[i].contiguous()
+            if hidden is not None:
+                h = hidden[i]
+                assert h.shape[1] == lab.shape[1]
+                stats = FusedVocabXentFn.apply(h.reshape(-1, h.shape[-1]), dict(pack=pack), lab, exclude, *params)
+            else:
+                lp = logps[i]
+                assert lp.shape[1] == lab.shape[1]
+                m = lab.ne(Constants.PAD)
+                g = lp.gather(2, lab.unsqueeze(2)).squeeze(2)
+                ind = m & lab.ne(Constants.MASK) if exclude else m
+                hit = (lp.argmax(-1).eq(lab) & ind).sum().float()
+                stats = torch.stack([-(g * m).sum(), hit, ind.sum().float(), (g * m).sum().detach(), m.sum().float()])
+            term = weights[i] * stats[0] / B
+            loss = term if loss is None else loss + term
+            acc_rows.append(stats[1:3].detach())
+            if not exclude:
+                ppl = stats[3:5].detach()
+        self._acc = self._acc_add(self._acc, torch.stack(acc_rows))
+        if ppl is not None:
+            self._ppl = self._acc_add(self._ppl, ppl)
+        return loss, B
+
+    def get_loss(self, results, **kwargs):
+        total = None
+        for i, name in enumerate(self.crit):
+            if name == 'lang':
+                li, n = self._lang(results, results[Constants.mapping['lang'][1]])
+            elif name == 'length':
+                pred = results[Constants.mapping['length'][0]]
+                li = KLDivMeanFn.apply(pred, results[Constants.mapping['length'][1]].to(pred.dtype))
+                n = pred.shape[0]
+            else:
+                raise NotImplementedError('criterion %s' % name)
+            self._loss_sum[i] = self._acc_add(self._loss_sum[i], li.detach() * n)
+            self._loss_cnt[i] += n
+            term = li * self.scales[i]
+            total = term if total is None else total + term
+        return total
+
+    def get_fieldsnames(self):
+        n_acc = 2 if self.vw else 1
+        return ['Word Acc%d' % i for i in range(n_acc)] + ['Perplexity'] + [n for n, c in zip(self.names, self.crit) if c != 'lang']
+
+    def get_loss_info(self):
+        names = list(self.names)
+        info = [float(s) / max(c, 1) if s is not None else 0.0 for s, c in zip(self._loss_sum, self._loss_cnt)]
+        if self._acc is not None:
+            acc = self._acc.tolist()
+            for i, (h, c) in enumerate(acc):
+                names.append('Word Acc%d' % i)
+                info.append(h / c if c > 0 else 0.0)   # the reference divides by zero here
+        if self._ppl is not None:
+            s, c = self._ppl.tolist()
+            names.append('Perplexity')
+            info.append(math.exp(-s / c) if c > 0 else float('nan'))
+        return names, info
+
+
+def get_criterion(opt, summarywriter=None):
+    assert isinstance(opt['crit'], list)
+    return Criterion(opt)

@@ -1,0 +1,81 @@
+"""Optimiser for the training step (reference: misc/optim.py:3-68 plus the
+`clip_grad_value_` of misc/run.py:260): elementwise clip to +-grad_clip, Adam
+with L2-in-gradient weight decay on every parameter, lr * min(step/(warmup+1),
+1), and a per-epoch x`decay` floor-ed at `minimum_learning_rate`.
+
+One `nacf_adam_step` launch walks the model's flat parameter / gradient / moment
+buffers (~0.5 GB of HBM traffic per step at 18.5 M parameters); the step count
+and the learning rate live in device memory so a captured hipGraph can replay it.
+"""
+import torch
+
+from ..runtime import ops
+
+
+class FusedAdam(object):
+    def __init__(self, model, weight_decay=5e-4, betas=(0.9, 0.999), eps=1e-8, grad_clip=5.0):
+        self.model = model
+        self.wd, self.betas, self.eps, self.grad_clip = weight_decay, betas, eps, grad_clip
+        self._alloc()
+
+    def _alloc(self):
+        flat = self.model.flat
+        self._flat = flat
+        self.exp_avg = torch.zeros_like(flat.data)
+        self.exp_avg_sq = torch.zeros_like(flat.data)
+        self.step_dev = torch.zeros(1, dtype=torch.int64, device=flat.data.device)
+        self.lr_dev = torch.zeros(1, dtype=torch.float32, device=flat.data.device)
+        self.param_groups = [{'lr': 0.0, 'params': flat.params}]
+
+    def set_lr(self, lr):
+        self.param_groups[0]['lr'] = lr
+        self.lr_dev.fill_(lr)
+
+    def zero_grad(self):
+        self.model.zero_grad()
+
+    def step(self, grad_scale=1.0):
+        if self._flat is not self.model.flat:   # model moved (.to/.cuda) after the optimiser was built
+            self._alloc()
+            self.lr_dev.fill_(self.param_groups[0]['lr'])
+        f = self._flat
+        ops.adam_step(f.data, f.grad, self.exp_avg, self.exp_avg_sq, self.lr_dev, self.step_dev, self.betas[0],
+                      self.betas[1], self.eps, self.wd, self.grad_clip, grad_scale)
+
+
+class ScheduledOptim(object):
+    def __init__(self, optimizer, learning_rate, minimum_learning_rate, epoch_decay_rate, grad_clip=2,
+                 n_warmup_steps=0, summarywriter=None):
+        self._optimizer = optimizer
+        self.n_current_steps = 0
+        self.lr, self.mlr, self.decay = learning_rate, minimum_learning_rate, epoch_decay_rate
+        self.grad_clip = grad_clip
+        self.n_warmup_steps = n_warmup_steps
+
+    def step(self, grad_scale=1.0):
+        self.step_update_learning_rate()
+        self._optimizer.step(grad_scale=grad_scale)
+
+    def zero_grad(self):
+        self._optimizer.zero_grad()
+
+    def epoch_update_learning_rate(self):
+        if self.n_current_steps > self.n_warmup_steps:
+            self.lr = max(self.mlr, self.decay * self.lr)
+
+    def step_update_learning_rate(self):
+        self.n_current_steps += 1
+        ratio = min(self.n_current_steps / (self.n_warmup_steps + 1.0), 1)
+        self._optimizer.set_lr(self.lr * ratio)
+
+    def get_lr(self):
+        return self.lr
+
+
+def get_optimizer(opt, model, summarywriter=None):
+    if opt['optim'].lower() != 'adam':
+        raise NotImplementedError('nacf_amd: only adam is built (reference default)')
+    inner = FusedAdam(model, weight_decay=opt['weight_decay'], grad_clip=opt.get('grad_clip', 5.0))
+    return ScheduledOptim(inner, learning_rate=opt['learning_rate'],
+                          minimum_learning_rate=opt['minimum_learning_rate'], epoch_decay_rate=opt['decay'],
+                          grad_clip=opt.get('grad_clip', 5.0), n_warmup_steps=opt.get('n_warmup_steps', 0))

@@ -1,0 +1,168 @@
+"""Transformer decoders (reference: models/Decoder.py:68-215).
+
+`BertDecoder` / `BertDecoderDisentangled` keep the reference call convention
+    decoder(tgt_seq, enc_output=..., category=..., [decoding_type=], [output_attentions=])
+      -> ([hidden], embs[, attentions])            (BertDecoder)
+      -> (hidden | [h_vis, h_mlm], embs[, attns])  (BertDecoderDisentangled)
+and add three keyword-only accelerators the NA decoding loop uses:
+    row_map=('div', k) | ('mod', B): which video a decoder row belongs to, so
+        the visual memory is never physically repeated (replaces enlarge(),
+        misc/utils.py:205-213);
+    memory_kv=[...]: per-layer K|V projections of the memory (project_memory),
+        computed once per video instead of once per pass;
+    pooled_memory: mean_t(enc_output) for enhance_input=2.
+Masks are never materialised: kernels derive key-padding / causal masks from
+the token ids (models/Decoder.py:9-39).  The two NACF / ARB2 passes run as ONE
+batch of 2B rows that share weights and memory (models/Decoder.py:201-215).
+"""
+import torch
+import torch.nn as nn
+
+from ..runtime import ops
+from ..runtime.functional import MeanTimeFn
+from .bert import BertEmbeddings, BertLayer
+
+__all__ = ('BertDecoder', 'BertDecoderDisentangled')
+
+
+class EmptyObject(object):
+    pass
+
+
+def dict2obj(d):
+    obj = EmptyObject()
+    obj.__dict__.update(d)
+    return obj
+
+
+class BertDecoder(nn.Module):
+    def __init__(self, config, embedding=None):
+        super().__init__()
+        if isinstance(config, dict):
+            config = dict2obj(config)
+        self.embedding = BertEmbeddings(config) if embedding is None else embedding
+        self.layer = nn.ModuleList([BertLayer(config, is_decoder_layer=True)
+                                    for _ in range(config.num_hidden_layers_decoder)])
+        self.pos_attention = config.pos_attention
+        self.enhance_input = config.enhance_input
+        if self.enhance_input not in (0, 2):
+            # enhance_input=1 (resampling) crashes in the reference itself on torch>=1.2 (Decoder.py:43)
+            raise ValueError('enhance_input shoud be either 0 or 2 in nacf_amd')
+        self.watch = config.watch
+        if self.watch != 0:
+            raise NotImplementedError('nacf_amd: watch != 0 is not built (reference default 0)')
+        self.decoding_type = config.decoding_type
+
+    def get_word_embeddings(self):
+        return self.embedding.word_embeddings
+
+    def set_word_embeddings(self, we):
+        self.embedding.word_embeddings = we
+
+    def nacf_groups(self):
+        return self.embedding.nacf_groups() + [g for l in self.layer for g in l.nacf_groups()]
+
+    def nacf_bind(self, flat, rt):
+        self.embedding.nacf_bind(flat, rt)
+        for l in self.layer:
+            l.nacf_bind(flat, rt)
+
+    def project_memory(self, enc_output):
+        return [l.project_memory(enc_output) for l in self.layer]
+
+    @staticmethod
+    def _row_map(row_map, R, Bv):
+        if row_map is None:
+            if R == Bv:
+                return 1, Bv
+            assert R % Bv == 0, 'decoder rows (%d) must be a multiple of the memory batch (%d)' % (R, Bv)
+            return R // Bv, Bv          # enlarge() semantics: row b*k+j reads video b
+        kind, val = row_map
+        if kind == 'mod':
+            assert val == Bv
+            return 1, Bv                # pass-major batching: row p*B+b reads video b
+        assert kind == 'div' and R == val * Bv
+        return val, Bv
+
+    def forward(self, tgt_seq, enc_output=None, category=None, signals=None, tags=None, **kwargs):
+        decoding_type = kwargs.get('decoding_type', self.decoding_type)
+        output_attentions = kwargs.get('output_attentions', False)
+        if isinstance(enc_output, list):
+            assert len(enc_output) == 1
+            enc_output = enc_output[0]
+        if signals is not None:
+            raise NotImplementedError('nacf_amd: `signals` is not built')
+        if decoding_type not in ('NARFormer', 'ARFormer'):
+            raise NotImplementedError('nacf_amd: decoding_type %s is not built' % decoding_type)
+        tgt_seq = tgt_seq.contiguous()
+        R, Lq = tgt_seq.shape
+        enc_output = enc_output.contiguous()
+        Bv, M, D = enc_output.shape
+        vdiv, vmod = self._row_map(kwargs.get('row_map'), R, Bv)
+        training = self.training
+        additional = None
+        if decoding_type == 'NARFormer' and self.enhance_input == 2:
+            additional = kwargs.get('pooled_memory')
+            if additional is None:
+                additional = MeanTimeFn.apply(enc_output)
+        hidden = self.embedding.run(tgt_seq, category, additional, vdiv, vmod, training)
+        memory_kv = kwargs.get('memory_kv')
+        x2 = hidden.reshape(R * Lq, D)
+        all_attentions = ()
+        for i, layer in enumerate(self.layer):
+            kv = memory_kv[i] if memory_kv is not None else layer.project_memory(enc_output)
+            x2, att = layer.run(x2, tgt_seq, decoding_type == 'ARFormer', kv, M, vdiv, vmod, training,
+                                output_attentions)
+            if output_attentions:
+                all_attentions = all_attentions + (att,)
+        hidden = x2.view(R, Lq, D)
+        with torch.no_grad():
+            embs = ops.masked_mean_fwd(hidden.detach(), tgt_seq, torch.empty(R, D, device=hidden.device))
+        outputs = ([hidden], embs,)
+        if output_attentions:
+            outputs = outputs + (all_attentions,)
+        return outputs
+
+
+class BertDecoderDisentangled(nn.Module):
+    def __init__(self, config):
+        super().__init__()
+        if isinstance(config, dict):
+            config = dict2obj(config)
+        self.bert = BertDecoder(config)
+
+    def get_word_embeddings(self):
+        return self.bert.get_word_embeddings()
+
+    def set_word_embeddings(self, we):
+        self.bert.set_word_embeddings(we)
+
+    def nacf_groups(self):
+        return self.bert.nacf_groups()
+
+    def nacf_bind(self, flat, rt):
+        self.bert.nacf_bind(flat, rt)
+
+    def project_memory(self, enc_output):
+        return self.bert.project_memory(enc_output)
+
+    def forward_(self, tgt_seq, enc_output, category, **kwargs):
+        seq_probs, embs, *_ = self.bert(tgt_seq, enc_output, category, **kwargs)
+        seq_probs = seq_probs[0]
+        if len(_):
+            return seq_probs, embs, _
+        return seq_probs, embs
+
+    def forward(self, tgt_seq, enc_output, category, **kwargs):
+        if isinstance(enc_output, list):
+            assert len(enc_output) == 1
+            enc_output = enc_output[0]
+        if isinstance(tgt_seq, (list, tuple)):
+            # visual-word pass + caption pass: one launch sequence over 2B rows
+            assert len(tgt_seq) == 2
+            B = tgt_seq[0].shape[0]
+            both = torch.cat([tgt_seq[0], tgt_seq[1]], dim=0)
+            kwargs = dict(kwargs, row_map=('mod', enc_output.shape[0]))
+            hidden, embs = self.forward_(both, enc_output, category, **kwargs)[:2]
+            return ([hidden[:B], hidden[B:]], embs[B:],)
+        return self.forward_(tgt_seq, enc_output, category, **kwargs)

@@ -1,0 +1,69 @@
+"""Visual encoder: per modality Linear -> HighWay -> Dropout.
+
+Drop-in for the reference's `models.Encoder` registry (models/Encoder.py:5-7,
+62-66): same class name, same sub-module / parameter names
+(`Encoder_M.0.weight`, `Encoder_M.1.w1.weight`, ...), same construction order
+(so torch's default initialisers consume the RNG identically).  The modules
+below only HOLD parameters; the compute is `EncoderStreamFn` (two MFMA GEMMs
+with fused bias / tanh|sigmoid epilogues + the gate-mix/dropout kernel), with
+HighWay's w1|w2 packed into one [2D, D] GEMM.
+"""
+import torch.nn as nn
+
+from ..runtime.functional import EncoderStreamFn
+
+__all__ = ('Encoder_HighWay',)
+
+
+class HighWay(nn.Module):
+    """parameter holder for the gated HighWay layer (models/Encoder.py:9-25)"""
+
+    def __init__(self, hidden_size, with_gate=True):
+        super().__init__()
+        if not with_gate:
+            raise NotImplementedError('nacf_amd: HighWay(with_gate=False) is not built (reference default is gated)')
+        self.w1 = nn.Linear(hidden_size, hidden_size)
+        self.w2 = nn.Linear(hidden_size, hidden_size)
+
+
+class Encoder_HighWay(nn.Module):
+    def __init__(self, opt):
+        super().__init__()
+        self.modality = opt['modality'].lower()
+        self.dropout = opt.get('encoder_dropout', 0.5)
+        dim_hidden = opt.get('dim_hidden', 512)
+        self.streams = []
+        for char in self.modality:
+            input_dim = opt.get('dim_' + char, None)
+            assert input_dim is not None, 'modality %s needs dim_%s in opt' % (self.modality, char)
+            seq = nn.Sequential(nn.Linear(input_dim, dim_hidden), HighWay(dim_hidden, opt.get('gate', True)),
+                                nn.Dropout(self.dropout))
+            self.add_module('Encoder_%s' % char.upper(), seq)
+            self.streams.append(seq)
+        self.num_feats = len(self.modality)
+        self._cfg = None
+
+    # --- flat-buffer binding -------------------------------------------------
+    def nacf_groups(self):
+        groups = []
+        for s in self.streams:
+            groups += [[s[0].weight], [s[0].bias], [s[1].w1.weight, s[1].w2.weight], [s[1].w1.bias, s[1].w2.bias]]
+        return groups
+
+    def nacf_bind(self, flat, rt):
+        self._rt = rt
+        self._cfg = []
+        for s in self.streams:
+            self._cfg.append(dict(lin=flat.pack([s[0].weight], [s[0].bias]),
+                                  hw=flat.pack([s[1].w1.weight, s[1].w2.weight], [s[1].w1.bias, s[1].w2.bias]),
+                                  p=self.dropout, salt=rt.next_salt(),
+                                  params=[s[0].weight, s[0].bias, s[1].w1.weight, s[1].w1.bias, s[1].w2.weight,
+                                          s[1].w2.bias]))
+
+    def forward(self, input_feats):
+        assert self.num_feats == len(input_feats)
+        outs = []
+        for cfg, x in zip(self._cfg, input_feats):
+            c = dict(cfg, training=self.training, rng=self._rt.rng(x.device))
+            outs.append(EncoderStreamFn.apply(x, c, *cfg['params']))
+        return outs, None  # hiddens (mean over time) are produced lazily by Seq2Seq.encode

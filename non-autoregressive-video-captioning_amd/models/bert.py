@@ -1,0 +1,164 @@
+"""BERT-style decoder blocks (reference: models/bert.py:46-303).
+
+The classes keep the reference's module / parameter names so checkpoints load
+unchanged, but they are parameter holders: `BertLayer.run` issues the layer as
+eight launches-with-fused-epilogues on the MI355X:
+
+  qkv   = x Wqkv^T + b                      (one packed [3D, D] MFMA GEMM)
+  att   = softmax(QK^T/sqrt(dk) masked) V   (LDS-resident per (row, head))
+  a     = (dropout(att Wo^T + b) + x) * non_pad          (fused epilogue)
+  q     = a Wq^T + b ;  kv = memory Wkv^T + b (once per VIDEO, shared by both
+          NACF passes / all length candidates / all decode iterations)
+  c     = (dropout(cross(q, kv) Wo^T + b) + a) * non_pad
+  u     = gelu_new(c W1^T + b)                            (fused epilogue)
+  y     = dropout(dropout(u W2^T + b) + c) * non_pad      (fused epilogue; the
+          reference's BertOutput really applies dropout twice, bert.py:242,247)
+
+Reference quirks kept: mask fill is -1e7 (not -inf); scaling happens after
+QK^T; PAD *queries* are not masked, their rows are zeroed by non_pad_mask.
+"""
+import torch.nn as nn
+
+from ..config import Constants
+from ..runtime import lib as L
+from ..runtime.functional import CrossAttentionFn, EmbedLNFn, LinearFn, SelfAttentionFn
+
+
+class BertEmbeddings(nn.Module):
+    """word + position (+ category) embeddings and LayerNorm (bert.py:46-67)"""
+
+    def __init__(self, config):
+        super().__init__()
+        if getattr(config, 'load_word_embeddings', False):
+            raise NotImplementedError('nacf_amd: load_word_embeddings (768-d projected embeddings) is not built')
+        self.word_embeddings = nn.Embedding(config.vocab_size, config.dim_hidden, padding_idx=Constants.PAD)
+        self.position_embeddings = nn.Embedding(config.max_len, config.dim_hidden)
+        self.category_embeddings = nn.Embedding(config.num_category, config.dim_hidden) if config.with_category else None
+        self.LayerNorm = nn.LayerNorm(config.dim_hidden, eps=config.layer_norm_eps)
+        self.p = config.hidden_dropout_prob
+        self.eps = config.layer_norm_eps
+
+    def nacf_groups(self):
+        g = [[self.word_embeddings.weight], [self.position_embeddings.weight]]
+        if self.category_embeddings is not None:
+            g.append([self.category_embeddings.weight])
+        return g + [[self.LayerNorm.weight], [self.LayerNorm.bias]]
+
+    def nacf_bind(self, flat, rt):
+        self._rt = rt
+        cat = self.category_embeddings
+        self._cfg = dict(word=flat.pack([self.word_embeddings.weight]), pos=flat.pack([self.position_embeddings.weight]),
+                         cat=flat.pack([cat.weight]) if cat is not None else None,
+                         ln=flat.pack([self.LayerNorm.weight], [self.LayerNorm.bias]), p=self.p, eps=self.eps,
+                         salt=rt.next_salt(), train_word=self.word_embeddings.weight.requires_grad)
+        self._params = [p for p in self.parameters()]
+
+    def run(self, tokens, category, additional, vdiv, vmod, training):
+        cfg = dict(self._cfg, vdiv=vdiv, vmod=vmod, training=training, rng=self._rt.rng(tokens.device))
+        if self.category_embeddings is not None:
+            assert category is not None, 'with_category models need `category`'
+            category = category.reshape(-1).contiguous()
+        return EmbedLNFn.apply(additional, cfg, tokens, category, *self._params)
+
+
+class _SelfAttnParams(nn.Module):
+    def __init__(self, d):
+        super().__init__()
+        self.query, self.key, self.value = nn.Linear(d, d), nn.Linear(d, d), nn.Linear(d, d)
+
+
+class _SelfOutputParams(nn.Module):
+    def __init__(self, d):
+        super().__init__()
+        self.dense = nn.Linear(d, d)
+
+
+class BertAttention(nn.Module):
+    """.self.{query,key,value} + .output.dense (bert.py:115-215)"""
+
+    def __init__(self, config):
+        super().__init__()
+        if config.dim_hidden % config.num_attention_heads != 0:
+            raise ValueError('The hidden size (%d) is not a multiple of the number of attention heads (%d)'
+                             % (config.dim_hidden, config.num_attention_heads))
+        self.self = _SelfAttnParams(config.dim_hidden)
+        self.output = _SelfOutputParams(config.dim_hidden)
+
+
+class _Dense(nn.Module):
+    def __init__(self, i, o):
+        super().__init__()
+        self.dense = nn.Linear(i, o)
+
+
+class BertLayer(nn.Module):
+    def __init__(self, config, is_decoder_layer=True):
+        super().__init__()
+        if config.with_layernorm or config.pos_attention or getattr(config, 'parallel_mlm', False):
+            raise NotImplementedError('nacf_amd: with_layernorm / pos_attention / parallel_mlm variants are not built '
+                                      '(reference defaults are off, opts.py:34-36)')
+        if config.attention_probs_dropout_prob != 0.0:
+            raise NotImplementedError('nacf_amd: attention_probs_dropout_prob must be 0 (reference default, opts.py:29)')
+        if config.hidden_act not in L.ACT_BY_NAME:
+            raise NotImplementedError('nacf_amd: hidden_act %s is not built' % config.hidden_act)
+        self.attention = BertAttention(config)
+        self.attend_to_enc_output = BertAttention(config)
+        self.intermediate = _Dense(config.dim_hidden, config.intermediate_size)
+        self.output = _Dense(config.intermediate_size, config.dim_hidden)
+        self.H = config.num_attention_heads
+        self.p = config.hidden_dropout_prob
+        self.act = L.ACT_BY_NAME[config.hidden_act]
+
+    def nacf_groups(self):
+        a, c = self.attention, self.attend_to_enc_output
+        return [
+            [a.self.query.weight, a.self.key.weight, a.self.value.weight],
+            [a.self.query.bias, a.self.key.bias, a.self.value.bias],
+            [a.output.dense.weight], [a.output.dense.bias],
+            [c.self.query.weight], [c.self.query.bias],
+            [c.self.key.weight, c.self.value.weight], [c.self.key.bias, c.self.value.bias],
+            [c.output.dense.weight], [c.output.dense.bias],
+            [self.intermediate.dense.weight], [self.intermediate.dense.bias],
+            [self.output.dense.weight], [self.output.dense.bias],
+        ]
+
+    def nacf_bind(self, flat, rt):
+        self._rt = rt
+        a, c = self.attention, self.attend_to_enc_output
+        self._pk = dict(
+            qkv=flat.pack([a.self.query.weight, a.self.key.weight, a.self.value.weight],
+                          [a.self.query.bias, a.self.key.bias, a.self.value.bias]),
+            so=flat.pack([a.output.dense.weight], [a.output.dense.bias]),
+            cq=flat.pack([c.self.query.weight], [c.self.query.bias]),
+            ckv=flat.pack([c.self.key.weight, c.self.value.weight], [c.self.key.bias, c.self.value.bias]),
+            co=flat.pack([c.output.dense.weight], [c.output.dense.bias]),
+            f1=flat.pack([self.intermediate.dense.weight], [self.intermediate.dense.bias]),
+            f2=flat.pack([self.output.dense.weight], [self.output.dense.bias]))
+        self._salts = [rt.next_salt() for _ in range(4)]
+        self._params = [p for p in self.parameters()]
+
+    def project_memory(self, enc_output):
+        """K|V projection of the visual memory: [Bv, M, D] -> [Bv*M, 2D]"""
+        Bv, M, D = enc_output.shape
+        return LinearFn.apply(enc_output.reshape(Bv * M, D), None, dict(pack=self._pk['ckv']), *self._params)
+
+    def run(self, x2, tokens, causal, memory_kv, M, vdiv, vmod, training, want_probs):
+        """x2: [R*L, D] hidden rows; tokens: [R, L]; memory_kv: [Bv*M, 2D]."""
+        R, Lq = tokens.shape
+        rng = self._rt.rng(x2.device)
+        tok_flat = tokens.reshape(-1)
+        P = self._params
+        pk = self._pk
+        s = self._salts
+        qkv = LinearFn.apply(x2, None, dict(pack=pk['qkv']), *P)
+        att, p_self = SelfAttentionFn.apply(qkv, tokens, int(causal), self.H, want_probs)
+        a = LinearFn.apply(att, x2, dict(pack=pk['so'], p1=self.p, salt1=s[0], row_tokens=tok_flat, rng=rng,
+                                         training=training), *P)
+        q = LinearFn.apply(a, None, dict(pack=pk['cq']), *P)
+        catt, p_cross = CrossAttentionFn.apply(q, memory_kv, self.H, Lq, M, vdiv, vmod, want_probs)
+        c = LinearFn.apply(catt, a, dict(pack=pk['co'], p1=self.p, salt1=s[1], row_tokens=tok_flat, rng=rng,
+                                         training=training), *P)
+        u = LinearFn.apply(c, None, dict(pack=pk['f1'], act=self.act), *P)
+        y = LinearFn.apply(u, c, dict(pack=pk['f2'], p1=self.p, salt1=s[2], p2=self.p, salt2=s[3], row_tokens=tok_flat,
+                                      rng=rng, training=training), *P)
+        return y, (p_self, p_cross)

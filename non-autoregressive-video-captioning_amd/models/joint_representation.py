@@ -1,0 +1,46 @@
+"""Feature fusion: per-modality BatchNorm1d over the flattened B*F rows, then
+temporal concatenation (reference: models/joint_representation.py:5-53).
+One kernel sequence per modality normalises and writes straight into its slice
+of the [B, sum F, D] memory (`BNConcatFn`)."""
+import torch
+import torch.nn as nn
+
+from ..runtime.functional import BNConcatFn
+
+
+class Joint_Representaion_Learner(nn.Module):  # (sic) upstream spelling is part of the state_dict contract
+    def __init__(self, feats_size, opt):
+        super().__init__()
+        self.fusion = opt.get('fusion', 'temporal_concat')
+        if self.fusion not in ('temporal_concat', 'none'):
+            # 'addition' asserts inside the reference itself (joint_representation.py:41)
+            raise ValueError('nacf_amd supports fusion temporal_concat | none (got %s)' % self.fusion)
+        self.norm_list = []
+        self.is_bn = opt.get('norm_type', 'bn').lower() == 'bn'
+        if not opt['no_encoder_bn'] and self.fusion != 'none':
+            if not self.is_bn:
+                raise NotImplementedError('nacf_amd: norm_type=ln fusion is not built yet (reference default is bn)')
+            for i, item in enumerate(feats_size):
+                m = nn.BatchNorm1d(item)
+                self.norm_list.append(m)
+                self.add_module('bn%d' % i, m)
+        self._packs = None
+
+    def nacf_groups(self):
+        return [[p] for m in self.norm_list for p in (m.weight, m.bias)]
+
+    def nacf_bind(self, flat, rt):
+        self._packs = [flat.pack([m.weight], [m.bias]) for m in self.norm_list]
+
+    def forward(self, encoder_outputs, encoder_hiddens=None):
+        if not isinstance(encoder_outputs, (list, tuple)):
+            encoder_outputs = [encoder_outputs]
+        if not self.norm_list:
+            return torch.cat(list(encoder_outputs), dim=1), encoder_hiddens  # pure data movement
+        assert len(encoder_outputs) == len(self.norm_list)
+        mods = [dict(pack=pk, running_mean=m.running_mean, running_var=m.running_var, nbt=m.num_batches_tracked)
+                for pk, m in zip(self._packs, self.norm_list)]
+        cfg = dict(mods=mods, training=self.training, momentum=self.norm_list[0].momentum, eps=self.norm_list[0].eps)
+        params = [p for m in self.norm_list for p in (m.weight, m.bias)]
+        out = BNConcatFn.apply(cfg, len(encoder_outputs), *encoder_outputs, *params)
+        return out, encoder_hiddens

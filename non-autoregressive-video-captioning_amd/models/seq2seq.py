@@ -1,0 +1,149 @@
+"""Seq2Seq wrapper: same surface as the reference (models/seq2seq.py:7-140) --
+`encode`, `prepare_inputs_for_decoder`, `forward(**kwargs)` dispatching on
+opt['decoding_type'] -- over the HIP operators.
+
+Additions that do not change the reference call convention:
+  * every parameter lives in ONE flat fp32 buffer (`self.flat.data`) and every
+    gradient in a second one (`self.flat.grad`): a single RCCL all-reduce
+    bucket and a single fused clip+Adam launch;
+  * opt['fused_loss'] (default False): skip materialising the [B, L, V]
+    log-probs and hand the criterion (`nacf_amd.misc.crit`) the hidden states,
+    which it turns into loss / word-accuracy / perplexity with the fused
+    vocabulary-projection + NLL operator.
+"""
+import torch
+import torch.nn as nn
+
+from ..config import Constants
+from ..runtime.functional import MeanTimeFn, VocabLogProbFn
+from ..runtime.state import FlatParams, Runtime
+
+
+class Seq2Seq(nn.Module):
+    def __init__(self, opt, preEncoder=None, encoder=None, joint_representation_learner=None,
+                 auxiliary_task_predictor=None, decoder=None, tgt_word_prj=None, **kwargs):
+        super().__init__()
+        assert preEncoder is None
+        self.opt = opt
+        self.preEncoder = preEncoder
+        self.encoder = encoder
+        self.joint_representation_learner = joint_representation_learner
+        self.auxiliary_task_predictor = auxiliary_task_predictor
+        self.decoder = decoder
+        self.tgt_word_prj = tgt_word_prj
+        if opt.get('tie_weights', False):
+            self._tie_weights(opt['vocab_size'])
+        self.rt = Runtime(seed=opt.get('seed', 0))
+        self.flat = None
+        self._flatten()
+
+    def _tie_weights(self, vocab_size):
+        word_embeddings = self.decoder.get_word_embeddings()
+        self.tgt_word_prj.weight = word_embeddings.weight
+        self.tgt_word_prj.bias = nn.Parameter(torch.zeros(vocab_size).float(), requires_grad=True)
+
+    # ------------------------------------------------------------- flat buffers
+    def _parts(self):
+        return [m for m in (self.encoder, self.joint_representation_learner, self.auxiliary_task_predictor,
+                            self.decoder) if m is not None]
+
+    def _flatten(self):
+        groups = [g for m in self._parts() for g in m.nacf_groups()]
+        groups.append([self.tgt_word_prj.weight])
+        if self.tgt_word_prj.bias is not None:
+            groups.append([self.tgt_word_prj.bias])
+        covered = {id(p) for g in groups for p in g}
+        missing = [n for n, p in self.named_parameters() if id(p) not in covered]
+        assert not missing, 'parameters outside the flat layout: %s' % missing
+        self.flat = FlatParams(groups)
+        for m in self._parts():
+            m.nacf_bind(self.flat, self.rt)
+        self._vocab_pack = self.flat.pack([self.tgt_word_prj.weight],
+                                          [self.tgt_word_prj.bias] if self.tgt_word_prj.bias is not None else None)
+
+    def _apply(self, fn, *args, **kwargs):
+        out = super()._apply(fn, *args, **kwargs)
+        self._flatten()  # .to()/.cuda() re-homes the tensors: rebuild the flat views on the new device
+        return out
+
+    def zero_grad(self, set_to_none=False):
+        self.flat.attach_grads(zero=True)
+
+    def _ensure_grads(self):
+        if not self.flat.grads_attached():
+            self.flat.attach_grads(zero=True)
+
+    # ------------------------------------------------------------- reference surface
+    def encode(self, feats, **kwargs):
+        results = {}
+        if self.opt.get('automatic_mask', False):
+            raise NotImplementedError('nacf_amd: automatic_mask is not built')
+        enc_streams, _ = self.encoder([f.contiguous() for f in feats])
+        with torch.no_grad():  # mean-over-time hidden: only LSTM decoders consume it (seq2seq.py:66-68)
+            hid = [MeanTimeFn.apply(s.detach()) for s in enc_streams]
+            enc_hidden = torch.stack(hid, dim=0).mean(0)
+        if self.joint_representation_learner is not None:
+            enc_output, enc_hidden = self.joint_representation_learner(enc_streams, enc_hidden)
+        else:
+            enc_output = torch.cat(enc_streams, dim=1)
+        pooled = MeanTimeFn.apply(enc_output)
+        if self.auxiliary_task_predictor is not None:
+            results.update(self.auxiliary_task_predictor(enc_output=enc_output, pooled=pooled))
+        results['enc_output'] = enc_output
+        results['enc_hidden'] = enc_hidden
+        results['_pooled_memory'] = pooled
+        return results
+
+    def prepare_inputs_for_decoder(self, encoder_outputs, category):
+        inputs_for_decoder = {'category': category, 'enc_output': encoder_outputs['enc_output']}
+        if isinstance(inputs_for_decoder['enc_output'], list):
+            assert len(inputs_for_decoder['enc_output']) == 1
+            inputs_for_decoder['enc_output'] = inputs_for_decoder['enc_output'][0]
+        return inputs_for_decoder
+
+    def vocab_logprobs(self, hidden):
+        """tgt_word_prj + log_softmax on [.., L, D] hidden states -> [.., L, V] log-probs"""
+        shape = hidden.shape
+        params = [p for p in self.tgt_word_prj.parameters()]
+        lp = VocabLogProbFn.apply(hidden.reshape(-1, shape[-1]), dict(pack=self._vocab_pack), *params)
+        return lp.view(*shape[:-1], lp.shape[-1])
+
+    def forward(self, **kwargs):
+        func_name = 'forward_' + self.opt['decoding_type']
+        fn = getattr(self, func_name, None)
+        if fn is None:
+            raise NotImplementedError('nacf_amd: decoding_type %s is not built' % self.opt['decoding_type'])
+        return fn(kwargs)
+
+    def _run(self, feats, tgt_tokens, category, decoding_type):
+        if self.training:
+            self._ensure_grads()
+            self.rt.rng(feats[0].device)
+            self.rt.advance()
+        results = self.encode(feats)
+        inputs_for_decoder = self.prepare_inputs_for_decoder(results, category)
+        hidden_states, embs, *_ = self.decoder(tgt_tokens, decoding_type=decoding_type,
+                                               pooled_memory=results['_pooled_memory'], **inputs_for_decoder)
+        if not isinstance(hidden_states, list):
+            hidden_states = [hidden_states]
+        if self.opt.get('fused_loss', False):
+            results['_nacf_hidden'] = hidden_states
+            results['_nacf_vocab'] = (self._vocab_pack, [p for p in self.tgt_word_prj.parameters()])
+        else:
+            results[Constants.mapping['lang'][0]] = [self.vocab_logprobs(h) for h in hidden_states]
+        return results
+
+    def forward_NARFormer(self, kwargs):
+        feats, tgt_tokens, category = (kwargs.get(k, None) for k in ('feats', 'tgt_tokens', 'category'))
+        return self._run(feats, tgt_tokens, category, 'NARFormer')
+
+    def forward_ARFormer(self, kwargs):
+        feats, tgt_tokens, category = (kwargs.get(k, None) for k in ('feats', 'tgt_tokens', 'category'))
+        decoding_type = kwargs.get('decoding_type', self.opt['decoding_type'])
+        if decoding_type != 'ARFormer':
+            raise NotImplementedError('nacf_amd: decoding_type %s is not built' % decoding_type)
+        if isinstance(tgt_tokens, (list, tuple)):   # teacher forcing: feed tokens[:, :-1] (seq2seq.py:120)
+            tgt_tokens = [t[:, :-1].contiguous() for t in tgt_tokens]
+        else:
+            tgt_tokens = tgt_tokens[:, :-1].contiguous()
+        return self._run(feats, tgt_tokens, category, 'ARFormer')

@@ -1,0 +1,432 @@
+"""torch.autograd.Function wrappers: each forward/backward is a short sequence
+of libnacf_hip launches.  Autograd is used only to chain them (plumbing).
+
+Parameter gradients are written by the kernels straight into the model's flat
+gradient buffer (views handed over in ``Pack`` objects, beta = 1 accumulate),
+so the optimiser and the RCCL all-reduce see one contiguous fp32 bucket; the
+Functions therefore return ``None`` for parameter inputs, which are passed
+only to connect the autograd graph.
+"""
+from __future__ import annotations
+
+from typing import List, Optional
+
+import torch
+from torch.autograd import Function
+
+from . import lib as L
+from . import ops
+
+Tensor = torch.Tensor
+
+
+class Pack:
+    """A (possibly packed) weight/bias pair living in the flat buffers:
+    ``w``/``b`` are data views, ``gw``/``gb`` the matching gradient views."""
+    __slots__ = ("w", "b", "gw", "gb")
+
+    def __init__(self, w, b, gw, gb):
+        self.w, self.b, self.gw, self.gb = w, b, gw, gb
+
+
+def _new(shape, like: Tensor, dtype=torch.float32) -> Tensor:
+    return torch.empty(shape, dtype=dtype, device=like.device)
+
+
+def _c2d(t: Tensor, rows: int, cols: int) -> Tensor:
+    t = t.reshape(rows, cols)
+    return t if t.stride(1) == 1 and t.stride(0) >= cols else t.contiguous()
+
+
+# ---------------------------------------------------------------- encoder
+class EncoderStreamFn(Function):
+    """Linear(2048->D) -> HighWay -> Dropout for one modality
+    (models/Encoder.py:9-25,62-66)."""
+
+    @staticmethod
+    def forward(ctx, x, cfg, *params):
+        B, F, Din = x.shape
+        p0: Pack = cfg["lin"]
+        p12: Pack = cfg["hw"]
+        D = p0.w.shape[0]
+        x2 = _c2d(x, B * F, Din)
+        h = _new((B * F, D), x)
+        ops.linear_fwd(x2, p0.w, h, ops.Epi(bias=p0.b))
+        tg = _new((B * F, 2 * D), x)
+        ops.linear_fwd(h, p12.w, tg, ops.Epi(bias=p12.b, act=L.ACT_TANH_SIGMOID, act_split=D))
+        out = _new((B * F, D), x)
+        p = cfg["p"] if cfg["training"] else 0.0
+        ops.highway_mix_fwd(h, tg, out, p, cfg["salt"], cfg["rng"])
+        ctx.cfg, ctx.p = cfg, p
+        ctx.x2, ctx.h, ctx.tg = x2, h, tg
+        ctx.shape = (B, F, Din)
+        return out.view(B, F, D)
+
+    @staticmethod
+    def backward(ctx, dout):
+        cfg = ctx.cfg
+        p0: Pack = cfg["lin"]
+        p12: Pack = cfg["hw"]
+        B, F, Din = ctx.shape
+        D = p0.w.shape[0]
+        d2 = _c2d(dout, B * F, D)
+        dh = _new((B * F, D), d2)
+        dp = _new((B * F, 2 * D), d2)
+        ops.highway_mix_bwd(d2, ctx.h, ctx.tg, dh, dp, ctx.p, cfg["salt"], cfg["rng"])
+        ops.linear_bwd_data(dp, p12.w, dh, beta=1.0)
+        ops.linear_bwd_weight(dp, ctx.h, p12.gw, p12.gb, beta=1.0)
+        ops.linear_bwd_weight(dh, ctx.x2, p0.gw, p0.gb, beta=1.0)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = _new((B * F, Din), d2)
+            ops.linear_bwd_data(dh, p0.w, dx)
+            dx = dx.view(B, F, Din)
+        ctx.x2 = ctx.h = ctx.tg = None
+        return (dx, None) + (None,) * (len(ctx.needs_input_grad) - 2)
+
+
+class BNConcatFn(Function):
+    """per-modality BatchNorm1d over B*F rows + temporal concat
+    (models/joint_representation.py:40-51)."""
+
+    @staticmethod
+    def forward(ctx, cfg, n_mod, *args):
+        xs = [a.contiguous() for a in args[:n_mod]]
+        B, _, D = xs[0].shape
+        M_total = sum(x.shape[1] for x in xs)
+        out = _new((B, M_total, D), xs[0])
+        saves = []
+        f_off = 0
+        for i, x in enumerate(xs):
+            m = cfg["mods"][i]
+            sm = _new((D,), x) if cfg["training"] else None
+            si = _new((D,), x) if cfg["training"] else None
+            ops.bn_concat_fwd(x, out, f_off, m["pack"].w, m["pack"].b, m["running_mean"], m["running_var"],
+                              m["nbt"], sm, si, cfg["training"], cfg.get("momentum", 0.1), cfg.get("eps", 1e-5))
+            saves.append((x, f_off, sm, si))
+            f_off += x.shape[1]
+        ctx.cfg, ctx.saves, ctx.n_mod = cfg, saves, n_mod
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        cfg = ctx.cfg
+        if not cfg["training"]:
+            raise L.NacfLibraryError("BNConcatFn.backward in eval mode is not supported")
+        dout = dout.contiguous()
+        grads: List[Optional[Tensor]] = []
+        for i, (x, f_off, sm, si) in enumerate(ctx.saves):
+            pk: Pack = cfg["mods"][i]["pack"]
+            dx = torch.empty_like(x)
+            ops.bn_concat_bwd(dout, x, dx, f_off, pk.w, sm, si, pk.gw, pk.gb, beta=1.0)
+            grads.append(dx if ctx.needs_input_grad[2 + i] else None)
+        ctx.saves = None
+        return (None, None) + tuple(grads) + (None,) * (len(ctx.needs_input_grad) - 2 - ctx.n_mod)
+
+
+class MeanTimeFn(Function):
+    @staticmethod
+    def forward(ctx, x):
+        x = x.contiguous()
+        B, T, D = x.shape
+        ctx.shape = (B, T, D)
+        return ops.mean_time_fwd(x, _new((B, D), x))
+
+    @staticmethod
+    def backward(ctx, dout):
+        dx = _new(ctx.shape, dout)
+        ops.mean_time_bwd(dout.contiguous(), dx, accumulate=False)
+        return dx
+
+
+class LengthHeadFn(Function):
+    """Predictor_length, models/Predictor.py:12-30."""
+
+    @staticmethod
+    def forward(ctx, pooled, cfg, *params):
+        p1: Pack = cfg["l1"]
+        p2: Pack = cfg["l2"]
+        B, D = pooled.shape
+        pooled = pooled.contiguous()
+        pre = _new((B, p1.w.shape[0]), pooled)
+        h = _new((B, p1.w.shape[0]), pooled)
+        p = cfg["p"] if cfg["training"] else 0.0
+        epi = ops.Epi(bias=p1.b, act=L.ACT_RELU, preact=pre, p1=p, salt1=cfg["salt"], rng=cfg["rng"])
+        ops.linear_fwd(pooled, p1.w, h, epi)
+        z = _new((B, p2.w.shape[0]), pooled)
+        ops.linear_fwd(h, p2.w, z, ops.Epi(bias=p2.b))
+        ops.log_softmax_rows(z, z)
+        ctx.cfg, ctx.epi = cfg, epi
+        ctx.pooled, ctx.h, ctx.logp = pooled, h, z
+        return z
+
+    @staticmethod
+    def backward(ctx, dlogp):
+        cfg = ctx.cfg
+        p1: Pack = cfg["l1"]
+        p2: Pack = cfg["l2"]
+        dz = torch.empty_like(ctx.logp)
+        ops.log_softmax_rows_bwd(dlogp.contiguous(), ctx.logp, dz)
+        dh = torch.empty_like(ctx.h)
+        ops.linear_bwd_data(dz, p2.w, dh)
+        ops.linear_bwd_weight(dz, ctx.h, p2.gw, p2.gb, beta=1.0)
+        ops.epilogue_bwd(dh, dh, None, ctx.epi)
+        dpooled = torch.empty_like(ctx.pooled)
+        ops.linear_bwd_data(dh, p1.w, dpooled)
+        ops.linear_bwd_weight(dh, ctx.pooled, p1.gw, p1.gb, beta=1.0)
+        return (dpooled, None) + (None,) * (len(ctx.needs_input_grad) - 2)
+
+
+# ---------------------------------------------------------------- decoder
+class EmbedLNFn(Function):
+    """BertEmbeddings, models/bert.py:70-96."""
+
+    @staticmethod
+    def forward(ctx, additional, cfg, tokens, category, *params):
+        R, Lq = tokens.shape
+        word, pos, cat = cfg["word"], cfg["pos"], cfg["cat"]
+        D = word.w.shape[1]
+        training = cfg["training"]
+        out = _new((R, Lq, D), word.w)
+        xhat = _new((R * Lq, D), word.w) if training else None
+        rstd = _new((R * Lq,), word.w) if training else None
+        p = cfg["p"] if training else 0.0
+        add = additional.contiguous() if additional is not None else None
+        ops.embed_ln_fwd(tokens, category if cat is not None else None, add, word.w, pos.w,
+                         cat.w if cat is not None else None, cfg["ln"].w, cfg["ln"].b, out, xhat, rstd,
+                         cfg["vdiv"], cfg["vmod"], cfg["eps"], p, cfg["salt"], cfg["rng"])
+        ctx.cfg, ctx.p = cfg, p
+        ctx.tokens, ctx.category, ctx.xhat, ctx.rstd = tokens, category, xhat, rstd
+        ctx.n_video = additional.shape[0] if additional is not None else 0
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        cfg = ctx.cfg
+        word, pos, cat, ln = cfg["word"], cfg["pos"], cfg["cat"], cfg["ln"]
+        R, Lq = ctx.tokens.shape
+        D = word.w.shape[1]
+        dE = _new((R * Lq, D), dout)
+        ops.embed_ln_bwd(dout.contiguous(), ctx.xhat, ctx.rstd, ln.w, dE, ln.gw, ln.gb, R, Lq, D, ctx.p,
+                         cfg["salt"], cfg["rng"], beta=1.0)
+        dadd = _new((ctx.n_video, D), dout) if (ctx.n_video and ctx.needs_input_grad[0]) else None
+        ops.embed_scatter_bwd(dE, ctx.tokens, ctx.category if cat is not None else None,
+                              word.gw if cfg.get("train_word", True) else None, pos.gw,
+                              cat.gw if cat is not None else None, dadd, R, Lq, D, word.w.shape[0],
+                              cat.w.shape[0] if cat is not None else 0, ctx.n_video, cfg["vdiv"], cfg["vmod"])
+        ctx.xhat = ctx.rstd = None
+        return (dadd, None, None, None) + (None,) * (len(ctx.needs_input_grad) - 4)
+
+
+class LinearFn(Function):
+    """nn.Linear with the fused epilogue of nacf_linear_fwd.
+    cfg keys: pack, act, p1, salt1, p2, salt2, row_tokens, rng, training."""
+
+    @staticmethod
+    def forward(ctx, x, residual, cfg, *params):
+        pk: Pack = cfg["pack"]
+        M, K = x.shape
+        N = pk.w.shape[0]
+        x = _c2d(x, M, K)
+        training = cfg.get("training", False)
+        act = cfg.get("act", L.ACT_NONE)
+        need_bwd = any(ctx.needs_input_grad)
+        pre = _new((M, N), x) if (act != L.ACT_NONE and need_bwd) else None
+        res = _c2d(residual, M, N) if residual is not None else None
+        epi = ops.Epi(bias=pk.b, act=act, preact=pre,
+                      p1=cfg.get("p1", 0.0) if training else 0.0, salt1=cfg.get("salt1", 0),
+                      residual=res, p2=cfg.get("p2", 0.0) if training else 0.0, salt2=cfg.get("salt2", 0),
+                      row_tokens=cfg.get("row_tokens"), rng=cfg.get("rng"))
+        out = _new((M, N), x)
+        ops.linear_fwd(x, pk.w, out, epi)
+        ctx.cfg, ctx.epi, ctx.x = cfg, epi, x
+        ctx.has_res = residual is not None
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        cfg, epi = ctx.cfg, ctx.epi
+        pk: Pack = cfg["pack"]
+        M, K = ctx.x.shape
+        N = pk.w.shape[0]
+        dy = _c2d(dy, M, N)
+        trivial = (epi.act == L.ACT_NONE and epi.p1 == 0.0 and epi.p2 == 0.0 and epi.row_tokens is None
+                   and not ctx.has_res)
+        dr = None
+        if trivial:
+            dz = dy
+        else:
+            dz = _new((M, N), dy)
+            dr = _new((M, N), dy) if ctx.has_res else None
+            epi.residual = dr  # only its presence matters to the kernel
+            ops.epilogue_bwd(dy, dz, dr, epi)
+            epi.residual = None
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = _new((M, K), dy)
+            ops.linear_bwd_data(dz, pk.w, dx)
+        if pk.gw is not None:
+            ops.linear_bwd_weight(dz, ctx.x, pk.gw, pk.gb, beta=1.0)
+        ctx.x = None
+        epi.preact = None
+        return (dx, dr if ctx.needs_input_grad[1] else None, None) + (None,) * (len(ctx.needs_input_grad) - 3)
+
+
+class SelfAttentionFn(Function):
+    """softmax(QK^T/sqrt(dk) masked) V on a packed [rows, 3D] q|k|v buffer
+    (models/bert.py:150-179; masks models/Decoder.py:13-39,105-124)."""
+
+    @staticmethod
+    def forward(ctx, qkv, tokens, causal, H, want_probs):
+        R, Lq = tokens.shape
+        D = qkv.shape[1] // 3
+        dk = D // H
+        q, k, v = qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:]
+        out = _new((R * Lq, D), qkv)
+        probs = _new((H, R, Lq, Lq), qkv) if want_probs else None
+        ops.attention_fwd(q, k, v, out, tokens, causal, probs, R, H, Lq, Lq, dk, 1, R)
+        ctx.qkv, ctx.tokens, ctx.causal, ctx.H = qkv, tokens, causal, H
+        if want_probs:
+            ctx.mark_non_differentiable(probs)
+            return out, probs
+        return out, None
+
+    @staticmethod
+    def backward(ctx, do, _dprobs=None):
+        qkv, tokens = ctx.qkv, ctx.tokens
+        R, Lq = tokens.shape
+        D = qkv.shape[1] // 3
+        dk = D // ctx.H
+        do = _c2d(do, R * Lq, D)
+        dqkv = torch.empty_like(qkv)
+        ops.attention_bwd(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], do, dqkv[:, :D], dqkv[:, D:2 * D],
+                          dqkv[:, 2 * D:], tokens, ctx.causal, R, R, ctx.H, Lq, Lq, dk, 1, R)
+        ctx.qkv = None
+        return dqkv, None, None, None, None
+
+
+class CrossAttentionFn(Function):
+    """decoder -> visual memory attention; K|V are the packed projection of the
+    memory, computed once per video and shared by every row mapped to it."""
+
+    @staticmethod
+    def forward(ctx, q, kv, H, Lq, Lk, kv_div, kv_mod, want_probs):
+        D = q.shape[1]
+        dk = D // H
+        R = q.shape[0] // Lq
+        k, v = kv[:, :D], kv[:, D:]
+        out = _new((R * Lq, D), q)
+        probs = _new((H, R, Lq, Lk), q) if want_probs else None
+        ops.attention_fwd(q, k, v, out, None, 0, probs, R, H, Lq, Lk, dk, kv_div, kv_mod)
+        ctx.q, ctx.kv = q, kv
+        ctx.dims = (R, H, Lq, Lk, dk, kv_div, kv_mod)
+        if want_probs:
+            ctx.mark_non_differentiable(probs)
+            return out, probs
+        return out, None
+
+    @staticmethod
+    def backward(ctx, do, _dprobs=None):
+        R, H, Lq, Lk, dk, kv_div, kv_mod = ctx.dims
+        q, kv = ctx.q, ctx.kv
+        D = q.shape[1]
+        n_kv = kv.shape[0] // Lk
+        do = _c2d(do, R * Lq, D)
+        dq = torch.empty_like(q)
+        dkv = torch.empty_like(kv)
+        ops.attention_bwd(q, kv[:, :D], kv[:, D:], do, dq, dkv[:, :D], dkv[:, D:], None, 0, R, n_kv, H, Lq, Lk, dk,
+                          kv_div, kv_mod)
+        ctx.q = ctx.kv = None
+        return dq, dkv, None, None, None, None, None, None
+
+
+# ---------------------------------------------------------------- vocabulary
+class VocabLogProbFn(Function):
+    """tgt_word_prj + log_softmax (models/seq2seq.py:102-103); returns real
+    [rows, V] log-probs so any criterion (incl. the reference's) can consume them."""
+
+    @staticmethod
+    def forward(ctx, h, cfg, *params):
+        pk: Pack = cfg["pack"]
+        rows, D = h.shape
+        V = pk.w.shape[0]
+        h = _c2d(h, rows, D)
+        buf = _new((rows, ops.vocab_ld(V)), h)
+        logits = buf[:, :V]
+        ops.linear_fwd(h, pk.w, logits, ops.Epi(bias=pk.b))
+        ops.vocab_logsoftmax_fwd(logits, V, None, None, None, None)
+        ctx.cfg, ctx.h, ctx.logp = cfg, h, logits
+        return logits
+
+    @staticmethod
+    def backward(ctx, dlogp):
+        pk: Pack = ctx.cfg["pack"]
+        rows, V = ctx.logp.shape
+        if dlogp.stride(1) != 1:
+            dlogp = dlogp.contiguous()
+        dbuf = _new((rows, ops.vocab_ld(V)), dlogp)
+        if ops.vocab_ld(V) != V:
+            dbuf[:, V:].zero_()
+        dlogits = dbuf[:, :V]
+        ops.vocab_logsoftmax_bwd(dlogp, ctx.logp, dlogits, V)
+        dh = torch.empty_like(ctx.h)
+        ops.linear_bwd_data(dlogits, pk.w, dh)
+        ops.linear_bwd_weight(dlogits, ctx.h, pk.gw, pk.gb, beta=1.0)
+        ctx.h = ctx.logp = None
+        return (dh, None) + (None,) * (len(ctx.needs_input_grad) - 2)
+
+
+class FusedVocabXentFn(Function):
+    """Vocabulary projection + log-softmax + NLL in one Function (K9): returns
+    stats[5] = (token-sum NLL, acc hits, acc count, sum logp, token count)
+    (misc/crit.py:62-114); the [rows, V] buffer is reused for the gradient."""
+
+    @staticmethod
+    def forward(ctx, h, cfg, labels, exclude_mask, *params):
+        pk: Pack = cfg["pack"]
+        rows, D = h.shape
+        V = pk.w.shape[0]
+        h = _c2d(h, rows, D)
+        labels = labels.reshape(-1).contiguous()
+        buf = _new((rows, ops.vocab_ld(V)), h)
+        if ops.vocab_ld(V) != V:
+            buf[:, V:].zero_()
+        logits = buf[:, :V]
+        ops.linear_fwd(h, pk.w, logits, ops.Epi(bias=pk.b))
+        label_logp = _new((rows,), h)
+        argmax = _new((rows,), h, torch.int64)
+        ops.vocab_logsoftmax_fwd(logits, V, labels, None, argmax, label_logp)
+        stats = _new((5,), h)
+        ops.nll_reduce(label_logp, argmax, labels, exclude_mask, stats)
+        ctx.cfg, ctx.h, ctx.logp, ctx.labels = cfg, h, logits, labels
+        return stats
+
+    @staticmethod
+    def backward(ctx, dstats):
+        pk: Pack = ctx.cfg["pack"]
+        rows, V = ctx.logp.shape
+        dstats = dstats.contiguous()
+        ops.xent_bwd(ctx.logp, ctx.logp, V, ctx.labels, dstats, 1.0)  # in place: logp -> dlogits * dstats[0]
+        dh = torch.empty_like(ctx.h)
+        ops.linear_bwd_data(ctx.logp, pk.w, dh)
+        ops.linear_bwd_weight(ctx.logp, ctx.h, pk.gw, pk.gb, beta=1.0)
+        ctx.h = ctx.logp = None
+        return (dh, None, None, None) + (None,) * (len(ctx.needs_input_grad) - 4)
+
+
+class KLDivMeanFn(Function):
+    """legacy nn.KLDivLoss() ('mean' over all elements), misc/crit.py:223."""
+
+    @staticmethod
+    def forward(ctx, x, t):
+        x, t = x.contiguous(), t.contiguous()
+        out = _new((1,), x)
+        ops.kldiv_mean(x, t, out, None)
+        ctx.x, ctx.t = x, t
+        return out.view(())
+
+    @staticmethod
+    def backward(ctx, dout):
+        dx = torch.empty_like(ctx.x)
+        ops.kldiv_mean(ctx.x, ctx.t, None, dx, gscale=dout.reshape(1).contiguous())
+        return dx, None

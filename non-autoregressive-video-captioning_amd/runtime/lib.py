@@ -1,0 +1,117 @@
+"""ctypes binding of libnacf_hip.so (the C ABI declared in include/nacf_hip.h).
+
+The product path has NO fallback: if the shared library is missing or an entry
+point fails, this raises -- it never routes around the HIP kernels.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import POINTER, c_char_p, c_float, c_int, c_int32, c_int64, c_size_t, c_uint32, c_void_p
+
+_PKG_DIR = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LIB_PATH = os.path.join(_PKG_DIR, "libnacf_hip.so")
+
+# activations (nacf_hip.h)
+ACT_NONE, ACT_RELU, ACT_GELU_NEW, ACT_TANH, ACT_SIGMOID, ACT_TANH_SIGMOID, ACT_GELU_ERF = range(7)
+ACT_BY_NAME = {"gelu_new": ACT_GELU_NEW, "gelu": ACT_GELU_ERF, "relu": ACT_RELU}
+
+
+class Epilogue(ctypes.Structure):
+    """struct nacf_epilogue."""
+    _fields_ = [
+        ("bias", c_void_p), ("act", c_int32), ("act_split", c_int32),
+        ("preact", c_void_p), ("ld_preact", c_int64),
+        ("p_drop1", c_float), ("salt1", c_uint32),
+        ("residual", c_void_p), ("ld_residual", c_int64),
+        ("p_drop2", c_float), ("salt2", c_uint32),
+        ("row_tokens", c_void_p), ("rng_state", c_void_p),
+    ]
+
+
+_P, _I, _L, _F, _U, _S = c_void_p, c_int, c_int64, c_float, c_uint32, c_size_t
+_EP = POINTER(Epilogue)
+
+# name -> (restype, argtypes); mirrors include/nacf_hip.h one to one
+SIGNATURES = {
+    "nacf_last_error": (c_char_p, []),
+    "nacf_version": (c_int, []),
+    "nacf_abi_count": (c_int, []),
+    "nacf_rng_advance": (c_int, [_P, _P]),
+    "nacf_linear_fwd": (c_int, [_P, _L, _P, _L, _P, _L, _I, _I, _I, _EP, _P]),
+    "nacf_linear_bwd_data": (c_int, [_P, _L, _P, _L, _P, _L, _I, _I, _I, _F, _P]),
+    "nacf_linear_bwd_weight_workspace": (_S, [_I, _I, _I]),
+    "nacf_linear_bwd_weight": (c_int, [_P, _L, _P, _L, _P, _L, _P, _I, _I, _I, _F, _P, _S, _P]),
+    "nacf_epilogue_bwd": (c_int, [_P, _L, _P, _L, _P, _L, _I, _I, _I, _EP, _P]),
+    "nacf_highway_mix_fwd": (c_int, [_P, _P, _P, _I, _I, _F, _U, _P, _P]),
+    "nacf_highway_mix_bwd": (c_int, [_P, _P, _P, _P, _P, _I, _I, _F, _U, _P, _P]),
+    "nacf_bn_workspace": (_S, [_I, _I]),
+    "nacf_bn_concat_fwd": (c_int, [_P, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _I, _F, _F, _P, _S, _P]),
+    "nacf_bn_concat_bwd": (c_int, [_P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _F, _P, _S, _P]),
+    "nacf_mean_time_fwd": (c_int, [_P, _P, _I, _I, _I, _P]),
+    "nacf_mean_time_bwd": (c_int, [_P, _P, _I, _I, _I, _I, _P]),
+    "nacf_log_softmax_rows": (c_int, [_P, _P, _I, _I, _P]),
+    "nacf_log_softmax_rows_bwd": (c_int, [_P, _P, _P, _I, _I, _P]),
+    "nacf_kldiv_mean": (c_int, [_P, _P, _P, _P, _P, _F, _I, _I, _P]),
+    "nacf_embed_ln_fwd": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _F, _U, _P, _P]),
+    "nacf_embed_ln_bwd_workspace": (_S, [_I, _I, _I]),
+    "nacf_embed_ln_bwd": (c_int, [_P, _P, _P, _P, _P, _P, _P, _F, _I, _I, _I, _F, _U, _P, _P, _S, _P]),
+    "nacf_embed_scatter_bwd": (c_int, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "nacf_attention_fwd": (c_int, [_P, _L, _P, _L, _P, _L, _P, _L, _P, _I, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "nacf_attention_bwd": (c_int, [_P, _L, _P, _L, _P, _L, _P, _L, _P, _L, _P, _L, _P, _L, _P, _I,
+                                   _I, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "nacf_masked_mean_fwd": (c_int, [_P, _P, _P, _I, _I, _I, _P]),
+    "nacf_vocab_logsoftmax_fwd": (c_int, [_P, _L, _I, _I, _P, _P, _P, _P, _P]),
+    "nacf_nll_reduce": (c_int, [_P, _P, _P, _I, _I, _P, _P]),
+    "nacf_xent_bwd": (c_int, [_P, _L, _P, _L, _I, _I, _P, _P, _F, _P]),
+    "nacf_vocab_logsoftmax_bwd": (c_int, [_P, _L, _P, _L, _P, _L, _I, _I, _P]),
+    "nacf_vocab_argmax_workspace": (_S, [_I, _I]),
+    "nacf_vocab_argmax": (c_int, [_P, _L, _P, _L, _P, _I, _I, _I, _P, _I, _P, _P, _P, _P, _S, _P]),
+    "nacf_length_beam": (c_int, [_P, _I, _I, _I, _I, _P, _P, _P]),
+    "nacf_canvas_init": (c_int, [_P, _I, _I, _P, _P]),
+    "nacf_select_mask": (c_int, [_P, _P, _P, _P, _I, _I, _I, _P, _P, _P]),
+    "nacf_token_replace": (c_int, [_P, _L, _L, _L, _P]),
+    "nacf_teacher_probs": (c_int, [_P, _P, _P, _L, _P]),
+    "nacf_init_probs": (c_int, [_P, _P, _L, _P]),
+    "nacf_apply_mask": (c_int, [_P, _P, _L, _L, _P]),
+    "nacf_mask_rank": (c_int, [_P, _I, _I, _P, _P, _P]),
+    "nacf_select_rank": (c_int, [_P, _I, _I, _I, _I, _P, _P, _P]),
+    "nacf_easy_first_update": (c_int, [_P, _P, _P, _P, _I, _I, _I, _P]),
+    "nacf_best_candidate": (c_int, [_P, _P, _P, _P, _F, _I, _I, _I, _P, _P, _P, _P]),
+    "nacf_adam_step": (c_int, [_P, _P, _P, _P, _L, _P, _P, _F, _F, _F, _F, _F, _F, _P]),
+}
+
+_lib = None
+
+
+class NacfLibraryError(RuntimeError):
+    pass
+
+
+def load() -> ctypes.CDLL:
+    """dlopen libnacf_hip.so and type every entry point.  Raises (never falls
+    back) when the library has not been built: run `python __graft_entry__.py`
+    or `make -C non-autoregressive-video-captioning_amd/csrc`."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise NacfLibraryError(
+            f"{LIB_PATH} not found: the HIP extension is not built. "
+            "Build it with `make -C non-autoregressive-video-captioning_amd/csrc` "
+            "(or `python -c 'import __graft_entry__ as g; g.build()'`). There is no CPU fallback.")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name, None)
+        if fn is None:
+            raise NacfLibraryError(f"{LIB_PATH} does not export {name}; rebuild the extension")
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str = "") -> None:
+    if rc != 0:
+        msg = load().nacf_last_error()
+        raise NacfLibraryError(f"{what} failed (code {rc}): {msg.decode() if msg else ''}")

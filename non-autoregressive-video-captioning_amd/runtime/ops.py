@@ -1,0 +1,384 @@
+"""Tensor-level wrappers over the C ABI (no autograd here).
+
+PyTorch is plumbing only: it owns device memory and the HIP stream; every
+computation below is a libnacf_hip kernel launched on torch's current stream.
+"""
+from __future__ import annotations
+
+import ctypes
+from typing import Optional
+
+import torch
+
+from . import lib as L
+
+Tensor = torch.Tensor
+
+
+def _stream() -> ctypes.c_void_p:
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _ptr(t: Optional[Tensor]):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def _chk_f32(*ts):
+    for t in ts:
+        if t is None:
+            continue
+        if not t.is_cuda:
+            raise L.NacfLibraryError("nacf ops need tensors on the HIP device (no CPU fallback)")
+        if t.dtype != torch.float32:
+            raise TypeError(f"expected float32, got {t.dtype}")
+
+
+def _rows2d(t: Tensor):
+    """(rows, cols, ld) of a 2-D view whose last dim is contiguous."""
+    assert t.dim() == 2 and t.stride(1) == 1, (t.shape, t.stride())
+    return t.shape[0], t.shape[1], t.stride(0)
+
+
+# ---------------------------------------------------------------- workspace
+class _Workspace:
+    """One grow-only scratch buffer per device; kernels on one stream run in
+    order, so consecutive ops can share it.  Must be warmed up (grown to its
+    final size) before a hipGraph capture."""
+
+    def __init__(self):
+        self.buf = {}
+
+    def get(self, nbytes: int, device) -> Tensor:
+        key = device.index if device.index is not None else torch.cuda.current_device()
+        b = self.buf.get(key)
+        if b is None or b.numel() < nbytes:
+            if torch.cuda.is_current_stream_capturing():
+                raise L.NacfLibraryError("workspace growth during graph capture: run a warm-up step first")
+            b = torch.empty(max(int(nbytes * 1.25), 1 << 20), dtype=torch.uint8, device=device)
+            self.buf[key] = b
+        return b
+
+
+WORKSPACE = _Workspace()
+
+
+class RngState:
+    """Device-side {seed, step} consumed by every dropout kernel."""
+
+    def __init__(self, seed: int, device):
+        self.state = torch.tensor([seed, 0], dtype=torch.int64, device=device)
+
+    def advance(self):
+        L.check(L.load().nacf_rng_advance(_ptr(self.state), _stream()), "nacf_rng_advance")
+
+
+# ---------------------------------------------------------------- linear
+class Epi:
+    """Python-side description of nacf_epilogue (kept alive through backward)."""
+    __slots__ = ("bias", "act", "act_split", "preact", "p1", "salt1", "residual", "p2", "salt2",
+                 "row_tokens", "rng")
+
+    def __init__(self, bias=None, act=L.ACT_NONE, act_split=0, preact=None, p1=0.0, salt1=0,
+                 residual=None, p2=0.0, salt2=0, row_tokens=None, rng: Optional[RngState] = None):
+        self.bias, self.act, self.act_split, self.preact = bias, act, act_split, preact
+        self.p1, self.salt1, self.residual, self.p2, self.salt2 = p1, salt1, residual, p2, salt2
+        self.row_tokens, self.rng = row_tokens, rng
+
+    def cstruct(self) -> L.Epilogue:
+        e = L.Epilogue()
+        e.bias = self.bias.data_ptr() if self.bias is not None else None
+        e.act, e.act_split = self.act, self.act_split
+        if self.preact is not None:
+            e.preact, e.ld_preact = self.preact.data_ptr(), self.preact.stride(0)
+        e.p_drop1, e.salt1 = float(self.p1), int(self.salt1) & 0xFFFFFFFF
+        if self.residual is not None:
+            e.residual, e.ld_residual = self.residual.data_ptr(), self.residual.stride(0)
+        e.p_drop2, e.salt2 = float(self.p2), int(self.salt2) & 0xFFFFFFFF
+        e.row_tokens = self.row_tokens.data_ptr() if self.row_tokens is not None else None
+        e.rng_state = self.rng.state.data_ptr() if self.rng is not None else None
+        return e
+
+
+def linear_fwd(x: Tensor, w: Tensor, out: Tensor, epi: Optional[Epi] = None) -> Tensor:
+    """out[M,N] = epilogue(x[M,K] @ w[N,K]^T)."""
+    _chk_f32(x, w, out)
+    M, K, ldx = _rows2d(x)
+    N, K2, ldw = _rows2d(w)
+    assert K == K2 and out.shape == (M, N), (x.shape, w.shape, out.shape)
+    ep = epi.cstruct() if epi is not None else L.Epilogue()
+    L.check(L.load().nacf_linear_fwd(_ptr(x), ldx, _ptr(w), ldw, _ptr(out), out.stride(0), M, N, K,
+                                     ctypes.byref(ep), _stream()), "nacf_linear_fwd")
+    return out
+
+
+def linear_bwd_data(dz: Tensor, w: Tensor, dx: Tensor, beta: float = 0.0) -> Tensor:
+    _chk_f32(dz, w, dx)
+    M, N, lddz = _rows2d(dz)
+    N2, K, ldw = _rows2d(w)
+    assert N == N2 and dx.shape == (M, K)
+    L.check(L.load().nacf_linear_bwd_data(_ptr(dz), lddz, _ptr(w), ldw, _ptr(dx), dx.stride(0), M, N, K,
+                                          float(beta), _stream()), "nacf_linear_bwd_data")
+    return dx
+
+
+def linear_bwd_weight(dz: Tensor, x: Tensor, dw: Tensor, db: Optional[Tensor], beta: float = 1.0) -> None:
+    _chk_f32(dz, x, dw, db)
+    M, N, lddz = _rows2d(dz)
+    M2, K, ldx = _rows2d(x)
+    assert M == M2 and dw.shape == (N, K), (dz.shape, x.shape, dw.shape)
+    lib = L.load()
+    need = lib.nacf_linear_bwd_weight_workspace(M, N, K)
+    ws = WORKSPACE.get(need, dz.device)
+    L.check(lib.nacf_linear_bwd_weight(_ptr(dz), lddz, _ptr(x), ldx, _ptr(dw), dw.stride(0), _ptr(db), M, N, K,
+                                       float(beta), _ptr(ws), ws.numel(), _stream()), "nacf_linear_bwd_weight")
+
+
+def epilogue_bwd(dy: Tensor, dz: Tensor, dr: Optional[Tensor], epi: Epi, accumulate_dr: bool = False) -> None:
+    _chk_f32(dy, dz, dr)
+    M, N, lddy = _rows2d(dy)
+    ep = epi.cstruct()
+    L.check(L.load().nacf_epilogue_bwd(_ptr(dy), lddy, _ptr(dz), dz.stride(0), _ptr(dr),
+                                       dr.stride(0) if dr is not None else 0, int(accumulate_dr), M, N,
+                                       ctypes.byref(ep), _stream()), "nacf_epilogue_bwd")
+
+
+# ---------------------------------------------------------------- encoder tail
+def highway_mix_fwd(h, tg, out, p, salt, rng):
+    _chk_f32(h, tg, out)
+    rows, D = h.shape
+    L.check(L.load().nacf_highway_mix_fwd(_ptr(h), _ptr(tg), _ptr(out), rows, D, float(p), int(salt),
+                                          _ptr(rng.state) if rng else None, _stream()), "nacf_highway_mix_fwd")
+    return out
+
+
+def highway_mix_bwd(dout, h, tg, dh, dp, p, salt, rng):
+    _chk_f32(dout, h, tg, dh, dp)
+    rows, D = h.shape
+    L.check(L.load().nacf_highway_mix_bwd(_ptr(dout), _ptr(h), _ptr(tg), _ptr(dh), _ptr(dp), rows, D, float(p),
+                                          int(salt), _ptr(rng.state) if rng else None, _stream()),
+            "nacf_highway_mix_bwd")
+
+
+def bn_concat_fwd(x, out, f_off, weight, bias, running_mean, running_var, nbt, save_mean, save_invstd,
+                  training, momentum=0.1, eps=1e-5):
+    _chk_f32(x, out, weight, bias, running_mean, running_var, save_mean, save_invstd)
+    B, F, D = x.shape
+    M_total = out.shape[1]
+    lib = L.load()
+    ws = WORKSPACE.get(lib.nacf_bn_workspace(B * F, D), x.device)
+    L.check(lib.nacf_bn_concat_fwd(_ptr(x), _ptr(out), B, F, D, M_total, f_off, _ptr(weight), _ptr(bias),
+                                   _ptr(running_mean), _ptr(running_var), _ptr(nbt), _ptr(save_mean),
+                                   _ptr(save_invstd), int(training), float(momentum), float(eps), _ptr(ws),
+                                   ws.numel(), _stream()), "nacf_bn_concat_fwd")
+
+
+def bn_concat_bwd(dout, x, dx, f_off, weight, save_mean, save_invstd, dweight, dbias, beta=1.0):
+    _chk_f32(dout, x, dx, weight, save_mean, save_invstd, dweight, dbias)
+    B, F, D = x.shape
+    M_total = dout.shape[1]
+    lib = L.load()
+    ws = WORKSPACE.get(lib.nacf_bn_workspace(B * F, D), x.device)
+    L.check(lib.nacf_bn_concat_bwd(_ptr(dout), _ptr(x), _ptr(dx), B, F, D, M_total, f_off, _ptr(weight),
+                                   _ptr(save_mean), _ptr(save_invstd), _ptr(dweight), _ptr(dbias), float(beta),
+                                   _ptr(ws), ws.numel(), _stream()), "nacf_bn_concat_bwd")
+
+
+def mean_time_fwd(x, out):
+    _chk_f32(x, out)
+    B, T, D = x.shape
+    L.check(L.load().nacf_mean_time_fwd(_ptr(x), _ptr(out), B, T, D, _stream()), "nacf_mean_time_fwd")
+    return out
+
+
+def mean_time_bwd(dout, dx, accumulate=False):
+    _chk_f32(dout, dx)
+    B, T, D = dx.shape
+    L.check(L.load().nacf_mean_time_bwd(_ptr(dout), _ptr(dx), B, T, D, int(accumulate), _stream()),
+            "nacf_mean_time_bwd")
+
+
+def log_softmax_rows(x, out):
+    _chk_f32(x, out)
+    rows, N = x.shape
+    L.check(L.load().nacf_log_softmax_rows(_ptr(x), _ptr(out), rows, N, _stream()), "nacf_log_softmax_rows")
+    return out
+
+
+def log_softmax_rows_bwd(dout, out, din):
+    _chk_f32(dout, out, din)
+    rows, N = out.shape
+    L.check(L.load().nacf_log_softmax_rows_bwd(_ptr(dout), _ptr(out), _ptr(din), rows, N, _stream()),
+            "nacf_log_softmax_rows_bwd")
+
+
+def kldiv_mean(x, t, loss_out, dx, gscale=None, scale=1.0):
+    _chk_f32(x, t, loss_out, dx, gscale)
+    rows, N = x.shape
+    L.check(L.load().nacf_kldiv_mean(_ptr(x), _ptr(t), _ptr(loss_out), _ptr(dx), _ptr(gscale), float(scale), rows, N,
+                                     _stream()), "nacf_kldiv_mean")
+
+
+# ---------------------------------------------------------------- decoder
+def embed_ln_fwd(tokens, category, additional, word, pos, cat, ln_w, ln_b, out, xhat, rstd, vdiv, vmod, eps,
+                 p, salt, rng):
+    _chk_f32(additional, word, pos, cat, ln_w, ln_b, out, xhat, rstd)
+    R, Lq = tokens.shape
+    D = word.shape[1]
+    L.check(L.load().nacf_embed_ln_fwd(_ptr(tokens), _ptr(category), _ptr(additional), _ptr(word), _ptr(pos),
+                                       _ptr(cat), _ptr(ln_w), _ptr(ln_b), _ptr(out), _ptr(xhat), _ptr(rstd), R, Lq,
+                                       D, vdiv, vmod, float(eps), float(p), int(salt),
+                                       _ptr(rng.state) if rng else None, _stream()), "nacf_embed_ln_fwd")
+    return out
+
+
+def embed_ln_bwd(dout, xhat, rstd, ln_w, dE, dln_w, dln_b, R, Lq, D, p, salt, rng, beta=1.0):
+    _chk_f32(dout, xhat, rstd, ln_w, dE, dln_w, dln_b)
+    lib = L.load()
+    ws = WORKSPACE.get(lib.nacf_embed_ln_bwd_workspace(R, Lq, D), dout.device)
+    L.check(lib.nacf_embed_ln_bwd(_ptr(dout), _ptr(xhat), _ptr(rstd), _ptr(ln_w), _ptr(dE), _ptr(dln_w),
+                                  _ptr(dln_b), float(beta), R, Lq, D, float(p), int(salt),
+                                  _ptr(rng.state) if rng else None, _ptr(ws), ws.numel(), _stream()),
+            "nacf_embed_ln_bwd")
+
+
+def embed_scatter_bwd(dE, tokens, category, dword, dpos, dcat, dadd, R, Lq, D, V, n_cat, n_video, vdiv, vmod):
+    L.check(L.load().nacf_embed_scatter_bwd(_ptr(dE), _ptr(tokens), _ptr(category), _ptr(dword), _ptr(dpos),
+                                            _ptr(dcat), _ptr(dadd), R, Lq, D, V, n_cat, n_video, vdiv, vmod,
+                                            _stream()), "nacf_embed_scatter_bwd")
+
+
+def attention_fwd(q, k, v, out, key_tokens, causal, probs, R, H, Lq, Lk, dk, kv_div, kv_mod):
+    """q/k/v/out are 2-D column slices (rows = seq*len, cols = H*dk) of packed buffers."""
+    _chk_f32(q, k, v, out, probs)
+    L.check(L.load().nacf_attention_fwd(_ptr(q), q.stride(0), _ptr(k), k.stride(0), _ptr(v), v.stride(0),
+                                        _ptr(out), out.stride(0), _ptr(key_tokens), int(causal), _ptr(probs),
+                                        R, H, Lq, Lk, dk, kv_div, kv_mod, _stream()), "nacf_attention_fwd")
+    return out
+
+
+def attention_bwd(q, k, v, do, dq, dk_, dv, key_tokens, causal, R, n_kv, H, Lq, Lk, dk, kv_div, kv_mod):
+    _chk_f32(q, k, v, do, dq, dk_, dv)
+    L.check(L.load().nacf_attention_bwd(_ptr(q), q.stride(0), _ptr(k), k.stride(0), _ptr(v), v.stride(0),
+                                        _ptr(do), do.stride(0), _ptr(dq), dq.stride(0), _ptr(dk_), dk_.stride(0),
+                                        _ptr(dv), dv.stride(0), _ptr(key_tokens), int(causal), R, n_kv, H, Lq, Lk,
+                                        dk, kv_div, kv_mod, _stream()), "nacf_attention_bwd")
+
+
+def masked_mean_fwd(y, tokens, out):
+    _chk_f32(y, out)
+    R, Lq, D = y.shape
+    L.check(L.load().nacf_masked_mean_fwd(_ptr(y), _ptr(tokens), _ptr(out), R, Lq, D, _stream()),
+            "nacf_masked_mean_fwd")
+    return out
+
+
+# ---------------------------------------------------------------- vocabulary / loss
+def vocab_ld(V: int) -> int:
+    """leading dimension of logits buffers: rows stay 16-byte aligned"""
+    return (V + 3) // 4 * 4
+
+
+def vocab_logsoftmax_fwd(logits2d, V, labels, lse, argmax, label_logp):
+    _chk_f32(logits2d, lse, label_logp)
+    rows = logits2d.shape[0]
+    L.check(L.load().nacf_vocab_logsoftmax_fwd(_ptr(logits2d), logits2d.stride(0), rows, V, _ptr(labels), _ptr(lse),
+                                               _ptr(argmax), _ptr(label_logp), _stream()),
+            "nacf_vocab_logsoftmax_fwd")
+
+
+def nll_reduce(label_logp, argmax, labels, exclude_mask, out5):
+    rows = label_logp.numel()
+    L.check(L.load().nacf_nll_reduce(_ptr(label_logp), _ptr(argmax), _ptr(labels), rows, int(exclude_mask),
+                                     _ptr(out5), _stream()), "nacf_nll_reduce")
+
+
+def xent_bwd(logp2d, dlogits2d, V, labels, gscale, scale):
+    rows = logp2d.shape[0]
+    L.check(L.load().nacf_xent_bwd(_ptr(logp2d), logp2d.stride(0), _ptr(dlogits2d), dlogits2d.stride(0), rows, V,
+                                   _ptr(labels), _ptr(gscale), float(scale), _stream()), "nacf_xent_bwd")
+
+
+def vocab_logsoftmax_bwd(dlogp2d, logp2d, dlogits2d, V):
+    rows = logp2d.shape[0]
+    L.check(L.load().nacf_vocab_logsoftmax_bwd(_ptr(dlogp2d), dlogp2d.stride(0), _ptr(logp2d), logp2d.stride(0),
+                                               _ptr(dlogits2d), dlogits2d.stride(0), rows, V, _stream()),
+            "nacf_vocab_logsoftmax_bwd")
+
+
+# ---------------------------------------------------------------- NA decoding
+def vocab_argmax(hidden2d, w, bias, pad_tokens, zero_mask_prob, update_mask, tokens, probs):
+    _chk_f32(hidden2d, w, bias, probs)
+    rows, K, ldh = _rows2d(hidden2d)
+    V = w.shape[0]
+    lib = L.load()
+    ws = WORKSPACE.get(lib.nacf_vocab_argmax_workspace(rows, V), hidden2d.device)
+    L.check(lib.nacf_vocab_argmax(_ptr(hidden2d), ldh, _ptr(w), w.stride(0), _ptr(bias), rows, V, K,
+                                  _ptr(pad_tokens), int(zero_mask_prob), _ptr(update_mask), _ptr(tokens),
+                                  _ptr(probs), _ptr(ws), ws.numel(), _stream()), "nacf_vocab_argmax")
+
+
+def length_beam(pred_length, lbs, length_bias, beam, beam_max):
+    _chk_f32(pred_length)
+    B, max_len = pred_length.shape
+    L.check(L.load().nacf_length_beam(_ptr(pred_length), B, max_len, lbs, length_bias, _ptr(beam), _ptr(beam_max),
+                                      _stream()), "nacf_length_beam")
+
+
+def canvas_init(beam, rows, Lp, tokens):
+    L.check(L.load().nacf_canvas_init(_ptr(beam), rows, Lp, _ptr(tokens), _stream()), "nacf_canvas_init")
+
+
+def select_mask(probs, teacher, pad_tokens, lut, mode, tokens, mask_out):
+    rows, Lp = tokens.shape
+    L.check(L.load().nacf_select_mask(_ptr(probs), _ptr(teacher), _ptr(pad_tokens), _ptr(lut), mode, rows, Lp,
+                                      _ptr(tokens), _ptr(mask_out), _stream()), "nacf_select_mask")
+
+
+def token_replace(tokens, src, dst):
+    L.check(L.load().nacf_token_replace(_ptr(tokens), tokens.numel(), int(src), int(dst), _stream()),
+            "nacf_token_replace")
+
+
+def teacher_probs(label_logp, pad_tokens, out):
+    L.check(L.load().nacf_teacher_probs(_ptr(label_logp), _ptr(pad_tokens), _ptr(out), out.numel(), _stream()),
+            "nacf_teacher_probs")
+
+
+def init_probs(pad_tokens, probs):
+    L.check(L.load().nacf_init_probs(_ptr(pad_tokens), _ptr(probs), probs.numel(), _stream()), "nacf_init_probs")
+
+
+def apply_mask(tokens, mask, value):
+    L.check(L.load().nacf_apply_mask(_ptr(tokens), _ptr(mask), int(value), tokens.numel(), _stream()),
+            "nacf_apply_mask")
+
+
+def mask_rank(tokens, rank, counts):
+    rows, Lp = tokens.shape
+    L.check(L.load().nacf_mask_rank(_ptr(tokens), rows, Lp, _ptr(rank), _ptr(counts), _stream()), "nacf_mask_rank")
+
+
+def select_rank(rank, cur, q, tokens, mask_out):
+    rows, Lp = tokens.shape
+    L.check(L.load().nacf_select_rank(_ptr(rank), int(cur), int(q), rows, Lp, _ptr(tokens), _ptr(mask_out),
+                                      _stream()), "nacf_select_rank")
+
+
+def easy_first_update(tokens, probs, new_tokens, new_probs, q):
+    rows, Lp = tokens.shape
+    L.check(L.load().nacf_easy_first_update(_ptr(tokens), _ptr(probs), _ptr(new_tokens), _ptr(new_probs), int(q),
+                                            rows, Lp, _stream()), "nacf_easy_first_update")
+
+
+def best_candidate(tokens, probs, teacher, beam, alpha, B, lbs, Lp, out_tokens, best_idx, cand_lprobs):
+    L.check(L.load().nacf_best_candidate(_ptr(tokens), _ptr(probs), _ptr(teacher), _ptr(beam), float(alpha), B, lbs,
+                                         Lp, _ptr(out_tokens), _ptr(best_idx), _ptr(cand_lprobs), _stream()),
+            "nacf_best_candidate")
+
+
+# ---------------------------------------------------------------- optimiser
+def adam_step(param, grad, m, v, lr_dev, step_dev, beta1, beta2, eps, weight_decay, grad_clip, grad_scale):
+    _chk_f32(param, grad, m, v, lr_dev)
+    L.check(L.load().nacf_adam_step(_ptr(param), _ptr(grad), _ptr(m), _ptr(v), param.numel(), _ptr(lr_dev),
+                                    _ptr(step_dev), float(beta1), float(beta2), float(eps), float(weight_decay),
+                                    float(grad_clip), float(grad_scale), _stream()), "nacf_adam_step")

@@ -1,0 +1,102 @@
+"""Per-model runtime state: flat fp32 parameter / gradient buffers (one RCCL
+bucket, one fused Adam launch), dropout RNG state, dropout-site salts."""
+from __future__ import annotations
+
+from typing import Dict, List, Optional, Sequence
+
+import torch
+import torch.nn as nn
+
+from .functional import Pack
+from .ops import RngState
+
+
+class Runtime:
+    def __init__(self, seed: int = 0):
+        self.seed = int(seed)
+        self._rng: Optional[RngState] = None
+        self._salt = 0
+
+    def next_salt(self) -> int:
+        self._salt += 1
+        return (self._salt * 0x9E3779B1 + 0x7F4A7C15) & 0xFFFFFFFF
+
+    def rng(self, device) -> RngState:
+        if self._rng is None or self._rng.state.device != torch.device(device):
+            self._rng = RngState(self.seed, device)
+        return self._rng
+
+    def advance(self) -> None:
+        if self._rng is not None:
+            self._rng.advance()
+
+
+class FlatParams:
+    """Re-homes every parameter of a model into one flat fp32 buffer (and its
+    gradient into a second one).  ``groups`` lists parameters that must be
+    adjacent, in order, so packed views (w1|w2, q|k|v, k|v) are plain slices."""
+
+    ALIGN = 4  # floats (16 B)
+
+    def __init__(self, groups: Sequence[Sequence[nn.Parameter]]):
+        seen = set()
+        layout: List[List[nn.Parameter]] = []
+        for g in groups:
+            g = [p for p in g if id(p) not in seen]
+            for p in g:
+                seen.add(id(p))
+            if g:
+                layout.append(g)
+        device = layout[0][0].device
+        self.offset: Dict[int, int] = {}
+        off = 0
+        for g in layout:
+            off = (off + self.ALIGN - 1) // self.ALIGN * self.ALIGN
+            for p in g:
+                assert p.dtype == torch.float32, "fp32 parameters only"
+                self.offset[id(p)] = off
+                off += p.numel()
+        self.total = (off + self.ALIGN - 1) // self.ALIGN * self.ALIGN
+        self.data = torch.zeros(self.total, dtype=torch.float32, device=device)
+        self.grad = torch.zeros(self.total, dtype=torch.float32, device=device)
+        self.params: List[nn.Parameter] = [p for g in layout for p in g]
+        with torch.no_grad():
+            for p in self.params:
+                o, n = self.offset[id(p)], p.numel()
+                v = self.data[o:o + n].view(p.shape)
+                v.copy_(p.data)
+                p.data = v
+        self.attach_grads(zero=False)
+
+    def attach_grads(self, zero: bool) -> None:
+        if zero:
+            self.grad.zero_()
+        for p in self.params:
+            o, n = self.offset[id(p)], p.numel()
+            if p.requires_grad:
+                p.grad = self.grad[o:o + n].view(p.shape)
+
+    def grads_attached(self) -> bool:
+        for p in self.params:
+            if p.requires_grad:
+                o = self.offset[id(p)]
+                return p.grad is not None and p.grad.data_ptr() == self.grad[o:].data_ptr()
+        return True
+
+    def pack(self, ws: Sequence[nn.Parameter], bs: Optional[Sequence[nn.Parameter]] = None) -> Pack:
+        """Packed (row-concatenated) view of adjacent weights [+ biases]."""
+        def cat(ps):
+            if ps is None or len(ps) == 0 or ps[0] is None:
+                return None, None
+            o0 = self.offset[id(ps[0])]
+            o = o0
+            for p in ps:
+                assert self.offset[id(p)] == o, "parameters of a pack must be adjacent in the flat buffer"
+                o += p.numel()
+            rows = sum(p.shape[0] for p in ps)
+            shape = (rows,) + tuple(ps[0].shape[1:])
+            gv = self.grad[o0:o].view(shape) if all(p.requires_grad for p in ps) else None
+            return self.data[o0:o].view(shape), gv
+        w, gw = cat(ws)
+        b, gb = cat(bs)
+        return Pack(w, b, gw, gb)
