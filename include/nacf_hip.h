@@ -111,6 +111,12 @@ int nacf_linear_bwd_weight(const float* dZ, int64_t lddz, const float* X, int64_
                            float* dW, int64_t lddw, float* db, int M, int N, int K,
                            float beta, void* ws, size_t ws_bytes, nacf_stream_t stream);
 
+/* Which GEMM kernel a call will launch (for profiling / roofline bookkeeping):
+ * kind 0 = linear_fwd (also vocab_argmax), 1 = linear_bwd_data, 2 = linear_bwd_weight,
+ * with the SAME (M, N, K) the entry point takes.  tile[0] = 128 or 64 (square
+ * workgroup tile), splits[0] = number of reduce-dimension splits. */
+int nacf_gemm_config(int kind, int M, int N, int K, int* tile, int* splits);
+
 /* Backward of the fused epilogue: from dY produce dZ (grad of the pre-bias
  * GEMM output) and, when ep->residual != NULL, dR (+= when accumulate_dR).
  * `ep` must be the struct used in forward (preact required when act != NONE).

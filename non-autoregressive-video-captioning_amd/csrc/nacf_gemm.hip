@@ -234,6 +234,24 @@ int nacf_linear_bwd_weight(const float* dZ, int64_t lddz, const float* X, int64_
   return NACF_OK;
 }
 
+int nacf_gemm_config(int kind, int M, int N, int K, int* tile, int* splits) {
+  NACF_CHECK(tile && splits && M > 0 && N > 0 && K > 0, NACF_EINVAL, "nacf_gemm_config: bad argument");
+  int t = 0, s = 1;
+  if (kind == 0) t = pick_tile(M, N, 1);
+  else if (kind == 1) t = pick_tile(M, K, 1);
+  else if (kind == 2) {
+    s = bwd_weight_splits(M, N, K, &t);
+    const int kps = cdiv(cdiv(M, s), 16) * 16;
+    s = cdiv(M, kps);
+  } else {
+    nacf_set_error("nacf_gemm_config: bad kind %d", kind);
+    return NACF_EINVAL;
+  }
+  *tile = t == 0 ? 128 : 64;
+  *splits = s;
+  return NACF_OK;
+}
+
 size_t nacf_vocab_argmax_workspace(int rows, int V) {
   const size_t tiles_n = (size_t)cdiv(V, 64);  // upper bound for either tile size
   return tiles_n * (size_t)rows * 3 * sizeof(float) + 256;

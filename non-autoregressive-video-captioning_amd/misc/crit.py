@@ -26,8 +26,13 @@ class Criterion(object):
     def __init__(self, opt):
         self.opt = opt
         self.crit = [c.lower() for c in opt['crit']]
-        self.names = list(opt.get('crit_name', ['Cap Loss', 'Length Loss'][:len(self.crit)]))
-        self.scales = list(opt.get('crit_scale', [1.0] * len(self.crit)))
+        default_names = {'lang': 'Cap Loss', 'length': 'Length Loss'}
+        self.names = list(opt.get('crit_name', []))
+        self.scales = list(opt.get('crit_scale', []))
+        if len(self.names) != len(self.crit):      # hand-written opt dicts: opts.py:185-189 defaults
+            self.names = [default_names[c] for c in self.crit]
+        if len(self.scales) != len(self.crit):
+            self.scales = [1.0] * len(self.crit)
         self.vw = opt.get('visual_word_generation', False)
         self.weights = list(opt.get('nv_weights', [0.8, 1.0])) if self.vw else None
         self.reset_loss_recorder()

@@ -41,6 +41,7 @@ SIGNATURES = {
     "nacf_linear_fwd": (c_int, [_P, _L, _P, _L, _P, _L, _I, _I, _I, _EP, _P]),
     "nacf_linear_bwd_data": (c_int, [_P, _L, _P, _L, _P, _L, _I, _I, _I, _F, _P]),
     "nacf_linear_bwd_weight_workspace": (_S, [_I, _I, _I]),
+    "nacf_gemm_config": (c_int, [_I, _I, _I, _I, _P, _P]),
     "nacf_linear_bwd_weight": (c_int, [_P, _L, _P, _L, _P, _L, _P, _I, _I, _I, _F, _P, _S, _P]),
     "nacf_epilogue_bwd": (c_int, [_P, _L, _P, _L, _P, _L, _I, _I, _I, _EP, _P]),
     "nacf_highway_mix_fwd": (c_int, [_P, _P, _P, _I, _I, _F, _U, _P, _P]),

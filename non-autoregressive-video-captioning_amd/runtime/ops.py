@@ -62,6 +62,48 @@ class _Workspace:
 WORKSPACE = _Workspace()
 
 
+class GemmProfiler:
+    """HIP-event timing of every GEMM launch, used by bench.py for the live
+    roofline figure.  The kernels run on torch's current stream, which is also
+    where torch.cuda.Event records, so the pair brackets exactly the launch."""
+    _LAYOUT = {0: ("true", "true"), 1: ("true", "false"), 2: ("false", "false")}
+
+    def __init__(self):
+        self.enabled = False
+        self.records = []
+
+    def kernel_name(self, kind, M, N, K, epi):
+        tile, splits = ctypes.c_int(0), ctypes.c_int(0)
+        L.check(L.load().nacf_gemm_config(kind, M, N, K, ctypes.byref(tile), ctypes.byref(splits)), "nacf_gemm_config")
+        q, p_ = self._LAYOUT[kind]
+        return "gemm_f32_kernel<%d, %d, 2, 2, %s, %s, true, %s>" % (tile.value, tile.value, q, p_, epi)
+
+    def begin(self, kind, M, N, K, epi):
+        if not self.enabled:
+            return None
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        return (self.kernel_name(kind, M, N, K, epi), 2.0 * M * N * K, (M, N, K), a, b)
+
+    def end(self, tok):
+        if tok is not None:
+            tok[4].record()
+            self.records.append(tok)
+
+    def summary(self):
+        out = {}
+        for name, flops, shape, a, b in self.records:
+            r = out.setdefault(name, dict(calls=0, flops=0.0, ms=0.0, shapes=set()))
+            r["calls"] += 1
+            r["flops"] += flops
+            r["ms"] += a.elapsed_time(b)
+            r["shapes"].add(shape)
+        return out
+
+
+PROFILER = GemmProfiler()
+
+
 class RngState:
     """Device-side {seed, step} consumed by every dropout kernel."""
 
@@ -106,8 +148,10 @@ def linear_fwd(x: Tensor, w: Tensor, out: Tensor, epi: Optional[Epi] = None) -> 
     N, K2, ldw = _rows2d(w)
     assert K == K2 and out.shape == (M, N), (x.shape, w.shape, out.shape)
     ep = epi.cstruct() if epi is not None else L.Epilogue()
+    tok = PROFILER.begin(0, M, N, K, "EpiLinear")
     L.check(L.load().nacf_linear_fwd(_ptr(x), ldx, _ptr(w), ldw, _ptr(out), out.stride(0), M, N, K,
                                      ctypes.byref(ep), _stream()), "nacf_linear_fwd")
+    PROFILER.end(tok)
     return out
 
 
@@ -116,8 +160,10 @@ def linear_bwd_data(dz: Tensor, w: Tensor, dx: Tensor, beta: float = 0.0) -> Ten
     M, N, lddz = _rows2d(dz)
     N2, K, ldw = _rows2d(w)
     assert N == N2 and dx.shape == (M, K)
+    tok = PROFILER.begin(1, M, N, K, "EpiStore")
     L.check(L.load().nacf_linear_bwd_data(_ptr(dz), lddz, _ptr(w), ldw, _ptr(dx), dx.stride(0), M, N, K,
                                           float(beta), _stream()), "nacf_linear_bwd_data")
+    PROFILER.end(tok)
     return dx
 
 
@@ -129,8 +175,10 @@ def linear_bwd_weight(dz: Tensor, x: Tensor, dw: Tensor, db: Optional[Tensor], b
     lib = L.load()
     need = lib.nacf_linear_bwd_weight_workspace(M, N, K)
     ws = WORKSPACE.get(need, dz.device)
+    tok = PROFILER.begin(2, M, N, K, "EpiStore")
     L.check(lib.nacf_linear_bwd_weight(_ptr(dz), lddz, _ptr(x), ldx, _ptr(dw), dw.stride(0), _ptr(db), M, N, K,
                                        float(beta), _ptr(ws), ws.numel(), _stream()), "nacf_linear_bwd_weight")
+    PROFILER.end(tok)
 
 
 def epilogue_bwd(dy: Tensor, dz: Tensor, dr: Optional[Tensor], epi: Epi, accumulate_dr: bool = False) -> None:
@@ -312,9 +360,11 @@ def vocab_argmax(hidden2d, w, bias, pad_tokens, zero_mask_prob, update_mask, tok
     V = w.shape[0]
     lib = L.load()
     ws = WORKSPACE.get(lib.nacf_vocab_argmax_workspace(rows, V), hidden2d.device)
+    tok = PROFILER.begin(0, rows, V, K, "EpiArgmax")
     L.check(lib.nacf_vocab_argmax(_ptr(hidden2d), ldh, _ptr(w), w.stride(0), _ptr(bias), rows, V, K,
                                   _ptr(pad_tokens), int(zero_mask_prob), _ptr(update_mask), _ptr(tokens),
                                   _ptr(probs), _ptr(ws), ws.numel(), _stream()), "nacf_vocab_argmax")
+    PROFILER.end(tok)
 
 
 def length_beam(pred_length, lbs, length_bias, beam, beam_max):

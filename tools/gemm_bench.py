@@ -1,0 +1,69 @@
+"""Per-shape timing of the fp32 MFMA GEMM entry points (tuning aid, GPU box only).
+usage: python tools/gemm_bench.py [--iters 20]"""
+import argparse
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa: E402
+
+import nacf_amd  # noqa: E402,F401
+from nacf_amd.runtime import ops  # noqa: E402
+
+# (label, kind, M, N, K): the GEMMs of one NACF train step at B=128 and of one decode pass
+SHAPES = [
+    ("enc_lin fwd", 0, 7680, 512, 2048), ("enc_hw fwd", 0, 7680, 1024, 512), ("qkv fwd", 0, 5120, 1536, 512),
+    ("kvmem fwd", 0, 15360, 1024, 512), ("proj fwd", 0, 5120, 512, 512), ("ffn1 fwd", 0, 5120, 2048, 512),
+    ("ffn2 fwd", 0, 5120, 512, 2048), ("vocab fwd", 0, 5120, 10547, 512), ("vocab dec", 0, 14592, 10547, 512),
+    ("vocab dX", 1, 5120, 10547, 512), ("ffn2 dX", 1, 5120, 512, 2048), ("ffn1 dX", 1, 5120, 2048, 512),
+    ("proj dX", 1, 5120, 512, 512), ("kvmem dX", 1, 15360, 1024, 512), ("hw dX", 1, 7680, 1024, 512),
+    ("vocab dW", 2, 5120, 10547, 512), ("enc_lin dW", 2, 7680, 512, 2048), ("ffn1 dW", 2, 5120, 2048, 512),
+    ("ffn2 dW", 2, 5120, 512, 2048), ("proj dW", 2, 5120, 512, 512), ("kvmem dW", 2, 15360, 1024, 512),
+]
+
+
+def run(kind, M, N, K, iters, dev):
+    g = torch.Generator(device="cpu").manual_seed(0)
+    r = lambda *s: (torch.rand(*s, generator=g) * 2 - 1).to(dev)
+    if kind == 0:
+        x, w, y = r(M, K), r(N, K), torch.empty(M, ops.vocab_ld(N), device=dev)[:, :N]
+        f = lambda: ops.linear_fwd(x, w, y, None)
+    elif kind == 1:
+        dz, w, dx = r(M, ops.vocab_ld(N))[:, :N], r(N, K), torch.empty(M, K, device=dev)
+        f = lambda: ops.linear_bwd_data(dz, w, dx)
+    else:
+        dz, x, dw = r(M, ops.vocab_ld(N))[:, :N], r(M, K), torch.empty(N, K, device=dev)
+        f = lambda: ops.linear_bwd_weight(dz, x, dw, None, beta=0.0)
+    for _ in range(3):
+        f()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    a.record()
+    for _ in range(iters):
+        f()
+    b.record()
+    torch.cuda.synchronize()
+    ms = a.elapsed_time(b) / iters
+    return ms, 2.0 * M * N * K / (ms * 1e-3) / 1e12
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--iters", type=int, default=20)
+    ap.add_argument("--only", type=str, default="")
+    args = ap.parse_args()
+    dev = torch.device("cuda:0")
+    print("%-12s %-26s %10s %10s %10s %10s" % ("gemm", "M,N,K", "ms@64", "TF@64", "ms@128", "TF@128"))
+    for label, kind, M, N, K in SHAPES:
+        if args.only and args.only not in label:
+            continue
+        res = []
+        for tile in ("64", "128"):
+            os.environ["NACF_GEMM_TILE"] = tile
+            res.append(run(kind, M, N, K, args.iters, dev))
+        print("%-12s %-26s %10.3f %10.1f %10.3f %10.1f" % (label, "%d,%d,%d" % (M, N, K), res[0][0], res[0][1],
+                                                           res[1][0], res[1][1]))
+
+
+if __name__ == "__main__":
+    main()
