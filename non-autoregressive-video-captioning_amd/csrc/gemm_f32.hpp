@@ -39,6 +39,7 @@ struct GemmShape {
   int64_t ldq, ldp;
   int M, N, K;
   int k_per_split;  // multiple of 16
+  int k_skew;       // != 0: every tile starts its k-loop at a different k-tile (wraps around)
   int tiles_m, tiles_n;
 };
 
@@ -230,6 +231,16 @@ struct EpiArgmax {
   __device__ __forceinline__ void operator()(int, int, f32x4, int, int, int) const {}
 };
 
+template <int IDX, int TM, int TN, class Epi>
+__device__ __forceinline__ void epilogue_all(const Epi& epi, f32x4 (&acc)[TM][TN], int mbase, int nbase, int M,
+                                             int N, int z) {
+  if constexpr (IDX < TM * TN) {
+    constexpr int a = IDX / TN, b = IDX % TN;
+    epi(mbase + a * 16, nbase + b * 16, acc[a][b], M, N, z);
+    epilogue_all<IDX + 1, TM, TN, Epi>(epi, acc, mbase, nbase, M, N, z);
+  }
+}
+
 // ---------------------------------------------------------------- kernel
 template <int BM, int BN, int WM, int WN, bool QKC, bool PKC, bool VEC, class Epi>
 __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmShape g, Epi epi) {
@@ -265,6 +276,10 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmShape g, Epi epi) {
   const int kbeg = z * g.k_per_split;
   const int kend = min(g.K, kbeg + g.k_per_split);
   const int nk = (kend - kbeg + BK - 1) / BK;
+  // k-skew: concurrently running tiles walk the reduce dimension from different
+  // starting offsets, so their row-strided (power-of-two pitch) operand reads do
+  // not all land on the same L2/HBM channels at the same time.
+  const int kskew = g.k_skew ? (int)(((unsigned)tile_m * 5u + (unsigned)tile_n * 3u) % (unsigned)(nk > 0 ? nk : 1)) : 0;
 
   f32x4 acc[TM][TN];
 #pragma unroll
@@ -273,8 +288,8 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmShape g, Epi epi) {
     for (int b = 0; b < TN; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   f32x4 qreg[BM / 64], preg[BN / 64];
-  tile_load<BM, QKC, VEC>(qreg, g.Q, g.ldq, m0, g.M, kbeg, kend, tid);
-  tile_load<BN, PKC, VEC>(preg, g.P, g.ldp, n0, g.N, kbeg, kend, tid);
+  tile_load<BM, QKC, VEC>(qreg, g.Q, g.ldq, m0, g.M, kbeg + kskew * BK, kend, tid);
+  tile_load<BN, PKC, VEC>(preg, g.P, g.ldp, n0, g.N, kbeg + kskew * BK, kend, tid);
   tile_store<BM, QKC>(smem, qreg, tid);
   tile_store<BN, PKC>(smem + QSZ, preg, tid);
   __syncthreads();
@@ -284,7 +299,9 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmShape g, Epi epi) {
     const float* ps = qs + QSZ;
     const bool more = (kt + 1) < nk;
     if (more) {
-      const int k0 = kbeg + (kt + 1) * BK;
+      int ktn = kt + 1 + kskew;
+      if (ktn >= nk) ktn -= nk;
+      const int k0 = kbeg + ktn * BK;
       tile_load<BM, QKC, VEC>(qreg, g.Q, g.ldq, m0, g.M, k0, kend, tid);
       tile_load<BN, PKC, VEC>(preg, g.P, g.ldp, n0, g.N, k0, kend, tid);
     }
@@ -309,14 +326,10 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmShape g, Epi epi) {
   }
 
   if constexpr (!Epi::kArgmax) {
-#pragma unroll
-    for (int a = 0; a < TM; ++a)
-#pragma unroll
-      for (int b = 0; b < TN; ++b) {
-        const int m = m0 + wm * WTM + a * 16 + li;
-        const int n = n0 + wn * WTN + b * 16 + lg * 4;
-        epi(m, n, acc[a][b], g.M, g.N, z);
-      }
+    // compile-time recursion, NOT a `#pragma unroll` loop: with the large fused epilogue the
+    // optimiser declined to unroll, indexed acc[][] dynamically and parked the accumulators
+    // in scratch (16 scratch_store_dwordx4 per k-tile in the main loop, 2x slower)
+    epilogue_all<0, TM, TN, Epi>(epi, acc, m0 + wm * WTM + li, n0 + wn * WTN + lg * 4, g.M, g.N, z);
   } else {
     // per-row (max, argmax, sum-exp) over this tile's BN columns
     float* redv = smem;                  // [WN][BM]

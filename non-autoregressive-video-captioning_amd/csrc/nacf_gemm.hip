@@ -21,9 +21,17 @@ int pick_tile(int M, int N, int splits) {
   return big >= 384 ? 0 : 1;  // >= 1.5 workgroups per CU with the big tile, else go small
 }
 
+int kskew_enabled() {
+  // tuning knob, default off: measured neutral on MI355X (gpurun gemm_bench2: the power-of-two
+  // row pitch of the K-contiguous operands is not what limited the forward GEMMs)
+  const char* e = getenv("NACF_GEMM_KSKEW");
+  return e ? atoi(e) : 0;
+}
+
 template <bool QKC, bool PKC, class Epi>
 void launch_gemm(const GemmShape& g0, const Epi& epi, int splits, int tile, bool vec, hipStream_t s) {
   GemmShape g = g0;
+  g.k_skew = kskew_enabled();
   if (tile == 0) {
     g.tiles_m = cdiv(g.M, 128);
     g.tiles_n = cdiv(g.N, 128);

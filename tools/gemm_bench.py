@@ -22,11 +22,14 @@ SHAPES = [
 ]
 
 
+PAD = 0
+
+
 def run(kind, M, N, K, iters, dev):
     g = torch.Generator(device="cpu").manual_seed(0)
     r = lambda *s: (torch.rand(*s, generator=g) * 2 - 1).to(dev)
     if kind == 0:
-        x, w, y = r(M, K), r(N, K), torch.empty(M, ops.vocab_ld(N), device=dev)[:, :N]
+        x, w, y = r(M, K + PAD)[:, :K], r(N, K + PAD)[:, :K], torch.empty(M, ops.vocab_ld(N), device=dev)[:, :N]
         f = lambda: ops.linear_fwd(x, w, y, None)
     elif kind == 1:
         dz, w, dx = r(M, ops.vocab_ld(N))[:, :N], r(N, K), torch.empty(M, K, device=dev)
@@ -51,7 +54,10 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--only", type=str, default="")
+    ap.add_argument("--pad", type=int, default=0, help="extra floats of row pitch on the K-contiguous fwd operands")
     args = ap.parse_args()
+    global PAD
+    PAD = args.pad
     dev = torch.device("cuda:0")
     print("%-12s %-26s %10s %10s %10s %10s" % ("gemm", "M,N,K", "ms@64", "TF@64", "ms@128", "TF@128"))
     for label, kind, M, N, K in SHAPES:
