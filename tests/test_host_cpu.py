@@ -1,0 +1,115 @@
+"""CPU (no GPU needed): the C-ABI library loads and exports every symbol the
+header declares, host-side logic (option overlays, flat parameter layout,
+registry, state_dict contract) behaves like the reference's."""
+import os
+import re
+
+import pytest
+import torch
+
+import nacf_amd
+from nacf_amd.runtime import lib
+from oracle import nacf_oracle as O
+from util import gold_opt, gold_state, load_gold
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_header_symbol():
+    hdr = open(os.path.join(ROOT, "include", "nacf_hip.h")).read()
+    declared = set(re.findall(r"^(?:int|size_t|const char\*)\s+(nacf_[a-z0-9_]+)\s*\(", hdr, re.M))
+    assert len(declared) >= 45
+    handle = lib.load()
+    for name in declared:
+        assert hasattr(handle, name), name
+    assert declared == set(lib.SIGNATURES), declared ^ set(lib.SIGNATURES)
+    assert handle.nacf_version() >= 1
+    assert handle.nacf_last_error() is not None
+
+
+def test_no_cpu_fallback():
+    opt = gold_opt(load_gold("tiny_nacf_train"))
+    m = nacf_amd.get_model(opt)
+    with pytest.raises(Exception):
+        m(feats=[torch.rand(2, 6, 32), torch.rand(2, 6, 32)], tgt_tokens=[torch.ones(2, 10, dtype=torch.long)] * 2,
+          category=torch.zeros(2, 1, dtype=torch.long))
+
+
+def test_method_overlays_match_reference_flags():
+    o = nacf_amd.opts.make_opt("NACF", "MSRVTT", default=True, vocab_size=10)
+    assert (o["encoder"], o["decoder"], o["decoding_type"]) == ("Encoder_HighWay", "BertDecoderDisentangled", "NARFormer")
+    assert o["visual_word_generation"] and o["use_ct"] and o["max_len"] == 30 and o["with_category"]
+    assert o["crit"] == ["lang", "length"] and o["beam_alpha"] == 1.35 and o["length_beam_size"] == 6
+    o = nacf_amd.opts.make_opt("ARB", "Youtube2Text", default=True)
+    assert o["decoding_type"] == "ARFormer" and o["beam_size"] == 5 and o["max_len"] == 20 and not o["with_category"]
+    assert o["crit"] == ["lang"]
+    with pytest.raises(AssertionError):
+        nacf_amd.opts.make_opt("NOPE")
+    with pytest.raises(ValueError):
+        nacf_amd.get_model(dict(o, vocab_size=10, decoder="Nope"))
+
+
+@pytest.mark.parametrize("name", ["tiny_nacf_train", "tiny_nab_train", "tiny_arb2_train", "tiny_arb_train"])
+def test_state_dict_contract_and_flat_layout(name):
+    g = load_gold(name)
+    opt = gold_opt(g)
+    m = nacf_amd.get_model(opt)
+    ref = gold_state(g, "after.")
+    sd = m.state_dict()
+    assert set(sd) == set(ref)
+    for k, v in ref.items():
+        assert tuple(sd[k].shape) == tuple(v.shape), k
+    m.load_state_dict(ref)
+    # every parameter is a view into the single flat buffer, gradients into the second one
+    lo, hi = m.flat.data.data_ptr(), m.flat.data.data_ptr() + m.flat.total * 4
+    for k, p in m.named_parameters():
+        assert lo <= p.data_ptr() < hi, k
+        assert p.grad is not None and m.flat.grad.data_ptr() <= p.grad.data_ptr() < m.flat.grad.data_ptr() + m.flat.total * 4
+        assert torch.equal(p.detach(), ref[k])
+    # packed operands are plain slices
+    dec = m.decoder.bert if hasattr(m.decoder, "bert") else m.decoder
+    layer = dec.layer[0]
+    D = opt["dim_hidden"]
+    qkv = layer._pk["qkv"].w
+    assert torch.equal(qkv[:D], layer.attention.self.query.weight) and torch.equal(qkv[2 * D:], layer.attention.self.value.weight)
+    ckv = layer._pk["ckv"]
+    assert torch.equal(ckv.w[D:], layer.attend_to_enc_output.self.value.weight)
+    assert torch.equal(ckv.b[:D], layer.attend_to_enc_output.self.key.bias)
+    hw = m.encoder._cfg[0]["hw"].w
+    assert torch.equal(hw[D:], m.encoder.Encoder_M[1].w2.weight)
+    # zero_grad / re-attach semantics
+    for p in m.parameters():
+        p.grad = None
+    assert not m.flat.grads_attached()
+    m._ensure_grads()
+    assert m.flat.grads_attached() and float(m.flat.grad.abs().sum()) == 0.0
+
+
+def test_default_init_consumes_rng_like_the_reference_layout():
+    # same seed -> same weights twice, and the PAD row of the word embedding is zero (padding_idx)
+    opt = gold_opt(load_gold("tiny_nacf_train"))
+    torch.manual_seed(0)
+    a = nacf_amd.get_model(opt).state_dict()
+    torch.manual_seed(0)
+    b = nacf_amd.get_model(opt).state_dict()
+    assert all(torch.equal(a[k], b[k]) for k in a)
+    assert float(a["decoder.bert.embedding.word_embeddings.weight"][0].abs().sum()) == 0.0
+    assert set(a) == set(O.param_shapes(opt))
+
+
+def test_unsupported_variants_fail_loudly():
+    opt = gold_opt(load_gold("tiny_nacf_train"))
+    for bad in (dict(with_layernorm=True), dict(pos_attention=True), dict(enhance_input=1), dict(fusion="addition"),
+                dict(hidden_act="swish"), dict(norm_type="ln")):
+        with pytest.raises((NotImplementedError, ValueError)):
+            nacf_amd.get_model(dict(opt, **bad))
+
+
+def test_num_mask_lut_matches_torch_float_semantics():
+    from nacf_amd.decoding.algorithms import Algorithm_Base
+    alg = Algorithm_Base({}, {}, None)
+    T, Lp = 6, 29
+    lut = alg.num_mask_lut([1.0 - (c / T) for c in range(T)], Lp, "cpu")
+    for c in range(T):
+        lens = torch.arange(Lp + 1)
+        assert torch.equal(lut[c].long(), (lens.float() * (1.0 - (c / T))).long())
