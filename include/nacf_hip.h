@@ -328,6 +328,24 @@ int nacf_best_candidate(const int64_t* tokens, const float* probs, const float* 
                         nacf_stream_t stream);
 
 /* ------------------------------------------------------------------------
+ * AR beam search  (models/Beam.py:68-130, models/Translator.py:94-161)
+ * ---------------------------------------------------------------------- */
+/* One step (t = 1 .. max_len-1) of Beam.advance for B instances at once.
+ * logp [B*n_bm, ldl]: log-probs of the next word for every hypothesis (row b*n_bm+k).
+ * Device state owned by the caller: seqs int64 [B, n_bm, max_len] (<bos> at [b,0,0], PAD elsewhere
+ * initially), scores [B, n_bm], finished list fin_scores/fin_len [B, want] + fin_tokens
+ * [B, want, max_len] + fin_count [B], done int32 [B] (zero-initialised).
+ * Semantics: t == 1 ranks beam 0 only; hypotheses whose last word is <eos> are masked with
+ * -1e20; flat top-n_bm over beam x vocab (ties: lower flat index); hypotheses are re-ordered
+ * by back-pointer and extended; every emitted <eos> (in beam order) is appended to the finished
+ * list; an instance is done once `want` are finished, or at t == max_len-1 (then, if none
+ * finished, all beams are appended).  n_active (optional device int32[1]) = #instances not done. */
+int nacf_beam_step(const float* logp, int64_t ldl, int B, int n_bm, int V, int t, int max_len, int want,
+                   int64_t* seqs, float* scores, float* fin_scores, int32_t* fin_len,
+                   int64_t* fin_tokens, int32_t* fin_count, int32_t* done, int32_t* n_active,
+                   nacf_stream_t stream);
+
+/* ------------------------------------------------------------------------
  * Optimiser  
  * ---------------------------------------------------------------------- */
 /* clip_grad_value_(+-clip) (misc/run.py:260) then Adam with L2 weight decay

@@ -179,6 +179,140 @@ __global__ void easy_first_update_kernel(int64_t* __restrict__ tokens, float* __
   if (in && rank < k) { tokens[o] = new_tokens[o]; probs[o] = s; }
 }
 
+// ---------------------------------------------------------------- AR beam search step
+constexpr int BEAM_MAX = 8;
+
+// One workgroup per instance: Beam.advance (models/Beam.py:68-117) for step t.
+__global__ __launch_bounds__(256) void beam_step_kernel(const float* __restrict__ logp, int64_t ldl, int n_bm, int V,
+                                                         int t, int max_len, int want, int64_t* __restrict__ seqs,
+                                                         float* __restrict__ scores, float* __restrict__ fin_scores,
+                                                         int32_t* __restrict__ fin_len, int64_t* __restrict__ fin_tokens,
+                                                         int32_t* __restrict__ fin_count, int32_t* __restrict__ done) {
+  __shared__ float s_val[256];
+  __shared__ int s_idx[256];
+  __shared__ float w_val[BEAM_MAX];
+  __shared__ int w_idx[BEAM_MAX];
+  __shared__ int64_t s_seq[BEAM_MAX * 64];
+  __shared__ float red_v[4];
+  __shared__ int red_i[4];
+  __shared__ int red_t[4];
+  const int b = blockIdx.x;
+  if (done[b]) return;
+  const int tid = threadIdx.x;
+  const int n_rows = (t == 1) ? 1 : n_bm;           // first step: only beam 0 holds <bos> (Beam.py:79-80)
+  const float NEG = -3.0e38f;
+  float lv[BEAM_MAX];
+  int li[BEAM_MAX];
+#pragma unroll
+  for (int k = 0; k < BEAM_MAX; ++k) { lv[k] = NEG; li[k] = 0x7fffffff; }
+  float tail_v = NEG;
+  int tail_i = 0x7fffffff;
+  for (int r = 0; r < n_rows; ++r) {
+    const bool ended = (t > 1) && seqs[((int64_t)b * n_bm + r) * max_len + (t - 1)] == NACF_EOS;
+    const float base = (t > 1) ? scores[b * n_bm + r] : 0.f;
+    const float* row = logp + ((int64_t)b * n_bm + r) * ldl;
+    for (int v = tid; v < V; v += 256) {
+      const float val = ended ? -1e20f : row[v] + base;      // beam_lk[i] = -1e20 (Beam.py:76-77)
+      const int idx = r * V + v;
+      if (val > tail_v || (val == tail_v && idx < tail_i)) {
+        // insert into the thread-local sorted list (descending value, ascending index on ties)
+        float cv = val;
+        int ci = idx;
+#pragma unroll
+        for (int k = 0; k < BEAM_MAX; ++k) {
+          if (k < n_bm && (cv > lv[k] || (cv == lv[k] && ci < li[k]))) {
+            const float tv = lv[k]; const int ti = li[k];
+            lv[k] = cv; li[k] = ci; cv = tv; ci = ti;
+          }
+          if (k == n_bm - 1) { tail_v = lv[k]; tail_i = li[k]; }   // static register indexing only
+        }
+      }
+    }
+  }
+  // n_bm rounds of "block argmax over every thread's current head"
+  int head = 0;
+  for (int k = 0; k < n_bm; ++k) {
+    float hv = NEG;
+    int hi = 0x7fffffff;
+#pragma unroll
+    for (int j = 0; j < BEAM_MAX; ++j)
+      if (j == head) { hv = lv[j]; hi = li[j]; }
+    if (head >= n_bm) { hv = NEG; hi = 0x7fffffff; }
+    float bv = hv;
+    int bi = hi, bt = tid;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const float ov = __shfl_xor(bv, o, 64);
+      const int oi = __shfl_xor(bi, o, 64);
+      const int ot = __shfl_xor(bt, o, 64);
+      if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; bt = ot; }
+    }
+    if ((tid & 63) == 0) { red_v[tid >> 6] = bv; red_i[tid >> 6] = bi; red_t[tid >> 6] = bt; }
+    __syncthreads();
+    bv = red_v[0]; bi = red_i[0]; bt = red_t[0];
+    for (int w = 1; w < 4; ++w)
+      if (red_v[w] > bv || (red_v[w] == bv && red_i[w] < bi)) { bv = red_v[w]; bi = red_i[w]; bt = red_t[w]; }
+    if (tid == bt) head++;
+    if (tid == 0) { w_val[k] = bv; w_idx[k] = bi; }
+    __syncthreads();
+  }
+  (void)s_val; (void)s_idx;
+  // reorder the hypotheses by back-pointer and append the new word (prev_ks / next_ys, Beam.py:91-97)
+  for (int e = tid; e < n_bm * max_len; e += 256) {
+    const int k = e / max_len, l = e % max_len;
+    const int pk = w_idx[k] / V;
+    s_seq[e] = (l == t) ? (int64_t)(w_idx[k] - pk * V) : seqs[((int64_t)b * n_bm + pk) * max_len + l];
+  }
+  __syncthreads();
+  for (int e = tid; e < n_bm * max_len; e += 256) seqs[(int64_t)b * n_bm * max_len + e] = s_seq[e];
+  if (tid < n_bm) scores[b * n_bm + tid] = w_val[tid];
+  __syncthreads();
+  if (tid == 0) {
+    int cnt = fin_count[b];
+    bool is_done = false;
+    for (int i = 0; i < n_bm && !is_done; ++i) {
+      if (s_seq[i * max_len + t] == NACF_EOS) {                  // Beam.py:99-103
+        if (cnt < want) {
+          fin_scores[b * want + cnt] = w_val[i];
+          fin_len[b * want + cnt] = t;
+          for (int l = 0; l < max_len; ++l) fin_tokens[((int64_t)b * want + cnt) * max_len + l] = s_seq[i * max_len + l];
+        }
+        cnt++;
+        if (cnt >= want) is_done = true;
+      }
+    }
+    if (!is_done && t + 1 == max_len) {                          // Beam.py:116-121: len(next_ys) == max_len
+      is_done = true;
+      if (cnt == 0) {
+        for (int i = 0; i < n_bm; ++i) {
+          if (cnt < want) {
+            fin_scores[b * want + cnt] = w_val[i];
+            fin_len[b * want + cnt] = t;
+            for (int l = 0; l < max_len; ++l) fin_tokens[((int64_t)b * want + cnt) * max_len + l] = s_seq[i * max_len + l];
+          }
+          cnt++;
+          if (cnt >= want) break;
+        }
+      }
+    }
+    fin_count[b] = cnt < want ? cnt : want;
+    if (is_done) done[b] = 1;
+  }
+}
+
+__global__ void count_active_kernel(const int32_t* __restrict__ done, int B, int32_t* __restrict__ n_active) {
+  __shared__ int red[256];
+  int c = 0;
+  for (int b = threadIdx.x; b < B; b += blockDim.x) c += done[b] ? 0 : 1;
+  red[threadIdx.x] = c;
+  __syncthreads();
+  for (int o = blockDim.x >> 1; o > 0; o >>= 1) {
+    if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) n_active[0] = red[0];
+}
+
 inline int flat_grid(int64_t n) {
   int64_t b = (n + 255) / 256;
   return (int)(b > 4096 ? 4096 : (b < 1 ? 1 : b));
@@ -187,6 +321,23 @@ inline int flat_grid(int64_t n) {
 }  // namespace
 
 extern "C" {
+
+int nacf_beam_step(const float* logp, int64_t ldl, int B, int n_bm, int V, int t, int max_len, int want,
+                   int64_t* seqs, float* scores, float* fin_scores, int32_t* fin_len, int64_t* fin_tokens,
+                   int32_t* fin_count, int32_t* done, int32_t* n_active, nacf_stream_t stream) {
+  NACF_CHECK(logp && seqs && scores && fin_scores && fin_len && fin_tokens && fin_count && done, NACF_EINVAL,
+             "nacf_beam_step: null pointer");
+  NACF_CHECK(B > 0 && V > 0 && n_bm >= 1 && n_bm <= BEAM_MAX && want >= 1 && want <= BEAM_MAX, NACF_EUNSUPPORTED,
+             "nacf_beam_step: beam_size / topk must be in 1..%d", BEAM_MAX);
+  NACF_CHECK(max_len >= 2 && max_len <= 64 && t >= 1 && t < max_len, NACF_EINVAL, "nacf_beam_step: bad step/max_len");
+  NACF_CHECK((long)n_bm * V < 0x7fffffffL, NACF_EUNSUPPORTED, "nacf_beam_step: beam x vocab too large");
+  hipStream_t s = as_hip(stream);
+  hipLaunchKernelGGL(beam_step_kernel, dim3(B), dim3(256), 0, s, logp, ldl, n_bm, V, t, max_len, want, seqs, scores,
+                     fin_scores, fin_len, fin_tokens, fin_count, done);
+  if (n_active) hipLaunchKernelGGL(count_active_kernel, dim3(1), dim3(256), 0, s, done, B, n_active);
+  NACF_LAUNCH_CHECK("nacf_beam_step");
+  return NACF_OK;
+}
 
 int nacf_token_replace(int64_t* tokens, int64_t n, int64_t from, int64_t to, nacf_stream_t stream) {
   NACF_CHECK(tokens && n > 0, NACF_EINVAL, "nacf_token_replace: bad argument");

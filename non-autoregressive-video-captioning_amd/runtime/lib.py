@@ -79,6 +79,7 @@ SIGNATURES = {
     "nacf_select_rank": (c_int, [_P, _I, _I, _I, _I, _P, _P, _P]),
     "nacf_easy_first_update": (c_int, [_P, _P, _P, _P, _I, _I, _I, _P]),
     "nacf_best_candidate": (c_int, [_P, _P, _P, _P, _F, _I, _I, _I, _P, _P, _P, _P]),
+    "nacf_beam_step": (c_int, [_P, _L, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "nacf_adam_step": (c_int, [_P, _P, _P, _P, _L, _P, _P, _F, _F, _F, _F, _F, _F, _P]),
 }
 

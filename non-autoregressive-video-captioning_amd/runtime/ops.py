@@ -432,3 +432,12 @@ def adam_step(param, grad, m, v, lr_dev, step_dev, beta1, beta2, eps, weight_dec
     L.check(L.load().nacf_adam_step(_ptr(param), _ptr(grad), _ptr(m), _ptr(v), param.numel(), _ptr(lr_dev),
                                     _ptr(step_dev), float(beta1), float(beta2), float(eps), float(weight_decay),
                                     float(grad_clip), float(grad_scale), _stream()), "nacf_adam_step")
+
+
+# ---------------------------------------------------------------- AR beam search
+def beam_step(logp2d, V, t, max_len, want, seqs, scores, fin_scores, fin_len, fin_tokens, fin_count, done, n_active):
+    _chk_f32(logp2d, scores, fin_scores)
+    B, n_bm = scores.shape
+    L.check(L.load().nacf_beam_step(_ptr(logp2d), logp2d.stride(0), B, n_bm, V, int(t), int(max_len), int(want),
+                                    _ptr(seqs), _ptr(scores), _ptr(fin_scores), _ptr(fin_len), _ptr(fin_tokens),
+                                    _ptr(fin_count), _ptr(done), _ptr(n_active), _stream()), "nacf_beam_step")

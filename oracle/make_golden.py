@@ -234,13 +234,16 @@ def decode_case(name, method, extra, V, B, F_, variants, teacher_method=None, da
     np.savez_compressed(os.path.join(GOLD, name + ".npz"), **npz(out))
 
 
-def ar_case(name, method, extra, V, B, F_, dataset="MSRVTT"):
+def ar_case(name, method, extra, V, B, F_, dataset="MSRVTT", beam_size=3, topk=1, alpha=1.0, eos_boost=1.0):
+    """AR beam search (models/Beam.py + Translator.translate_batch_ARFormer).  `eos_boost` scales the
+    <eos> row of tgt_word_prj so that some hypotheses really end with <eos> at random init."""
     opt = ref_opt(method, dataset, TINY + list(extra))
     opt["vocab_size"] = V
-    opt["beam_size"] = 3
-    opt["beam_alpha"] = 1.0
-    opt["topk"] = 1
+    opt["beam_size"] = beam_size
+    opt["beam_alpha"] = alpha
+    opt["topk"] = topk
     sd = O.init_state_dict(opt, seed=11)
+    sd["tgt_word_prj.weight"][O.EOS] *= eos_boost
     model = ref_model(opt, sd); model.eval()
     batch = O.synth_batch(opt, B, F_, seed=13)
     os.chdir(REF)
@@ -251,20 +254,25 @@ def ar_case(name, method, extra, V, B, F_, dataset="MSRVTT"):
     tr = Translator(model, opt, device=torch.device("cpu"))
     hyps, scores = tr.translate_batch({k: v for k, v in enc.items()}, batch["category"], None, None)
     o_enc = O.encode(sd, opt, batch["feats"], training=False)
-    o_h, o_s = O.ar_beam_search(sd, opt, o_enc, batch["category"], beam_size=3, alpha=1.0, topk=1)
-    assert [h[0] for h in hyps] == [h[0] for h in o_h], (hyps, o_h)
+    o_h, o_s = O.ar_beam_search(sd, opt, o_enc, batch["category"], beam_size=beam_size, alpha=alpha, topk=topk)
+    assert hyps == o_h, (hyps, o_h)
     for a, b in zip(scores, o_s):
-        assert abs(a[0] - b[0]) < 1e-5
-    Lm = max(len(h[0]) for h in hyps)
-    arr = np.zeros((B, Lm), dtype=np.int64)
+        assert len(a) == len(b) and all(abs(x - y) < 1e-5 for x, y in zip(a, b))
+    nb = max(len(h) for h in hyps)
+    Lm = max(len(x) for h in hyps for x in h)
+    arr = np.zeros((B, nb, Lm), dtype=np.int64)
+    lens = np.zeros((B, nb), dtype=np.int64)
+    sc = np.zeros((B, nb), dtype=np.float64)
     for i, h in enumerate(hyps):
-        arr[i, :len(h[0])] = h[0]
+        for j, x in enumerate(h):
+            arr[i, j, :len(x)] = x; lens[i, j] = len(x); sc[i, j] = scores[i][j]
     out = {"opt_json": opt_blob(opt), "B": B, "F": F_, "in.category": batch["category"],
-           "hyp": arr, "hyp_len": np.array([len(h[0]) for h in hyps]), "score": np.array([s[0] for s in scores])}
+           "hyp": arr, "hyp_len": lens, "score": sc, "n_best": np.array([len(h) for h in hyps]),
+           "beam_size": beam_size, "topk": topk, "alpha": alpha, "eos_boost": eos_boost}
     for i, f in enumerate(batch["feats"]):
         out[f"in.feats{i}"] = f
     np.savez_compressed(os.path.join(GOLD, name + ".npz"), **npz(out))
-    print(f"[{name}] ok  lens {[len(h[0]) for h in hyps]}")
+    print(f"[{name}] ok  lens {lens.tolist()}  n_eos {int(sum(x[-1] == O.EOS for h in hyps for x in h))}")
 
 
 def full_shape_case(name="full_nacf", B=4, V=10547, L=20, F_=60):
@@ -314,8 +322,17 @@ def full_shape_case(name="full_nacf", B=4, V=10547, L=20, F_=60):
     print(f"[{name}] ok  min top1-top2 margin {float(out['logit_margin'].min()):.3e}")
 
 
+EOS_BOOST = float(os.environ.get("EOS_BOOST", "8.0"))
+
+
 def main():
     torch.manual_seed(0)
+    if os.environ.get("ONLY_AR"):
+        ar_case("tiny_arb2_beam", "ARB2", ["-wc"], V=101, B=3, F_=6)
+        ar_case("tiny_arb_beam", "ARB", ["-wc"], V=101, B=3, F_=6)
+        ar_case("tiny_arb_beam_eos", "ARB", ["-wc"], V=101, B=6, F_=6, beam_size=5, topk=3, alpha=1.0, eos_boost=EOS_BOOST)
+        ar_case("tiny_arb2_beam_eos", "ARB2", ["-wc"], V=101, B=6, F_=6, beam_size=4, topk=1, alpha=0.7, eos_boost=EOS_BOOST)
+        return
     # training: forward + loss + grads + Adam (tiny, dropout 0)
     train_case("tiny_nacf_train", "NACF", ["-wc"], V=101, B=3, F_=6)
     train_case("tiny_nab_train", "NAB", [], V=101, B=3, F_=6, dataset="Youtube2Text", beta=(0.0, 1.0))
@@ -341,6 +358,8 @@ def main():
     })
     ar_case("tiny_arb2_beam", "ARB2", ["-wc"], V=101, B=3, F_=6)
     ar_case("tiny_arb_beam", "ARB", ["-wc"], V=101, B=3, F_=6)
+    ar_case("tiny_arb_beam_eos", "ARB", ["-wc"], V=101, B=6, F_=6, beam_size=5, topk=3, alpha=1.0, eos_boost=EOS_BOOST)
+    ar_case("tiny_arb2_beam_eos", "ARB2", ["-wc"], V=101, B=6, F_=6, beam_size=4, topk=1, alpha=0.7, eos_boost=EOS_BOOST)
     full_shape_case()
 
 

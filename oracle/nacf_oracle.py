@@ -610,6 +610,7 @@ def ar_beam_search(sd: SD, opt: dict, enc_res: Dict[str, Tensor], category: Tens
     max_len = opt["max_len"]
     B = enc_res["enc_output"].shape[0]
     all_h, all_s = [], []
+    n_best = topk  # shrinks monotonically ACROSS instances upstream (Translator.py:84-92): kept as is
     for b in range(B):
         enc = enc_res["enc_output"][b:b + 1].expand(beam_size, -1, -1)
         cat = category[b:b + 1].expand(beam_size, -1)
@@ -664,7 +665,8 @@ def ar_beam_search(sd: SD, opt: dict, enc_res: Dict[str, Tensor], category: Tens
             it[0] /= it[1] ** alpha
         finished.sort(key=lambda a: -a[0])
         hyps, scs = [], []
-        for sc, t, k in finished[:topk]:
+        n_best = min(n_best, len(finished))
+        for sc, t, k in finished[:n_best]:
             h = []
             for j in range(t - 1, -1, -1):
                 h.append(int(ys[j + 1][k]))

@@ -129,6 +129,29 @@ def test_na_decode_with_ar_teacher_rescoring(dev):
         assert torch.equal(it_tok.cpu(), t(g[v + ".iter_tokens"]).long()), v
 
 
+@pytest.mark.parametrize("name", ["tiny_arb2_beam", "tiny_arb_beam", "tiny_arb_beam_eos", "tiny_arb2_beam_eos"])
+def test_ar_beam_search_vs_reference_golden(dev, name):
+    """config-5 comparator: batched device beam search == the reference's per-instance Beam objects"""
+    from nacf_amd.models.Translator import Translator
+    g = load_gold(name)
+    opt = gold_opt(g)
+    b = gold_batch(g, dev)
+    sd = O.init_state_dict(opt, seed=11)
+    sd["tgt_word_prj.weight"][O.EOS] *= float(g["eos_boost"])
+    model = build(opt, sd, dev); model.eval()
+    dopt = dict(model.opt, beam_size=int(g["beam_size"]), beam_alpha=float(g["alpha"]), topk=int(g["topk"]))
+    with torch.no_grad():
+        enc = model.encode(feats=b["feats"])
+    hyps, scores = Translator(model, dopt, device=dev).translate_batch(enc, b["category"], None, None)
+    assert len(hyps) == int(g["B"])
+    for i, h in enumerate(hyps):
+        assert len(h) == int(g["n_best"][i]), (i, h)
+        for j, x in enumerate(h):
+            n = int(g["hyp_len"][i, j])
+            assert x == g["hyp"][i, j, :n].tolist(), (i, j, x)
+            assert abs(scores[i][j] - float(g["score"][i, j])) < 2e-4
+
+
 def test_full_shape_logits_and_decode(dev):
     """d=512, F=60, V=10547: weights regenerated from the seeded generator."""
     g = load_gold("full_nacf")

@@ -78,18 +78,22 @@ def test_decode_with_teacher_matches_reference():
         assert torch.equal(hyp, t(g[v + ".hyp"])), v
 
 
-@pytest.mark.parametrize("name", ["tiny_arb2_beam", "tiny_arb_beam"])
+@pytest.mark.parametrize("name", ["tiny_arb2_beam", "tiny_arb_beam", "tiny_arb_beam_eos", "tiny_arb2_beam_eos"])
 def test_ar_beam_matches_reference(name):
     g = load_gold(name)
     opt = gold_opt(g)
     b = gold_batch(g)
     sd = O.init_state_dict(opt, seed=11)
+    sd["tgt_word_prj.weight"][O.EOS] *= float(g["eos_boost"])
     enc = O.encode(sd, opt, b["feats"], training=False)
-    hyps, scores = O.ar_beam_search(sd, opt, enc, b["category"], beam_size=3, alpha=1.0, topk=1)
+    hyps, scores = O.ar_beam_search(sd, opt, enc, b["category"], beam_size=int(g["beam_size"]),
+                                    alpha=float(g["alpha"]), topk=int(g["topk"]))
     for i, h in enumerate(hyps):
-        n = int(g["hyp_len"][i])
-        assert h[0] == g["hyp"][i, :n].tolist()
-        assert abs(scores[i][0] - float(g["score"][i])) < 1e-5
+        assert len(h) == int(g["n_best"][i])
+        for j, x in enumerate(h):
+            n = int(g["hyp_len"][i, j])
+            assert x == g["hyp"][i, j, :n].tolist()
+            assert abs(scores[i][j] - float(g["score"][i, j])) < 1e-5
 
 
 def test_weight_generator_is_reproducible():
