@@ -200,13 +200,17 @@ int nacf_embed_ln_bwd(const float* dOut, const float* xhat, const float* rstd,
                       int R, int L, int D, float p_drop, uint32_t salt, const uint64_t* rng_state,
                       void* ws, size_t ws_bytes, nacf_stream_t stream);
 /* Deterministic scatter of dE into the embedding tables (fixed summation order):
- *   dword[tok] += dE rows (PAD row left untouched: padding_idx, models/bert.py:55)
+ *   dword[tok] += dE rows (PAD row left untouched: padding_idx, models/bert.py:55); the special
+ *                 ids 1..5 (<unk> <bos> <eos> <mask> <vis>) label thousands of rows each and are
+ *                 summed chunk-parallel, every other id by the workgroup of its first occurrence
  *   dpos[l]    += sum_r dE[r,l]
- *   dcat[c]    += sum over rows of that category, dadd[v] (+)= sum over rows/positions of video v */
+ *   dadd[v]     = sum over rows/positions of video v ; dcat[c] += sum of those over the videos of category c
+ * ws: nacf_embed_scatter_bwd_workspace(R, L, D, n_video) bytes. */
+size_t nacf_embed_scatter_bwd_workspace(int R, int L, int D, int n_video);
 int nacf_embed_scatter_bwd(const float* dE, const int64_t* tokens, const int64_t* category,
                            float* dword, float* dpos, float* dcat, float* dadd,
                            int R, int L, int D, int V, int n_cat, int n_video, int vdiv, int vmod,
-                           nacf_stream_t stream);
+                           void* ws, size_t ws_bytes, nacf_stream_t stream);
 
 /* Multi-head attention core, models/bert.py:150-179:
  *   S = Q K^T / sqrt(dk) ; S[key masked] = -1e7 ; P = softmax(S) ; O = P V

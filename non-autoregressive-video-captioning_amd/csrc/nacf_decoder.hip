@@ -141,12 +141,12 @@ __global__ void embed_ln_bwd_final_kernel(const float* __restrict__ part, int nb
 __global__ __launch_bounds__(EMB_THREADS) void embed_scatter_word_kernel(const float* __restrict__ dE,
                                                                           const int64_t* __restrict__ tokens,
                                                                           float* __restrict__ dword, int n_rows,
-                                                                          int D) {
+                                                                          int D, int first_tok) {
   __shared__ int list[EMB_THREADS];
   __shared__ int wcnt[2];
   const int me = blockIdx.x;
   const int64_t tok = tokens[me];
-  if (tok == NACF_PAD) return;
+  if (tok < first_tok) return;  // PAD never gets a gradient; ids < first_tok go through the chunked path
   for (int base = 0; base < me; base += EMB_THREADS) {
     const int idx = base + threadIdx.x;
     const int found = (idx < me && tokens[idx] == tok) ? 1 : 0;
@@ -188,24 +188,99 @@ __global__ __launch_bounds__(EMB_THREADS) void embed_scatter_word_kernel(const f
   }
 }
 
-// mode 0: dpos[l] += sum_r dE[r,l]          (grid = L)
-// mode 1: dcat[c] += sum over rows whose video has category c  (grid = n_cat)
-// mode 2: dadd[v]  = sum over rows of video v (all positions)  (grid = n_video)
-__global__ __launch_bounds__(EMB_THREADS) void embed_scatter_misc_kernel(const float* __restrict__ dE,
-                                                                          const int64_t* __restrict__ category,
-                                                                          float* __restrict__ dst, int mode, int R,
-                                                                          int L, int D, int vdiv, int vmod) {
+// The special ids (<unk>, <bos>, <eos>, <mask>, <vis>) label thousands of rows each (every masked /
+// visual-word slot), so their rows are summed chunk-parallel: partial[chunk][tok-1][D] over 128-row
+// chunks, then a fixed-order combine.  grid = (n_chunks, SPECIAL_N)
+constexpr int SPECIAL_N = 5;          // ids 1..5
+constexpr int SCATTER_CHUNK = 128;
+__global__ __launch_bounds__(EMB_THREADS) void embed_scatter_special_partial_kernel(
+    const float* __restrict__ dE, const int64_t* __restrict__ tokens, float* __restrict__ part, int n_rows, int D) {
+  __shared__ int list[SCATTER_CHUNK];
+  __shared__ int wcnt[2];
+  const int chunk = blockIdx.x;
+  const int64_t tok = blockIdx.y + 1;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int idx = chunk * SCATTER_CHUNK + threadIdx.x;
+  const bool match = idx < n_rows && tokens[idx] == tok;
+  const unsigned long long bal = __ballot(match);
+  const int pre = __popcll(bal & ((1ull << lane) - 1ull));
+  if (lane == 0) wcnt[wave] = __popcll(bal);
+  __syncthreads();
+  const int off = (wave == 0) ? 0 : wcnt[0];
+  const int n = wcnt[0] + wcnt[1];
+  if (match) list[off + pre] = idx;
+  __syncthreads();
   f32x4 acc[EMB_MAXJ];
 #pragma unroll
   for (int j = 0; j < EMB_MAXJ; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int i = 0; i < n; ++i) {
+    const int64_t src = (int64_t)list[i] * D;
+#pragma unroll
+    for (int j = 0; j < EMB_MAXJ; ++j) {
+      const int d = (threadIdx.x + EMB_THREADS * j) * 4;
+      if (d < D) acc[j] += *reinterpret_cast<const f32x4*>(dE + src + d);
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < EMB_MAXJ; ++j) {
+    const int d = (threadIdx.x + EMB_THREADS * j) * 4;
+    if (d < D) *reinterpret_cast<f32x4*>(part + ((int64_t)chunk * SPECIAL_N + blockIdx.y) * D + d) = acc[j];
+  }
+}
+
+// dst[(row0 + blockIdx.x)] (+)= sum_{c < n_parts} part[c][blockIdx.x]  (fixed order)
+__global__ __launch_bounds__(EMB_THREADS) void embed_scatter_combine_kernel(const float* __restrict__ part, int n_parts,
+                                                                             int n_items, float* __restrict__ dst,
+                                                                             int row0, int D, int accumulate) {
+  const int item = blockIdx.x;
+#pragma unroll
+  for (int j = 0; j < EMB_MAXJ; ++j) {
+    const int d = (threadIdx.x + EMB_THREADS * j) * 4;
+    if (d < D) {
+      f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int c = 0; c < n_parts; ++c) acc += *reinterpret_cast<const f32x4*>(part + ((int64_t)c * n_items + item) * D + d);
+      float* o = dst + (int64_t)(row0 + item) * D + d;
+      if (accumulate) acc += *reinterpret_cast<const f32x4*>(o);
+      *reinterpret_cast<f32x4*>(o) = acc;
+    }
+  }
+}
+
+// part[pc][l][D] = sum over the rows r of chunk pc of dE[r, l]   grid = (L, n_pchunks)
+__global__ __launch_bounds__(EMB_THREADS) void embed_scatter_pos_partial_kernel(const float* __restrict__ dE,
+                                                                                 float* __restrict__ part, int R, int L,
+                                                                                 int D, int rows_per) {
+  const int l = blockIdx.x, pc = blockIdx.y;
+  const int r0 = pc * rows_per, r1 = min(R, r0 + rows_per);
+  f32x4 acc[EMB_MAXJ];
+#pragma unroll
+  for (int j = 0; j < EMB_MAXJ; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int r = r0; r < r1; ++r) {
+    const int64_t src = ((int64_t)r * L + l) * D;
+#pragma unroll
+    for (int j = 0; j < EMB_MAXJ; ++j) {
+      const int d = (threadIdx.x + EMB_THREADS * j) * 4;
+      if (d < D) acc[j] += *reinterpret_cast<const f32x4*>(dE + src + d);
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < EMB_MAXJ; ++j) {
+    const int d = (threadIdx.x + EMB_THREADS * j) * 4;
+    if (d < D) *reinterpret_cast<f32x4*>(part + ((int64_t)pc * L + l) * D + d) = acc[j];
+  }
+}
+
+// vsum[v] = sum over the decoder rows of video v and all positions   grid = n_video
+__global__ __launch_bounds__(EMB_THREADS) void embed_scatter_video_kernel(const float* __restrict__ dE,
+                                                                           float* __restrict__ vsum, int R, int L, int D,
+                                                                           int vdiv, int vmod) {
   const int me = blockIdx.x;
+  f32x4 acc[EMB_MAXJ];
+#pragma unroll
+  for (int j = 0; j < EMB_MAXJ; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
   for (int r = 0; r < R; ++r) {
-    const int v = (r / vdiv) % vmod;
-    int l0 = 0, l1 = L;
-    if (mode == 0) { l0 = me; l1 = me + 1; }
-    else if (mode == 1) { if (category[v] != me) continue; }
-    else { if (v != me) continue; }
-    for (int l = l0; l < l1; ++l) {
+    if ((r / vdiv) % vmod != me) continue;
+    for (int l = 0; l < L; ++l) {
       const int64_t src = ((int64_t)r * L + l) * D;
 #pragma unroll
       for (int j = 0; j < EMB_MAXJ; ++j) {
@@ -217,13 +292,33 @@ __global__ __launch_bounds__(EMB_THREADS) void embed_scatter_misc_kernel(const f
 #pragma unroll
   for (int j = 0; j < EMB_MAXJ; ++j) {
     const int d = (threadIdx.x + EMB_THREADS * j) * 4;
+    if (d < D) *reinterpret_cast<f32x4*>(vsum + (int64_t)me * D + d) = acc[j];
+  }
+}
+
+// dcat[c] += sum of vsum[v] over the videos of category c (ascending v)   grid = n_cat
+__global__ __launch_bounds__(EMB_THREADS) void embed_scatter_cat_kernel(const float* __restrict__ vsum,
+                                                                         const int64_t* __restrict__ category,
+                                                                         float* __restrict__ dcat, int n_video, int D) {
+  const int me = blockIdx.x;
+  f32x4 acc[EMB_MAXJ];
+#pragma unroll
+  for (int j = 0; j < EMB_MAXJ; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int v = 0; v < n_video; ++v) {
+    if (category[v] != me) continue;
+#pragma unroll
+    for (int j = 0; j < EMB_MAXJ; ++j) {
+      const int d = (threadIdx.x + EMB_THREADS * j) * 4;
+      if (d < D) acc[j] += *reinterpret_cast<const f32x4*>(vsum + (int64_t)v * D + d);
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < EMB_MAXJ; ++j) {
+    const int d = (threadIdx.x + EMB_THREADS * j) * 4;
     if (d < D) {
-      float* o = dst + (int64_t)me * D + d;
-      if (mode == 2) *reinterpret_cast<f32x4*>(o) = acc[j];
-      else {
-        f32x4 cur = *reinterpret_cast<f32x4*>(o);
-        *reinterpret_cast<f32x4*>(o) = cur + acc[j];
-      }
+      float* o = dcat + (int64_t)me * D + d;
+      f32x4 cur = *reinterpret_cast<f32x4*>(o);
+      *reinterpret_cast<f32x4*>(o) = cur + acc[j];
     }
   }
 }
@@ -452,23 +547,58 @@ int nacf_embed_ln_bwd(const float* dOut, const float* xhat, const float* rstd, c
   return NACF_OK;
 }
 
+static int scatter_pos_chunks(int R) { int c = R / 16; return c < 1 ? 1 : (c > 16 ? 16 : c); }
+
+size_t nacf_embed_scatter_bwd_workspace(int R, int L, int D, int n_video) {
+  const size_t chunks = (size_t)cdiv(R * L, SCATTER_CHUNK);
+  const size_t special = chunks * SPECIAL_N * D;
+  const size_t pos = (size_t)scatter_pos_chunks(R) * L * D;
+  const size_t vid = (size_t)(n_video > 0 ? n_video : 1) * D;
+  return (special + pos + vid) * sizeof(float) + 256;
+}
+
 int nacf_embed_scatter_bwd(const float* dE, const int64_t* tokens, const int64_t* category, float* dword, float* dpos,
                            float* dcat, float* dadd, int R, int L, int D, int V, int n_cat, int n_video, int vdiv,
-                           int vmod, nacf_stream_t stream) {
+                           int vmod, void* ws, size_t ws_bytes, nacf_stream_t stream) {
   NACF_CHECK(dE && tokens, NACF_EINVAL, "nacf_embed_scatter_bwd: null pointer");
   NACF_CHECK(R > 0 && L > 0 && D > 0 && D % 4 == 0 && D <= EMB_MAXJ * EMB_THREADS * 4 && vdiv > 0 && vmod > 0,
              NACF_EINVAL, "nacf_embed_scatter_bwd: bad shape");
   NACF_CHECK(!(dcat && !category), NACF_EINVAL, "nacf_embed_scatter_bwd: dcat needs category");
-  (void)V;
+  NACF_CHECK(!((dcat || dadd) && n_video <= 0), NACF_EINVAL, "nacf_embed_scatter_bwd: n_video must be > 0");
+  NACF_CHECK(ws && ws_bytes >= nacf_embed_scatter_bwd_workspace(R, L, D, n_video), NACF_EWORKSPACE,
+             "nacf_embed_scatter_bwd: workspace too small");
   hipStream_t s = as_hip(stream);
-  if (dword)
-    hipLaunchKernelGGL(embed_scatter_word_kernel, dim3(R * L), dim3(EMB_THREADS), 0, s, dE, tokens, dword, R * L, D);
-  if (dpos)
-    hipLaunchKernelGGL(embed_scatter_misc_kernel, dim3(L), dim3(EMB_THREADS), 0, s, dE, category, dpos, 0, R, L, D, vdiv, vmod);
-  if (dcat)
-    hipLaunchKernelGGL(embed_scatter_misc_kernel, dim3(n_cat), dim3(EMB_THREADS), 0, s, dE, category, dcat, 1, R, L, D, vdiv, vmod);
-  if (dadd)
-    hipLaunchKernelGGL(embed_scatter_misc_kernel, dim3(n_video), dim3(EMB_THREADS), 0, s, dE, category, dadd, 2, R, L, D, vdiv, vmod);
+  const int rows = R * L;
+  const int chunks = cdiv(rows, SCATTER_CHUNK);
+  float* part_special = reinterpret_cast<float*>(ws);
+  float* part_pos = part_special + (size_t)chunks * SPECIAL_N * D;
+  float* vsum_ws = part_pos + (size_t)scatter_pos_chunks(R) * L * D;
+  if (dword) {
+    const int n_special = V - 1 < SPECIAL_N ? V - 1 : SPECIAL_N;   // tiny vocabularies
+    if (n_special > 0) {
+      hipLaunchKernelGGL(embed_scatter_special_partial_kernel, dim3(chunks, n_special), dim3(EMB_THREADS), 0, s, dE, tokens,
+                         part_special, rows, D);
+      // partial layout is [chunk][SPECIAL_N][D]: combine with n_items = SPECIAL_N, only the first n_special used
+      hipLaunchKernelGGL(embed_scatter_combine_kernel, dim3(n_special), dim3(EMB_THREADS), 0, s, part_special, chunks,
+                         SPECIAL_N, dword, 1, D, 1);
+    }
+    hipLaunchKernelGGL(embed_scatter_word_kernel, dim3(rows), dim3(EMB_THREADS), 0, s, dE, tokens, dword, rows, D,
+                       1 + n_special);
+  }
+  if (dpos) {
+    const int pch = scatter_pos_chunks(R);
+    const int rows_per = cdiv(R, pch);
+    const int real = cdiv(R, rows_per);
+    hipLaunchKernelGGL(embed_scatter_pos_partial_kernel, dim3(L, real), dim3(EMB_THREADS), 0, s, dE, part_pos, R, L, D,
+                       rows_per);
+    hipLaunchKernelGGL(embed_scatter_combine_kernel, dim3(L), dim3(EMB_THREADS), 0, s, part_pos, real, L, dpos, 0, D, 1);
+  }
+  if (dcat || dadd) {
+    float* vs = dadd ? dadd : vsum_ws;
+    hipLaunchKernelGGL(embed_scatter_video_kernel, dim3(n_video), dim3(EMB_THREADS), 0, s, dE, vs, R, L, D, vdiv, vmod);
+    if (dcat)
+      hipLaunchKernelGGL(embed_scatter_cat_kernel, dim3(n_cat), dim3(EMB_THREADS), 0, s, vs, category, dcat, n_video, D);
+  }
   NACF_LAUNCH_CHECK("nacf_embed_scatter_bwd");
   return NACF_OK;
 }

@@ -213,7 +213,7 @@ class EmbedLNFn(Function):
         ops.embed_scatter_bwd(dE, ctx.tokens, ctx.category if cat is not None else None,
                               word.gw if cfg.get("train_word", True) else None, pos.gw,
                               cat.gw if cat is not None else None, dadd, R, Lq, D, word.w.shape[0],
-                              cat.w.shape[0] if cat is not None else 0, ctx.n_video, cfg["vdiv"], cfg["vmod"])
+                              cat.w.shape[0] if cat is not None else 0, cfg["vmod"], cfg["vdiv"], cfg["vmod"])
         ctx.xhat = ctx.rstd = None
         return (dadd, None, None, None) + (None,) * (len(ctx.needs_input_grad) - 4)
 

@@ -290,9 +290,11 @@ def embed_ln_bwd(dout, xhat, rstd, ln_w, dE, dln_w, dln_b, R, Lq, D, p, salt, rn
 
 
 def embed_scatter_bwd(dE, tokens, category, dword, dpos, dcat, dadd, R, Lq, D, V, n_cat, n_video, vdiv, vmod):
-    L.check(L.load().nacf_embed_scatter_bwd(_ptr(dE), _ptr(tokens), _ptr(category), _ptr(dword), _ptr(dpos),
-                                            _ptr(dcat), _ptr(dadd), R, Lq, D, V, n_cat, n_video, vdiv, vmod,
-                                            _stream()), "nacf_embed_scatter_bwd")
+    lib = L.load()
+    ws = WORKSPACE.get(lib.nacf_embed_scatter_bwd_workspace(R, Lq, D, n_video), dE.device)
+    L.check(lib.nacf_embed_scatter_bwd(_ptr(dE), _ptr(tokens), _ptr(category), _ptr(dword), _ptr(dpos), _ptr(dcat),
+                                       _ptr(dadd), R, Lq, D, V, n_cat, n_video, vdiv, vmod, _ptr(ws), ws.numel(),
+                                       _stream()), "nacf_embed_scatter_bwd")
 
 
 def attention_fwd(q, k, v, out, key_tokens, causal, probs, R, H, Lq, Lk, dk, kv_div, kv_mod):

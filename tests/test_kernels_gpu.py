@@ -324,7 +324,7 @@ def test_embed_ln_fwd_bwd_scatter(dev, R, Lq, D, V, with_cat):
     if with_cat:
         assert err(dcat, cat.grad) < 2e-4
     d2 = torch.zeros(V, D, device=dev)
-    ops.embed_scatter_bwd(dE, tok.to(dev), None, d2, None, None, None, R, Lq, D, V, 0, 0, 1, Bv)
+    ops.embed_scatter_bwd(dE, tok.to(dev), None, d2, None, None, None, R, Lq, D, V, 0, Bv, 1, Bv)
     assert torch.equal(d2, dword)                           # fixed summation order
 
 
