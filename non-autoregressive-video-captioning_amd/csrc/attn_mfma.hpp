@@ -1,0 +1,355 @@
+// Register-resident multi-head attention on the CDNA4 matrix cores (fp32,
+// v_mfma_f32_16x16x4_f32), forward and backward.  One WAVE owns one
+// (sequence, head) pair: Lq <= 32 queries (2 MFMA row tiles), Lk <= 16*NKT keys,
+// dk = 16*DK16.  Nothing is staged through LDS in the forward pass: the MFMA
+// fragment layouts are chosen so that every operand is either a coalesced
+// global load or already sitting in the accumulator registers:
+//
+//  S^T = K Q^T   : a = K[key=i][d], b = Q[q=i][d] with the reduce index d
+//                  k-permuted (lane group g walks d = g*dk/4 + step), so a lane
+//                  fetches dk/4 CONTIGUOUS floats of its own K / Q row.
+//                  Result: lane (i, g) holds S[q = 16*tm + i][key = 16*tn + 4g + rr].
+//  softmax       : per q row = 32 values in-lane + 2 xor-shuffles across g.
+//  O = P V       : reduce index = key, k-permuted so that lane group g consumes
+//                  exactly the keys whose P it already holds (b operand = the
+//                  accumulator register itself); a = V[key][DK16*i + td], i.e.
+//                  each lane loads DK16 contiguous floats of a V row and the
+//                  output-column permutation d = DK16*n + td makes the lane's
+//                  results DK16 contiguous floats of O again.
+//
+// Backward re-computes P the same way, gets dP = dO V^T and dQ = dS K with the
+// two forward contractions, and only the reductions over q (dK = dS^T Q,
+// dV = P^T dO) need a transpose, done through a wave-private LDS tile.
+#pragma once
+#include "common.hpp"
+
+namespace attn {
+
+template <int N> struct Ld;
+template <> struct Ld<1> {
+  static __device__ __forceinline__ void ld(const float* p, float (&v)[1]) { v[0] = p[0]; }
+  static __device__ __forceinline__ void st(float* p, const float (&v)[1]) { p[0] = v[0]; }
+};
+template <> struct Ld<2> {
+  static __device__ __forceinline__ void ld(const float* p, float (&v)[2]) {
+    const float2 t = *reinterpret_cast<const float2*>(p); v[0] = t.x; v[1] = t.y;
+  }
+  static __device__ __forceinline__ void st(float* p, const float (&v)[2]) {
+    *reinterpret_cast<float2*>(p) = make_float2(v[0], v[1]);
+  }
+};
+template <> struct Ld<4> {
+  static __device__ __forceinline__ void ld(const float* p, float (&v)[4]) {
+    const f32x4 t = *reinterpret_cast<const f32x4*>(p); v[0] = t[0]; v[1] = t[1]; v[2] = t[2]; v[3] = t[3];
+  }
+  static __device__ __forceinline__ void st(float* p, const float (&v)[4]) {
+    *reinterpret_cast<f32x4*>(p) = f32x4{v[0], v[1], v[2], v[3]};
+  }
+};
+
+// row fragments of a [rows, dk] operand for the "reduce over d" contractions:
+// lane (i, g) loads floats [g*dk/4, (g+1)*dk/4) of row (16*t + i); rows >= n_rows read as zero
+template <int DK16>
+__device__ __forceinline__ void load_row_frag(f32x4 (&f)[DK16], const float* __restrict__ base, int64_t ld, int row,
+                                              int n_rows, int g) {
+  constexpr int DK = 16 * DK16;
+#pragma unroll
+  for (int j = 0; j < DK16; ++j) {
+    f[j] = (row < n_rows) ? *reinterpret_cast<const f32x4*>(base + (int64_t)row * ld + g * (DK / 4) + 4 * j)
+                          : f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+}
+
+// acc[tm][tn] (+)= sum_d  A[16*tn + i][d] * B[16*tm + i][d]   (A: keys side, B: queries side)
+template <int NKT, int DK16>
+__device__ __forceinline__ void contract_d(f32x4 (&acc)[2][NKT], const float* __restrict__ A, int64_t lda, int n_a,
+                                           const f32x4 (&bf)[2][DK16], int i, int g) {
+#pragma unroll
+  for (int tn = 0; tn < NKT; ++tn) {
+    f32x4 af[DK16];
+    load_row_frag<DK16>(af, A, lda, tn * 16 + i, n_a, g);
+#pragma unroll
+    for (int j = 0; j < DK16; ++j)
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int tm = 0; tm < 2; ++tm)
+          acc[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[j][e], bf[tm][j][e], acc[tm][tn], 0, 0, 0);
+  }
+}
+
+// o[tm][td] = sum_key  P[16*tm + i][key] * A[key][DK16*n + td]   with P in the accumulator layout of contract_d
+template <int NKT, int DK16>
+__device__ __forceinline__ void contract_key(f32x4 (&o)[2][DK16], const f32x4 (&p)[2][NKT],
+                                             const float* __restrict__ A, int64_t lda, int n_a, int i, int g) {
+#pragma unroll
+  for (int tn = 0; tn < NKT; ++tn)
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) {
+      int key = tn * 16 + g * 4 + rr;
+      key = key < n_a ? key : n_a - 1;          // P is exactly 0 there; keep the address in range
+      float af[DK16];
+      Ld<DK16>::ld(A + (int64_t)key * lda + DK16 * i, af);
+#pragma unroll
+      for (int td = 0; td < DK16; ++td)
+#pragma unroll
+        for (int tm = 0; tm < 2; ++tm)
+          o[tm][td] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[td], p[tm][tn][rr], o[tm][td], 0, 0, 0);
+    }
+}
+
+// store o[tm][td] (layout of contract_key) as rows of a [rows, dk] matrix
+template <int DK16>
+__device__ __forceinline__ void store_rows(const f32x4 (&o)[2][DK16], float* __restrict__ out, int64_t ld, int n_rows,
+                                           int i, int g) {
+#pragma unroll
+  for (int tm = 0; tm < 2; ++tm) {
+    const int q = tm * 16 + i;
+    if (q < n_rows) {
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr) {
+        float v[DK16];
+#pragma unroll
+        for (int td = 0; td < DK16; ++td) v[td] = o[tm][td][rr];
+        Ld<DK16>::st(out + (int64_t)q * ld + DK16 * (g * 4 + rr), v);
+      }
+    }
+  }
+}
+
+// scores (accumulator layout) -> probabilities, in place.  Mirrors models/bert.py:157-167:
+// divide by sqrt(dk) AFTER the product, masked_fill(-10e6), softmax over keys.
+template <int NKT>
+__device__ __forceinline__ void softmax_rows(f32x4 (&s)[2][NKT], float sq, const int64_t* __restrict__ key_tok,
+                                             int causal, int Lk, int i, int g) {
+  unsigned long long padbits = 0ull;  // bit (tn*4+rr): key is PAD or beyond Lk handled separately
+  if (key_tok) {
+#pragma unroll
+    for (int tn = 0; tn < NKT; ++tn)
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr) {
+        const int key = tn * 16 + g * 4 + rr;
+        if (key < Lk && key_tok[key] == NACF_PAD) padbits |= 1ull << (tn * 4 + rr);
+      }
+  }
+#pragma unroll
+  for (int tm = 0; tm < 2; ++tm) {
+    const int q = tm * 16 + i;
+    float mx = -3.0e38f;
+#pragma unroll
+    for (int tn = 0; tn < NKT; ++tn)
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr) {
+        const int key = tn * 16 + g * 4 + rr;
+        float v = s[tm][tn][rr] / sq;
+        if ((padbits >> (tn * 4 + rr)) & 1ull) v = -10e6f;
+        if (causal && key > q) v = -10e6f;
+        if (key >= Lk) v = -3.0e38f;             // tile padding: contributes exactly 0
+        s[tm][tn][rr] = v;
+        mx = fmaxf(mx, v);
+      }
+    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    float sum = 0.f;
+#pragma unroll
+    for (int tn = 0; tn < NKT; ++tn)
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr) {
+        const float e = expf(s[tm][tn][rr] - mx);
+        s[tm][tn][rr] = e;
+        sum += e;
+      }
+    sum += __shfl_xor(sum, 16, 64);
+    sum += __shfl_xor(sum, 32, 64);
+#pragma unroll
+    for (int tn = 0; tn < NKT; ++tn)
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr) s[tm][tn][rr] = s[tm][tn][rr] / sum;
+  }
+}
+
+template <int NKT, int DK16>
+__global__ __launch_bounds__(256) void fwd_kernel(const float* __restrict__ Q, int64_t ldq, const float* __restrict__ K,
+                                                   int64_t ldk, const float* __restrict__ V, int64_t ldv,
+                                                   float* __restrict__ O, int64_t ldo,
+                                                   const int64_t* __restrict__ key_tokens, int causal,
+                                                   float* __restrict__ probs, int R, int H, int Lq, int Lk, int kv_div,
+                                                   int kv_mod) {
+  constexpr int DK = 16 * DK16;
+  const int lane = threadIdx.x & 63;
+  const int item = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (item >= R * H) return;
+  const int r = item / H, h = item % H;
+  const int kvr = (r / kv_div) % kv_mod;
+  const int i = lane & 15, g = lane >> 4;
+  const float* Qb = Q + (int64_t)r * Lq * ldq + h * DK;
+  const float* Kb = K + (int64_t)kvr * Lk * ldk + h * DK;
+  const float* Vb = V + (int64_t)kvr * Lk * ldv + h * DK;
+  f32x4 qf[2][DK16];
+#pragma unroll
+  for (int tm = 0; tm < 2; ++tm) load_row_frag<DK16>(qf[tm], Qb, ldq, tm * 16 + i, Lq, g);
+  f32x4 s[2][NKT];
+#pragma unroll
+  for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+    for (int tn = 0; tn < NKT; ++tn) s[tm][tn] = f32x4{0.f, 0.f, 0.f, 0.f};
+  contract_d<NKT, DK16>(s, Kb, ldk, Lk, qf, i, g);
+  softmax_rows<NKT>(s, sqrtf((float)DK), key_tokens ? key_tokens + (int64_t)r * Lk : nullptr, causal, Lk, i, g);
+  if (probs) {
+#pragma unroll
+    for (int tm = 0; tm < 2; ++tm) {
+      const int q = tm * 16 + i;
+      if (q < Lq) {
+#pragma unroll
+        for (int tn = 0; tn < NKT; ++tn)
+#pragma unroll
+          for (int rr = 0; rr < 4; ++rr) {
+            const int key = tn * 16 + g * 4 + rr;
+            if (key < Lk) probs[(((int64_t)h * R + r) * Lq + q) * Lk + key] = s[tm][tn][rr];
+          }
+      }
+    }
+  }
+  f32x4 o[2][DK16];
+#pragma unroll
+  for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+    for (int td = 0; td < DK16; ++td) o[tm][td] = f32x4{0.f, 0.f, 0.f, 0.f};
+  contract_key<NKT, DK16>(o, s, Vb, ldv, Lk, i, g);
+  store_rows<DK16>(o, O + (int64_t)r * Lq * ldo + h * DK, ldo, Lq, i, g);
+}
+
+// dst[key][d] (+)= sum_q T[q][key] * A[q][d]  for key tiles [tk0, tk0+TKC), T = wave-private LDS tile [32][PITCH]
+template <int NKT, int DK16, int TKC>
+__device__ __forceinline__ void contract_q(const float* T, int pitch, const float* __restrict__ A,
+                                           int64_t lda, int n_q, float* __restrict__ dst, int64_t ldd, int n_keys,
+                                           bool accumulate, int i, int g) {
+#pragma unroll
+  for (int tk0 = 0; tk0 < NKT; tk0 += TKC) {
+    f32x4 acc[DK16][TKC];
+#pragma unroll
+    for (int td = 0; td < DK16; ++td)
+#pragma unroll
+      for (int t = 0; t < TKC; ++t) acc[td][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int st = 0; st < 8; ++st) {
+      const int q = st * 4 + g;                 // k-permutation of the reduce index q (Lq padded to 32)
+      float af[DK16];
+#pragma unroll
+      for (int td = 0; td < DK16; ++td) af[td] = 0.f;
+      if (q < n_q) Ld<DK16>::ld(A + (int64_t)q * lda + DK16 * i, af);
+#pragma unroll
+      for (int t = 0; t < TKC; ++t) {
+        const float b = T[q * pitch + (tk0 + t) * 16 + i];
+#pragma unroll
+        for (int td = 0; td < DK16; ++td)
+          acc[td][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[td], b, acc[td][t], 0, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int t = 0; t < TKC; ++t) {
+      const int key = (tk0 + t) * 16 + i;
+      if (key < n_keys) {
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+          float* p = dst + (int64_t)key * ldd + DK16 * (g * 4 + rr);
+          float v[DK16];
+          if (accumulate) Ld<DK16>::ld(p, v);
+#pragma unroll
+          for (int td = 0; td < DK16; ++td) v[td] = accumulate ? v[td] + acc[td][t][rr] : acc[td][t][rr];
+          Ld<DK16>::st(p, v);
+        }
+      }
+    }
+  }
+}
+
+template <int NKT>
+__device__ __forceinline__ void tile_to_lds(float* T, int pitch, const f32x4 (&p)[2][NKT], int i, int g) {
+#pragma unroll
+  for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+    for (int tn = 0; tn < NKT; ++tn)
+      *reinterpret_cast<f32x4*>(&T[(tm * 16 + i) * pitch + tn * 16 + g * 4]) = p[tm][tn];
+}
+
+template <int NKT, int DK16>
+__global__ __launch_bounds__(256) void bwd_kernel(const float* __restrict__ Q, int64_t ldq, const float* __restrict__ K,
+                                                   int64_t ldk, const float* __restrict__ V, int64_t ldv,
+                                                   const float* __restrict__ dO, int64_t lddo, float* __restrict__ dQ,
+                                                   int64_t lddq, float* __restrict__ dK, int64_t lddk,
+                                                   float* __restrict__ dV, int64_t lddv,
+                                                   const int64_t* __restrict__ key_tokens, int causal, int R, int n_kv,
+                                                   int H, int Lq, int Lk, int kv_div, int kv_mod) {
+  constexpr int DK = 16 * DK16;
+  constexpr int PITCH = NKT * 16 + 16;          // = 16 mod 32 dwords: the q = 4*st + g rows of a read land 16 banks apart
+  constexpr int TKC = NKT < 4 ? NKT : 4;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float* T = smem + wave * 32 * PITCH;
+  const int item = blockIdx.x * 4 + wave;
+  if (item >= n_kv * H) return;
+  const int kvr = item / H, h = item % H;
+  const int i = lane & 15, g = lane >> 4;
+  const float sq = sqrtf((float)DK);
+  const float* Kb = K + (int64_t)kvr * Lk * ldk + h * DK;
+  const float* Vb = V + (int64_t)kvr * Lk * ldv + h * DK;
+  float* dKb = dK + (int64_t)kvr * Lk * lddk + h * DK;
+  float* dVb = dV + (int64_t)kvr * Lk * lddv + h * DK;
+  bool seen = false;
+  for (int r = 0; r < R; ++r) {
+    if ((r / kv_div) % kv_mod != kvr) continue;
+    const float* Qb = Q + (int64_t)r * Lq * ldq + h * DK;
+    const float* dOb = dO + (int64_t)r * Lq * lddo + h * DK;
+    f32x4 p[2][NKT], dp[2][NKT];
+#pragma unroll
+    for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+      for (int tn = 0; tn < NKT; ++tn) { p[tm][tn] = f32x4{0.f, 0.f, 0.f, 0.f}; dp[tm][tn] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+    {
+      f32x4 qf[2][DK16];
+#pragma unroll
+      for (int tm = 0; tm < 2; ++tm) load_row_frag<DK16>(qf[tm], Qb, ldq, tm * 16 + i, Lq, g);
+      contract_d<NKT, DK16>(p, Kb, ldk, Lk, qf, i, g);
+    }
+    softmax_rows<NKT>(p, sq, key_tokens ? key_tokens + (int64_t)r * Lk : nullptr, causal, Lk, i, g);
+    {
+      f32x4 gf[2][DK16];
+#pragma unroll
+      for (int tm = 0; tm < 2; ++tm) load_row_frag<DK16>(gf[tm], dOb, lddo, tm * 16 + i, Lq, g);
+      contract_d<NKT, DK16>(dp, Vb, ldv, Lk, gf, i, g);   // dP = dO V^T
+    }
+    // dS = P * (dP - rowsum(P * dP)) / sqrt(dk)
+#pragma unroll
+    for (int tm = 0; tm < 2; ++tm) {
+      float dot = 0.f;
+#pragma unroll
+      for (int tn = 0; tn < NKT; ++tn)
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) dot += p[tm][tn][rr] * dp[tm][tn][rr];
+      dot += __shfl_xor(dot, 16, 64);
+      dot += __shfl_xor(dot, 32, 64);
+#pragma unroll
+      for (int tn = 0; tn < NKT; ++tn)
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) dp[tm][tn][rr] = p[tm][tn][rr] * (dp[tm][tn][rr] - dot) / sq;
+    }
+    {
+      f32x4 o[2][DK16];
+#pragma unroll
+      for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+        for (int td = 0; td < DK16; ++td) o[tm][td] = f32x4{0.f, 0.f, 0.f, 0.f};
+      contract_key<NKT, DK16>(o, dp, Kb, ldk, Lk, i, g);   // dQ = dS K
+      store_rows<DK16>(o, dQ + (int64_t)r * Lq * lddq + h * DK, lddq, Lq, i, g);
+    }
+    // reductions over q: transpose dS / P through the wave-private LDS tile
+    tile_to_lds<NKT>(T, PITCH, dp, i, g);
+    contract_q<NKT, DK16, TKC>(T, PITCH, Qb, ldq, Lq, dKb, lddk, Lk, seen, i, g);    // dK (+)= dS^T Q
+    tile_to_lds<NKT>(T, PITCH, p, i, g);
+    contract_q<NKT, DK16, TKC>(T, PITCH, dOb, lddo, Lq, dVb, lddv, Lk, seen, i, g);  // dV (+)= P^T dO
+    seen = true;
+  }
+}
+
+}  // namespace attn

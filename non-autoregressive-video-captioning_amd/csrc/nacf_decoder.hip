@@ -6,8 +6,21 @@
 // FLOPs) so it runs on the fp32 VALU out of LDS; one workgroup
 // per (sequence, head) keeps K/V/scores on chip for the whole softmax(QK^T)V.
 #include "common.hpp"
+#include "attn_mfma.hpp"
+#include <stdlib.h>
 
 namespace {
+
+// shapes the register-resident MFMA attention covers; anything else (or NACF_ATTN_VALU=1)
+// takes the generic LDS/VALU kernels below
+inline bool attn_mfma_ok(int Lq, int Lk, int dk) {
+  const char* e = getenv("NACF_ATTN_VALU");
+  if (e && atoi(e) != 0) return false;
+  return Lq <= 32 && Lk <= 128 && (dk == 16 || dk == 64);
+}
+inline bool attn_aligned(const void* p, int64_t ld) {
+  return (reinterpret_cast<uintptr_t>(p) & 15) == 0 && (ld % 4) == 0;
+}
 
 constexpr int EMB_THREADS = 128;
 constexpr int EMB_MAXJ = 4;  // D <= 4 * 128 * 4 = 2048
@@ -617,6 +630,20 @@ int nacf_attention_fwd(const float* Q, int64_t ldq, const float* K, int64_t ldk,
   NACF_CHECK(R > 0 && H > 0 && Lq > 0 && Lk > 0 && dk > 0 && kv_div > 0 && kv_mod > 0, NACF_EINVAL,
              "nacf_attention_fwd: bad shape");
   NACF_CHECK(!(causal && Lq != Lk), NACF_EINVAL, "nacf_attention_fwd: causal mask needs Lq == Lk");
+  if (attn_mfma_ok(Lq, Lk, dk) && attn_aligned(Q, ldq) && attn_aligned(K, ldk) && attn_aligned(V, ldv) &&
+      attn_aligned(O, ldo)) {
+    // matrix-core path: one wave per (sequence, head), operands straight from HBM/L2 into MFMA fragments
+    const dim3 grid(cdiv(R * H, 4));
+    hipStream_t s = as_hip(stream);
+#define NACF_ATTN_FWD(NKT, DK16)                                                                                      \
+  hipLaunchKernelGGL((attn::fwd_kernel<NKT, DK16>), grid, dim3(256), 0, s, Q, ldq, K, ldk, V, ldv, O, ldo, key_tokens, \
+                     causal, probs, R, H, Lq, Lk, kv_div, kv_mod)
+    if (Lk <= 32) { if (dk == 64) NACF_ATTN_FWD(2, 4); else NACF_ATTN_FWD(2, 1); }
+    else { if (dk == 64) NACF_ATTN_FWD(8, 4); else NACF_ATTN_FWD(8, 1); }
+#undef NACF_ATTN_FWD
+    NACF_LAUNCH_CHECK("nacf_attention_fwd(mfma)");
+    return NACF_OK;
+  }
   const size_t lds = ((size_t)Lq * (dk + 1) + (size_t)Lk * (dk + 1) + (size_t)Lq * Lk) * sizeof(float);
   NACF_CHECK(lds <= 160 * 1024, NACF_EUNSUPPORTED, "nacf_attention_fwd: tile does not fit LDS (%zu B)", lds);
   static bool attr_set = false;
@@ -642,6 +669,29 @@ int nacf_attention_bwd(const float* Q, int64_t ldq, const float* K, int64_t ldk,
              "nacf_attention_bwd: n_kv must equal kv_mod (or R for the identity map)");
   NACF_CHECK(Lk * dk <= ATT_BWD_MAXJ * 256, NACF_EUNSUPPORTED, "nacf_attention_bwd: Lk*dk > %d", ATT_BWD_MAXJ * 256);
   NACF_CHECK(!(causal && Lq != Lk), NACF_EINVAL, "nacf_attention_bwd: causal mask needs Lq == Lk");
+  if (attn_mfma_ok(Lq, Lk, dk) && attn_aligned(Q, ldq) && attn_aligned(K, ldk) && attn_aligned(V, ldv) &&
+      attn_aligned(dO, lddo) && attn_aligned(dQ, lddq) && attn_aligned(dK, lddk) && attn_aligned(dV, lddv)) {
+    const dim3 grid(cdiv(n_kv * H, 4));
+    hipStream_t s = as_hip(stream);
+    const int nkt = Lk <= 32 ? 2 : 8;
+    const size_t lds_m = (size_t)4 * 32 * (nkt * 16 + 16) * sizeof(float);   // one transpose tile per wave
+#define NACF_ATTN_BWD(NKT, DK16)                                                                                       \
+  do {                                                                                                                \
+    static bool set_##NKT##_##DK16 = false;                                                                           \
+    if (!set_##NKT##_##DK16) {                                                                                        \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn::bwd_kernel<NKT, DK16>),                           \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                              \
+      set_##NKT##_##DK16 = true;                                                                                      \
+    }                                                                                                                 \
+    hipLaunchKernelGGL((attn::bwd_kernel<NKT, DK16>), grid, dim3(256), lds_m, s, Q, ldq, K, ldk, V, ldv, dO, lddo, dQ,  \
+                       lddq, dK, lddk, dV, lddv, key_tokens, causal, R, n_kv, H, Lq, Lk, kv_div, kv_mod);              \
+  } while (0)
+    if (nkt == 2) { if (dk == 64) NACF_ATTN_BWD(2, 4); else NACF_ATTN_BWD(2, 1); }
+    else { if (dk == 64) NACF_ATTN_BWD(8, 4); else NACF_ATTN_BWD(8, 1); }
+#undef NACF_ATTN_BWD
+    NACF_LAUNCH_CHECK("nacf_attention_bwd(mfma)");
+    return NACF_OK;
+  }
   const size_t lds = ((size_t)2 * Lq * (dk + 1) + (size_t)2 * Lk * (dk + 1) + (size_t)2 * Lq * Lk) * sizeof(float);
   NACF_CHECK(lds <= 160 * 1024, NACF_EUNSUPPORTED, "nacf_attention_bwd: tile does not fit LDS (%zu B)", lds);
   static bool attr_set = false;

@@ -170,7 +170,10 @@ int nacf_linear_bwd_data(const float* dZ, int64_t lddz, const float* W, int64_t 
 
 static int bwd_weight_splits(int M, int N, int K, int* tile_out) {
   // enough workgroups to fill 256 CUs, each split at least 256 reduce rows
-  int tile = ((long)cdiv(N, 128) * cdiv(K, 128) >= 192) ? 0 : 1;
+  // the reduce-dimension split supplies the parallelism, so the big tile wins as soon as the
+  // weight has >= 32 of them (measured: 512x2048 / 2048x512 / 1024x512 / Vx512 are 10-20 % faster
+  // on 128x128; only 512x512 prefers 64x64) -- profiles/r01_gemm_microbench.txt
+  int tile = ((long)cdiv(N, 128) * cdiv(K, 128) >= 32) ? 0 : 1;
   const int forced = forced_tile();
   if (forced >= 0) tile = forced;
   const int t = tile == 0 ? 128 : 64;

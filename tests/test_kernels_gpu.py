@@ -411,6 +411,29 @@ def test_attention_full_size_cross(dev):
     assert err(out, o_ref.reshape(R * Lq, D)) < 5e-5
 
 
+@pytest.mark.parametrize("R,Lq,H,dk,causal", [(5, 7, 4, 16, False), (3, 9, 4, 16, True), (2, 20, 8, 64, False)])
+def test_attention_generic_lds_kernels(dev, R, Lq, H, dk, causal, monkeypatch):
+    """the LDS/VALU attention kernels (shapes the MFMA path does not cover) stay correct"""
+    monkeypatch.setenv("NACF_ATTN_VALU", "1")
+    test_self_attention_fwd_bwd(dev, R, Lq, H, dk, causal)
+    test_cross_attention_shared_memory_fwd_bwd(dev, "mod")
+    test_cross_attention_shared_memory_fwd_bwd(dev, "div")
+
+
+def test_attention_odd_head_dim_uses_generic_path(dev):
+    ops, _ = _ops()
+    R, Lq, H, dk = 3, 6, 2, 24                      # dk = 24: not an MFMA-path shape
+    D = H * dk
+    qkv = rnd(R * Lq, 3 * D, seed=1)
+    tok = torch.randint(1, 9, (R, Lq), generator=torch.Generator().manual_seed(2))
+    q, k, v = [qkv[:, j * D:(j + 1) * D].double().reshape(R, Lq, D) for j in range(3)]
+    o_ref, _ = _mha_ref(q, k, v, H, tok.eq(PAD), False)
+    x = qkv.to(dev)
+    out = torch.empty(R * Lq, D, device=dev)
+    ops.attention_fwd(x[:, :D], x[:, D:2 * D], x[:, 2 * D:], out, tok.to(dev), False, None, R, H, Lq, Lq, dk, 1, R)
+    assert err(out, o_ref.reshape(R * Lq, D)) < 2e-5
+
+
 def test_masked_mean(dev):
     ops, _ = _ops()
     y = rnd(4, 6, 32, seed=1)
