@@ -94,14 +94,33 @@ typedef struct nacf_epilogue {
   const uint64_t* rng_state; /* required when a p_drop > 0 */
 } nacf_epilogue;
 
+/* Live-row list ("varlen" without repacking).  Decoder activations are [sequence, position]
+ * slots of which 40-70 % are <pad>; every GEMM entry point takes an optional device-side list
+ * of the live slots (ascending indices + device count).  The GEMM then walks only those rows
+ * (gathering operands / scattering results through the list; dW reduces over them) and tiles
+ * beyond `count` exit at once.  Buffers keep their dense layout, shapes stay static, the host
+ * never reads the count (hipGraph-safe).  Rows outside the list are NOT written: callers
+ * zero-initialise outputs whose dead rows are consumed.  NULL = all rows. */
+typedef struct nacf_rowset {
+  const int32_t* rows;   /* [<= n] ascending slot indices */
+  const int32_t* count;  /* device int32[1] */
+} nacf_rowset;
+/* rows[] = { i : (tokens == NULL || tokens[i] != PAD) && (flags == NULL || flags[i] != 0) }, count[0] = |rows| */
+int nacf_rowset_build(const int64_t* tokens, const uint8_t* flags, int64_t n, int32_t* rows,
+                      int32_t* count, nacf_stream_t stream);
+
 int nacf_linear_fwd(const float* X, int64_t ldx, const float* W, int64_t ldw,
                     float* Y, int64_t ldy, int M, int N, int K,
-                    const nacf_epilogue* ep, nacf_stream_t stream);
+                    const nacf_epilogue* ep, const nacf_rowset* rows, nacf_stream_t stream);
 
-/* dX[M,K] = beta*dX + dZ[M,N] W[N,K]   (autograd of nn.Linear wrt input) */
+/* dX[M,K] = beta*dX + dZ[M,N] W[N,K]   (autograd of nn.Linear wrt input).  When the reduce
+ * dimension N is long and the output narrow (the vocabulary projection), N is split over
+ * workgroups into fp32 slabs in `ws` (nacf_linear_bwd_data_workspace bytes; 256 when no split
+ * is used, ws may then be NULL) and combined in a fixed order. */
+size_t nacf_linear_bwd_data_workspace(int M, int N, int K);
 int nacf_linear_bwd_data(const float* dZ, int64_t lddz, const float* W, int64_t ldw,
                          float* dX, int64_t lddx, int M, int N, int K, float beta,
-                         nacf_stream_t stream);
+                         void* ws, size_t ws_bytes, const nacf_rowset* rows, nacf_stream_t stream);
 
 /* dW[N,K] = beta*dW + dZ^T X ; db[N] = beta*db + colsum(dZ) (db may be NULL).
  * The M reduction is split over workgroups; partial slabs live in `ws`
@@ -109,7 +128,8 @@ int nacf_linear_bwd_data(const float* dZ, int64_t lddz, const float* W, int64_t 
 size_t nacf_linear_bwd_weight_workspace(int M, int N, int K);
 int nacf_linear_bwd_weight(const float* dZ, int64_t lddz, const float* X, int64_t ldx,
                            float* dW, int64_t lddw, float* db, int M, int N, int K,
-                           float beta, void* ws, size_t ws_bytes, nacf_stream_t stream);
+                           float beta, void* ws, size_t ws_bytes, const nacf_rowset* rows,
+                           nacf_stream_t stream);
 
 /* Which GEMM kernel a call will launch (for profiling / roofline bookkeeping):
  * kind 0 = linear_fwd (also vocab_argmax), 1 = linear_bwd_data, 2 = linear_bwd_weight,
@@ -246,9 +266,11 @@ int nacf_masked_mean_fwd(const float* y, const int64_t* tokens, float* out, int 
  * Also emits, per row: lse, argmax (for Word Acc, misc/crit.py:86-98), and
  * the log-prob of labels[row] (for the NLL / perplexity, misc/crit.py:62-114);
  * labels may be NULL. */
+/* skip_pad_rows != 0: rows whose label is PAD are left untouched (they were not projected
+ * because the caller used a live-row list built from the labels). */
 int nacf_vocab_logsoftmax_fwd(float* logits, int64_t ld, int rows, int V,
                               const int64_t* labels, float* lse, int64_t* argmax,
-                              float* label_logp, nacf_stream_t stream);
+                              float* label_logp, int skip_pad_rows, nacf_stream_t stream);
 /* Reduce per-row results to the scalars the criterion reports:
  * out[0] = -sum_{label!=PAD} logp[label]      (token-SUM NLL, misc/crit.py:82)
  * out[1] = #(argmax == label) over the accuracy set, out[2] = |accuracy set|
@@ -259,7 +281,8 @@ int nacf_nll_reduce(const float* label_logp, const int64_t* argmax, const int64_
 /* dlogits = (exp(logp) - onehot(label)) * gscale[0]*scale for rows with label != PAD, else 0.
  * gscale: optional device float[1] (upstream gradient of the loss). In place on logp allowed. */
 int nacf_xent_bwd(const float* logp, int64_t ld, float* dlogits, int64_t ldd, int rows, int V,
-                  const int64_t* labels, const float* gscale, float scale, nacf_stream_t stream);
+                  const int64_t* labels, const float* gscale, float scale, int skip_pad_rows,
+                  nacf_stream_t stream);
 /* Generic log_softmax backward for wide rows (when the caller consumes the
  * log-probs with its own criterion): dlogits = dlogp - exp(logp)*rowsum(dlogp) */
 int nacf_vocab_logsoftmax_bwd(const float* dlogp, int64_t ldg, const float* logp, int64_t ld,
@@ -275,13 +298,15 @@ int nacf_vocab_logsoftmax_bwd(const float* dlogp, int64_t ldg, const float* logp
  *   pad_tokens[row] == PAD      -> (PAD, 1.0)
  *   zero_mask_prob && idx==MASK -> prob = 0          (coarse-grained template pass)
  *   update_mask != NULL         -> tokens/probs only overwritten where update_mask != 0
+ * `rows` (optional live-row list over the hidden rows): only those slots are projected and
+ * written, e.g. the slots re-masked in this iteration.
  * ws: nacf_vocab_argmax_workspace(rows, V) bytes. */
 size_t nacf_vocab_argmax_workspace(int rows, int V);
 int nacf_vocab_argmax(const float* hidden, int64_t ldh, const float* W, int64_t ldw, const float* bias,
                       int rows, int V, int K,
                       const int64_t* pad_tokens, int zero_mask_prob, const uint8_t* update_mask,
                       int64_t* tokens, float* probs, void* ws, size_t ws_bytes,
-                      nacf_stream_t stream);
+                      const nacf_rowset* live_rows, nacf_stream_t stream);
 
 /* predict_length_beam + canvas, decoding/na_generate.py:35-50,116-135:
  * beam[b,j] = clamp(top-k index of pred_length[b,:] (descending) + bias, 4, max_len-1);

@@ -12,6 +12,15 @@
 //     dx = dz W      is (Q=dz KC, P=W  MC)       [reduce over n]
 //     dW = dz^T x    is (Q=dz MC, P=x  MC)       [reduce over m; Q rows = n]
 //
+// Row sets ("varlen" without repacking): the activation rows of the decoder are
+// [sequence, position] slots of which 40-70 % are <pad>.  A GEMM can be handed a
+// device-side list of the live rows (`rows`, `count`): the activation-row index
+// of the tile walk is then an index INTO that list, operands are gathered and
+// results scattered through it, and tiles beyond `count` exit at once.  Buffers
+// keep their dense [slots, D] layout, so nothing else in the pipeline changes,
+// shapes stay static (hipGraph-safe) and the host never learns the count.
+//   NT / NN: Q rows and C rows go through the list;   TN: the reduce index does.
+//
 // Workgroup: 256 threads = 4 waves (WM x WN), block tile BM x BN, BK = 16,
 // double-buffered LDS with register prefetch of the next k-tile (one barrier
 // per k-tile).  Wave tile = (BM/WM) x (BN/WN) = TM x TN MFMA tiles of 16x16.
@@ -24,7 +33,8 @@
 //      lane fetches its 4 steps with ONE ds_read_b128 of columns 4g..4g+3; the
 //      16-B column slot is XOR-swizzled with sw(row) = (-(row>>2))&3, which
 //      makes every ds_read_b128 lane group {rows x g} hit 16 distinct slots
-//      and keeps the staging ds_write_b128 conflict-free as well;
+//      and keeps the staging ds_write_b128 conflict-free as well
+//      (SQ_LDS_BANK_CONFLICT = 0 measured);
 //   MC tiles are stored [16][rows+4] (row stride = 4 mod 8 dwords) and read
 //      with ds_read_b32 at [(4g+s)][row]: the two g's of a 32-lane group land
 //      16 banks apart.
@@ -41,36 +51,56 @@ struct GemmShape {
   int k_per_split;  // multiple of 16
   int k_skew;       // != 0: every tile starts its k-loop at a different k-tile (wraps around)
   int tiles_m, tiles_n;
+  const int* rows;   // optional live-row list (see "Row sets" above)
+  const int* count;  // device int: number of valid entries of `rows`
 };
 
 __device__ __forceinline__ int lds_sw(int row) { return (-(row >> 2)) & 3; }
 
-template <int R, bool KC, bool VEC>
-__device__ __forceinline__ void tile_load(f32x4 (&reg)[R / 64], const float* __restrict__ base,
-                                          int64_t ld, int row0, int rows_total, int k0, int k_end,
-                                          int tid) {
+// KC tile: `prow[u]` = physical row of this thread's u-th vector (or -1: out of range -> zeros)
+template <int R, bool VEC>
+__device__ __forceinline__ void tile_load_kc(f32x4 (&reg)[R / 64], const float* __restrict__ base, int64_t ld,
+                                             const int (&prow)[R / 64], int k0, int k_end, int tid) {
+#pragma unroll
+  for (int u = 0; u < R / 64; ++u) {
+    const int c = (tid + 256 * u) & 3;
+    const int gk = k0 + c * 4;
+    const int nv = k_end - gk;
+    f32x4 t = {0.f, 0.f, 0.f, 0.f};
+    if (prow[u] >= 0) {
+      const float* p = base + (int64_t)prow[u] * ld + gk;
+      if (nv >= 4) {
+        if (VEC) {
+          t = *reinterpret_cast<const f32x4*>(p);
+        } else {
+          t[0] = p[0]; t[1] = p[1]; t[2] = p[2]; t[3] = p[3];
+        }
+      } else {
+        if (nv > 0) t[0] = p[0];
+        if (nv > 1) t[1] = p[1];
+        if (nv > 2) t[2] = p[2];
+      }
+    }
+    reg[u] = t;
+  }
+}
+
+// MC tile: rows are the contiguous dimension; the reduce index k may go through `kmap`
+template <int R, bool VEC>
+__device__ __forceinline__ void tile_load_mc(f32x4 (&reg)[R / 64], const float* __restrict__ base, int64_t ld,
+                                             int row0, int rows_total, int k0, int k_end,
+                                             const int* __restrict__ kmap, int tid) {
+  constexpr int RV = R / 4;
 #pragma unroll
   for (int u = 0; u < R / 64; ++u) {
     const int q = tid + 256 * u;
-    const float* p;
-    int nv;      // valid elements along the vector
-    bool ok;     // the other coordinate in range
-    if (KC) {
-      const int rr = q >> 2, c = q & 3;
-      const int gr = row0 + rr, gk = k0 + c * 4;
-      p = base + (int64_t)gr * ld + gk;
-      nv = k_end - gk;
-      ok = gr < rows_total;
-    } else {
-      constexpr int RV = R / 4;
-      const int kk = q / RV, r4 = q % RV;
-      const int gk = k0 + kk, gr = row0 + r4 * 4;
-      p = base + (int64_t)gk * ld + gr;
-      nv = rows_total - gr;
-      ok = gk < k_end;
-    }
+    const int kk = q / RV, r4 = q % RV;
+    const int gk = k0 + kk, gr = row0 + r4 * 4;
+    const int nv = rows_total - gr;
     f32x4 t = {0.f, 0.f, 0.f, 0.f};
-    if (ok) {
+    if (gk < k_end) {
+      const int pk = kmap ? kmap[gk] : gk;
+      const float* p = base + (int64_t)pk * ld + gr;
       if (nv >= 4) {
         if (VEC) {
           t = *reinterpret_cast<const f32x4*>(p);
@@ -120,6 +150,7 @@ __device__ __forceinline__ f32x4 frag_load(const float* lds, int rb, int i, int 
 }
 
 // ---------------------------------------------------------------- epilogues
+// Epilogue call: (m = logical row for guards, mp = physical row for addressing, n, 4 values).
 // plain / accumulate / split-K slab store
 struct EpiStore {
   float* C;
@@ -128,9 +159,9 @@ struct EpiStore {
   int64_t slab_stride;  // elements between blockIdx.z slabs (0: none)
   int vec_out;
   static constexpr bool kArgmax = false;
-  __device__ __forceinline__ void operator()(int m, int n, f32x4 v, int M, int N, int z) const {
+  __device__ __forceinline__ void operator()(int m, int mp, int n, f32x4 v, int M, int N, int z) const {
     if (m >= M || n >= N) return;
-    float* p = C + (int64_t)z * slab_stride + (int64_t)m * ldc + n;
+    float* p = C + (int64_t)z * slab_stride + (int64_t)mp * ldc + n;
     const int nv = N - n;
     if (nv >= 4 && vec_out) {
       if (beta != 0.f) {
@@ -153,7 +184,7 @@ struct EpiLinear {
   nacf_epilogue ep;
   int vec_out;  // Y / preact / residual all float4-addressable
   static constexpr bool kArgmax = false;
-  __device__ __forceinline__ void operator()(int m, int n, f32x4 v, int M, int N, int /*z*/) const {
+  __device__ __forceinline__ void operator()(int m, int mp, int n, f32x4 v, int M, int N, int /*z*/) const {
     if (m >= M || n >= N) return;
     const int nv = N - n;
     if (ep.bias) {
@@ -162,7 +193,7 @@ struct EpiLinear {
         if (e < nv) v[e] += ep.bias[n + e];
     }
     if (ep.preact) {
-      float* z = ep.preact + (int64_t)m * ep.ld_preact + n;
+      float* z = ep.preact + (int64_t)mp * ep.ld_preact + n;
       if (nv >= 4 && vec_out) *reinterpret_cast<f32x4*>(z) = v;
       else {
 #pragma unroll
@@ -177,7 +208,7 @@ struct EpiLinear {
     const bool any_drop = (ep.p_drop1 > 0.f) || (ep.p_drop2 > 0.f);
     DropRng rng;
     if (any_drop) rng.init(ep.rng_state);
-    const uint64_t e0 = (uint64_t)m * (uint64_t)N + (uint64_t)n;
+    const uint64_t e0 = (uint64_t)mp * (uint64_t)N + (uint64_t)n;   // physical slot: masks do not depend on packing
     const bool grp_ok = (N & 3) == 0;  // aligned groups of 4 share one Philox call
     if (ep.p_drop1 > 0.f) {
       if (grp_ok) {
@@ -189,7 +220,7 @@ struct EpiLinear {
       }
     }
     if (ep.residual) {
-      const float* r = ep.residual + (int64_t)m * ep.ld_residual + n;
+      const float* r = ep.residual + (int64_t)mp * ep.ld_residual + n;
       if (nv >= 4 && vec_out) {
         f32x4 o = *reinterpret_cast<const f32x4*>(r);
         v[0] += o[0]; v[1] += o[1]; v[2] += o[2]; v[3] += o[3];
@@ -209,9 +240,9 @@ struct EpiLinear {
       }
     }
     if (ep.row_tokens) {
-      if (ep.row_tokens[m] == NACF_PAD) { v[0] = 0.f; v[1] = 0.f; v[2] = 0.f; v[3] = 0.f; }
+      if (ep.row_tokens[mp] == NACF_PAD) { v[0] = 0.f; v[1] = 0.f; v[2] = 0.f; v[3] = 0.f; }
     }
-    float* y = Y + (int64_t)m * ldy + n;
+    float* y = Y + (int64_t)mp * ldy + n;
     if (nv >= 4 && vec_out) *reinterpret_cast<f32x4*>(y) = v;
     else {
 #pragma unroll
@@ -221,23 +252,23 @@ struct EpiLinear {
   }
 };
 
-// fused "softmax-max" partials: per (n-tile, row): max logit, its index, sum exp(l - max)
+// fused "softmax-max" partials: per (n-tile, logical row): max logit, its index, sum exp(l - max)
 struct EpiArgmax {
   const float* bias;
   float* pmax;   // [tiles_n][M]
   float* psum;   // [tiles_n][M]
   int* pidx;     // [tiles_n][M]
   static constexpr bool kArgmax = true;
-  __device__ __forceinline__ void operator()(int, int, f32x4, int, int, int) const {}
+  __device__ __forceinline__ void operator()(int, int, int, f32x4, int, int, int) const {}
 };
 
 template <int IDX, int TM, int TN, class Epi>
-__device__ __forceinline__ void epilogue_all(const Epi& epi, f32x4 (&acc)[TM][TN], int mbase, int nbase, int M,
-                                             int N, int z) {
+__device__ __forceinline__ void epilogue_all(const Epi& epi, f32x4 (&acc)[TM][TN], int mbase, const int (&mphys)[TM],
+                                             int nbase, int M, int N, int z) {
   if constexpr (IDX < TM * TN) {
     constexpr int a = IDX / TN, b = IDX % TN;
-    epi(mbase + a * 16, nbase + b * 16, acc[a][b], M, N, z);
-    epilogue_all<IDX + 1, TM, TN, Epi>(epi, acc, mbase, nbase, M, N, z);
+    epi(mbase + a * 16, mphys[a], nbase + b * 16, acc[a][b], M, N, z);
+    epilogue_all<IDX + 1, TM, TN, Epi>(epi, acc, mbase, mphys, nbase, M, N, z);
   }
 }
 
@@ -264,8 +295,21 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmShape g, Epi epi) {
   // XCD-aware tile order: workgroup b runs on XCD b%8; give every XCD a
   // contiguous run of logical tiles (n fastest) so the tiles that share a
   // Q row panel hit the same private L2 (bijective for any grid size).
-  const int nwg = g.tiles_m * g.tiles_n;
+  // live-row list: NT/NN bound the row walk, TN bounds the reduce walk
+  constexpr bool ROWS_ARE_K = !QKC && !PKC;
+  int Meff = g.M, Keff = g.K;
+  if (g.count) {
+    const int c = *g.count;
+    if (ROWS_ARE_K) Keff = min(Keff, c);
+    else Meff = min(Meff, c);
+  }
+  // only the first (live row tiles x tiles_n) workgroups have work; the remap below is done over
+  // THAT count so the live tiles spread over all 8 XCDs (dead row tiles would otherwise idle the
+  // XCDs whose contiguous chunk of the tile list lies beyond the live rows)
+  const int tiles_m_live = (Meff + BM - 1) / BM;
+  const int nwg = tiles_m_live * g.tiles_n;
   const int bid = blockIdx.x;
+  if (bid >= nwg) return;
   const int xq = nwg >> 3, xr = nwg & 7;
   const int xcd = bid & 7, slot = bid >> 3;
   const int logical = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + slot;
@@ -273,13 +317,32 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmShape g, Epi epi) {
   const int m0 = tile_m * BM, n0 = tile_n * BN;
 
   const int z = blockIdx.z;
-  const int kbeg = z * g.k_per_split;
-  const int kend = min(g.K, kbeg + g.k_per_split);
-  const int nk = (kend - kbeg + BK - 1) / BK;
+  int kps = g.k_per_split;
+  if (ROWS_ARE_K && g.count && gridDim.z > 1) {
+    // re-balance the reduce-dimension splits over the LIVE rows only
+    kps = (((Keff + (int)gridDim.z - 1) / (int)gridDim.z) + BK - 1) / BK * BK;
+    if (kps < BK) kps = BK;
+  }
+  const int kbeg = z * kps;
+  const int kend = min(Keff, kbeg + kps);
+  const int nk = kend > kbeg ? (kend - kbeg + BK - 1) / BK : 0;
   // k-skew: concurrently running tiles walk the reduce dimension from different
-  // starting offsets, so their row-strided (power-of-two pitch) operand reads do
-  // not all land on the same L2/HBM channels at the same time.
+  // starting offsets (tuning knob, measured neutral on MI355X)
   const int kskew = g.k_skew ? (int)(((unsigned)tile_m * 5u + (unsigned)tile_n * 3u) % (unsigned)(nk > 0 ? nk : 1)) : 0;
+
+  // physical rows of this thread's K-contiguous vectors (fixed for the whole k-loop)
+  int qrow[BM / 64], prow[BN / 64];
+#pragma unroll
+  for (int u = 0; u < BM / 64; ++u) {
+    const int gr = m0 + ((tid + 256 * u) >> 2);
+    qrow[u] = (gr < Meff) ? ((g.rows && !ROWS_ARE_K) ? g.rows[gr] : gr) : -1;
+  }
+#pragma unroll
+  for (int u = 0; u < BN / 64; ++u) {
+    const int gr = n0 + ((tid + 256 * u) >> 2);
+    prow[u] = (gr < g.N) ? gr : -1;
+  }
+  const int* kmap = ROWS_ARE_K ? g.rows : nullptr;
 
   f32x4 acc[TM][TN];
 #pragma unroll
@@ -288,10 +351,17 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmShape g, Epi epi) {
     for (int b = 0; b < TN; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   f32x4 qreg[BM / 64], preg[BN / 64];
-  tile_load<BM, QKC, VEC>(qreg, g.Q, g.ldq, m0, g.M, kbeg + kskew * BK, kend, tid);
-  tile_load<BN, PKC, VEC>(preg, g.P, g.ldp, n0, g.N, kbeg + kskew * BK, kend, tid);
-  tile_store<BM, QKC>(smem, qreg, tid);
-  tile_store<BN, PKC>(smem + QSZ, preg, tid);
+  auto load_tiles = [&](int k0) {
+    if constexpr (QKC) tile_load_kc<BM, VEC>(qreg, g.Q, g.ldq, qrow, k0, kend, tid);
+    else tile_load_mc<BM, VEC>(qreg, g.Q, g.ldq, m0, Meff, k0, kend, kmap, tid);
+    if constexpr (PKC) tile_load_kc<BN, VEC>(preg, g.P, g.ldp, prow, k0, kend, tid);
+    else tile_load_mc<BN, VEC>(preg, g.P, g.ldp, n0, g.N, k0, kend, kmap, tid);
+  };
+  if (nk > 0) {
+    load_tiles(kbeg + kskew * BK);
+    tile_store<BM, QKC>(smem, qreg, tid);
+    tile_store<BN, PKC>(smem + QSZ, preg, tid);
+  }
   __syncthreads();
 
   for (int kt = 0; kt < nk; ++kt) {
@@ -301,9 +371,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmShape g, Epi epi) {
     if (more) {
       int ktn = kt + 1 + kskew;
       if (ktn >= nk) ktn -= nk;
-      const int k0 = kbeg + ktn * BK;
-      tile_load<BM, QKC, VEC>(qreg, g.Q, g.ldq, m0, g.M, k0, kend, tid);
-      tile_load<BN, PKC, VEC>(preg, g.P, g.ldp, n0, g.N, k0, kend, tid);
+      load_tiles(kbeg + ktn * BK);
     }
     f32x4 qf[TM], pf[TN];
 #pragma unroll
@@ -329,7 +397,14 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmShape g, Epi epi) {
     // compile-time recursion, NOT a `#pragma unroll` loop: with the large fused epilogue the
     // optimiser declined to unroll, indexed acc[][] dynamically and parked the accumulators
     // in scratch (16 scratch_store_dwordx4 per k-tile in the main loop, 2x slower)
-    epilogue_all<0, TM, TN, Epi>(epi, acc, m0 + wm * WTM + li, n0 + wn * WTN + lg * 4, g.M, g.N, z);
+    const int mbase = m0 + wm * WTM + li;
+    int mphys[TM];
+#pragma unroll
+    for (int a = 0; a < TM; ++a) {
+      const int m = mbase + a * 16;
+      mphys[a] = (g.rows && !ROWS_ARE_K && m < Meff) ? g.rows[m] : m;
+    }
+    epilogue_all<0, TM, TN, Epi>(epi, acc, mbase, mphys, n0 + wn * WTN + lg * 4, Meff, g.N, z);
   } else {
     // per-row (max, argmax, sum-exp) over this tile's BN columns
     float* redv = smem;                  // [WN][BM]
@@ -385,7 +460,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmShape g, Epi epi) {
     __syncthreads();
     for (int row = tid; row < BM; row += 256) {
       const int m = m0 + row;
-      if (m >= g.M) continue;
+      if (m >= Meff) continue;
       float best = redv[row];
       int bidx = redi[row];
       float s = reds[row];

@@ -274,11 +274,15 @@ __global__ __launch_bounds__(256) void vocab_logsoftmax_fwd_kernel(float* __rest
                                                                     const int64_t* __restrict__ labels,
                                                                     float* __restrict__ lse_out,
                                                                     int64_t* __restrict__ argmax_out,
-                                                                    float* __restrict__ label_logp) {
+                                                                    float* __restrict__ label_logp, int skip_pad_rows) {
   __shared__ float redv[4];
   __shared__ int redi[4];
   __shared__ float reds[16];
   const int row = blockIdx.x;
+  if (skip_pad_rows && labels && labels[row] == NACF_PAD) {   // row never projected (live-row GEMM): nothing to normalise
+    if (threadIdx.x == 0 && label_logp) label_logp[row] = 0.f;
+    return;
+  }
   float* p = logits + (int64_t)row * ld;
   float best = -3.0e38f;
   int bidx = 0x7fffffff;
@@ -342,9 +346,11 @@ __global__ void nll_reduce_kernel(const float* __restrict__ label_logp, const in
 __global__ __launch_bounds__(256) void xent_bwd_kernel(const float* __restrict__ logp, int64_t ld,
                                                         float* __restrict__ dlogits, int64_t ldd, int V,
                                                         const int64_t* __restrict__ labels,
-                                                        const float* __restrict__ gscale, float scale) {
+                                                        const float* __restrict__ gscale, float scale,
+                                                        int skip_pad_rows) {
   const int row = blockIdx.x;
   const int64_t lab = labels[row];
+  if (skip_pad_rows && lab == NACF_PAD) return;   // row is outside the live-row list of the backward GEMMs
   const float g = (gscale ? gscale[0] : 1.f) * scale;
   const float* p = logp + (int64_t)row * ld;
   float* d = dlogits + (int64_t)row * ldd;
@@ -541,10 +547,10 @@ int nacf_epilogue_bwd(const float* dY, int64_t lddy, float* dZ, int64_t lddz, fl
 }
 
 int nacf_vocab_logsoftmax_fwd(float* logits, int64_t ld, int rows, int V, const int64_t* labels, float* lse,
-                              int64_t* argmax, float* label_logp, nacf_stream_t stream) {
+                              int64_t* argmax, float* label_logp, int skip_pad_rows, nacf_stream_t stream) {
   NACF_CHECK(logits && rows > 0 && V > 0 && ld >= V, NACF_EINVAL, "nacf_vocab_logsoftmax_fwd: bad argument");
   hipLaunchKernelGGL(vocab_logsoftmax_fwd_kernel, dim3(rows), dim3(256), 0, as_hip(stream), logits, ld, V, labels, lse,
-                     argmax, label_logp);
+                     argmax, label_logp, skip_pad_rows);
   NACF_LAUNCH_CHECK("nacf_vocab_logsoftmax_fwd");
   return NACF_OK;
 }
@@ -559,10 +565,10 @@ int nacf_nll_reduce(const float* label_logp, const int64_t* argmax, const int64_
 }
 
 int nacf_xent_bwd(const float* logp, int64_t ld, float* dlogits, int64_t ldd, int rows, int V, const int64_t* labels,
-                  const float* gscale, float scale, nacf_stream_t stream) {
+                  const float* gscale, float scale, int skip_pad_rows, nacf_stream_t stream) {
   NACF_CHECK(logp && dlogits && labels && rows > 0 && V > 0, NACF_EINVAL, "nacf_xent_bwd: bad argument");
   hipLaunchKernelGGL(xent_bwd_kernel, dim3(rows), dim3(256), 0, as_hip(stream), logp, ld, dlogits, ldd, V, labels, gscale,
-                     scale);
+                     scale, skip_pad_rows);
   NACF_LAUNCH_CHECK("nacf_xent_bwd");
   return NACF_OK;
 }

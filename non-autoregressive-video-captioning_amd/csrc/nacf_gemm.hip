@@ -14,11 +14,13 @@ int forced_tile() {
   return e ? (atoi(e) == 64 ? 1 : (atoi(e) == 128 ? 0 : -1)) : -1;
 }
 
-int pick_tile(int M, int N, int splits) {
+int pick_tile(int M, int N, int splits, bool has_rows = false) {
   const int forced = forced_tile();
   if (forced >= 0) return forced;
   const long big = (long)cdiv(M, 128) * cdiv(N, 128) * splits;
-  return big >= 384 ? 0 : 1;  // >= 1.5 workgroups per CU with the big tile, else go small
+  // >= 1.5 workgroups per CU with the big tile, else go small.  With a live-row list the host does
+  // not know how many row tiles survive (typically 40-60 %), so ask for twice the tiles.
+  return big >= (has_rows ? 768 : 384) ? 0 : 1;
 }
 
 int kskew_enabled() {
@@ -47,6 +49,28 @@ void launch_gemm(const GemmShape& g0, const Epi& epi, int splits, int tile, bool
   }
 }
 
+inline void set_rows(GemmShape& g, const nacf_rowset* rs) {
+  g.rows = rs ? rs->rows : nullptr;
+  g.count = rs ? rs->count : nullptr;
+}
+
+// dst[rows[r]][c] = beta*dst + sum_z slab[z][rows[r]][c] over the live rows only (split-K combine of dX)
+__global__ void splitk_reduce_rows_kernel(const float* __restrict__ slabs, int64_t slab_stride, int splits,
+                                          float* __restrict__ dst, int64_t ldd, int rows, int cols, float beta,
+                                          const int* __restrict__ live, const int* __restrict__ count) {
+  const int n_live = count ? min(rows, *count) : rows;
+  const int64_t total = (int64_t)n_live * cols;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (int64_t)gridDim.x * blockDim.x) {
+    const int r = (int)(idx / cols), c = (int)(idx % cols);
+    const int pr = live ? live[r] : r;
+    float acc = 0.f;
+    for (int zz = 0; zz < splits; ++zz) acc += slabs[(int64_t)zz * slab_stride + (int64_t)pr * cols + c];
+    float* d = dst + (int64_t)pr * ldd + c;
+    *d = (beta != 0.f) ? acc + beta * (*d) : acc;
+  }
+}
+
 // dst[i] = beta*dst[i] + sum_z slab[z][i], fixed z order (deterministic split-K combine)
 __global__ void splitk_reduce_kernel(const float* __restrict__ slabs, int64_t slab_stride, int splits,
                                      float* __restrict__ dst, int64_t ldd, int rows, int cols, float beta) {
@@ -61,17 +85,19 @@ __global__ void splitk_reduce_kernel(const float* __restrict__ slabs, int64_t sl
   }
 }
 
-// column sums of dZ[M,N]: stage 1 -> part[S][N], stage 2 -> db
+// column sums of dZ[M,N] (optionally only over a live-row list): stage 1 -> part[S][N], stage 2 -> db
 __global__ void colsum_partial_kernel(const float* __restrict__ dz, int64_t ld, int M, int N, int rows_per,
+                                      const int* __restrict__ rows, const int* __restrict__ count,
                                       float* __restrict__ part) {
   __shared__ float red[4][64];
   const int c = blockIdx.x * 64 + (threadIdx.x & 63);
   const int rl = threadIdx.x >> 6;
+  const int Meff = count ? min(M, *count) : M;
   const int r0 = blockIdx.y * rows_per;
-  const int r1 = min(M, r0 + rows_per);
+  const int r1 = min(Meff, r0 + rows_per);
   float acc = 0.f;
   if (c < N)
-    for (int r = r0 + rl; r < r1; r += 4) acc += dz[(int64_t)r * ld + c];
+    for (int r = r0 + rl; r < r1; r += 4) acc += dz[(int64_t)(rows ? rows[r] : r) * ld + c];
   red[rl][threadIdx.x & 63] = acc;
   __syncthreads();
   if (rl == 0 && c < N)
@@ -88,12 +114,14 @@ __global__ void colsum_final_kernel(const float* __restrict__ part, int S, int N
 // merge the per-tile (max, idx, sumexp) partials and apply the decode bookkeeping
 __global__ void argmax_merge_kernel(const float* __restrict__ pmax, const float* __restrict__ psum,
                                     const int* __restrict__ pidx, int tiles_n, int rows,
+                                    const int* __restrict__ live, const int* __restrict__ count,
                                     const int64_t* __restrict__ pad_tokens, int zero_mask_prob,
                                     const uint8_t* __restrict__ update_mask,
                                     int64_t* __restrict__ tokens, float* __restrict__ probs) {
-  const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);   // logical row
   const int lane = threadIdx.x & 63;
   if (row >= rows) return;
+  if (count && row >= *count) return;
   float best = -3.0e38f;
   int bidx = 0x7fffffff;
   for (int t = lane; t < tiles_n; t += 64) {
@@ -112,23 +140,65 @@ __global__ void argmax_merge_kernel(const float* __restrict__ pmax, const float*
     s += psum[(int64_t)t * rows + row] * __expf(pmax[(int64_t)t * rows + row] - best);
   s = wave_sum(s);
   if (lane == 0) {
+    const int prow = live ? live[row] : row;     // physical slot
     int64_t tok = bidx;
     float p = 1.0f / s;
-    if (pad_tokens && pad_tokens[row] == NACF_PAD) { tok = NACF_PAD; p = 1.0f; }
+    if (pad_tokens && pad_tokens[prow] == NACF_PAD) { tok = NACF_PAD; p = 1.0f; }
     if (zero_mask_prob && tok == NACF_MASK) p = 0.f;
-    if (!update_mask || update_mask[row]) { tokens[row] = tok; probs[row] = p; }
+    if (!update_mask || update_mask[prow]) { tokens[prow] = tok; probs[prow] = p; }
   }
+}
+
+// stable compaction: rows[] = ascending i with (tokens ? tokens[i] != PAD) && (flags ? flags[i] != 0); one workgroup
+__global__ __launch_bounds__(1024) void rowset_build_kernel(const int64_t* __restrict__ tokens,
+                                                             const uint8_t* __restrict__ flags, int n,
+                                                             int* __restrict__ rows, int* __restrict__ count) {
+  __shared__ int wsum[16];
+  __shared__ int base_s;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (threadIdx.x == 0) base_s = 0;
+  __syncthreads();
+  for (int c0 = 0; c0 < n; c0 += 1024) {
+    const int i = c0 + threadIdx.x;
+    bool live = i < n;
+    if (live && tokens) live = tokens[i] != NACF_PAD;
+    if (live && flags) live = flags[i] != 0;
+    const unsigned long long bal = __ballot(live);
+    const int pre = __popcll(bal & ((1ull << lane) - 1ull));
+    if (lane == 0) wsum[wave] = __popcll(bal);
+    __syncthreads();
+    int off = base_s;
+    for (int w = 0; w < wave; ++w) off += wsum[w];
+    if (live) rows[off + pre] = i;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      int t = 0;
+      for (int w = 0; w < 16; ++w) t += wsum[w];
+      base_s += t;
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) count[0] = base_s;
 }
 
 }  // namespace
 
 extern "C" {
 
+int nacf_rowset_build(const int64_t* tokens, const uint8_t* flags, int64_t n, int32_t* rows, int32_t* count,
+                      nacf_stream_t stream) {
+  NACF_CHECK((tokens || flags) && rows && count && n > 0 && n < 0x7fffffffLL, NACF_EINVAL, "nacf_rowset_build: bad argument");
+  hipLaunchKernelGGL(rowset_build_kernel, dim3(1), dim3(1024), 0, as_hip(stream), tokens, flags, (int)n, rows, count);
+  NACF_LAUNCH_CHECK("nacf_rowset_build");
+  return NACF_OK;
+}
+
 int nacf_linear_fwd(const float* X, int64_t ldx, const float* W, int64_t ldw, float* Y, int64_t ldy,
-                    int M, int N, int K, const nacf_epilogue* ep, nacf_stream_t stream) {
+                    int M, int N, int K, const nacf_epilogue* ep, const nacf_rowset* rs, nacf_stream_t stream) {
   NACF_CHECK(X && W && Y, NACF_EINVAL, "nacf_linear_fwd: null pointer");
   NACF_CHECK(M > 0 && N > 0 && K > 0, NACF_EINVAL, "nacf_linear_fwd: bad shape M=%d N=%d K=%d", M, N, K);
   NACF_CHECK(ldx >= K && ldw >= K && ldy >= N, NACF_EINVAL, "nacf_linear_fwd: leading dimension too small");
+  NACF_CHECK(!rs || (rs->rows && rs->count), NACF_EINVAL, "nacf_linear_fwd: incomplete row set");
   EpiLinear epi;
   memset(&epi, 0, sizeof(epi));
   epi.Y = Y;
@@ -144,32 +214,70 @@ int nacf_linear_fwd(const float* X, int64_t ldx, const float* W, int64_t ldw, fl
   GemmShape g;
   g.Q = X; g.P = W; g.ldq = ldx; g.ldp = ldw; g.M = M; g.N = N; g.K = K;
   g.k_per_split = cdiv(K, 16) * 16;
+  set_rows(g, rs);
   const bool vec = (ldx % 4 == 0) && (ldw % 4 == 0) && aligned16(X) && aligned16(W);
-  launch_gemm<true, true, EpiLinear>(g, epi, 1, pick_tile(M, N, 1), vec, as_hip(stream));
+  launch_gemm<true, true, EpiLinear>(g, epi, 1, pick_tile(M, N, 1, rs != nullptr), vec, as_hip(stream));
   NACF_LAUNCH_CHECK("nacf_linear_fwd");
   return NACF_OK;
 }
 
+// dX = dZ W with a long reduce dimension and a narrow output (the vocabulary projection: N = V,
+// K = D) has too few output tiles to fill 256 CUs: split the reduce dimension over workgroups.
+static int bwd_data_splits(int M, int N, int K) {
+  if (N < 4096) return 1;
+  const long tiles = (long)cdiv(M, 64) * cdiv(K, 64);
+  if (tiles >= 1024) return 1;
+  int s = (int)((1536 + tiles - 1) / tiles);
+  const int max_s = N / 1024;
+  if (s > max_s) s = max_s;
+  if (s > 16) s = 16;
+  return s < 1 ? 1 : s;
+}
+
+size_t nacf_linear_bwd_data_workspace(int M, int N, int K) {
+  const int s = bwd_data_splits(M, N, K);
+  return (s > 1 ? (size_t)s * M * K * sizeof(float) : 0) + 256;
+}
+
 int nacf_linear_bwd_data(const float* dZ, int64_t lddz, const float* W, int64_t ldw, float* dX, int64_t lddx,
-                         int M, int N, int K, float beta, nacf_stream_t stream) {
+                         int M, int N, int K, float beta, void* ws, size_t ws_bytes, const nacf_rowset* rs,
+                         nacf_stream_t stream) {
   NACF_CHECK(dZ && W && dX, NACF_EINVAL, "nacf_linear_bwd_data: null pointer");
   NACF_CHECK(M > 0 && N > 0 && K > 0, NACF_EINVAL, "nacf_linear_bwd_data: bad shape");
   NACF_CHECK(lddz >= N && ldw >= K && lddx >= K, NACF_EINVAL, "nacf_linear_bwd_data: leading dimension too small");
+  NACF_CHECK(!rs || (rs->rows && rs->count), NACF_EINVAL, "nacf_linear_bwd_data: incomplete row set");
   // dX[m][k] = sum_n dZ[m][n] W[n][k]: Q = dZ (KC, reduce = n), P rows = k, P element (k, n) at W[n*ldw + k] (MC)
-  EpiStore epi;
-  epi.C = dX; epi.ldc = lddx; epi.beta = beta; epi.slab_stride = 0;
-  epi.vec_out = ((lddx % 4 == 0) && aligned16(dX)) ? 1 : 0;
+  const int splits = bwd_data_splits(M, N, K);
+  NACF_CHECK(splits == 1 || (ws && ws_bytes >= nacf_linear_bwd_data_workspace(M, N, K) && aligned16(ws)), NACF_EWORKSPACE,
+             "nacf_linear_bwd_data: workspace too small / misaligned");
+  hipStream_t s = as_hip(stream);
   GemmShape g;
   g.Q = dZ; g.P = W; g.ldq = lddz; g.ldp = ldw; g.M = M; g.N = K; g.K = N;
-  g.k_per_split = cdiv(N, 16) * 16;
+  g.k_per_split = cdiv(cdiv(N, splits), 16) * 16;
+  set_rows(g, rs);
+  const int real_splits = cdiv(N, g.k_per_split);
   const bool vec = (lddz % 4 == 0) && (ldw % 4 == 0) && aligned16(dZ) && aligned16(W);
-  launch_gemm<true, false, EpiStore>(g, epi, 1, pick_tile(M, K, 1), vec, as_hip(stream));
+  EpiStore epi;
+  if (real_splits > 1) {
+    epi.C = reinterpret_cast<float*>(ws); epi.ldc = K; epi.beta = 0.f; epi.slab_stride = (int64_t)M * K;
+    epi.vec_out = (K % 4 == 0) ? 1 : 0;
+  } else {
+    epi.C = dX; epi.ldc = lddx; epi.beta = beta; epi.slab_stride = 0;
+    epi.vec_out = ((lddx % 4 == 0) && aligned16(dX)) ? 1 : 0;
+  }
+  launch_gemm<true, false, EpiStore>(g, epi, real_splits, pick_tile(M, K, real_splits, rs != nullptr), vec, s);
   NACF_LAUNCH_CHECK("nacf_linear_bwd_data");
+  if (real_splits > 1) {
+    const int64_t total = (int64_t)M * K;
+    const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+    hipLaunchKernelGGL(splitk_reduce_rows_kernel, dim3(blocks), dim3(256), 0, s, epi.C, (int64_t)M * K, real_splits, dX,
+                       lddx, M, K, beta, rs ? rs->rows : nullptr, rs ? rs->count : nullptr);
+    NACF_LAUNCH_CHECK("nacf_linear_bwd_data(reduce)");
+  }
   return NACF_OK;
 }
 
 static int bwd_weight_splits(int M, int N, int K, int* tile_out) {
-  // enough workgroups to fill 256 CUs, each split at least 256 reduce rows
   // the reduce-dimension split supplies the parallelism, so the big tile wins as soon as the
   // weight has >= 32 of them (measured: 512x2048 / 2048x512 / 1024x512 / Vx512 are 10-20 % faster
   // on 128x128; only 512x512 prefers 64x64) -- profiles/r01_gemm_microbench.txt
@@ -197,7 +305,7 @@ size_t nacf_linear_bwd_weight_workspace(int M, int N, int K) {
 
 int nacf_linear_bwd_weight(const float* dZ, int64_t lddz, const float* X, int64_t ldx, float* dW, int64_t lddw,
                            float* db, int M, int N, int K, float beta, void* ws, size_t ws_bytes,
-                           nacf_stream_t stream) {
+                           const nacf_rowset* rs, nacf_stream_t stream) {
   NACF_CHECK(dZ && X && dW, NACF_EINVAL, "nacf_linear_bwd_weight: null pointer");
   NACF_CHECK(M > 0 && N > 0 && K > 0, NACF_EINVAL, "nacf_linear_bwd_weight: bad shape");
   NACF_CHECK(lddz >= N && ldx >= K && lddw >= K, NACF_EINVAL, "nacf_linear_bwd_weight: leading dimension too small");
@@ -205,14 +313,16 @@ int nacf_linear_bwd_weight(const float* dZ, int64_t lddz, const float* X, int64_
              "nacf_linear_bwd_weight: workspace too small (%zu < %zu)", ws_bytes,
              nacf_linear_bwd_weight_workspace(M, N, K));
   NACF_CHECK(aligned16(ws), NACF_EINVAL, "nacf_linear_bwd_weight: workspace must be 16-byte aligned");
+  NACF_CHECK(!rs || (rs->rows && rs->count), NACF_EINVAL, "nacf_linear_bwd_weight: incomplete row set");
   int tile;
   const int splits = bwd_weight_splits(M, N, K, &tile);
   hipStream_t s = as_hip(stream);
   // dW[n][k] = sum_m dZ[m][n] X[m][k]: output rows = n (Q = dZ, MC: element (n, m) at dZ[m*lddz + n]),
-  // output cols = k (P = X, MC: element (k, m) at X[m*ldx + k]), reduce = m
+  // output cols = k (P = X, MC: element (k, m) at X[m*ldx + k]), reduce = m (through the live-row list if given)
   GemmShape g;
   g.Q = dZ; g.P = X; g.ldq = lddz; g.ldp = ldx; g.M = N; g.N = K; g.K = M;
   g.k_per_split = cdiv(cdiv(M, splits), 16) * 16;
+  set_rows(g, rs);
   const int real_splits = cdiv(M, g.k_per_split);
   const bool vec = (lddz % 4 == 0) && (ldx % 4 == 0) && aligned16(dZ) && aligned16(X);
   float* slabs = reinterpret_cast<float*>(ws);
@@ -238,7 +348,8 @@ int nacf_linear_bwd_weight(const float* dZ, int64_t lddz, const float* X, int64_
     if (S > 64) S = 64;
     const int rows_per = cdiv(M, S);
     S = cdiv(M, rows_per);
-    hipLaunchKernelGGL(colsum_partial_kernel, dim3(cdiv(N, 64), S), dim3(256), 0, s, dZ, lddz, M, N, rows_per, part);
+    hipLaunchKernelGGL(colsum_partial_kernel, dim3(cdiv(N, 64), S), dim3(256), 0, s, dZ, lddz, M, N, rows_per,
+                       rs ? rs->rows : nullptr, rs ? rs->count : nullptr, part);
     hipLaunchKernelGGL(colsum_final_kernel, dim3(cdiv(N, 256)), dim3(256), 0, s, part, S, N, db, beta);
     NACF_LAUNCH_CHECK("nacf_linear_bwd_weight(bias)");
   }
@@ -249,7 +360,12 @@ int nacf_gemm_config(int kind, int M, int N, int K, int* tile, int* splits) {
   NACF_CHECK(tile && splits && M > 0 && N > 0 && K > 0, NACF_EINVAL, "nacf_gemm_config: bad argument");
   int t = 0, s = 1;
   if (kind == 0) t = pick_tile(M, N, 1);
-  else if (kind == 1) t = pick_tile(M, K, 1);
+  else if (kind == 1) {
+    s = bwd_data_splits(M, N, K);
+    const int kps = cdiv(cdiv(N, s), 16) * 16;
+    s = cdiv(N, kps);
+    t = pick_tile(M, K, s);
+  }
   else if (kind == 2) {
     s = bwd_weight_splits(M, N, K, &t);
     const int kps = cdiv(cdiv(M, s), 16) * 16;
@@ -271,11 +387,12 @@ size_t nacf_vocab_argmax_workspace(int rows, int V) {
 int nacf_vocab_argmax(const float* hidden, int64_t ldh, const float* W, int64_t ldw, const float* bias,
                       int rows, int V, int K, const int64_t* pad_tokens, int zero_mask_prob,
                       const uint8_t* update_mask, int64_t* tokens, float* probs, void* ws, size_t ws_bytes,
-                      nacf_stream_t stream) {
+                      const nacf_rowset* rs, nacf_stream_t stream) {
   NACF_CHECK(hidden && W && tokens && probs, NACF_EINVAL, "nacf_vocab_argmax: null pointer");
   NACF_CHECK(rows > 0 && V > 0 && K > 0, NACF_EINVAL, "nacf_vocab_argmax: bad shape");
   NACF_CHECK(ws && ws_bytes >= nacf_vocab_argmax_workspace(rows, V), NACF_EWORKSPACE,
              "nacf_vocab_argmax: workspace too small");
+  NACF_CHECK(!rs || (rs->rows && rs->count), NACF_EINVAL, "nacf_vocab_argmax: incomplete row set");
   const int tile = pick_tile(rows, V, 1);
   const int tn = cdiv(V, tile == 0 ? 128 : 64);
   EpiArgmax epi;
@@ -286,12 +403,14 @@ int nacf_vocab_argmax(const float* hidden, int64_t ldh, const float* W, int64_t 
   GemmShape g;
   g.Q = hidden; g.P = W; g.ldq = ldh; g.ldp = ldw; g.M = rows; g.N = V; g.K = K;
   g.k_per_split = cdiv(K, 16) * 16;
+  set_rows(g, rs);
   const bool vec = (ldh % 4 == 0) && (ldw % 4 == 0) && aligned16(hidden) && aligned16(W);
   hipStream_t s = as_hip(stream);
   launch_gemm<true, true, EpiArgmax>(g, epi, 1, tile, vec, s);
   NACF_LAUNCH_CHECK("nacf_vocab_argmax(gemm)");
   hipLaunchKernelGGL(argmax_merge_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, s, epi.pmax, epi.psum, epi.pidx, tn, rows,
-                     pad_tokens, zero_mask_prob, update_mask, tokens, probs);
+                     rs ? rs->rows : nullptr, rs ? rs->count : nullptr, pad_tokens, zero_mask_prob, update_mask, tokens,
+                     probs);
   NACF_LAUNCH_CHECK("nacf_vocab_argmax(merge)");
   return NACF_OK;
 }

@@ -26,12 +26,14 @@ class DecodeContext(object):
         self.memory_kv = model.decoder.project_memory(enc_output)
         self.vocab_w = model.tgt_word_prj.weight
         self.vocab_b = model.tgt_word_prj.bias
+        self.row_set = None     # live slots of the canvas (set by the algorithm once the canvas exists)
 
-    def hidden(self, tokens, decoding_type='NARFormer', output_attentions=False):
+    def hidden(self, tokens, decoding_type='NARFormer', output_attentions=False, row_set='canvas'):
         out = self.model.decoder(tokens, enc_output=self.enc_output, category=self.category,
                                  decoding_type=decoding_type, row_map=('div', self.lbs),
                                  memory_kv=self.memory_kv, pooled_memory=self.pooled,
-                                 output_attentions=output_attentions)
+                                 output_attentions=output_attentions,
+                                 row_set=self.row_set if row_set == 'canvas' else row_set)
         h = out[0]
         if isinstance(h, list):
             h = h[-1]
@@ -66,12 +68,21 @@ class Algorithm_Base(object):
                 out_tokens=None, out_probs=None):
         """generate_non_autoregressive (algorithms.py:143-167): decoder pass + fused
         projection/softmax/max; results land in (out_tokens, out_probs) or in place."""
+        if ctx.row_set is None:
+            # canvas slots that are not <pad>: fixed for the whole decode (pad_mask never changes), so the
+            # decoder GEMMs of every pass skip the 35-60 % of slots beyond each candidate's length
+            ctx.row_set = ops.rowset_build(tokens=pad_tokens.reshape(-1))
+            if out_probs is None:
+                ops.init_probs(pad_tokens.reshape(-1), probs.reshape(-1))   # <pad> slots: (PAD, 1.0) for good
         h, _ = ctx.hidden(tokens)
         R, Lp, D = h.shape
+        # project only the slots this pass may change: live canvas slots, and within them the re-masked ones
+        live = ctx.row_set if update_mask is None else ops.rowset_build(tokens=pad_tokens.reshape(-1),
+                                                                        flags=update_mask.reshape(-1))
         ops.vocab_argmax(h.reshape(R * Lp, D), ctx.vocab_w, ctx.vocab_b, pad_tokens.reshape(-1), zero_mask_prob,
                          update_mask.reshape(-1) if update_mask is not None else None,
                          (out_tokens if out_tokens is not None else tokens).reshape(-1),
-                         (out_probs if out_probs is not None else probs).reshape(-1))
+                         (out_probs if out_probs is not None else probs).reshape(-1), rows=live)
 
     def num_mask_lut(self, ratios, Lp, device):
         """floor(len * ratio) exactly as `(seq_lens.float() * ratio).long()` computes it
@@ -99,7 +110,7 @@ class Algorithm_Base(object):
             toks = lut.to(tokens.device)[tokens]
         R, Lp = toks.shape
         with_bos = torch.cat([toks.new_full((R, 1), Constants.BOS), toks[:, :-1]], dim=1).contiguous()
-        h, _ = teacher_ctx.hidden(with_bos, decoding_type='ARFormer')
+        h, _ = teacher_ctx.hidden(with_bos, decoding_type='ARFormer', row_set=None)
         V = teacher_ctx.vocab_w.shape[0]
         buf = torch.empty(R * Lp, ops.vocab_ld(V), device=h.device)
         logits = buf[:, :V]

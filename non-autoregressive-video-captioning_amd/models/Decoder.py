@@ -52,6 +52,7 @@ class BertDecoder(nn.Module):
         if self.watch != 0:
             raise NotImplementedError('nacf_amd: watch != 0 is not built (reference default 0)')
         self.decoding_type = config.decoding_type
+        self.pack_rows = bool(getattr(config, 'pack_rows', True))   # skip <pad> slots in the row-wise GEMMs
 
     def get_word_embeddings(self):
         return self.embedding.word_embeddings
@@ -107,12 +108,18 @@ class BertDecoder(nn.Module):
                 additional = MeanTimeFn.apply(enc_output)
         hidden = self.embedding.run(tgt_seq, category, additional, vdiv, vmod, training)
         memory_kv = kwargs.get('memory_kv')
+        # live-row list of the [R, L] slot grid: by default every non-<pad> slot of tgt_seq; the NA
+        # decoding loop passes the list of its initial canvas (a superset that stays valid while
+        # slots are re-masked / re-predicted)
+        rows = kwargs.get('row_set')
+        if rows is None and self.pack_rows:
+            rows = ops.rowset_build(tokens=tgt_seq.reshape(-1))
         x2 = hidden.reshape(R * Lq, D)
         all_attentions = ()
         for i, layer in enumerate(self.layer):
             kv = memory_kv[i] if memory_kv is not None else layer.project_memory(enc_output)
             x2, att = layer.run(x2, tgt_seq, decoding_type == 'ARFormer', kv, M, vdiv, vmod, training,
-                                output_attentions)
+                                output_attentions, rows)
             if output_attentions:
                 all_attentions = all_attentions + (att,)
         hidden = x2.view(R, Lq, D)

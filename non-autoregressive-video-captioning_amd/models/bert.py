@@ -142,23 +142,24 @@ class BertLayer(nn.Module):
         Bv, M, D = enc_output.shape
         return LinearFn.apply(enc_output.reshape(Bv * M, D), None, dict(pack=self._pk['ckv']), *self._params)
 
-    def run(self, x2, tokens, causal, memory_kv, M, vdiv, vmod, training, want_probs):
-        """x2: [R*L, D] hidden rows; tokens: [R, L]; memory_kv: [Bv*M, 2D]."""
+    def run(self, x2, tokens, causal, memory_kv, M, vdiv, vmod, training, want_probs, rows=None):
+        """x2: [R*L, D] hidden rows; tokens: [R, L]; memory_kv: [Bv*M, 2D]; rows: live (non-<pad>)
+        slot list -- the row-wise GEMMs skip <pad> slots, whose outputs are exact zeros anyway."""
         R, Lq = tokens.shape
         rng = self._rt.rng(x2.device)
         tok_flat = tokens.reshape(-1)
         P = self._params
         pk = self._pk
         s = self._salts
-        qkv = LinearFn.apply(x2, None, dict(pack=pk['qkv']), *P)
+        qkv = LinearFn.apply(x2, None, dict(pack=pk['qkv'], rows=rows), *P)
         att, p_self = SelfAttentionFn.apply(qkv, tokens, int(causal), self.H, want_probs)
         a = LinearFn.apply(att, x2, dict(pack=pk['so'], p1=self.p, salt1=s[0], row_tokens=tok_flat, rng=rng,
-                                         training=training), *P)
-        q = LinearFn.apply(a, None, dict(pack=pk['cq']), *P)
+                                         training=training, rows=rows), *P)
+        q = LinearFn.apply(a, None, dict(pack=pk['cq'], rows=rows), *P)
         catt, p_cross = CrossAttentionFn.apply(q, memory_kv, self.H, Lq, M, vdiv, vmod, want_probs)
         c = LinearFn.apply(catt, a, dict(pack=pk['co'], p1=self.p, salt1=s[1], row_tokens=tok_flat, rng=rng,
-                                         training=training), *P)
-        u = LinearFn.apply(c, None, dict(pack=pk['f1'], act=self.act), *P)
+                                         training=training, rows=rows), *P)
+        u = LinearFn.apply(c, None, dict(pack=pk['f1'], act=self.act, rows=rows), *P)
         y = LinearFn.apply(u, c, dict(pack=pk['f2'], p1=self.p, salt1=s[2], p2=self.p, salt2=s[3], row_tokens=tok_flat,
-                                      rng=rng, training=training), *P)
+                                      rng=rng, training=training, rows=rows), *P)
         return y, (p_self, p_cross)

@@ -33,6 +33,10 @@ def _new(shape, like: Tensor, dtype=torch.float32) -> Tensor:
     return torch.empty(shape, dtype=dtype, device=like.device)
 
 
+def _zeros(shape, like: Tensor, dtype=torch.float32) -> Tensor:
+    return torch.zeros(shape, dtype=dtype, device=like.device)
+
+
 def _c2d(t: Tensor, rows: int, cols: int) -> Tensor:
     t = t.reshape(rows, cols)
     return t if t.stride(1) == 1 and t.stride(0) >= cols else t.contiguous()
@@ -231,15 +235,17 @@ class LinearFn(Function):
         training = cfg.get("training", False)
         act = cfg.get("act", L.ACT_NONE)
         need_bwd = any(ctx.needs_input_grad)
-        pre = _new((M, N), x) if (act != L.ACT_NONE and need_bwd) else None
+        rows = cfg.get("rows")      # live-row list: dead (<pad>) slots are neither computed nor written
+        mk = _zeros if rows is not None else _new
+        pre = mk((M, N), x) if (act != L.ACT_NONE and need_bwd) else None
         res = _c2d(residual, M, N) if residual is not None else None
         epi = ops.Epi(bias=pk.b, act=act, preact=pre,
                       p1=cfg.get("p1", 0.0) if training else 0.0, salt1=cfg.get("salt1", 0),
                       residual=res, p2=cfg.get("p2", 0.0) if training else 0.0, salt2=cfg.get("salt2", 0),
                       row_tokens=cfg.get("row_tokens"), rng=cfg.get("rng"))
-        out = _new((M, N), x)
-        ops.linear_fwd(x, pk.w, out, epi)
-        ctx.cfg, ctx.epi, ctx.x = cfg, epi, x
+        out = mk((M, N), x)
+        ops.linear_fwd(x, pk.w, out, epi, rows)
+        ctx.cfg, ctx.epi, ctx.x, ctx.rows = cfg, epi, x, rows
         ctx.has_res = residual is not None
         return out
 
@@ -262,11 +268,12 @@ class LinearFn(Function):
             ops.epilogue_bwd(dy, dz, dr, epi)
             epi.residual = None
         dx = None
+        rows = ctx.rows
         if ctx.needs_input_grad[0]:
-            dx = _new((M, K), dy)
-            ops.linear_bwd_data(dz, pk.w, dx)
+            dx = (_zeros if rows is not None else _new)((M, K), dy)
+            ops.linear_bwd_data(dz, pk.w, dx, rows=rows)
         if pk.gw is not None:
-            ops.linear_bwd_weight(dz, ctx.x, pk.gw, pk.gb, beta=1.0)
+            ops.linear_bwd_weight(dz, ctx.x, pk.gw, pk.gb, beta=1.0, rows=rows)
         ctx.x = None
         epi.preact = None
         return (dx, dr if ctx.needs_input_grad[1] else None, None) + (None,) * (len(ctx.needs_input_grad) - 3)
@@ -388,17 +395,18 @@ class FusedVocabXentFn(Function):
         V = pk.w.shape[0]
         h = _c2d(h, rows, D)
         labels = labels.reshape(-1).contiguous()
+        # only slots that carry a label (label != PAD) reach the loss, the meters or the gradient:
+        # project / normalise / back-propagate just those rows (live-row list built from the labels)
+        live = ops.rowset_build(tokens=labels)
         buf = _new((rows, ops.vocab_ld(V)), h)
-        if ops.vocab_ld(V) != V:
-            buf[:, V:].zero_()
         logits = buf[:, :V]
-        ops.linear_fwd(h, pk.w, logits, ops.Epi(bias=pk.b))
+        ops.linear_fwd(h, pk.w, logits, ops.Epi(bias=pk.b), live)
         label_logp = _new((rows,), h)
         argmax = _new((rows,), h, torch.int64)
-        ops.vocab_logsoftmax_fwd(logits, V, labels, None, argmax, label_logp)
+        ops.vocab_logsoftmax_fwd(logits, V, labels, None, argmax, label_logp, skip_pad_rows=True)
         stats = _new((5,), h)
         ops.nll_reduce(label_logp, argmax, labels, exclude_mask, stats)
-        ctx.cfg, ctx.h, ctx.logp, ctx.labels = cfg, h, logits, labels
+        ctx.cfg, ctx.h, ctx.logp, ctx.labels, ctx.live = cfg, h, logits, labels, live
         return stats
 
     @staticmethod
@@ -406,11 +414,11 @@ class FusedVocabXentFn(Function):
         pk: Pack = ctx.cfg["pack"]
         rows, V = ctx.logp.shape
         dstats = dstats.contiguous()
-        ops.xent_bwd(ctx.logp, ctx.logp, V, ctx.labels, dstats, 1.0)  # in place: logp -> dlogits * dstats[0]
-        dh = torch.empty_like(ctx.h)
-        ops.linear_bwd_data(ctx.logp, pk.w, dh)
-        ops.linear_bwd_weight(ctx.logp, ctx.h, pk.gw, pk.gb, beta=1.0)
-        ctx.h = ctx.logp = None
+        ops.xent_bwd(ctx.logp, ctx.logp, V, ctx.labels, dstats, 1.0, skip_pad_rows=True)  # in place: logp -> dlogits
+        dh = torch.zeros_like(ctx.h)
+        ops.linear_bwd_data(ctx.logp, pk.w, dh, rows=ctx.live)
+        ops.linear_bwd_weight(ctx.logp, ctx.h, pk.gw, pk.gb, beta=1.0, rows=ctx.live)
+        ctx.h = ctx.logp = ctx.live = None
         return (dh, None, None, None) + (None,) * (len(ctx.needs_input_grad) - 4)
 
 

@@ -29,8 +29,14 @@ class Epilogue(ctypes.Structure):
     ]
 
 
+class RowSet(ctypes.Structure):
+    """struct nacf_rowset."""
+    _fields_ = [("rows", c_void_p), ("count", c_void_p)]
+
+
 _P, _I, _L, _F, _U, _S = c_void_p, c_int, c_int64, c_float, c_uint32, c_size_t
 _EP = POINTER(Epilogue)
+_RS = POINTER(RowSet)
 
 # name -> (restype, argtypes); mirrors include/nacf_hip.h one to one
 SIGNATURES = {
@@ -38,11 +44,13 @@ SIGNATURES = {
     "nacf_version": (c_int, []),
     "nacf_abi_count": (c_int, []),
     "nacf_rng_advance": (c_int, [_P, _P]),
-    "nacf_linear_fwd": (c_int, [_P, _L, _P, _L, _P, _L, _I, _I, _I, _EP, _P]),
-    "nacf_linear_bwd_data": (c_int, [_P, _L, _P, _L, _P, _L, _I, _I, _I, _F, _P]),
+    "nacf_rowset_build": (c_int, [_P, _P, _L, _P, _P, _P]),
+    "nacf_linear_fwd": (c_int, [_P, _L, _P, _L, _P, _L, _I, _I, _I, _EP, _RS, _P]),
+    "nacf_linear_bwd_data_workspace": (_S, [_I, _I, _I]),
+    "nacf_linear_bwd_data": (c_int, [_P, _L, _P, _L, _P, _L, _I, _I, _I, _F, _P, _S, _RS, _P]),
     "nacf_linear_bwd_weight_workspace": (_S, [_I, _I, _I]),
     "nacf_gemm_config": (c_int, [_I, _I, _I, _I, _P, _P]),
-    "nacf_linear_bwd_weight": (c_int, [_P, _L, _P, _L, _P, _L, _P, _I, _I, _I, _F, _P, _S, _P]),
+    "nacf_linear_bwd_weight": (c_int, [_P, _L, _P, _L, _P, _L, _P, _I, _I, _I, _F, _P, _S, _RS, _P]),
     "nacf_epilogue_bwd": (c_int, [_P, _L, _P, _L, _P, _L, _I, _I, _I, _EP, _P]),
     "nacf_highway_mix_fwd": (c_int, [_P, _P, _P, _I, _I, _F, _U, _P, _P]),
     "nacf_highway_mix_bwd": (c_int, [_P, _P, _P, _P, _P, _I, _I, _F, _U, _P, _P]),
@@ -63,12 +71,12 @@ SIGNATURES = {
     "nacf_attention_bwd": (c_int, [_P, _L, _P, _L, _P, _L, _P, _L, _P, _L, _P, _L, _P, _L, _P, _I,
                                    _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     "nacf_masked_mean_fwd": (c_int, [_P, _P, _P, _I, _I, _I, _P]),
-    "nacf_vocab_logsoftmax_fwd": (c_int, [_P, _L, _I, _I, _P, _P, _P, _P, _P]),
+    "nacf_vocab_logsoftmax_fwd": (c_int, [_P, _L, _I, _I, _P, _P, _P, _P, _I, _P]),
     "nacf_nll_reduce": (c_int, [_P, _P, _P, _I, _I, _P, _P]),
-    "nacf_xent_bwd": (c_int, [_P, _L, _P, _L, _I, _I, _P, _P, _F, _P]),
+    "nacf_xent_bwd": (c_int, [_P, _L, _P, _L, _I, _I, _P, _P, _F, _I, _P]),
     "nacf_vocab_logsoftmax_bwd": (c_int, [_P, _L, _P, _L, _P, _L, _I, _I, _P]),
     "nacf_vocab_argmax_workspace": (_S, [_I, _I]),
-    "nacf_vocab_argmax": (c_int, [_P, _L, _P, _L, _P, _I, _I, _I, _P, _I, _P, _P, _P, _P, _S, _P]),
+    "nacf_vocab_argmax": (c_int, [_P, _L, _P, _L, _P, _I, _I, _I, _P, _I, _P, _P, _P, _P, _S, _RS, _P]),
     "nacf_length_beam": (c_int, [_P, _I, _I, _I, _I, _P, _P, _P]),
     "nacf_canvas_init": (c_int, [_P, _I, _I, _P, _P]),
     "nacf_select_mask": (c_int, [_P, _P, _P, _P, _I, _I, _I, _P, _P, _P]),

@@ -76,26 +76,34 @@ class GemmProfiler:
         tile, splits = ctypes.c_int(0), ctypes.c_int(0)
         L.check(L.load().nacf_gemm_config(kind, M, N, K, ctypes.byref(tile), ctypes.byref(splits)), "nacf_gemm_config")
         q, p_ = self._LAYOUT[kind]
+        self._last_splits = splits.value
         return "gemm_f32_kernel<%d, %d, 2, 2, %s, %s, true, %s>" % (tile.value, tile.value, q, p_, epi)
 
-    def begin(self, kind, M, N, K, epi):
+    def begin(self, kind, M, N, K, epi, rows=None):
         if not self.enabled:
             return None
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         a.record()
-        return (self.kernel_name(kind, M, N, K, epi), 2.0 * M * N * K, (M, N, K), a, b)
+        # kind 2 (dW: GEMM + split-K combine + bias column-sum) and EpiArgmax (GEMM + merge) spans hold
+        # more than one kernel; only single-kernel spans are comparable with rocprof's per-kernel average
+        name = self.kernel_name(kind, M, N, K, epi)
+        single = kind != 2 and epi != "EpiArgmax" and self._last_splits == 1
+        return (name, (M, N, K), a, b, single, rows)
 
     def end(self, tok):
         if tok is not None:
-            tok[4].record()
+            tok[3].record()
             self.records.append(tok)
 
     def summary(self):
         out = {}
-        for name, flops, shape, a, b in self.records:
-            r = out.setdefault(name, dict(calls=0, flops=0.0, ms=0.0, shapes=set()))
+        for name, shape, a, b, single, rows in self.records:
+            r = out.setdefault(name, dict(calls=0, flops=0.0, dense_flops=0.0, ms=0.0, shapes=set(), single=single))
+            M, N, K = shape
+            m_live = min(M, int(rows.count)) if rows is not None else M   # flops actually executed (live rows only)
             r["calls"] += 1
-            r["flops"] += flops
+            r["flops"] += 2.0 * m_live * N * K
+            r["dense_flops"] += 2.0 * M * N * K
             r["ms"] += a.elapsed_time(b)
             r["shapes"].add(shape)
         return out
@@ -112,6 +120,35 @@ class RngState:
 
     def advance(self):
         L.check(L.load().nacf_rng_advance(_ptr(self.state), _stream()), "nacf_rng_advance")
+
+
+# ---------------------------------------------------------------- live-row lists
+class RowSet:
+    """Device-side list of the live (non-<pad>) activation slots; see nacf_rowset in nacf_hip.h."""
+    __slots__ = ("rows", "count")
+
+    def __init__(self, rows: Tensor, count: Tensor):
+        self.rows, self.count = rows, count
+
+    def c(self):
+        r = L.RowSet()
+        r.rows, r.count = self.rows.data_ptr(), self.count.data_ptr()
+        return ctypes.byref(r)
+
+
+def _rs(rows: Optional["RowSet"]):
+    return rows.c() if rows is not None else None
+
+
+def rowset_build(tokens: Optional[Tensor] = None, flags: Optional[Tensor] = None) -> RowSet:
+    """slots i with tokens[i] != PAD (and flags[i] != 0), ascending; no host sync"""
+    ref = tokens if tokens is not None else flags
+    n = ref.numel()
+    rows = torch.empty(n, dtype=torch.int32, device=ref.device)
+    count = torch.empty(1, dtype=torch.int32, device=ref.device)
+    L.check(L.load().nacf_rowset_build(_ptr(tokens), _ptr(flags), n, _ptr(rows), _ptr(count), _stream()),
+            "nacf_rowset_build")
+    return RowSet(rows, count)
 
 
 # ---------------------------------------------------------------- linear
@@ -141,33 +178,36 @@ class Epi:
         return e
 
 
-def linear_fwd(x: Tensor, w: Tensor, out: Tensor, epi: Optional[Epi] = None) -> Tensor:
+def linear_fwd(x: Tensor, w: Tensor, out: Tensor, epi: Optional[Epi] = None, rows: Optional[RowSet] = None) -> Tensor:
     """out[M,N] = epilogue(x[M,K] @ w[N,K]^T)."""
     _chk_f32(x, w, out)
     M, K, ldx = _rows2d(x)
     N, K2, ldw = _rows2d(w)
     assert K == K2 and out.shape == (M, N), (x.shape, w.shape, out.shape)
     ep = epi.cstruct() if epi is not None else L.Epilogue()
-    tok = PROFILER.begin(0, M, N, K, "EpiLinear")
+    tok = PROFILER.begin(0, M, N, K, "EpiLinear", rows)
     L.check(L.load().nacf_linear_fwd(_ptr(x), ldx, _ptr(w), ldw, _ptr(out), out.stride(0), M, N, K,
-                                     ctypes.byref(ep), _stream()), "nacf_linear_fwd")
+                                     ctypes.byref(ep), _rs(rows), _stream()), "nacf_linear_fwd")
     PROFILER.end(tok)
     return out
 
 
-def linear_bwd_data(dz: Tensor, w: Tensor, dx: Tensor, beta: float = 0.0) -> Tensor:
+def linear_bwd_data(dz: Tensor, w: Tensor, dx: Tensor, beta: float = 0.0, rows: Optional[RowSet] = None) -> Tensor:
     _chk_f32(dz, w, dx)
     M, N, lddz = _rows2d(dz)
     N2, K, ldw = _rows2d(w)
     assert N == N2 and dx.shape == (M, K)
-    tok = PROFILER.begin(1, M, N, K, "EpiStore")
-    L.check(L.load().nacf_linear_bwd_data(_ptr(dz), lddz, _ptr(w), ldw, _ptr(dx), dx.stride(0), M, N, K,
-                                          float(beta), _stream()), "nacf_linear_bwd_data")
+    lib = L.load()
+    ws = WORKSPACE.get(lib.nacf_linear_bwd_data_workspace(M, N, K), dz.device)
+    tok = PROFILER.begin(1, M, N, K, "EpiStore", rows)
+    L.check(lib.nacf_linear_bwd_data(_ptr(dz), lddz, _ptr(w), ldw, _ptr(dx), dx.stride(0), M, N, K,
+                                     float(beta), _ptr(ws), ws.numel(), _rs(rows), _stream()), "nacf_linear_bwd_data")
     PROFILER.end(tok)
     return dx
 
 
-def linear_bwd_weight(dz: Tensor, x: Tensor, dw: Tensor, db: Optional[Tensor], beta: float = 1.0) -> None:
+def linear_bwd_weight(dz: Tensor, x: Tensor, dw: Tensor, db: Optional[Tensor], beta: float = 1.0,
+                      rows: Optional[RowSet] = None) -> None:
     _chk_f32(dz, x, dw, db)
     M, N, lddz = _rows2d(dz)
     M2, K, ldx = _rows2d(x)
@@ -175,9 +215,10 @@ def linear_bwd_weight(dz: Tensor, x: Tensor, dw: Tensor, db: Optional[Tensor], b
     lib = L.load()
     need = lib.nacf_linear_bwd_weight_workspace(M, N, K)
     ws = WORKSPACE.get(need, dz.device)
-    tok = PROFILER.begin(2, M, N, K, "EpiStore")
+    tok = PROFILER.begin(2, M, N, K, "EpiStore", rows)
     L.check(lib.nacf_linear_bwd_weight(_ptr(dz), lddz, _ptr(x), ldx, _ptr(dw), dw.stride(0), _ptr(db), M, N, K,
-                                       float(beta), _ptr(ws), ws.numel(), _stream()), "nacf_linear_bwd_weight")
+                                       float(beta), _ptr(ws), ws.numel(), _rs(rows), _stream()),
+            "nacf_linear_bwd_weight")
     PROFILER.end(tok)
 
 
@@ -328,11 +369,11 @@ def vocab_ld(V: int) -> int:
     return (V + 3) // 4 * 4
 
 
-def vocab_logsoftmax_fwd(logits2d, V, labels, lse, argmax, label_logp):
+def vocab_logsoftmax_fwd(logits2d, V, labels, lse, argmax, label_logp, skip_pad_rows=False):
     _chk_f32(logits2d, lse, label_logp)
     rows = logits2d.shape[0]
     L.check(L.load().nacf_vocab_logsoftmax_fwd(_ptr(logits2d), logits2d.stride(0), rows, V, _ptr(labels), _ptr(lse),
-                                               _ptr(argmax), _ptr(label_logp), _stream()),
+                                               _ptr(argmax), _ptr(label_logp), int(skip_pad_rows), _stream()),
             "nacf_vocab_logsoftmax_fwd")
 
 
@@ -342,10 +383,11 @@ def nll_reduce(label_logp, argmax, labels, exclude_mask, out5):
                                      _ptr(out5), _stream()), "nacf_nll_reduce")
 
 
-def xent_bwd(logp2d, dlogits2d, V, labels, gscale, scale):
+def xent_bwd(logp2d, dlogits2d, V, labels, gscale, scale, skip_pad_rows=False):
     rows = logp2d.shape[0]
     L.check(L.load().nacf_xent_bwd(_ptr(logp2d), logp2d.stride(0), _ptr(dlogits2d), dlogits2d.stride(0), rows, V,
-                                   _ptr(labels), _ptr(gscale), float(scale), _stream()), "nacf_xent_bwd")
+                                   _ptr(labels), _ptr(gscale), float(scale), int(skip_pad_rows), _stream()),
+            "nacf_xent_bwd")
 
 
 def vocab_logsoftmax_bwd(dlogp2d, logp2d, dlogits2d, V):
@@ -356,16 +398,16 @@ def vocab_logsoftmax_bwd(dlogp2d, logp2d, dlogits2d, V):
 
 
 # ---------------------------------------------------------------- NA decoding
-def vocab_argmax(hidden2d, w, bias, pad_tokens, zero_mask_prob, update_mask, tokens, probs):
+def vocab_argmax(hidden2d, w, bias, pad_tokens, zero_mask_prob, update_mask, tokens, probs, rows=None):
     _chk_f32(hidden2d, w, bias, probs)
-    rows, K, ldh = _rows2d(hidden2d)
+    n_rows, K, ldh = _rows2d(hidden2d)
     V = w.shape[0]
     lib = L.load()
-    ws = WORKSPACE.get(lib.nacf_vocab_argmax_workspace(rows, V), hidden2d.device)
-    tok = PROFILER.begin(0, rows, V, K, "EpiArgmax")
-    L.check(lib.nacf_vocab_argmax(_ptr(hidden2d), ldh, _ptr(w), w.stride(0), _ptr(bias), rows, V, K,
+    ws = WORKSPACE.get(lib.nacf_vocab_argmax_workspace(n_rows, V), hidden2d.device)
+    tok = PROFILER.begin(0, n_rows, V, K, "EpiArgmax", rows)
+    L.check(lib.nacf_vocab_argmax(_ptr(hidden2d), ldh, _ptr(w), w.stride(0), _ptr(bias), n_rows, V, K,
                                   _ptr(pad_tokens), int(zero_mask_prob), _ptr(update_mask), _ptr(tokens),
-                                  _ptr(probs), _ptr(ws), ws.numel(), _stream()), "nacf_vocab_argmax")
+                                  _ptr(probs), _ptr(ws), ws.numel(), _rs(rows), _stream()), "nacf_vocab_argmax")
     PROFILER.end(tok)
 
 

@@ -149,6 +149,64 @@ def test_linear_bwd_weight_splitk_large_m(dev):
     assert torch.equal(a, dw)    # deterministic combine
 
 
+@pytest.mark.parametrize("M,N,K,tile", [(300, 136, 72, "64"), (1000, 512, 256, "128"), (700, 101, 64, "64")])
+def test_live_row_gemms(dev, M, N, K, tile, monkeypatch):
+    """row-set ("varlen") GEMMs: only listed slots are computed / written / reduced over"""
+    ops, L = _ops()
+    monkeypatch.setenv("NACF_GEMM_TILE", tile)
+    g = torch.Generator().manual_seed(0)
+    tok = torch.randint(0, 3, (M,), generator=g)                  # ~1/3 PAD slots, anywhere
+    live = tok.ne(PAD)
+    rs = ops.rowset_build(tokens=tok.to(dev))
+    assert int(rs.count) == int(live.sum())
+    assert torch.equal(rs.rows[:int(rs.count)].cpu().long(), live.nonzero().squeeze(1))
+    flags = (torch.arange(M) % 2).to(torch.uint8)
+    rs2 = ops.rowset_build(tokens=tok.to(dev), flags=flags.to(dev))
+    assert torch.equal(rs2.rows[:int(rs2.count)].cpu().long(), (live & flags.bool()).nonzero().squeeze(1))
+    x, w, b, r = rnd(M, K, seed=1), rnd(N, K, seed=2), rnd(N, seed=3), rnd(M, N, seed=4)
+    y = torch.full((M, N), 7.0, device=dev)
+    pre = torch.full((M, N), 5.0, device=dev)
+    ops.linear_fwd(x.to(dev), w.to(dev), y, ops.Epi(bias=b.to(dev), act=L.ACT_GELU_NEW, preact=pre, residual=r.to(dev),
+                                                    row_tokens=tok.to(dev)), rows=rs)
+    z = x.double() @ w.double().t() + b.double()
+    ref = 0.5 * z * (1 + torch.tanh(math.sqrt(2 / math.pi) * (z + 0.044715 * z ** 3))) + r.double()
+    assert err(y[live.to(dev)], ref[live]) < 1e-4 and err(pre[live.to(dev)], z[live]) < 1e-4
+    assert float((y[~live.to(dev)] - 7.0).abs().max()) == 0 and float((pre[~live.to(dev)] - 5.0).abs().max()) == 0
+    dz = rnd(M, N, seed=5)
+    dx = torch.full((M, K), 3.0, device=dev)
+    ops.linear_bwd_data(dz.to(dev), w.to(dev), dx, rows=rs)
+    assert err(dx[live.to(dev)], (dz.double() @ w.double())[live]) < 1e-4
+    assert float((dx[~live.to(dev)] - 3.0).abs().max()) == 0
+    dw, db = torch.zeros(N, K, device=dev), torch.zeros(N, device=dev)
+    ops.linear_bwd_weight(dz.to(dev), x.to(dev), dw, db, beta=0.0, rows=rs)
+    assert err(dw, dz.double()[live].t() @ x.double()[live]) < 2e-4 * math.sqrt(M / 64)
+    assert err(db, dz.double()[live].sum(0)) < 2e-4
+    # empty list: nothing is touched, dW becomes zero
+    none = ops.rowset_build(tokens=torch.zeros(M, dtype=torch.int64, device=dev))
+    assert int(none.count) == 0
+    ops.linear_fwd(x.to(dev), w.to(dev), y, None, rows=none)
+    ops.linear_bwd_weight(dz.to(dev), x.to(dev), dw, None, beta=0.0, rows=none)
+    assert float(dw.abs().max()) == 0
+
+
+def test_vocab_argmax_live_rows(dev):
+    ops, _ = _ops()
+    rows, V, K = 200, 333, 64
+    h, w = rnd(rows, K, seed=1), rnd(V, K, seed=2, scale=0.5)
+    pad = torch.randint(0, 3, (rows,), generator=torch.Generator().manual_seed(3))
+    upd = (torch.arange(rows) % 3 == 0).to(torch.uint8)
+    full_t = torch.full((rows,), 9, dtype=torch.int64, device=dev)
+    full_p = torch.full((rows,), 0.5, device=dev)
+    ops.vocab_argmax(h.to(dev), w.to(dev), None, pad.to(dev), False, upd.to(dev), full_t, full_p)
+    rs = ops.rowset_build(tokens=pad.to(dev), flags=upd.to(dev))
+    t2 = torch.full((rows,), 9, dtype=torch.int64, device=dev)
+    p2 = torch.full((rows,), 0.5, device=dev)
+    ops.vocab_argmax(h.to(dev), w.to(dev), None, pad.to(dev), False, upd.to(dev), t2, p2, rows=rs)
+    sel = (pad.ne(0) & upd.bool()).to(dev)
+    assert torch.equal(t2[sel], full_t[sel]) and torch.equal(p2[sel], full_p[sel])   # same math on the live slots
+    assert torch.equal(t2[~sel], torch.full_like(t2[~sel], 9))                        # everything else untouched
+
+
 def test_epilogue_bwd_matches_autograd(dev):
     ops, L = _ops()
     M, N = 64, 128
