@@ -51,6 +51,7 @@ def main():
     ap.add_argument("--no-decode", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--decode-batches", type=int, default=5)
+    ap.add_argument("--no-compare", action="store_true", help="skip the ARB2 beam-5 vs NACF decode comparison (config 5)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -218,6 +219,42 @@ def main():
                       "paradigm": "mp+ct", "iterations": 5, "length_beam_size": 6, "width": int(hyp.shape[1])}
             model.train()
 
+        # ---- BASELINE.json configs[4]: ARB2 beam-5 autoregressive decode vs NACF parallel decode, batch 256
+        compare = None
+        if not args.no_compare and not args.no_decode:
+            CB = 256
+            cb = O.synth_batch(opt, CB, F_, seed=7)
+            cfeats = [f.to(dev) for f in cb["feats"]]
+            ccat = cb["category"].to(dev)
+            def timed(fn, n=2):
+                fn(); torch.cuda.synchronize()
+                t_ = time.perf_counter()
+                for _ in range(n):
+                    fn()
+                torch.cuda.synchronize()
+                return (time.perf_counter() - t_) / n
+            model.eval()
+            tr_na = Translator(model, dict(model.opt), device=dev)
+            def na():
+                with torch.no_grad():
+                    return tr_na.translate_batch(model.encode(feats=cfeats), ccat, None, None)
+            t_na = timed(na)
+            aopt = nacf_amd.opts.make_opt("ARB2", "MSRVTT", with_category=True, max_len=L, vocab_size=V, n_frames=60,
+                                          beam_size=5, beam_alpha=1.0, topk=1)
+            amodel = nacf_amd.get_model(aopt)
+            amodel.load_state_dict({k: v.clone() for k, v in O.init_state_dict(aopt, seed=0).items()})
+            amodel.to(dev).eval()
+            tr_ar = Translator(amodel, dict(amodel.opt), device=dev)
+            def ar():
+                with torch.no_grad():
+                    return tr_ar.translate_batch(amodel.encode(feats=cfeats), ccat, None, None)
+            t_ar = timed(ar)
+            compare = {"batch": CB, "nacf_mp_ct_captions_per_s": round(CB / t_na, 1),
+                       "arb2_beam5_captions_per_s": round(CB / t_ar, 1), "nacf_over_arb2": round(t_ar / t_na, 2),
+                       "note": "random-init weights: AR hypotheses rarely emit <eos>, so beam search runs all max_len-1 steps"}
+            del amodel
+            model.train()
+
         # ---- CPU baseline: the oracle (plain eager PyTorch fp32 restatement) on this box's host cores
         cpu = None
         if not args.no_cpu_baseline:
@@ -247,7 +284,8 @@ def main():
                                       "feats, seq_len %d, V=%d, dropout 0.5, Adam" % (B, L, V),
                           "global_batch": B * world, "seq_len": L, "vocab": V, "params": n_params,
                           "parallelism": "dp%d" % world, "hipgraph": bool(use_graph)},
-               "roofline": roofline, "cpu_baseline": cpu, "decode": decode, "final_loss": round(final_loss, 4),
+               "roofline": roofline, "cpu_baseline": cpu, "decode": decode, "config5_ar_vs_na": compare,
+               "final_loss": round(final_loss, 4),
                "gemm_kernels": gemm_table}
     if world > 1:
         dist.barrier()

@@ -96,19 +96,31 @@ __global__ void colsum_partial_kernel(const float* __restrict__ dz, int64_t ld, 
   const int r0 = blockIdx.y * rows_per;
   const int r1 = min(Meff, r0 + rows_per);
   float acc = 0.f;
-  if (c < N)
+  if (c < N) {
+#pragma unroll 4
     for (int r = r0 + rl; r < r1; r += 4) acc += dz[(int64_t)(rows ? rows[r] : r) * ld + c];
+  }
   red[rl][threadIdx.x & 63] = acc;
   __syncthreads();
   if (rl == 0 && c < N)
     part[(int64_t)blockIdx.y * N + c] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
 }
+// 64 columns per workgroup, 4 lanes of partials each; fixed combine order (s ascending within a lane, lanes 0..3)
 __global__ void colsum_final_kernel(const float* __restrict__ part, int S, int N, float* __restrict__ db, float beta) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= N) return;
+  __shared__ float red[4][64];
+  const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int rl = threadIdx.x >> 6;
   float acc = 0.f;
-  for (int s = 0; s < S; ++s) acc += part[(int64_t)s * N + c];
-  db[c] = (beta != 0.f) ? acc + beta * db[c] : acc;
+  if (c < N) {
+#pragma unroll 4
+    for (int s = rl; s < S; s += 4) acc += part[(int64_t)s * N + c];
+  }
+  red[rl][threadIdx.x & 63] = acc;
+  __syncthreads();
+  if (rl == 0 && c < N) {
+    const float t = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+    db[c] = (beta != 0.f) ? t + beta * db[c] : t;
+  }
 }
 
 // merge the per-tile (max, idx, sumexp) partials and apply the decode bookkeeping
@@ -350,7 +362,7 @@ int nacf_linear_bwd_weight(const float* dZ, int64_t lddz, const float* X, int64_
     S = cdiv(M, rows_per);
     hipLaunchKernelGGL(colsum_partial_kernel, dim3(cdiv(N, 64), S), dim3(256), 0, s, dZ, lddz, M, N, rows_per,
                        rs ? rs->rows : nullptr, rs ? rs->count : nullptr, part);
-    hipLaunchKernelGGL(colsum_final_kernel, dim3(cdiv(N, 256)), dim3(256), 0, s, part, S, N, db, beta);
+    hipLaunchKernelGGL(colsum_final_kernel, dim3(cdiv(N, 64)), dim3(256), 0, s, part, S, N, db, beta);
     NACF_LAUNCH_CHECK("nacf_linear_bwd_weight(bias)");
   }
   return NACF_OK;
