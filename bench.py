@@ -14,7 +14,11 @@ Also reported (same JSON line): NA-decode captions/s (mask-predict + coarse
 templates, T=5, lbs=6), the live roofline of the dominant GEMM kernel (HIP
 events around every launch of it) and the CPU baseline (the oracle timed on the
 host cores, bounded sample).  Arithmetic is fp32 on the MFMA f32 path (exact
-parity mode); nothing is skipped or cached inside the timed region.
+parity mode).  Nothing is cached across steps; the only work not executed is
+work whose result is identically zero in the reference too: decoder rows whose
+token is <pad> and vocabulary rows without a label (live-row GEMMs, DESIGN.md
+section 4) -- gradients, loss and decoded tokens are unchanged (parity tests run this
+same path).  The roofline counts only the FLOPs actually executed.
 """
 import argparse
 import json
@@ -70,7 +74,7 @@ def main():
     from nacf_amd.models.Translator import Translator
     from nacf_amd.runtime import ops
     from nacf_amd.runtime.ddp import DataParallel
-    from oracle import nacf_oracle as O   # synthetic-input generator + (cpu_baseline leg only) the CPU checker
+    from nacf_amd import synthetic as O   # seeded synthetic weights / batches (input generators only)
 
     B, L, V, F_ = args.batch, args.seq_len, args.vocab, 60
     opt = make_opt(nacf_amd, L, V)
@@ -194,6 +198,18 @@ def main():
                     "flops_per_step": r["flops"] / n_prof,
                     "all_gemm_ms_per_step": round(gemm_ms, 3),
                     "all_gemm_tflops": round(sum(v["flops"] for v in summ.values()) / n_prof / (gemm_ms * 1e-3) / 1e12, 2)}
+        # HBM traffic of that kernel: PMC counters cannot be collected from inside this process, so the
+        # figure comes from the committed rocprofv3 --pmc passes of this same command (tools/pmc_traffic.py),
+        # averaged per launch over all launches of the kernel; null if the table is missing.
+        try:
+            tab = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
+            hits = [e for e in tab["kernels"] if e["kernel"].startswith("void " + name)]
+            if hits:
+                n_l = sum(e["launches_sampled"] for e in hits)
+                roofline["traffic"] = int(sum(e["hbm_bytes"] * e["launches_sampled"] for e in hits) / n_l)
+                roofline["traffic_source"] = "profiles/r01_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, bytes/launch)"
+        except (OSError, ValueError, KeyError):
+            pass
         gemm_table = {k: {"calls_per_step": v["calls"] // n_prof, "ms_per_step": round(v["ms"] / n_prof, 3),
                           "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2),
                           "span_is_one_kernel": v["single"]} for k, v in summ.items()}
@@ -258,13 +274,14 @@ def main():
         # ---- CPU baseline: the oracle (plain eager PyTorch fp32 restatement) on this box's host cores
         cpu = None
         if not args.no_cpu_baseline:
+            from oracle import nacf_oracle as ORACLE   # the CPU checker: imported for THIS leg only, never measured as product
             cb = 32
             cbatch = O.synth_batch(opt, cb, F_, seed=1)
             sd_c = {k: v.clone() for k, v in sd.items()}
             st = {}
             copt = dict(opt)
             def cpu_step():
-                return O.train_step(sd_c, copt, cbatch["feats"], [cbatch["tokens_1"], cbatch["tokens"]],
+                return ORACLE.train_step(sd_c, copt, cbatch["feats"], [cbatch["tokens_1"], cbatch["tokens"]],
                                     cbatch["category"], [cbatch["labels_1"], cbatch["labels"]],
                                     cbatch["tgt_length"], st, lr=opt["learning_rate"], training=True)
             cpu_step()
@@ -283,7 +300,7 @@ def main():
                "config": {"workload": "NACF train step, MSRVTT-shape (configs[2]/[3]): %d videos/GPU, 2x60x2048 fp32 "
                                       "feats, seq_len %d, V=%d, dropout 0.5, Adam" % (B, L, V),
                           "global_batch": B * world, "seq_len": L, "vocab": V, "params": n_params,
-                          "parallelism": "dp%d" % world, "hipgraph": bool(use_graph)},
+                          "parallelism": "dp%d" % world, "hipgraph": bool(use_graph), "live_row_gemms": True},
                "roofline": roofline, "cpu_baseline": cpu, "decode": decode, "config5_ar_vs_na": compare,
                "final_loss": round(final_loss, 4),
                "gemm_kernels": gemm_table}

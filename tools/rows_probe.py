@@ -24,7 +24,6 @@ print("rows  dX ms", t(lambda: ops.linear_bwd_data(dz, w, dx, rows=rs)))
 print("dense dW ms", t(lambda: ops.linear_bwd_weight(dz, x, dw, None, beta=0.0)))
 print("rows  dW ms", t(lambda: ops.linear_bwd_weight(dz, x, dw, None, beta=0.0, rows=rs)))
 # model-level: is the decoder using row sets?
-from oracle import nacf_oracle as O
 opt = nacf_amd.opts.make_opt("NACF", "MSRVTT", with_category=True, max_len=20, vocab_size=10547, fused_loss=True)
 m = nacf_amd.get_model(opt).to(dev).train()
 dec = m.decoder.bert
