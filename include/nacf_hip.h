@@ -232,6 +232,22 @@ int nacf_embed_scatter_bwd(const float* dE, const int64_t* tokens, const int64_t
                            int R, int L, int D, int V, int n_cat, int n_video, int vdiv, int vmod,
                            void* ws, size_t ws_bytes, nacf_stream_t stream);
 
+/* Generic LayerNorm over the last dimension (with_layernorm: models/bert.py:189,196-199,237,244-245;
+ * norm_type=ln: models/joint_representation.py:21,47):
+ *   out[orow] = (row_tokens[r] == PAD ? 0 : dropout(LN(x[r]), p_drop)),
+ *   orow = (r / seg_in) * seg_out + seg_off + r % seg_in   (seg_in = seg_out = rows, seg_off = 0: in place layout;
+ *   otherwise a modality's [B, F, D] rows land in their slice of the [B, sum F, D] memory).
+ * xhat [rows, D] / rstd [rows] are saved for backward when non-NULL. */
+int nacf_layernorm_fwd(const float* x, const float* ln_w, const float* ln_b, float* out, float* xhat, float* rstd,
+                       int rows, int D, float eps, int seg_in, int seg_out, int seg_off,
+                       float p_drop, uint32_t salt, const uint64_t* rng_state, const int64_t* row_tokens,
+                       nacf_stream_t stream);
+size_t nacf_layernorm_bwd_workspace(int rows, int D);
+int nacf_layernorm_bwd(const float* dOut, const float* xhat, const float* rstd, const float* ln_w, float* dX,
+                       float* dln_w, float* dln_b, float beta, int rows, int D, int seg_in, int seg_out, int seg_off,
+                       float p_drop, uint32_t salt, const uint64_t* rng_state, const int64_t* row_tokens,
+                       void* ws, size_t ws_bytes, nacf_stream_t stream);
+
 /* Multi-head attention core, models/bert.py:150-179:
  *   S = Q K^T / sqrt(dk) ; S[key masked] = -1e7 ; P = softmax(S) ; O = P V
  * Q: [R, Lq, *] row stride ldq (head h at column h*dk); K, V: [n_kv, Lk, *];

@@ -149,6 +149,114 @@ __global__ void embed_ln_bwd_final_kernel(const float* __restrict__ part, int nb
   if (dln_b) dln_b[d] = (beta != 0.f) ? b + beta * dln_b[d] : b;
 }
 
+// ------------------------------------------------------------------ generic LayerNorm (with_layernorm / norm_type=ln)
+// out[orow] = mask(dropout(LN(x[r]))),  orow = (r / seg_in) * seg_out + seg_off + r % seg_in
+__global__ __launch_bounds__(EMB_THREADS) void layernorm_fwd_kernel(
+    const float* __restrict__ x, const float* __restrict__ ln_w, const float* __restrict__ ln_b, float* __restrict__ out,
+    float* __restrict__ xhat, float* __restrict__ rstd_out, int D, float eps, int seg_in, int seg_out, int seg_off,
+    float p, uint32_t salt, const uint64_t* __restrict__ rng_state, const int64_t* __restrict__ row_tokens) {
+  __shared__ float red[16];
+  const int row = blockIdx.x;
+  const int64_t orow = (int64_t)(row / seg_in) * seg_out + seg_off + row % seg_in;
+  f32x4 v[EMB_MAXJ];
+  float sum = 0.f;
+#pragma unroll
+  for (int j = 0; j < EMB_MAXJ; ++j) {
+    const int d = (threadIdx.x + EMB_THREADS * j) * 4;
+    v[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (d < D) {
+      v[j] = *reinterpret_cast<const f32x4*>(x + (int64_t)row * D + d);
+      sum += v[j][0] + v[j][1] + v[j][2] + v[j][3];
+    }
+  }
+  const float mean = block_sum(sum, red) / (float)D;
+  float sq = 0.f;
+#pragma unroll
+  for (int j = 0; j < EMB_MAXJ; ++j) {
+    const int d = (threadIdx.x + EMB_THREADS * j) * 4;
+    if (d < D) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { const float dv = v[j][e] - mean; sq += dv * dv; }
+    }
+  }
+  const float rstd = 1.0f / sqrtf(block_sum(sq, red) / (float)D + eps);
+  const bool dead = row_tokens && row_tokens[row] == NACF_PAD;
+  DropRng rng;
+  if (p > 0.f) rng.init(rng_state);
+#pragma unroll
+  for (int j = 0; j < EMB_MAXJ; ++j) {
+    const int d = (threadIdx.x + EMB_THREADS * j) * 4;
+    if (d < D) {
+      f32x4 xh;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) xh[e] = (v[j][e] - mean) * rstd;
+      if (xhat) *reinterpret_cast<f32x4*>(xhat + (int64_t)row * D + d) = xh;
+      f32x4 y = xh * *reinterpret_cast<const f32x4*>(ln_w + d) + *reinterpret_cast<const f32x4*>(ln_b + d);
+      if (p > 0.f) y *= rng.keep4(((uint64_t)row * D + d) >> 2, salt, p);
+      if (dead) y = f32x4{0.f, 0.f, 0.f, 0.f};
+      *reinterpret_cast<f32x4*>(out + orow * D + d) = y;
+    }
+  }
+  if (threadIdx.x == 0 && rstd_out) rstd_out[row] = rstd;
+}
+
+__global__ __launch_bounds__(EMB_THREADS) void layernorm_bwd_kernel(
+    const float* __restrict__ dOut, const float* __restrict__ xhat, const float* __restrict__ rstd,
+    const float* __restrict__ ln_w, float* __restrict__ dX, float* __restrict__ part, int rows, int D, int seg_in,
+    int seg_out, int seg_off, float p, uint32_t salt, const uint64_t* __restrict__ rng_state,
+    const int64_t* __restrict__ row_tokens) {
+  __shared__ float red[16];
+  f32x4 dw[EMB_MAXJ], db[EMB_MAXJ];
+#pragma unroll
+  for (int j = 0; j < EMB_MAXJ; ++j) { dw[j] = f32x4{0.f, 0.f, 0.f, 0.f}; db[j] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+  DropRng rng;
+  if (p > 0.f) rng.init(rng_state);
+  const float invD = 1.f / (float)D;
+  for (int row = blockIdx.x; row < rows; row += gridDim.x) {
+    const int64_t orow = (int64_t)(row / seg_in) * seg_out + seg_off + row % seg_in;
+    const bool dead = row_tokens && row_tokens[row] == NACF_PAD;
+    f32x4 dxh[EMB_MAXJ], xh[EMB_MAXJ];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int j = 0; j < EMB_MAXJ; ++j) {
+      const int d = (threadIdx.x + EMB_THREADS * j) * 4;
+      dxh[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+      xh[j] = dxh[j];
+      if (d < D) {
+        f32x4 dy = dead ? f32x4{0.f, 0.f, 0.f, 0.f} : *reinterpret_cast<const f32x4*>(dOut + orow * D + d);
+        if (p > 0.f) dy *= rng.keep4(((uint64_t)row * D + d) >> 2, salt, p);
+        xh[j] = *reinterpret_cast<const f32x4*>(xhat + (int64_t)row * D + d);
+        dw[j] += dy * xh[j];
+        db[j] += dy;
+        dxh[j] = dy * *reinterpret_cast<const f32x4*>(ln_w + d);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { s1 += dxh[j][e]; s2 += dxh[j][e] * xh[j][e]; }
+      }
+    }
+    s1 = block_sum(s1, red) * invD;
+    s2 = block_sum(s2, red) * invD;
+    const float rs = rstd[row];
+#pragma unroll
+    for (int j = 0; j < EMB_MAXJ; ++j) {
+      const int d = (threadIdx.x + EMB_THREADS * j) * 4;
+      if (d < D) {
+        f32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = rs * (dxh[j][e] - s1 - xh[j][e] * s2);
+        *reinterpret_cast<f32x4*>(dX + (int64_t)row * D + d) = o;
+      }
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < EMB_MAXJ; ++j) {
+    const int d = (threadIdx.x + EMB_THREADS * j) * 4;
+    if (d < D) {
+      *reinterpret_cast<f32x4*>(part + ((int64_t)blockIdx.x * 2 + 0) * D + d) = dw[j];
+      *reinterpret_cast<f32x4*>(part + ((int64_t)blockIdx.x * 2 + 1) * D + d) = db[j];
+    }
+  }
+}
+
 // dword[tok] += sum of the dE rows carrying `tok`, in ascending row order; the
 // workgroup of the FIRST occurrence of a token does the whole sum.
 __global__ __launch_bounds__(EMB_THREADS) void embed_scatter_word_kernel(const float* __restrict__ dE,
@@ -557,6 +665,43 @@ int nacf_embed_ln_bwd(const float* dOut, const float* xhat, const float* rstd, c
                      p_drop, salt, rng_state);
   hipLaunchKernelGGL(embed_ln_bwd_final_kernel, dim3(cdiv(D, 256)), dim3(256), 0, s, part, nblk, D, dln_w, dln_b, beta);
   NACF_LAUNCH_CHECK("nacf_embed_ln_bwd");
+  return NACF_OK;
+}
+
+int nacf_layernorm_fwd(const float* x, const float* ln_w, const float* ln_b, float* out, float* xhat, float* rstd,
+                       int rows, int D, float eps, int seg_in, int seg_out, int seg_off, float p_drop, uint32_t salt,
+                       const uint64_t* rng_state, const int64_t* row_tokens, nacf_stream_t stream) {
+  NACF_CHECK(x && ln_w && ln_b && out && rows > 0 && seg_in > 0 && seg_out >= seg_in && seg_off >= 0, NACF_EINVAL,
+             "nacf_layernorm_fwd: bad argument");
+  NACF_CHECK(D % 4 == 0 && D > 0 && D <= EMB_MAXJ * EMB_THREADS * 4, NACF_EUNSUPPORTED,
+             "nacf_layernorm_fwd: D must be a multiple of 4 and <= 2048 (got %d)", D);
+  NACF_CHECK(p_drop < 1.f && !(p_drop > 0.f && !rng_state), NACF_EINVAL, "nacf_layernorm_fwd: dropout needs rng_state, p<1");
+  hipLaunchKernelGGL(layernorm_fwd_kernel, dim3(rows), dim3(EMB_THREADS), 0, as_hip(stream), x, ln_w, ln_b, out, xhat, rstd, D,
+                     eps, seg_in, seg_out, seg_off, p_drop, salt, rng_state, row_tokens);
+  NACF_LAUNCH_CHECK("nacf_layernorm_fwd");
+  return NACF_OK;
+}
+
+size_t nacf_layernorm_bwd_workspace(int rows, int D) {
+  return (size_t)embed_bwd_blocks(rows) * 2 * D * sizeof(float) + 256;
+}
+
+int nacf_layernorm_bwd(const float* dOut, const float* xhat, const float* rstd, const float* ln_w, float* dX,
+                       float* dln_w, float* dln_b, float beta, int rows, int D, int seg_in, int seg_out, int seg_off,
+                       float p_drop, uint32_t salt, const uint64_t* rng_state, const int64_t* row_tokens, void* ws,
+                       size_t ws_bytes, nacf_stream_t stream) {
+  NACF_CHECK(dOut && xhat && rstd && ln_w && dX && rows > 0 && seg_in > 0 && seg_out >= seg_in && seg_off >= 0, NACF_EINVAL,
+             "nacf_layernorm_bwd: bad argument");
+  NACF_CHECK(D % 4 == 0 && D > 0 && D <= EMB_MAXJ * EMB_THREADS * 4, NACF_EUNSUPPORTED, "nacf_layernorm_bwd: bad D");
+  NACF_CHECK(ws && ws_bytes >= nacf_layernorm_bwd_workspace(rows, D), NACF_EWORKSPACE, "nacf_layernorm_bwd: workspace too small");
+  NACF_CHECK(p_drop < 1.f && !(p_drop > 0.f && !rng_state), NACF_EINVAL, "nacf_layernorm_bwd: dropout needs rng_state, p<1");
+  const int nblk = embed_bwd_blocks(rows);
+  float* part = reinterpret_cast<float*>(ws);
+  hipStream_t s = as_hip(stream);
+  hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(nblk), dim3(EMB_THREADS), 0, s, dOut, xhat, rstd, ln_w, dX, part, rows, D,
+                     seg_in, seg_out, seg_off, p_drop, salt, rng_state, row_tokens);
+  hipLaunchKernelGGL(embed_ln_bwd_final_kernel, dim3(cdiv(D, 256)), dim3(256), 0, s, part, nblk, D, dln_w, dln_b, beta);
+  NACF_LAUNCH_CHECK("nacf_layernorm_bwd");
   return NACF_OK;
 }
 

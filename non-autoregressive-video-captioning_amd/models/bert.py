@@ -21,7 +21,7 @@ import torch.nn as nn
 
 from ..config import Constants
 from ..runtime import lib as L
-from ..runtime.functional import CrossAttentionFn, EmbedLNFn, LinearFn, SelfAttentionFn
+from ..runtime.functional import CrossAttentionFn, EmbedLNFn, LayerNormFn, LinearFn, SelfAttentionFn
 
 
 class BertEmbeddings(nn.Module):
@@ -68,9 +68,10 @@ class _SelfAttnParams(nn.Module):
 
 
 class _SelfOutputParams(nn.Module):
-    def __init__(self, d):
+    def __init__(self, d, with_layernorm=False, eps=1e-5):
         super().__init__()
         self.dense = nn.Linear(d, d)
+        self.LayerNorm = nn.LayerNorm(d, eps=eps) if with_layernorm else None
 
 
 class BertAttention(nn.Module):
@@ -82,21 +83,23 @@ class BertAttention(nn.Module):
             raise ValueError('The hidden size (%d) is not a multiple of the number of attention heads (%d)'
                              % (config.dim_hidden, config.num_attention_heads))
         self.self = _SelfAttnParams(config.dim_hidden)
-        self.output = _SelfOutputParams(config.dim_hidden)
+        self.output = _SelfOutputParams(config.dim_hidden, config.with_layernorm, config.layer_norm_eps)
 
 
 class _Dense(nn.Module):
-    def __init__(self, i, o):
+    def __init__(self, i, o, with_layernorm=False, eps=1e-5):
         super().__init__()
         self.dense = nn.Linear(i, o)
+        if with_layernorm:
+            self.LayerNorm = nn.LayerNorm(o, eps=eps)
 
 
 class BertLayer(nn.Module):
     def __init__(self, config, is_decoder_layer=True):
         super().__init__()
-        if config.with_layernorm or config.pos_attention or getattr(config, 'parallel_mlm', False):
-            raise NotImplementedError('nacf_amd: with_layernorm / pos_attention / parallel_mlm variants are not built '
-                                      '(reference defaults are off, opts.py:34-36)')
+        if config.pos_attention or getattr(config, 'parallel_mlm', False):
+            raise NotImplementedError('nacf_amd: pos_attention / parallel_mlm variants are not built '
+                                      '(reference defaults are off, opts.py:34-35)')
         if config.attention_probs_dropout_prob != 0.0:
             raise NotImplementedError('nacf_amd: attention_probs_dropout_prob must be 0 (reference default, opts.py:29)')
         if config.hidden_act not in L.ACT_BY_NAME:
@@ -104,7 +107,9 @@ class BertLayer(nn.Module):
         self.attention = BertAttention(config)
         self.attend_to_enc_output = BertAttention(config)
         self.intermediate = _Dense(config.dim_hidden, config.intermediate_size)
-        self.output = _Dense(config.intermediate_size, config.dim_hidden)
+        self.output = _Dense(config.intermediate_size, config.dim_hidden, config.with_layernorm, config.layer_norm_eps)
+        self.with_layernorm = bool(config.with_layernorm)
+        self.eps = config.layer_norm_eps
         self.H = config.num_attention_heads
         self.p = config.hidden_dropout_prob
         self.act = L.ACT_BY_NAME[config.hidden_act]
@@ -120,7 +125,8 @@ class BertLayer(nn.Module):
             [c.output.dense.weight], [c.output.dense.bias],
             [self.intermediate.dense.weight], [self.intermediate.dense.bias],
             [self.output.dense.weight], [self.output.dense.bias],
-        ]
+        ] + ([[m.LayerNorm.weight] for m in (a.output, c.output, self.output)] +
+             [[m.LayerNorm.bias] for m in (a.output, c.output, self.output)] if self.with_layernorm else [])
 
     def nacf_bind(self, flat, rt):
         self._rt = rt
@@ -134,6 +140,9 @@ class BertLayer(nn.Module):
             co=flat.pack([c.output.dense.weight], [c.output.dense.bias]),
             f1=flat.pack([self.intermediate.dense.weight], [self.intermediate.dense.bias]),
             f2=flat.pack([self.output.dense.weight], [self.output.dense.bias]))
+        if self.with_layernorm:
+            for key, m in (('ln_so', a.output), ('ln_co', c.output), ('ln_f2', self.output)):
+                self._pk[key] = flat.pack([m.LayerNorm.weight], [m.LayerNorm.bias])
         self._salts = [rt.next_salt() for _ in range(4)]
         self._params = [p for p in self.parameters()]
 
@@ -151,6 +160,8 @@ class BertLayer(nn.Module):
         P = self._params
         pk = self._pk
         s = self._salts
+        if self.with_layernorm:
+            return self._run_layernorm(x2, tokens, causal, memory_kv, M, vdiv, vmod, training, want_probs, rows)
         qkv = LinearFn.apply(x2, None, dict(pack=pk['qkv'], rows=rows), *P)
         att, p_self = SelfAttentionFn.apply(qkv, tokens, int(causal), self.H, want_probs)
         a = LinearFn.apply(att, x2, dict(pack=pk['so'], p1=self.p, salt1=s[0], row_tokens=tok_flat, rng=rng,
@@ -162,4 +173,28 @@ class BertLayer(nn.Module):
         u = LinearFn.apply(c, None, dict(pack=pk['f1'], act=self.act, rows=rows), *P)
         y = LinearFn.apply(u, c, dict(pack=pk['f2'], p1=self.p, salt1=s[2], p2=self.p, salt2=s[3], row_tokens=tok_flat,
                                       rng=rng, training=training, rows=rows), *P)
+        return y, (p_self, p_cross)
+
+    def _run_layernorm(self, x2, tokens, causal, memory_kv, M, vdiv, vmod, training, want_probs, rows):
+        """with_layernorm=True (opts.py:36): LayerNorm sits between the residual add and the <pad> mask,
+        so the GEMM epilogue stops at the residual and a LayerNorm kernel finishes the block:
+           a = LN(dropout(dense(att)) + x) * non_pad                  (BertSelfOutput, bert.py:192-200)
+           y = dropout(LN(dropout(dense(u)) + c)) * non_pad           (BertOutput, bert.py:240-247)"""
+        R, Lq = tokens.shape
+        rng = self._rt.rng(x2.device)
+        tok_flat = tokens.reshape(-1)
+        P, pk, s = self._params, self._pk, self._salts
+        ln = lambda key, p=0.0, salt=0: dict(ln=pk[key], eps=self.eps, p=p, salt=salt, rng=rng, training=training,
+                                             row_tokens=tok_flat)
+        qkv = LinearFn.apply(x2, None, dict(pack=pk['qkv'], rows=rows), *P)
+        att, p_self = SelfAttentionFn.apply(qkv, tokens, int(causal), self.H, want_probs)
+        a = LinearFn.apply(att, x2, dict(pack=pk['so'], p1=self.p, salt1=s[0], rng=rng, training=training, rows=rows), *P)
+        a = LayerNormFn.apply(a, ln('ln_so'), *P)
+        q = LinearFn.apply(a, None, dict(pack=pk['cq'], rows=rows), *P)
+        catt, p_cross = CrossAttentionFn.apply(q, memory_kv, self.H, Lq, M, vdiv, vmod, want_probs)
+        c = LinearFn.apply(catt, a, dict(pack=pk['co'], p1=self.p, salt1=s[1], rng=rng, training=training, rows=rows), *P)
+        c = LayerNormFn.apply(c, ln('ln_co'), *P)
+        u = LinearFn.apply(c, None, dict(pack=pk['f1'], act=self.act, rows=rows), *P)
+        y = LinearFn.apply(u, c, dict(pack=pk['f2'], p1=self.p, salt1=s[2], rng=rng, training=training, rows=rows), *P)
+        y = LayerNormFn.apply(y, ln('ln_f2', self.p, s[3]), *P)
         return y, (p_self, p_cross)

@@ -5,7 +5,7 @@ of the [B, sum F, D] memory (`BNConcatFn`)."""
 import torch
 import torch.nn as nn
 
-from ..runtime.functional import BNConcatFn
+from ..runtime.functional import BNConcatFn, LNConcatFn
 
 
 class Joint_Representaion_Learner(nn.Module):  # (sic) upstream spelling is part of the state_dict contract
@@ -18,12 +18,10 @@ class Joint_Representaion_Learner(nn.Module):  # (sic) upstream spelling is part
         self.norm_list = []
         self.is_bn = opt.get('norm_type', 'bn').lower() == 'bn'
         if not opt['no_encoder_bn'] and self.fusion != 'none':
-            if not self.is_bn:
-                raise NotImplementedError('nacf_amd: norm_type=ln fusion is not built yet (reference default is bn)')
             for i, item in enumerate(feats_size):
-                m = nn.BatchNorm1d(item)
+                m = nn.BatchNorm1d(item) if self.is_bn else nn.LayerNorm(item)
                 self.norm_list.append(m)
-                self.add_module('bn%d' % i, m)
+                self.add_module('%s%d' % ('bn' if self.is_bn else 'ln', i), m)
         self._packs = None
 
     def nacf_groups(self):
@@ -38,6 +36,10 @@ class Joint_Representaion_Learner(nn.Module):  # (sic) upstream spelling is part
         if not self.norm_list:
             return torch.cat(list(encoder_outputs), dim=1), encoder_hiddens  # pure data movement
         assert len(encoder_outputs) == len(self.norm_list)
+        params = [p for m in self.norm_list for p in (m.weight, m.bias)]
+        if not self.is_bn:
+            cfg = dict(packs=self._packs, eps=self.norm_list[0].eps)
+            return LNConcatFn.apply(cfg, len(encoder_outputs), *encoder_outputs, *params), encoder_hiddens
         mods = [dict(pack=pk, running_mean=m.running_mean, running_var=m.running_var, nbt=m.num_batches_tracked)
                 for pk, m in zip(self._packs, self.norm_list)]
         cfg = dict(mods=mods, training=self.training, momentum=self.norm_list[0].momentum, eps=self.norm_list[0].eps)

@@ -438,3 +438,72 @@ class KLDivMeanFn(Function):
         dx = torch.empty_like(ctx.x)
         ops.kldiv_mean(ctx.x, ctx.t, None, dx, gscale=dout.reshape(1).contiguous())
         return dx, None
+
+
+class LayerNormFn(Function):
+    """nn.LayerNorm over the last dimension with the optional tail of the blocks that use it
+    (with_layernorm: BertSelfOutput / BertOutput, models/bert.py:189-200,237-247):
+        out = (row is <pad> ? 0 : dropout(LN(x)))
+    cfg keys: ln (Pack), eps, p, salt, rng, training, row_tokens."""
+
+    @staticmethod
+    def forward(ctx, x, cfg, *params):
+        rows, D = x.shape
+        x = _c2d(x, rows, D)
+        ln: Pack = cfg["ln"]
+        training = cfg.get("training", False)
+        need = ctx.needs_input_grad[0] or ln.gw is not None
+        xhat = _new((rows, D), x) if (training or need) else None
+        rstd = _new((rows,), x) if (training or need) else None
+        p = cfg.get("p", 0.0) if training else 0.0
+        out = _new((rows, D), x)
+        ops.layernorm_fwd(x, ln.w, ln.b, out, xhat, rstd, cfg["eps"], rows, rows, 0, p, cfg.get("salt", 0),
+                          cfg.get("rng"), cfg.get("row_tokens"))
+        ctx.cfg, ctx.p, ctx.xhat, ctx.rstd = cfg, p, xhat, rstd
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        cfg = ctx.cfg
+        ln: Pack = cfg["ln"]
+        rows, D = ctx.xhat.shape
+        dx = _new((rows, D), dout)
+        ops.layernorm_bwd(_c2d(dout, rows, D), ctx.xhat, ctx.rstd, ln.w, dx, ln.gw, ln.gb, rows, rows, 0, ctx.p,
+                          cfg.get("salt", 0), cfg.get("rng"), cfg.get("row_tokens"), beta=1.0)
+        ctx.xhat = ctx.rstd = None
+        return (dx, None) + (None,) * (len(ctx.needs_input_grad) - 2)
+
+
+class LNConcatFn(Function):
+    """per-modality LayerNorm + temporal concat (norm_type='ln', models/joint_representation.py:21,47-51)"""
+
+    @staticmethod
+    def forward(ctx, cfg, n_mod, *args):
+        xs = [a.contiguous() for a in args[:n_mod]]
+        B, _, D = xs[0].shape
+        M_total = sum(x.shape[1] for x in xs)
+        out = _new((B, M_total, D), xs[0])
+        saves, f_off = [], 0
+        for i, x in enumerate(xs):
+            F_ = x.shape[1]
+            pk: Pack = cfg["packs"][i]
+            xhat, rstd = _new((B * F_, D), x), _new((B * F_,), x)
+            ops.layernorm_fwd(x.view(B * F_, D), pk.w, pk.b, out, xhat, rstd, cfg["eps"], F_, M_total, f_off, 0.0, 0,
+                              None, None)
+            saves.append((xhat, rstd, F_, f_off))
+            f_off += F_
+        ctx.cfg, ctx.saves, ctx.n_mod, ctx.dims = cfg, saves, n_mod, (B, M_total, D)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        B, M_total, D = ctx.dims
+        dout = dout.contiguous()
+        grads = []
+        for i, (xhat, rstd, F_, f_off) in enumerate(ctx.saves):
+            pk: Pack = ctx.cfg["packs"][i]
+            dx = _new((B * F_, D), dout)
+            ops.layernorm_bwd(dout, xhat, rstd, pk.w, dx, pk.gw, pk.gb, F_, M_total, f_off, 0.0, 0, None, None, beta=1.0)
+            grads.append(dx.view(B, F_, D) if ctx.needs_input_grad[2 + i] else None)
+        ctx.saves = None
+        return (None, None) + tuple(grads) + (None,) * (len(ctx.needs_input_grad) - 2 - ctx.n_mod)

@@ -67,6 +67,9 @@ SIGNATURES = {
     "nacf_embed_ln_bwd": (c_int, [_P, _P, _P, _P, _P, _P, _P, _F, _I, _I, _I, _F, _U, _P, _P, _S, _P]),
     "nacf_embed_scatter_bwd_workspace": (_S, [_I, _I, _I, _I]),
     "nacf_embed_scatter_bwd": (c_int, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P, _S, _P]),
+    "nacf_layernorm_fwd": (c_int, [_P, _P, _P, _P, _P, _P, _I, _I, _F, _I, _I, _I, _F, _U, _P, _P, _P]),
+    "nacf_layernorm_bwd_workspace": (_S, [_I, _I]),
+    "nacf_layernorm_bwd": (c_int, [_P, _P, _P, _P, _P, _P, _P, _F, _I, _I, _I, _I, _I, _F, _U, _P, _P, _P, _S, _P]),
     "nacf_attention_fwd": (c_int, [_P, _L, _P, _L, _P, _L, _P, _L, _P, _I, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
     "nacf_attention_bwd": (c_int, [_P, _L, _P, _L, _P, _L, _P, _L, _P, _L, _P, _L, _P, _L, _P, _I,
                                    _I, _I, _I, _I, _I, _I, _I, _I, _P]),

@@ -338,6 +338,28 @@ def embed_scatter_bwd(dE, tokens, category, dword, dpos, dcat, dadd, R, Lq, D, V
                                        _stream()), "nacf_embed_scatter_bwd")
 
 
+def layernorm_fwd(x2d, ln_w, ln_b, out, xhat, rstd, eps, seg_in, seg_out, seg_off, p, salt, rng, row_tokens):
+    _chk_f32(x2d, ln_w, ln_b, out, xhat, rstd)
+    rows, D = x2d.shape
+    L.check(L.load().nacf_layernorm_fwd(_ptr(x2d), _ptr(ln_w), _ptr(ln_b), _ptr(out), _ptr(xhat), _ptr(rstd), rows, D,
+                                        float(eps), seg_in, seg_out, seg_off, float(p), int(salt),
+                                        _ptr(rng.state) if rng else None, _ptr(row_tokens), _stream()),
+            "nacf_layernorm_fwd")
+    return out
+
+
+def layernorm_bwd(dout, xhat, rstd, ln_w, dx, dln_w, dln_b, seg_in, seg_out, seg_off, p, salt, rng, row_tokens,
+                  beta=1.0):
+    _chk_f32(dout, xhat, rstd, ln_w, dx, dln_w, dln_b)
+    rows, D = xhat.shape
+    lib = L.load()
+    ws = WORKSPACE.get(lib.nacf_layernorm_bwd_workspace(rows, D), dout.device)
+    L.check(lib.nacf_layernorm_bwd(_ptr(dout), _ptr(xhat), _ptr(rstd), _ptr(ln_w), _ptr(dx), _ptr(dln_w), _ptr(dln_b),
+                                   float(beta), rows, D, seg_in, seg_out, seg_off, float(p), int(salt),
+                                   _ptr(rng.state) if rng else None, _ptr(row_tokens), _ptr(ws), ws.numel(),
+                                   _stream()), "nacf_layernorm_bwd")
+
+
 def attention_fwd(q, k, v, out, key_tokens, causal, probs, R, H, Lq, Lk, dk, kv_div, kv_mod):
     """q/k/v/out are 2-D column slices (rows = seq*len, cols = H*dk) of packed buffers."""
     _chk_f32(q, k, v, out, probs)

@@ -36,10 +36,14 @@ def param_shapes(opt: dict) -> Dict[str, Tuple[int, ...]]:
             sh[n + f"1.{w}.weight"] = (d, d); sh[n + f"1.{w}.bias"] = (d,)
     if not opt["no_encoder_bn"]:
         for i in range(len(opt["modality"])):
-            n = f"joint_representation_learner.bn{i}."
-            for k in ("weight", "bias", "running_mean", "running_var"):
-                sh[n + k] = (d,)
-            sh[n + "num_batches_tracked"] = ()
+            if opt.get("norm_type", "bn").lower() == "bn":
+                n = f"joint_representation_learner.bn{i}."
+                for k in ("weight", "bias", "running_mean", "running_var"):
+                    sh[n + k] = (d,)
+                sh[n + "num_batches_tracked"] = ()
+            else:
+                n = f"joint_representation_learner.ln{i}."
+                sh[n + "weight"] = (d,); sh[n + "bias"] = (d,)
     if "length" in opt["crit"]:
         n = "auxiliary_task_predictor.layers.0.net."
         sh[n + "0.weight"] = (d, d); sh[n + "0.bias"] = (d,)
@@ -58,7 +62,12 @@ def param_shapes(opt: dict) -> Dict[str, Tuple[int, ...]]:
             sh[f"{l}{a}.output.dense.weight"] = (d, d); sh[f"{l}{a}.output.dense.bias"] = (d,)
         sh[l + "intermediate.dense.weight"] = (ff, d); sh[l + "intermediate.dense.bias"] = (ff,)
         sh[l + "output.dense.weight"] = (d, ff); sh[l + "output.dense.bias"] = (d,)
+        if opt.get("with_layernorm", False):
+            for m in ("attention.output", "attend_to_enc_output.output", "output"):
+                sh[f"{l}{m}.LayerNorm.weight"] = (d,); sh[f"{l}{m}.LayerNorm.bias"] = (d,)
     sh["tgt_word_prj.weight"] = (V, d)
+    if opt.get("tie_weights", False):      # models/seq2seq.py:30-33: shared with the word embedding + a bias
+        sh["tgt_word_prj.bias"] = (V,)
     return sh
 
 
@@ -78,10 +87,14 @@ def init_state_dict(opt: dict, seed: int = 0) -> SD:
             sd[name] = torch.zeros(shape)
         elif name.endswith("running_var"):
             sd[name] = torch.ones(shape)
-        elif "LayerNorm.weight" in name or (".bn" in name and name.endswith("weight")):
+        elif "embedding.LayerNorm.weight" in name or (".bn" in name and name.endswith("weight")):
             sd[name] = torch.ones(shape)
-        elif "LayerNorm.bias" in name or (".bn" in name and name.endswith("bias")):
+        elif "embedding.LayerNorm.bias" in name or (".bn" in name and name.endswith("bias")):
             sd[name] = torch.zeros(shape)
+        elif "LayerNorm.weight" in name or (".ln" in name and name.endswith("weight")):
+            sd[name] = 1.0 + 0.2 * (torch.rand(shape, generator=g) * 2 - 1)      # optional LayerNorms: non-trivial affine
+        elif "LayerNorm.bias" in name or (".ln" in name and name.endswith("bias")):
+            sd[name] = 0.1 * (torch.rand(shape, generator=g) * 2 - 1)
         elif "embeddings.weight" in name:
             w = torch.randn(shape, generator=g)
             if "word_embeddings" in name:
@@ -94,6 +107,8 @@ def init_state_dict(opt: dict, seed: int = 0) -> SD:
                 fan_in = param_shapes(opt)[wname][1]
             bound = 1.0 / math.sqrt(fan_in)
             sd[name] = (torch.rand(shape, generator=g) * 2 - 1) * bound
+    if full_opt(opt).get("tie_weights", False):
+        sd["tgt_word_prj.weight"] = sd[decoder_prefix(full_opt(opt)) + "embedding.word_embeddings.weight"]
     return sd
 
 

@@ -327,6 +327,14 @@ EOS_BOOST = float(os.environ.get("EOS_BOOST", "8.0"))
 
 def main():
     torch.manual_seed(0)
+    if os.environ.get("ONLY_LN"):
+        train_case("tiny_nacf_ln_train", "NACF", ["-wc", "--with_layernorm", "--norm_type", "ln"], V=101, B=3, F_=6)
+        return
+    if os.environ.get("ONLY_VARIANTS"):
+        train_case("tiny_nab_variants_train", "NAB", ["--num_hidden_layers_decoder", "2", "--hidden_act", "gelu",
+                                                      "--enhance_input", "0", "--no_encoder_bn", "-tie"],
+                   V=101, B=3, F_=6, dataset="Youtube2Text", beta=(0.0, 1.0))
+        return
     if os.environ.get("ONLY_AR"):
         ar_case("tiny_arb2_beam", "ARB2", ["-wc"], V=101, B=3, F_=6)
         ar_case("tiny_arb_beam", "ARB", ["-wc"], V=101, B=3, F_=6)
@@ -338,6 +346,11 @@ def main():
     train_case("tiny_nab_train", "NAB", [], V=101, B=3, F_=6, dataset="Youtube2Text", beta=(0.0, 1.0))
     train_case("tiny_arb2_train", "ARB2", ["-wc"], V=101, B=3, F_=6)
     train_case("tiny_arb_train", "ARB", ["-wc"], V=101, B=3, F_=6)
+    # option variants the reference runs: 2 layers, erf-gelu, no mean-pooled input, no encoder BN, tied weights
+    train_case("tiny_nab_variants_train", "NAB", ["--num_hidden_layers_decoder", "2", "--hidden_act", "gelu",
+                                                  "--enhance_input", "0", "--no_encoder_bn", "-tie"],
+               V=101, B=3, F_=6, dataset="Youtube2Text", beta=(0.0, 1.0))
+    train_case("tiny_nacf_ln_train", "NACF", ["-wc", "--with_layernorm", "--norm_type", "ln"], V=101, B=3, F_=6)
     # NA decode: all paradigms, +-ct, per-iteration tokens/probs
     decode_case("tiny_nacf_decode", "NACF", ["-wc"], V=101, B=4, F_=6, variants={
         "mp_ct": dict(paradigm="mp", use_ct=True, iterations=5, length_beam_size=6, beam_alpha=1.35),

@@ -169,7 +169,8 @@ def embeddings(sd: SD, pfx: str, opt: dict, ids: Tensor, category: Optional[Tens
                additional: Optional[Tensor], training: bool) -> Tensor:
     """BertEmbeddings.forward (return_pos=False branch), models/bert.py:70-96."""
     L = ids.shape[1]
-    e = sd[pfx + "embedding.word_embeddings.weight"][ids] \
+    # nn.Embedding(padding_idx=PAD): the PAD row never receives gradient from the lookup (bert.py:53-56)
+    e = F.embedding(ids, sd[pfx + "embedding.word_embeddings.weight"], padding_idx=PAD) \
         + sd[pfx + "embedding.position_embeddings.weight"][:L].unsqueeze(0)
     if opt["with_category"]:
         e = e + sd[pfx + "embedding.category_embeddings.weight"][category.reshape(-1)].unsqueeze(1)
@@ -361,22 +362,27 @@ def train_step(sd: SD, opt: dict, feats, tgt_tokens, category, labels, tgt_lengt
     (loss, info, grads)."""
     opt = full_opt(opt)
     keys = trainable_keys(sd)
+    wkey = decoder_prefix(opt) + "embedding.word_embeddings.weight"
+    tied = bool(opt.get("tie_weights", False))
+    if tied:  # ONE parameter serves the embedding and the projection (models/seq2seq.py:27-33)
+        keys = [k for k in keys if k != "tgt_word_prj.weight"]
     leaves = {k: sd[k].detach().clone().requires_grad_(True) for k in keys}
     work = dict(sd)
     work.update(leaves)
+    if tied:
+        work["tgt_word_prj.weight"] = leaves[wkey]
     new_stats: dict = {}
     res = forward_train(work, opt, feats, tgt_tokens, category, training, new_stats)
     loss, info = criterion(opt, res, labels, tgt_length)
     loss.backward()
     grads = {k: (leaves[k].grad if leaves[k].grad is not None else torch.zeros_like(leaves[k])) for k in keys}
-    # nn.Embedding(padding_idx=PAD): the PAD row never receives gradient (bert.py:53-56)
-    wkey = decoder_prefix(opt) + "embedding.word_embeddings.weight"
-    grads[wkey][PAD].zero_()
     params = {k: sd[k] for k in keys}
     with torch.no_grad():
         adam_step(params, grads, state, lr, opt.get("grad_clip", 5.0), opt.get("weight_decay", 5e-4))
         for k, v in new_stats.items():
             sd[k] = v
+        if tied:
+            sd["tgt_word_prj.weight"] = sd[wkey]
     return loss.detach(), info, grads
 
 

@@ -663,3 +663,53 @@ def test_adam_step_matches_torch(dev):
         ops.adam_step(pd, g.to(dev), m, v, lr, step, 0.9, 0.999, 1e-8, 5e-4, 5.0, 0.5)
     assert int(step) == 3
     assert err(pd, p) < 2e-6
+
+
+# ------------------------------------------------------------------ generic LayerNorm (with_layernorm / norm_type=ln)
+@pytest.mark.parametrize("B,Fr,D", [(3, 6, 64), (5, 8, 512), (2, 7, 100)])
+def test_layernorm_segment_write_and_mask(dev, B, Fr, D):
+    ops, _ = _ops()
+    x = rnd(B * Fr, D, seed=1) * 2 + 0.3
+    w, b = rnd(D, seed=2) + 1.5, rnd(D, seed=3)
+    toks = torch.randint(0, 3, (B * Fr,), generator=torch.Generator().manual_seed(4))
+    M_total, f_off = Fr + 4, 3
+    xr, wr, br = x.double().requires_grad_(True), w.double().requires_grad_(True), b.double().requires_grad_(True)
+    yr = F.layer_norm(xr, (D,), wr, br, 1e-5) * (toks != PAD).double()[:, None]
+    dout = rnd(B, M_total, D, seed=5)
+    yr.backward(dout[:, f_off:f_off + Fr].reshape(B * Fr, D).double())
+    out = torch.zeros(B, M_total, D, device=dev)
+    xhat, rstd = torch.empty(B * Fr, D, device=dev), torch.empty(B * Fr, device=dev)
+    ops.layernorm_fwd(x.to(dev), w.to(dev), b.to(dev), out, xhat, rstd, 1e-5, Fr, M_total, f_off, 0.0, 0, None,
+                      toks.to(dev))
+    assert err(out[:, f_off:f_off + Fr].reshape(B * Fr, D), yr) < 2e-5
+    assert float(out[:, :f_off].abs().max()) == 0 and float(out[:, f_off + Fr:].abs().max()) == 0
+    dx = torch.empty(B * Fr, D, device=dev)
+    dw, db = torch.full((D,), 0.5, device=dev), torch.full((D,), -0.25, device=dev)
+    ops.layernorm_bwd(dout.to(dev), xhat, rstd, w.to(dev), dx, dw, db, Fr, M_total, f_off, 0.0, 0, None, toks.to(dev),
+                      beta=1.0)
+    assert err(dx, xr.grad) < 5e-5
+    assert err(dw - 0.5, wr.grad) < 1e-4 and err(db + 0.25, br.grad) < 1e-4
+    # inference: no saved statistics
+    out2 = torch.zeros(B * Fr, D, device=dev)
+    ops.layernorm_fwd(x.to(dev), w.to(dev), b.to(dev), out2, None, None, 1e-5, B * Fr, B * Fr, 0, 0.0, 0, None, None)
+    assert err(out2, F.layer_norm(x.double(), (D,), w.double(), b.double(), 1e-5)) < 2e-5
+
+
+def test_layernorm_dropout_mask_replays_in_backward(dev):
+    ops, _ = _ops()
+    rows, D, p = 64, 128, 0.3
+    x, w, b = rnd(rows, D, seed=1).to(dev), (rnd(D, seed=2) + 1.5).to(dev), rnd(D, seed=3).to(dev)
+    rng = ops.RngState(123, dev)
+    out, xhat, rstd = torch.empty(rows, D, device=dev), torch.empty(rows, D, device=dev), torch.empty(rows, device=dev)
+    ops.layernorm_fwd(x, w, b, out, xhat, rstd, 1e-5, rows, rows, 0, p, 9, rng, None)
+    ref = F.layer_norm(x, (D,), w, b, 1e-5)
+    keep = out != 0
+    frac = float(keep.float().mean())
+    assert abs(frac - (1 - p)) < 0.03
+    assert err(out[keep], ref[keep] / (1 - p)) < 2e-5
+    # backward applies the same mask: d/dx of sum(out) == d/dx of sum(ref * keep/(1-p))
+    xr = x.double().cpu().requires_grad_(True)
+    (F.layer_norm(xr, (D,), w.double().cpu(), b.double().cpu(), 1e-5) * keep.cpu().double() / (1 - p)).sum().backward()
+    dx, dw, db = torch.empty(rows, D, device=dev), torch.zeros(D, device=dev), torch.zeros(D, device=dev)
+    ops.layernorm_bwd(torch.ones(rows, D, device=dev), xhat, rstd, w, dx, dw, db, rows, rows, 0, p, 9, rng, None)
+    assert err(dx, xr.grad) < 5e-5

@@ -30,7 +30,8 @@ def _tok_labels(opt, b):
     return tokens, labels
 
 
-TRAIN_CASES = ["tiny_nacf_train", "tiny_nab_train", "tiny_arb2_train", "tiny_arb_train"]
+TRAIN_CASES = ["tiny_nacf_train", "tiny_nab_train", "tiny_arb2_train", "tiny_arb_train", "tiny_nab_variants_train",
+               "tiny_nacf_ln_train"]
 
 
 @pytest.mark.parametrize("name", TRAIN_CASES)
@@ -70,10 +71,20 @@ def test_train_step_vs_reference_golden(dev, name, fused):
             worst = (k, e)
     assert worst[1] < 5e-5, worst
     optim.step()
+    grads_ref = gold_state(g, "grad.")
     for k, v in gold_state(g, "after.").items():
-        cur = model.state_dict()[k]
+        cur = model.state_dict()[k].detach().cpu()
         if v.is_floating_point():
-            assert maxerr(cur, v) < 1.5e-4, k      # Adam step 1 is lr*g/(|g|+eps): ill-conditioned where |g|~eps
+            # Adam step 1 is lr*g/(|g|+eps): where the reference gradient itself is round-off noise
+            # (|g| ~ eps, e.g. attention key biases, whose exact gradient is 0) the step direction is
+            # arbitrary in the reference too -- there only the step SIZE (<= lr) is checked.
+            d = (cur - v).abs()
+            if k in grads_ref:
+                solid = grads_ref[k].abs() > 2e-6
+                assert float(d[solid].max() if solid.any() else 0.0) < 1.5e-4, k
+                assert float(d.max()) <= 2.05 * opt["learning_rate"], k
+            else:
+                assert float(d.max()) < 1.5e-4, k
         else:
             assert int(cur) == int(v), k
     # meters: loss info names/values as the reference's Criterion reports them
