@@ -22,8 +22,9 @@
 //   NT / NN: Q rows and C rows go through the list;   TN: the reduce index does.
 //
 // Workgroup: 256 threads = 4 waves (WM x WN), block tile BM x BN, BK = 16,
-// double-buffered LDS with register prefetch of the next k-tile (one barrier
-// per k-tile).  Wave tile = (BM/WM) x (BN/WN) = TM x TN MFMA tiles of 16x16.
+// two LDS images + prefetched fragment registers + global->register staging
+// three k-tiles ahead (one barrier per k-tile, see "software pipeline" in the
+// kernel).  Wave tile = (BM/WM) x (BN/WN) = TM x TN MFMA tiles of 16x16.
 //
 // LDS images and the k-permutation trick: the 16x16x4 MFMA wants, from lane
 // (i = lane&15, g = lane>>4), A[i][k=g].  Which physical k each (step, g)
@@ -42,6 +43,7 @@
 // ends up with 4 CONSECUTIVE n of one row m: epilogues store float4s.
 #pragma once
 #include "common.hpp"
+#include <type_traits>
 
 struct GemmShape {
   const float* Q;
@@ -49,7 +51,6 @@ struct GemmShape {
   int64_t ldq, ldp;
   int M, N, K;
   int k_per_split;  // multiple of 16
-  int k_skew;       // != 0: every tile starts its k-loop at a different k-tile (wraps around)
   int tiles_m, tiles_n;
   const int* rows;   // optional live-row list (see "Row sets" above)
   const int* count;  // device int: number of valid entries of `rows`
@@ -175,6 +176,34 @@ struct EpiStore {
         if (e < nv) p[e] = (beta != 0.f) ? v[e] + beta * p[e] : v[e];
     }
   }
+  // interior tile (every row < M, every column group < N, float4-addressable): all loads are issued
+  // before the first store, nothing is guarded.  The per-call path above serialises one load -> wait ->
+  // store chain per 16x16 sub-tile, which made the epilogue of a 128x128 tile cost ~8 % of a K=512 GEMM.
+  __device__ __forceinline__ bool fast_ok() const { return vec_out != 0; }
+  template <int TM, int TN>
+  __device__ __forceinline__ void tile_fast(f32x4 (&acc)[TM][TN], const int (&mphys)[TM], int nbase, int, int z) const {
+    float* base = C + (int64_t)z * slab_stride + nbase;
+    if (beta != 0.f) {
+      f32x4 old[TM][TN];
+#pragma unroll
+      for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int b = 0; b < TN; ++b) old[a][b] = *reinterpret_cast<const f32x4*>(base + (int64_t)mphys[a] * ldc + b * 16);
+#pragma unroll
+      for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int b = 0; b < TN; ++b) {
+          f32x4 v = acc[a][b];
+          v[0] += beta * old[a][b][0]; v[1] += beta * old[a][b][1]; v[2] += beta * old[a][b][2]; v[3] += beta * old[a][b][3];
+          *reinterpret_cast<f32x4*>(base + (int64_t)mphys[a] * ldc + b * 16) = v;
+        }
+    } else {
+#pragma unroll
+      for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int b = 0; b < TN; ++b) *reinterpret_cast<f32x4*>(base + (int64_t)mphys[a] * ldc + b * 16) = acc[a][b];
+    }
+  }
 };
 
 // nn.Linear forward epilogue (see nacf_epilogue in nacf_hip.h)
@@ -182,7 +211,8 @@ struct EpiLinear {
   float* Y;
   int64_t ldy;
   nacf_epilogue ep;
-  int vec_out;  // Y / preact / residual all float4-addressable
+  int vec_out;   // Y / preact / residual all float4-addressable
+  int vec_bias;  // bias float4-addressable (or absent); N % 4 == 0 when a dropout is on (aligned Philox groups)
   static constexpr bool kArgmax = false;
   __device__ __forceinline__ void operator()(int m, int mp, int n, f32x4 v, int M, int N, int /*z*/) const {
     if (m >= M || n >= N) return;
@@ -248,6 +278,55 @@ struct EpiLinear {
 #pragma unroll
       for (int e = 0; e < 4; ++e)
         if (e < nv) y[e] = v[e];
+    }
+  }
+  // interior tile: bias / residual / row-token loads are all issued up front (see EpiStore::tile_fast)
+  __device__ __forceinline__ bool fast_ok() const { return vec_out != 0 && vec_bias != 0; }
+  template <int TM, int TN>
+  __device__ __forceinline__ void tile_fast(f32x4 (&acc)[TM][TN], const int (&mphys)[TM], int nbase, int N, int) const {
+    f32x4 bias[TN];
+    f32x4 res[TM][TN];
+    bool dead[TM];
+#pragma unroll
+    for (int b = 0; b < TN; ++b)
+      bias[b] = ep.bias ? *reinterpret_cast<const f32x4*>(ep.bias + nbase + b * 16) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int a = 0; a < TM; ++a) {
+      dead[a] = ep.row_tokens ? (ep.row_tokens[mphys[a]] == NACF_PAD) : false;
+#pragma unroll
+      for (int b = 0; b < TN; ++b)
+        res[a][b] = ep.residual ? *reinterpret_cast<const f32x4*>(ep.residual + (int64_t)mphys[a] * ep.ld_residual + nbase + b * 16)
+                                : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    const bool any_drop = (ep.p_drop1 > 0.f) || (ep.p_drop2 > 0.f);
+    DropRng rng;
+    if (any_drop) rng.init(ep.rng_state);
+    fast_body<0, TM, TN>(acc, mphys, nbase, N, bias, res, dead, rng);
+  }
+  // compile-time recursion over the TM x TN sub-tiles (a `#pragma unroll` loop over this body is declined by
+  // the optimiser and the register arrays end up in scratch)
+  template <int IDX, int TM, int TN>
+  __device__ __forceinline__ void fast_body(f32x4 (&acc)[TM][TN], const int (&mphys)[TM], int nbase, int N,
+                                            const f32x4 (&bias)[TN], const f32x4 (&res)[TM][TN], const bool (&dead)[TM],
+                                            const DropRng& rng) const {
+    if constexpr (IDX < TM * TN) {
+      constexpr int a = IDX / TN, b = IDX % TN;
+      const int n = nbase + b * 16;
+      f32x4 v = acc[a][b] + bias[b];
+      if (ep.preact) *reinterpret_cast<f32x4*>(ep.preact + (int64_t)mphys[a] * ep.ld_preact + n) = v;
+      if (ep.act != NACF_ACT_NONE) {
+        v[0] = apply_act(ep.act, v[0], n, ep.act_split);
+        v[1] = apply_act(ep.act, v[1], n + 1, ep.act_split);
+        v[2] = apply_act(ep.act, v[2], n + 2, ep.act_split);
+        v[3] = apply_act(ep.act, v[3], n + 3, ep.act_split);
+      }
+      const uint64_t grp = ((uint64_t)mphys[a] * (uint64_t)N + (uint64_t)n) >> 2;
+      if (ep.p_drop1 > 0.f) v *= rng.keep4(grp, ep.salt1, ep.p_drop1);
+      v += res[a][b];
+      if (ep.p_drop2 > 0.f) v *= rng.keep4(grp, ep.salt2, ep.p_drop2);
+      if (dead[a]) v = f32x4{0.f, 0.f, 0.f, 0.f};
+      *reinterpret_cast<f32x4*>(Y + (int64_t)mphys[a] * ldy + n) = v;
+      fast_body<IDX + 1, TM, TN>(acc, mphys, nbase, N, bias, res, dead, rng);
     }
   }
 };
@@ -326,23 +405,43 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmShape g, Epi epi) {
   const int kbeg = z * kps;
   const int kend = min(Keff, kbeg + kps);
   const int nk = kend > kbeg ? (kend - kbeg + BK - 1) / BK : 0;
-  // k-skew: concurrently running tiles walk the reduce dimension from different
-  // starting offsets (tuning knob, measured neutral on MI355X)
-  const int kskew = g.k_skew ? (int)(((unsigned)tile_m * 5u + (unsigned)tile_n * 3u) % (unsigned)(nk > 0 ? nk : 1)) : 0;
-
-  // physical rows of this thread's K-contiguous vectors (fixed for the whole k-loop)
+  // physical rows of this thread's K-contiguous vectors (fixed for the whole k-loop).  `*row` = -1 marks a row
+  // beyond the edge for the checked loader; the fast loader reads the CLAMPED row instead - whatever that
+  // produces lands in accumulator rows / columns every epilogue discards (m >= Meff, n >= N).
   int qrow[BM / 64], prow[BN / 64];
+  const float* qfast[BM / 64];
+  const float* pfast[BN / 64];
 #pragma unroll
   for (int u = 0; u < BM / 64; ++u) {
-    const int gr = m0 + ((tid + 256 * u) >> 2);
-    qrow[u] = (gr < Meff) ? ((g.rows && !ROWS_ARE_K) ? g.rows[gr] : gr) : -1;
+    const int q = tid + 256 * u;
+    if constexpr (QKC) {
+      const int gr = m0 + (q >> 2);
+      const int gc = min(gr, Meff - 1);
+      const int ph = g.rows ? g.rows[gc] : gc;
+      qrow[u] = (gr < Meff) ? ph : -1;
+      qfast[u] = g.Q + (int64_t)ph * g.ldq + (q & 3) * 4;
+    } else {
+      qrow[u] = 0;
+      qfast[u] = g.Q + m0 + (q % (BM / 4)) * 4;
+    }
   }
 #pragma unroll
   for (int u = 0; u < BN / 64; ++u) {
-    const int gr = n0 + ((tid + 256 * u) >> 2);
-    prow[u] = (gr < g.N) ? gr : -1;
+    const int q = tid + 256 * u;
+    if constexpr (PKC) {
+      const int gr = n0 + (q >> 2);
+      const int gc = min(gr, g.N - 1);
+      prow[u] = (gr < g.N) ? gr : -1;
+      pfast[u] = g.P + (int64_t)gc * g.ldp + (q & 3) * 4;
+    } else {
+      prow[u] = 0;
+      pfast[u] = g.P + n0 + (q % (BN / 4)) * 4;
+    }
   }
   const int* kmap = ROWS_ARE_K ? g.rows : nullptr;
+  // row-contiguous (MC) operands take the unchecked loader only when the whole row tile is inside the matrix
+  const bool q_full = QKC || (m0 + BM <= Meff);
+  const bool p_full = PKC || (n0 + BN <= g.N);
 
   f32x4 acc[TM][TN];
 #pragma unroll
@@ -350,47 +449,137 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmShape g, Epi epi) {
 #pragma unroll
     for (int b = 0; b < TN; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+  // ---- global -> register staging of one k-tile.  Interior k-tiles (block-uniform test) use plain
+  // 16-byte loads with no per-lane guards; the last partial k-tile and ragged row tiles use the checked loaders.
   f32x4 qreg[BM / 64], preg[BN / 64];
-  auto load_tiles = [&](int k0) {
-    if constexpr (QKC) tile_load_kc<BM, VEC>(qreg, g.Q, g.ldq, qrow, k0, kend, tid);
-    else tile_load_mc<BM, VEC>(qreg, g.Q, g.ldq, m0, Meff, k0, kend, kmap, tid);
-    if constexpr (PKC) tile_load_kc<BN, VEC>(preg, g.P, g.ldp, prow, k0, kend, tid);
-    else tile_load_mc<BN, VEC>(preg, g.P, g.ldp, n0, g.N, k0, kend, kmap, tid);
+  // row-list dW GEMMs walk the reduce dimension through `kmap`: the indices of the NEXT staged k-tile are
+  // fetched one iteration ahead (kq / kp), so the data loads never wait on an index load issued just before them
+  int kq[BM / 64], kp[BN / 64];
+  auto load_kidx = [&](int k0) {
+    if constexpr (ROWS_ARE_K) {
+      if (kmap) {
+#pragma unroll
+        for (int u = 0; u < BM / 64; ++u) kq[u] = kmap[min(k0 + (tid + 256 * u) / (BM / 4), Keff - 1)];
+#pragma unroll
+        for (int u = 0; u < BN / 64; ++u) kp[u] = kmap[min(k0 + (tid + 256 * u) / (BN / 4), Keff - 1)];
+      }
+    }
   };
+  auto load_fast = [&](int k0, bool idx_ready) {
+#pragma unroll
+    for (int u = 0; u < BM / 64; ++u) {
+      if constexpr (QKC) {
+        qreg[u] = *reinterpret_cast<const f32x4*>(qfast[u] + k0);
+      } else {
+        const int gk = k0 + (tid + 256 * u) / (BM / 4);
+        const int pk = kmap ? (idx_ready ? kq[u] : kmap[gk]) : gk;
+        qreg[u] = *reinterpret_cast<const f32x4*>(qfast[u] + (int64_t)pk * g.ldq);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < BN / 64; ++u) {
+      if constexpr (PKC) {
+        preg[u] = *reinterpret_cast<const f32x4*>(pfast[u] + k0);
+      } else {
+        const int gk = k0 + (tid + 256 * u) / (BN / 4);
+        const int pk = kmap ? (idx_ready ? kp[u] : kmap[gk]) : gk;
+        preg[u] = *reinterpret_cast<const f32x4*>(pfast[u] + (int64_t)pk * g.ldp);
+      }
+    }
+  };
+  auto load_tiles = [&](int k0) {
+    if (VEC && q_full && p_full && (k0 + BK <= kend)) {
+      load_fast(k0, false);
+    } else {
+      if constexpr (QKC) tile_load_kc<BM, VEC>(qreg, g.Q, g.ldq, qrow, k0, kend, tid);
+      else tile_load_mc<BM, VEC>(qreg, g.Q, g.ldq, m0, Meff, k0, kend, kmap, tid);
+      if constexpr (PKC) tile_load_kc<BN, VEC>(preg, g.P, g.ldp, prow, k0, kend, tid);
+      else tile_load_mc<BN, VEC>(preg, g.P, g.ldp, n0, g.N, k0, kend, kmap, tid);
+    }
+  };
+  auto store_tiles = [&](float* buf) {
+    tile_store<BM, QKC>(buf, qreg, tid);
+    tile_store<BN, PKC>(buf + QSZ, preg, tid);
+  };
+
+  // ---- software pipeline.  Stages of k-tile t:  G(t) global->regs, W(t) regs->LDS[t&1], R(t) LDS->fragments,
+  // C(t) MFMAs.  Iteration t runs C(t) while it issues R(t+1), W(t+2) and G(t+3): the fragment registers are the
+  // third stage, so two LDS images are enough, there is ONE barrier per k-tile and nothing after it waits on
+  // memory - the next iteration's first MFMAs have their operands in registers already.
+  //   * W(t+2) overwrites the image of tile t, whose last read (R(t)) was issued in iteration t-1, before
+  //     that iteration's barrier;  R(t+2) happens in iteration t+1, after this iteration's barrier.
+  //   * the Q fragments are consumed one 16-row group at a time (group a = TN*4 MFMAs), so the fragment of group a
+  //     is reloaded for tile t+1 as soon as group a of tile t has been issued; only the P fragments, which every
+  //     group reads, are double-buffered.
+  f32x4 qf[TM], pf[2][TN];
+  auto read_q = [&](const float* buf, int a) { qf[a] = frag_load<BM, QKC>(buf, wm * WTM + a * 16, li, lg); };
   if (nk > 0) {
-    load_tiles(kbeg + kskew * BK);
-    tile_store<BM, QKC>(smem, qreg, tid);
-    tile_store<BN, PKC>(smem + QSZ, preg, tid);
+    load_tiles(kbeg);
+    store_tiles(smem);
+    if (nk > 1) load_tiles(kbeg + BK);
+  }
+  __syncthreads();
+  if (nk > 0) {
+#pragma unroll
+    for (int b = 0; b < TN; ++b) pf[0][b] = frag_load<BN, PKC>(smem + QSZ, wn * WTN + b * 16, li, lg);
+#pragma unroll
+    for (int a = 0; a < TM; ++a) read_q(smem, a);
+    if (nk > 1) {
+      store_tiles(smem + BUF);
+      if (nk > 2) load_tiles(kbeg + 2 * BK);
+    }
   }
   __syncthreads();
 
-  for (int kt = 0; kt < nk; ++kt) {
-    const float* qs = smem + (kt & 1) * BUF;
-    const float* ps = qs + QSZ;
-    const bool more = (kt + 1) < nk;
-    if (more) {
-      int ktn = kt + 1 + kskew;
-      if (ktn >= nk) ktn -= nk;
-      load_tiles(kbeg + ktn * BK);
-    }
-    f32x4 qf[TM], pf[TN];
+  // STEADY iterations are straight-line code (no guards: tile kt+3 exists and is an interior tile of fully
+  // populated row tiles), so the scheduler is free to interleave the LDS / global traffic with the MFMAs.
+  // The loop is deliberately NOT unrolled by two (the P-fragment double buffer is rotated with 4*TN register
+  // moves instead): with both parities in one body the optimiser sinks G(kt+3) down to its consumer W(kt+3)
+  // in the second half and every other k-tile eats a full memory latency.
+  auto iteration = [&](auto steady, int kt) {
+    constexpr bool STEADY = decltype(steady)::value;
+    const float* nbuf = smem + ((kt + 1) & 1) * BUF;   // image of tile kt+1
+    float* wbuf = smem + (kt & 1) * BUF;               // image of tile kt, about to become tile kt+2
+    const bool has1 = STEADY || kt + 1 < nk, has2 = STEADY || kt + 2 < nk, has3 = STEADY || kt + 3 < nk;
 #pragma unroll
-    for (int a = 0; a < TM; ++a) qf[a] = frag_load<BM, QKC>(qs, wm * WTM + a * 16, li, lg);
+    for (int a = 0; a < TM; ++a) {
 #pragma unroll
-    for (int b = 0; b < TN; ++b) pf[b] = frag_load<BN, PKC>(ps, wn * WTN + b * 16, li, lg);
-#pragma unroll
-    for (int s = 0; s < 4; ++s)
-#pragma unroll
-      for (int a = 0; a < TM; ++a)
+      for (int s = 0; s < 4; ++s)
 #pragma unroll
         for (int b = 0; b < TN; ++b)
-          acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(pf[b][s], qf[a][s], acc[a][b], 0, 0, 0);
-    if (more) {
-      float* qd = smem + ((kt + 1) & 1) * BUF;
-      tile_store<BM, QKC>(qd, qreg, tid);
-      tile_store<BN, PKC>(qd + QSZ, preg, tid);
+          acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(pf[0][b][s], qf[a][s], acc[a][b], 0, 0, 0);
+      if (a == 0) {
+        if (has1) {
+#pragma unroll
+          for (int b = 0; b < TN; ++b) pf[1][b] = frag_load<BN, PKC>(nbuf + QSZ, wn * WTN + b * 16, li, lg);
+        }
+        if (has2) store_tiles(wbuf);
+        if constexpr (STEADY) {
+          load_fast(kbeg + (kt + 3) * BK, true);
+          load_kidx(kbeg + (kt + 4) * BK);
+          // keep W(kt+2) / G(kt+3) up here, a whole k-tile of MFMAs ahead of their consumers
+          // (MFMA, VALU, SALU and LDS reads may still be scheduled across; VMEM and LDS writes may not)
+          __builtin_amdgcn_sched_barrier(0x10E);
+        } else if (has3) {
+          load_tiles(kbeg + (kt + 3) * BK);
+        }
+      }
+      if (has1) read_q(nbuf, a);
     }
+#pragma unroll
+    for (int b = 0; b < TN; ++b) pf[0][b] = pf[1][b];
     __syncthreads();
+  };
+  {
+    // number of leading iterations whose G(kt+3) is an unguarded interior tile
+    int n_steady = 0;
+    if (VEC && q_full && p_full) n_steady = min(nk - 3, (kend - kbeg) / BK - 3);
+    int kt = 0;
+    if (n_steady > 0) load_kidx(kbeg + 3 * BK);
+#pragma nounroll
+    for (; kt < n_steady; ++kt) iteration(std::true_type{}, kt);
+#pragma nounroll
+    for (; kt < nk; ++kt) iteration(std::false_type{}, kt);
   }
 
   if constexpr (!Epi::kArgmax) {
@@ -404,7 +593,9 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmShape g, Epi epi) {
       const int m = mbase + a * 16;
       mphys[a] = (g.rows && !ROWS_ARE_K && m < Meff) ? g.rows[m] : m;
     }
-    epilogue_all<0, TM, TN, Epi>(epi, acc, mbase, mphys, n0 + wn * WTN + lg * 4, Meff, g.N, z);
+    const int nbase = n0 + wn * WTN + lg * 4;
+    if (epi.fast_ok() && m0 + BM <= Meff && n0 + BN <= g.N) epi.template tile_fast<TM, TN>(acc, mphys, nbase, g.N, z);
+    else epilogue_all<0, TM, TN, Epi>(epi, acc, mbase, mphys, nbase, Meff, g.N, z);
   } else {
     // per-row (max, argmax, sum-exp) over this tile's BN columns
     float* redv = smem;                  // [WN][BM]

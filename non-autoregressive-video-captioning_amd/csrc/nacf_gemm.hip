@@ -23,17 +23,9 @@ int pick_tile(int M, int N, int splits, bool has_rows = false) {
   return big >= (has_rows ? 768 : 384) ? 0 : 1;
 }
 
-int kskew_enabled() {
-  // tuning knob, default off: measured neutral on MI355X (gpurun gemm_bench2: the power-of-two
-  // row pitch of the K-contiguous operands is not what limited the forward GEMMs)
-  const char* e = getenv("NACF_GEMM_KSKEW");
-  return e ? atoi(e) : 0;
-}
-
 template <bool QKC, bool PKC, class Epi>
 void launch_gemm(const GemmShape& g0, const Epi& epi, int splits, int tile, bool vec, hipStream_t s) {
   GemmShape g = g0;
-  g.k_skew = kskew_enabled();
   if (tile == 0) {
     g.tiles_m = cdiv(g.M, 128);
     g.tiles_n = cdiv(g.N, 128);
@@ -223,6 +215,9 @@ int nacf_linear_fwd(const float* X, int64_t ldx, const float* W, int64_t ldw, fl
   if (epi.ep.preact) vo = vo && (epi.ep.ld_preact % 4 == 0) && aligned16(epi.ep.preact);
   if (epi.ep.residual) vo = vo && (epi.ep.ld_residual % 4 == 0) && aligned16(epi.ep.residual);
   epi.vec_out = vo ? 1 : 0;
+  // the interior-tile epilogue wants a float4-addressable bias and (for dropout) 4-aligned Philox groups
+  const bool no_drop = !(epi.ep.p_drop1 > 0.f) && !(epi.ep.p_drop2 > 0.f);
+  epi.vec_bias = ((!epi.ep.bias || aligned16(epi.ep.bias)) && (no_drop || N % 4 == 0)) ? 1 : 0;
   GemmShape g;
   g.Q = X; g.P = W; g.ldq = ldx; g.ldp = ldw; g.M = M; g.N = N; g.K = K;
   g.k_per_split = cdiv(K, 16) * 16;

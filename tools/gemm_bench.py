@@ -54,13 +54,17 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--only", type=str, default="")
+    ap.add_argument("--shapes", type=str, default="", help="extra shapes 'kind:M:N:K,...' (kind 0 fwd, 1 dX, 2 dW)")
     ap.add_argument("--pad", type=int, default=0, help="extra floats of row pitch on the K-contiguous fwd operands")
     args = ap.parse_args()
     global PAD
     PAD = args.pad
     dev = torch.device("cuda:0")
     print("%-12s %-26s %10s %10s %10s %10s" % ("gemm", "M,N,K", "ms@64", "TF@64", "ms@128", "TF@128"))
-    for label, kind, M, N, K in SHAPES:
+    shapes = SHAPES
+    if args.shapes:
+        shapes = [("custom k%s" % t.split(":")[0],) + tuple(int(v) for v in t.split(":")) for t in args.shapes.split(",")]
+    for label, kind, M, N, K in shapes:
         if args.only and args.only not in label:
             continue
         res = []
