@@ -134,23 +134,35 @@ __device__ __forceinline__ void tile_store(float* lds, const f32x4 (&reg)[R / 64
   }
 }
 
-template <int R, bool KC>
-__device__ __forceinline__ f32x4 frag_load(const float* lds, int rb, int i, int g) {
-  if (KC) {
-    const int row = rb + i;
-    return *reinterpret_cast<const f32x4*>(&lds[row * 16 + ((g ^ lds_sw(row)) << 2)]);
-  } else {
-    f32x4 v;
-    const float* p = lds + (g * 4) * (R + 4) + rb + i;
-    v[0] = p[0];
-    v[1] = p[R + 4];
-    v[2] = p[2 * (R + 4)];
-    v[3] = p[3 * (R + 4)];
-    return v;
-  }
+// KC fragment: the 4 k-steps of one 16-row MFMA tile in one ds_read_b128
+template <int R>
+__device__ __forceinline__ f32x4 frag_load_kc(const float* lds, int rb, int i, int g) {
+  const int row = rb + i;
+  return *reinterpret_cast<const f32x4*>(&lds[row * 16 + ((g ^ lds_sw(row)) << 2)]);
+}
+// MC fragment: ONE k-step of all T 16-row MFMA tiles of the wave in one ds_read_b128 (T = 4) / b64 (T = 2).
+// The MC image is [k][rows], so what is contiguous for a lane is a run of ROWS; the wave tile's rows are
+// therefore dealt to the MFMA tiles round-robin -- MFMA tile t, row index i  <->  wave-tile row T*i + t --
+// and the lane reads rows T*i .. T*i+T-1 of image row k = 4g+s.  (A per-tile layout would need one
+// ds_read_b32 per (tile, k-step): 4x the LDS instructions.)  The accumulator -> (m, n) map changes with it,
+// see "accumulator map" in the kernel.
+template <int N>
+using fvec = float __attribute__((ext_vector_type(N)));
+template <int R, int T>
+__device__ __forceinline__ fvec<T> frag_load_mc(const float* lds, int rb, int i, int g, int s) {
+  return *reinterpret_cast<const fvec<T>*>(&lds[(g * 4 + s) * (R + 4) + rb + T * i]);
 }
 
 // ---------------------------------------------------------------- epilogues
+// float4 of 4 consecutive output columns, slot j of row group a (see "accumulator map" in the kernel): with a KC
+// P operand that is acc[a][j]; with an MC P the 4 columns live in the TN different MFMA tiles.
+template <bool PKC, int TM, int TN>
+__device__ __forceinline__ f32x4 out_vec(const f32x4 (&acc)[TM][TN], int a, int j) {
+  if constexpr (PKC) return acc[a][j];
+  else if constexpr (TN == 4) return f32x4{acc[a][0][j], acc[a][1][j], acc[a][2][j], acc[a][3][j]};
+  else return f32x4{acc[a][0][2 * j], acc[a][1][2 * j], acc[a][0][2 * j + 1], acc[a][1][2 * j + 1]};
+}
+
 // Epilogue call: (m = logical row for guards, mp = physical row for addressing, n, 4 values).
 // plain / accumulate / split-K slab store
 struct EpiStore {
@@ -180,28 +192,22 @@ struct EpiStore {
   // before the first store, nothing is guarded.  The per-call path above serialises one load -> wait ->
   // store chain per 16x16 sub-tile, which made the epilogue of a 128x128 tile cost ~8 % of a K=512 GEMM.
   __device__ __forceinline__ bool fast_ok() const { return vec_out != 0; }
-  template <int TM, int TN>
-  __device__ __forceinline__ void tile_fast(f32x4 (&acc)[TM][TN], const int (&mphys)[TM], int nbase, int, int z) const {
-    float* base = C + (int64_t)z * slab_stride + nbase;
-    if (beta != 0.f) {
-      f32x4 old[TM][TN];
+  template <int TM, int TN, bool PKC>
+  __device__ __forceinline__ void tile_fast(f32x4 (&acc)[TM][TN], const int (&mphys)[TM], const int (&ncol)[TN], int, int z) const {
+    float* base = C + (int64_t)z * slab_stride;
 #pragma unroll
-      for (int a = 0; a < TM; ++a)
+    for (int a = 0; a < TM; ++a) {
+      float* row = base + (int64_t)mphys[a] * ldc;
+      if (beta != 0.f) {
+        f32x4 old[TN];
 #pragma unroll
-        for (int b = 0; b < TN; ++b) old[a][b] = *reinterpret_cast<const f32x4*>(base + (int64_t)mphys[a] * ldc + b * 16);
+        for (int b = 0; b < TN; ++b) old[b] = *reinterpret_cast<const f32x4*>(row + ncol[b]);
 #pragma unroll
-      for (int a = 0; a < TM; ++a)
+        for (int b = 0; b < TN; ++b) *reinterpret_cast<f32x4*>(row + ncol[b]) = out_vec<PKC>(acc, a, b) + beta * old[b];
+      } else {
 #pragma unroll
-        for (int b = 0; b < TN; ++b) {
-          f32x4 v = acc[a][b];
-          v[0] += beta * old[a][b][0]; v[1] += beta * old[a][b][1]; v[2] += beta * old[a][b][2]; v[3] += beta * old[a][b][3];
-          *reinterpret_cast<f32x4*>(base + (int64_t)mphys[a] * ldc + b * 16) = v;
-        }
-    } else {
-#pragma unroll
-      for (int a = 0; a < TM; ++a)
-#pragma unroll
-        for (int b = 0; b < TN; ++b) *reinterpret_cast<f32x4*>(base + (int64_t)mphys[a] * ldc + b * 16) = acc[a][b];
+        for (int b = 0; b < TN; ++b) *reinterpret_cast<f32x4*>(row + ncol[b]) = out_vec<PKC>(acc, a, b);
+      }
     }
   }
 };
@@ -282,36 +288,37 @@ struct EpiLinear {
   }
   // interior tile: bias / residual / row-token loads are all issued up front (see EpiStore::tile_fast)
   __device__ __forceinline__ bool fast_ok() const { return vec_out != 0 && vec_bias != 0; }
-  template <int TM, int TN>
-  __device__ __forceinline__ void tile_fast(f32x4 (&acc)[TM][TN], const int (&mphys)[TM], int nbase, int N, int) const {
+  template <int TM, int TN, bool PKC>
+  __device__ __forceinline__ void tile_fast(f32x4 (&acc)[TM][TN], const int (&mphys)[TM], const int (&ncol)[TN], int N, int) const {
+    static_assert(PKC, "nn.Linear forward is an NT GEMM");
     f32x4 bias[TN];
     f32x4 res[TM][TN];
     bool dead[TM];
 #pragma unroll
     for (int b = 0; b < TN; ++b)
-      bias[b] = ep.bias ? *reinterpret_cast<const f32x4*>(ep.bias + nbase + b * 16) : f32x4{0.f, 0.f, 0.f, 0.f};
+      bias[b] = ep.bias ? *reinterpret_cast<const f32x4*>(ep.bias + ncol[b]) : f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int a = 0; a < TM; ++a) {
       dead[a] = ep.row_tokens ? (ep.row_tokens[mphys[a]] == NACF_PAD) : false;
 #pragma unroll
       for (int b = 0; b < TN; ++b)
-        res[a][b] = ep.residual ? *reinterpret_cast<const f32x4*>(ep.residual + (int64_t)mphys[a] * ep.ld_residual + nbase + b * 16)
+        res[a][b] = ep.residual ? *reinterpret_cast<const f32x4*>(ep.residual + (int64_t)mphys[a] * ep.ld_residual + ncol[b])
                                 : f32x4{0.f, 0.f, 0.f, 0.f};
     }
     const bool any_drop = (ep.p_drop1 > 0.f) || (ep.p_drop2 > 0.f);
     DropRng rng;
     if (any_drop) rng.init(ep.rng_state);
-    fast_body<0, TM, TN>(acc, mphys, nbase, N, bias, res, dead, rng);
+    fast_body<0, TM, TN>(acc, mphys, ncol, N, bias, res, dead, rng);
   }
   // compile-time recursion over the TM x TN sub-tiles (a `#pragma unroll` loop over this body is declined by
   // the optimiser and the register arrays end up in scratch)
   template <int IDX, int TM, int TN>
-  __device__ __forceinline__ void fast_body(f32x4 (&acc)[TM][TN], const int (&mphys)[TM], int nbase, int N,
+  __device__ __forceinline__ void fast_body(f32x4 (&acc)[TM][TN], const int (&mphys)[TM], const int (&ncol)[TN], int N,
                                             const f32x4 (&bias)[TN], const f32x4 (&res)[TM][TN], const bool (&dead)[TM],
                                             const DropRng& rng) const {
     if constexpr (IDX < TM * TN) {
       constexpr int a = IDX / TN, b = IDX % TN;
-      const int n = nbase + b * 16;
+      const int n = ncol[b];
       f32x4 v = acc[a][b] + bias[b];
       if (ep.preact) *reinterpret_cast<f32x4*>(ep.preact + (int64_t)mphys[a] * ep.ld_preact + n) = v;
       if (ep.act != NACF_ACT_NONE) {
@@ -326,7 +333,7 @@ struct EpiLinear {
       if (ep.p_drop2 > 0.f) v *= rng.keep4(grp, ep.salt2, ep.p_drop2);
       if (dead[a]) v = f32x4{0.f, 0.f, 0.f, 0.f};
       *reinterpret_cast<f32x4*>(Y + (int64_t)mphys[a] * ldy + n) = v;
-      fast_body<IDX + 1, TM, TN>(acc, mphys, nbase, N, bias, res, dead, rng);
+      fast_body<IDX + 1, TM, TN>(acc, mphys, ncol, N, bias, res, dead, rng);
     }
   }
 };
@@ -341,13 +348,13 @@ struct EpiArgmax {
   __device__ __forceinline__ void operator()(int, int, int, f32x4, int, int, int) const {}
 };
 
-template <int IDX, int TM, int TN, class Epi>
-__device__ __forceinline__ void epilogue_all(const Epi& epi, f32x4 (&acc)[TM][TN], int mbase, const int (&mphys)[TM],
-                                             int nbase, int M, int N, int z) {
+template <int IDX, int TM, int TN, bool PKC, class Epi>
+__device__ __forceinline__ void epilogue_all(const Epi& epi, f32x4 (&acc)[TM][TN], const int (&mlog)[TM], const int (&mphys)[TM],
+                                             const int (&ncol)[TN], int M, int N, int z) {
   if constexpr (IDX < TM * TN) {
     constexpr int a = IDX / TN, b = IDX % TN;
-    epi(mbase + a * 16, mphys[a], nbase + b * 16, acc[a][b], M, N, z);
-    epilogue_all<IDX + 1, TM, TN, Epi>(epi, acc, mbase, mphys, nbase, M, N, z);
+    epi(mlog[a], mphys[a], ncol[b], out_vec<PKC>(acc, a, b), M, N, z);
+    epilogue_all<IDX + 1, TM, TN, PKC, Epi>(epi, acc, mlog, mphys, ncol, M, N, z);
   }
 }
 
@@ -508,11 +515,22 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmShape g, Epi epi) {
   // memory - the next iteration's first MFMAs have their operands in registers already.
   //   * W(t+2) overwrites the image of tile t, whose last read (R(t)) was issued in iteration t-1, before
   //     that iteration's barrier;  R(t+2) happens in iteration t+1, after this iteration's barrier.
-  //   * the Q fragments are consumed one 16-row group at a time (group a = TN*4 MFMAs), so the fragment of group a
-  //     is reloaded for tile t+1 as soon as group a of tile t has been issued; only the P fragments, which every
-  //     group reads, are double-buffered.
-  f32x4 qf[TM], pf[2][TN];
-  auto read_q = [&](const float* buf, int a) { qf[a] = frag_load<BM, QKC>(buf, wm * WTM + a * 16, li, lg); };
+  //   * fragments ROLL where the MFMA order allows it: a fragment register is reloaded for tile t+1 as soon as
+  //     the last MFMA of tile t that reads it has been issued.  KC fragments hold the 4 k-steps of one 16-row
+  //     tile, MC fragments hold one k-step of all the wave's tiles (frag_load_mc), so
+  //        NT (KC, KC): groups by Q tile a -> qf[a] rolls, pf is double-buffered;
+  //        NN (KC, MC) / TN (MC, MC): groups by k-step s -> the MC fragments roll, a KC Q is double-buffered.
+  //     Inside a group the same accumulator comes back after >= 4 MFMAs (16 in the s-grouped order).
+  constexpr bool GROUP_BY_S = !PKC;
+  static_assert(PKC || TM == TN, "MC fragments of both operands assume square wave tiles");
+  f32x4 qf[(QKC && GROUP_BY_S) ? 2 : 1][TM];   // KC Q: [a] = 4 k-steps of tile a
+  f32x4 pf[2][TN];                              // KC P: [b] = 4 k-steps of tile b (double-buffered)
+  fvec<TM> qv[4];                               // MC Q: [s] = tiles 0..TM-1 at k-step s
+  fvec<TN> pv[4];                               // MC P: [s] = tiles 0..TN-1 at k-step s
+  auto read_q_kc = [&](const float* buf, int set, int a) { qf[set][a] = frag_load_kc<BM>(buf, wm * WTM + a * 16, li, lg); };
+  auto read_p_kc = [&](const float* buf, int set, int b) { pf[set][b] = frag_load_kc<BN>(buf + QSZ, wn * WTN + b * 16, li, lg); };
+  auto read_q_mc = [&](const float* buf, int s) { qv[s] = frag_load_mc<BM, TM>(buf, wm * WTM, li, lg, s); };
+  auto read_p_mc = [&](const float* buf, int s) { pv[s] = frag_load_mc<BN, TN>(buf + QSZ, wn * WTN, li, lg, s); };
   if (nk > 0) {
     load_tiles(kbeg);
     store_tiles(smem);
@@ -521,9 +539,18 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmShape g, Epi epi) {
   __syncthreads();
   if (nk > 0) {
 #pragma unroll
-    for (int b = 0; b < TN; ++b) pf[0][b] = frag_load<BN, PKC>(smem + QSZ, wn * WTN + b * 16, li, lg);
+    for (int i = 0; i < 4; ++i) {
+      if constexpr (!QKC) read_q_mc(smem, i);
+      if constexpr (!PKC) read_p_mc(smem, i);
+    }
+    if constexpr (QKC) {
 #pragma unroll
-    for (int a = 0; a < TM; ++a) read_q(smem, a);
+      for (int a = 0; a < TM; ++a) read_q_kc(smem, 0, a);
+    }
+    if constexpr (PKC) {
+#pragma unroll
+      for (int b = 0; b < TN; ++b) read_p_kc(smem, 0, b);
+    }
     if (nk > 1) {
       store_tiles(smem + BUF);
       if (nk > 2) load_tiles(kbeg + 2 * BK);
@@ -533,41 +560,75 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmShape g, Epi epi) {
 
   // STEADY iterations are straight-line code (no guards: tile kt+3 exists and is an interior tile of fully
   // populated row tiles), so the scheduler is free to interleave the LDS / global traffic with the MFMAs.
-  // The loop is deliberately NOT unrolled by two (the P-fragment double buffer is rotated with 4*TN register
-  // moves instead): with both parities in one body the optimiser sinks G(kt+3) down to its consumer W(kt+3)
+  // The loop is deliberately NOT unrolled by two (double-buffered fragments are rotated with register moves
+  // instead): with both parities in one body the optimiser sinks G(kt+3) down to its consumer W(kt+3)
   // in the second half and every other k-tile eats a full memory latency.
   auto iteration = [&](auto steady, int kt) {
     constexpr bool STEADY = decltype(steady)::value;
     const float* nbuf = smem + ((kt + 1) & 1) * BUF;   // image of tile kt+1
     float* wbuf = smem + (kt & 1) * BUF;               // image of tile kt, about to become tile kt+2
     const bool has1 = STEADY || kt + 1 < nk, has2 = STEADY || kt + 2 < nk, has3 = STEADY || kt + 3 < nk;
+    auto stage_ahead = [&]() {   // W(kt+2), G(kt+3)
+      if (has2) store_tiles(wbuf);
+      if constexpr (STEADY) {
+        load_fast(kbeg + (kt + 3) * BK, true);
+        load_kidx(kbeg + (kt + 4) * BK);
+        // keep W(kt+2) / G(kt+3) up here, a whole k-tile of MFMAs ahead of their consumers
+        // (MFMA, VALU, SALU and LDS reads may still be scheduled across; VMEM and LDS writes may not)
+        __builtin_amdgcn_sched_barrier(0x10E);
+      } else if (has3) {
+        load_tiles(kbeg + (kt + 3) * BK);
+      }
+    };
+    if constexpr (!GROUP_BY_S) {
 #pragma unroll
-    for (int a = 0; a < TM; ++a) {
+      for (int a = 0; a < TM; ++a) {
 #pragma unroll
-      for (int s = 0; s < 4; ++s)
+        for (int s = 0; s < 4; ++s)
 #pragma unroll
-        for (int b = 0; b < TN; ++b)
-          acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(pf[0][b][s], qf[a][s], acc[a][b], 0, 0, 0);
-      if (a == 0) {
-        if (has1) {
+          for (int b = 0; b < TN; ++b)
+            acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(pf[0][b][s], qf[0][a][s], acc[a][b], 0, 0, 0);
+        if (a == 0) {
+          if (has1) {
 #pragma unroll
-          for (int b = 0; b < TN; ++b) pf[1][b] = frag_load<BN, PKC>(nbuf + QSZ, wn * WTN + b * 16, li, lg);
+            for (int b = 0; b < TN; ++b) read_p_kc(nbuf, 1, b);
+          }
+          stage_ahead();
         }
-        if (has2) store_tiles(wbuf);
-        if constexpr (STEADY) {
-          load_fast(kbeg + (kt + 3) * BK, true);
-          load_kidx(kbeg + (kt + 4) * BK);
-          // keep W(kt+2) / G(kt+3) up here, a whole k-tile of MFMAs ahead of their consumers
-          // (MFMA, VALU, SALU and LDS reads may still be scheduled across; VMEM and LDS writes may not)
-          __builtin_amdgcn_sched_barrier(0x10E);
-        } else if (has3) {
-          load_tiles(kbeg + (kt + 3) * BK);
+        if (has1) read_q_kc(nbuf, 0, a);
+      }
+#pragma unroll
+      for (int b = 0; b < TN; ++b) pf[0][b] = pf[1][b];
+    } else {
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+#pragma unroll
+        for (int a = 0; a < TM; ++a)
+#pragma unroll
+          for (int b = 0; b < TN; ++b) {
+            float qa;
+            if constexpr (QKC) qa = qf[0][a][s]; else qa = qv[s][a];
+            acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(pv[s][b], qa, acc[a][b], 0, 0, 0);
+          }
+        if (s == 0) {
+          if constexpr (QKC) {
+            if (has1) {
+#pragma unroll
+              for (int a = 0; a < TM; ++a) read_q_kc(nbuf, 1, a);
+            }
+          }
+          stage_ahead();
+        }
+        if (has1) {
+          read_p_mc(nbuf, s);
+          if constexpr (!QKC) read_q_mc(nbuf, s);
         }
       }
-      if (has1) read_q(nbuf, a);
-    }
+      if constexpr (QKC) {
 #pragma unroll
-    for (int b = 0; b < TN; ++b) pf[0][b] = pf[1][b];
+        for (int a = 0; a < TM; ++a) qf[0][a] = qf[1][a];
+      }
+    }
     __syncthreads();
   };
   {
@@ -582,20 +643,26 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmShape g, Epi epi) {
     for (; kt < nk; ++kt) iteration(std::false_type{}, kt);
   }
 
+  // ---- accumulator map: which (m, n) this lane's acc[a][b][e] is.
+  //   KC Q: row  = a*16 + li                  MC Q: row = TM*li + a            (inside the wave tile)
+  //   KC P: col  = b*16 + lg*4 + e            MC P: col = TN*(lg*4 + e) + b
+  // The epilogues want float4s of 4 consecutive columns: with a KC P that is acc[a][b] itself; with an MC P
+  // the 4 consecutive columns are spread over the TN tiles (and, for TN = 2, two values of e): out_vec().
+  int mlog[TM], ncol[TN];
+#pragma unroll
+  for (int a = 0; a < TM; ++a) mlog[a] = m0 + wm * WTM + (QKC ? a * 16 + li : TM * li + a);
+#pragma unroll
+  for (int j = 0; j < TN; ++j) ncol[j] = n0 + wn * WTN + (PKC ? j * 16 + lg * 4 : 4 * TN * lg + 4 * j);
+
   if constexpr (!Epi::kArgmax) {
     // compile-time recursion, NOT a `#pragma unroll` loop: with the large fused epilogue the
     // optimiser declined to unroll, indexed acc[][] dynamically and parked the accumulators
     // in scratch (16 scratch_store_dwordx4 per k-tile in the main loop, 2x slower)
-    const int mbase = m0 + wm * WTM + li;
     int mphys[TM];
 #pragma unroll
-    for (int a = 0; a < TM; ++a) {
-      const int m = mbase + a * 16;
-      mphys[a] = (g.rows && !ROWS_ARE_K && m < Meff) ? g.rows[m] : m;
-    }
-    const int nbase = n0 + wn * WTN + lg * 4;
-    if (epi.fast_ok() && m0 + BM <= Meff && n0 + BN <= g.N) epi.template tile_fast<TM, TN>(acc, mphys, nbase, g.N, z);
-    else epilogue_all<0, TM, TN, Epi>(epi, acc, mbase, mphys, nbase, Meff, g.N, z);
+    for (int a = 0; a < TM; ++a) mphys[a] = (g.rows && !ROWS_ARE_K && mlog[a] < Meff) ? g.rows[mlog[a]] : mlog[a];
+    if (epi.fast_ok() && m0 + BM <= Meff && n0 + BN <= g.N) epi.template tile_fast<TM, TN, PKC>(acc, mphys, ncol, g.N, z);
+    else epilogue_all<0, TM, TN, PKC, Epi>(epi, acc, mlog, mphys, ncol, Meff, g.N, z);
   } else {
     // per-row (max, argmax, sum-exp) over this tile's BN columns
     float* redv = smem;                  // [WN][BM]

@@ -18,9 +18,10 @@ int pick_tile(int M, int N, int splits, bool has_rows = false) {
   const int forced = forced_tile();
   if (forced >= 0) return forced;
   const long big = (long)cdiv(M, 128) * cdiv(N, 128) * splits;
-  // >= 1.5 workgroups per CU with the big tile, else go small.  With a live-row list the host does
-  // not know how many row tiles survive (typically 40-60 %), so ask for twice the tiles.
-  return big >= (has_rows ? 768 : 384) ? 0 : 1;
+  // >= 3 workgroups per CU with the big tile, else go small (tools/gemm_bench.py: 64x64 wins or ties up to
+  // 640 big tiles, 128x128 wins from 960).  With a live-row list the host does not know how many row tiles
+  // survive (typically 40-60 %), so ask for twice the tiles.
+  return big >= (has_rows ? 1536 : 768) ? 0 : 1;
 }
 
 template <bool QKC, bool PKC, class Epi>
@@ -230,19 +231,27 @@ int nacf_linear_fwd(const float* X, int64_t ldx, const float* W, int64_t ldw, fl
 
 // dX = dZ W with a long reduce dimension and a narrow output (the vocabulary projection: N = V,
 // K = D) has too few output tiles to fill 256 CUs: split the reduce dimension over workgroups.
-static int bwd_data_splits(int M, int N, int K) {
-  if (N < 4096) return 1;
-  const long tiles = (long)cdiv(M, 64) * cdiv(K, 64);
-  if (tiles >= 1024) return 1;
-  int s = (int)((1536 + tiles - 1) / tiles);
-  const int max_s = N / 1024;
-  if (s > max_s) s = max_s;
-  if (s > 16) s = 16;
-  return s < 1 ? 1 : s;
+static int bwd_data_splits(int M, int N, int K, bool has_rows) {
+  { const char* e = getenv("NACF_GEMM_SPLITS"); if (e && atoi(e) > 0) return atoi(e); }
+  // output tiles the 64x64 kernel would have (a live-row list typically keeps ~55 % of the row tiles)
+  long tiles = (long)cdiv(M, 64) * cdiv(K, 64);
+  if (has_rows) tiles = tiles * 11 / 20;
+  if (N >= 4096) {   // the vocabulary projection: long reduce dimension, narrow output
+    if (tiles >= 1024) return 1;
+    int s = (int)((1536 + tiles - 1) / tiles);
+    const int max_s = N / 1024;
+    if (s > max_s) s = max_s;
+    if (s > 16) s = 16;
+    return s < 1 ? 1 : s;
+  }
+  // fewer than two output tiles per CU and a reduce dimension worth halving (tools/sweep_dx_splits.sh:
+  // 2980x512 <- 2048: 92 -> 77 us, <- 1536: 70 -> 61 us; <- 512 loses)
+  return (tiles < 512 && N >= 1024) ? 2 : 1;
 }
 
 size_t nacf_linear_bwd_data_workspace(int M, int N, int K) {
-  const int s = bwd_data_splits(M, N, K);
+  const int a = bwd_data_splits(M, N, K, false), b = bwd_data_splits(M, N, K, true);
+  const int s = a > b ? a : b;
   return (s > 1 ? (size_t)s * M * K * sizeof(float) : 0) + 256;
 }
 
@@ -254,7 +263,7 @@ int nacf_linear_bwd_data(const float* dZ, int64_t lddz, const float* W, int64_t 
   NACF_CHECK(lddz >= N && ldw >= K && lddx >= K, NACF_EINVAL, "nacf_linear_bwd_data: leading dimension too small");
   NACF_CHECK(!rs || (rs->rows && rs->count), NACF_EINVAL, "nacf_linear_bwd_data: incomplete row set");
   // dX[m][k] = sum_n dZ[m][n] W[n][k]: Q = dZ (KC, reduce = n), P rows = k, P element (k, n) at W[n*ldw + k] (MC)
-  const int splits = bwd_data_splits(M, N, K);
+  const int splits = bwd_data_splits(M, N, K, rs != nullptr);
   NACF_CHECK(splits == 1 || (ws && ws_bytes >= nacf_linear_bwd_data_workspace(M, N, K) && aligned16(ws)), NACF_EWORKSPACE,
              "nacf_linear_bwd_data: workspace too small / misaligned");
   hipStream_t s = as_hip(stream);
@@ -284,27 +293,31 @@ int nacf_linear_bwd_data(const float* dZ, int64_t lddz, const float* W, int64_t 
   return NACF_OK;
 }
 
-static int bwd_weight_splits(int M, int N, int K, int* tile_out) {
-  // the reduce-dimension split supplies the parallelism, so the big tile wins as soon as the
-  // weight has >= 32 of them (measured: 512x2048 / 2048x512 / 1024x512 / Vx512 are 10-20 % faster
-  // on 128x128; only 512x512 prefers 64x64) -- profiles/r01_gemm_microbench.txt
-  int tile = ((long)cdiv(N, 128) * cdiv(K, 128) >= 32) ? 0 : 1;
+static int bwd_weight_splits(int M, int N, int K, bool has_rows, int* tile_out) {
+  // dW = dZ^T X: small output (N x K), long reduce dimension (M rows, ~55 % of them live under a row list).
+  // The reduce-dimension split supplies the parallelism.  tools/sweep_dw_splits.sh: the 128x128 tile wins
+  // only with >= 32 of them AND a long reduce walk (7680+ rows); otherwise 64x64 with ~1024 workgroups.
+  const int m_eff = has_rows ? M * 11 / 20 : M;
+  int tile = ((long)cdiv(N, 128) * cdiv(K, 128) >= 32 && m_eff >= 4096) ? 0 : 1;
   const int forced = forced_tile();
   if (forced >= 0) tile = forced;
   const int t = tile == 0 ? 128 : 64;
   const long tiles = (long)cdiv(N, t) * cdiv(K, t);
-  int s = (int)((768 + tiles - 1) / tiles);
-  const int max_s = M / 256 > 0 ? M / 256 : 1;
+  const long want = tile == 0 ? 512 : 1024;
+  int s = (int)((want + tiles - 1) / tiles);
+  const int max_s = m_eff / 128 > 0 ? m_eff / 128 : 1;   // >= 8 k-tiles per split
   if (s > max_s) s = max_s;
   if (s < 1) s = 1;
   if (s > 64) s = 64;
+  { const char* e = getenv("NACF_GEMM_SPLITS"); if (e && atoi(e) > 0) s = atoi(e); }
   *tile_out = tile;
   return s;
 }
 
 size_t nacf_linear_bwd_weight_workspace(int M, int N, int K) {
   int tile;
-  const int s = bwd_weight_splits(M, N, K, &tile);
+  const int a = bwd_weight_splits(M, N, K, false, &tile), b = bwd_weight_splits(M, N, K, true, &tile);
+  const int s = a > b ? a : b;
   const size_t slabs = s > 1 ? (size_t)s * N * K * sizeof(float) : 0;
   const size_t col = (size_t)64 * N * sizeof(float);
   return slabs + col + 256;
@@ -322,7 +335,7 @@ int nacf_linear_bwd_weight(const float* dZ, int64_t lddz, const float* X, int64_
   NACF_CHECK(aligned16(ws), NACF_EINVAL, "nacf_linear_bwd_weight: workspace must be 16-byte aligned");
   NACF_CHECK(!rs || (rs->rows && rs->count), NACF_EINVAL, "nacf_linear_bwd_weight: incomplete row set");
   int tile;
-  const int splits = bwd_weight_splits(M, N, K, &tile);
+  const int splits = bwd_weight_splits(M, N, K, rs != nullptr, &tile);
   hipStream_t s = as_hip(stream);
   // dW[n][k] = sum_m dZ[m][n] X[m][k]: output rows = n (Q = dZ, MC: element (n, m) at dZ[m*lddz + n]),
   // output cols = k (P = X, MC: element (k, m) at X[m*ldx + k]), reduce = m (through the live-row list if given)
@@ -368,13 +381,13 @@ int nacf_gemm_config(int kind, int M, int N, int K, int* tile, int* splits) {
   int t = 0, s = 1;
   if (kind == 0) t = pick_tile(M, N, 1);
   else if (kind == 1) {
-    s = bwd_data_splits(M, N, K);
+    s = bwd_data_splits(M, N, K, false);
     const int kps = cdiv(cdiv(N, s), 16) * 16;
     s = cdiv(N, kps);
     t = pick_tile(M, K, s);
   }
   else if (kind == 2) {
-    s = bwd_weight_splits(M, N, K, &t);
+    s = bwd_weight_splits(M, N, K, false, &t);
     const int kps = cdiv(cdiv(M, s), 16) * 16;
     s = cdiv(M, kps);
   } else {
