@@ -54,6 +54,12 @@ struct GemmShape {
   int tiles_m, tiles_n;
   const int* rows;   // optional live-row list (see "Row sets" above)
   const int* count;  // device int: number of valid entries of `rows`
+  // TN only (dW = dZ^T X): the bias gradient db[n] = sum_m dZ[m][n] is the row sum of the Q operand this GEMM
+  // stages anyway.  The workgroups of column tile 0 add up what they stage: straight into `colsum_out`
+  // (= beta * old + sum) without a reduce split, else into colsum_part[z][n] for the split-K combine kernel.
+  float* colsum_part;
+  float* colsum_out;
+  float colsum_beta;
 };
 
 __device__ __forceinline__ int lds_sw(int row) { return (-(row >> 2)) & 3; }
@@ -504,9 +510,17 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmShape g, Epi epi) {
       else tile_load_mc<BN, VEC>(preg, g.P, g.ldp, n0, g.N, k0, kend, kmap, tid);
     }
   };
+  const bool do_colsum = ROWS_ARE_K && (g.colsum_part || g.colsum_out) && tile_n == 0;
+  f32x4 qsum = {0.f, 0.f, 0.f, 0.f};   // running row sums of the staged Q vectors (every k-tile is stored exactly once)
   auto store_tiles = [&](float* buf) {
     tile_store<BM, QKC>(buf, qreg, tid);
     tile_store<BN, PKC>(buf + QSZ, preg, tid);
+    if constexpr (ROWS_ARE_K) {
+      if (do_colsum) {
+#pragma unroll
+        for (int u = 0; u < BM / 64; ++u) qsum += qreg[u];
+      }
+    }
   };
 
   // ---- software pipeline.  Stages of k-tile t:  G(t) global->regs, W(t) regs->LDS[t&1], R(t) LDS->fragments,
@@ -641,6 +655,30 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmShape g, Epi epi) {
     for (; kt < n_steady; ++kt) iteration(std::true_type{}, kt);
 #pragma nounroll
     for (; kt < nk; ++kt) iteration(std::false_type{}, kt);
+  }
+
+  if constexpr (ROWS_ARE_K) {
+    if (do_colsum) {
+      // thread (kk = q / (BM/4), r4 = q % (BM/4)) holds the sums of rows 4*r4 .. 4*r4+3 over its k rows: fold the
+      // lanes of a wave that share r4, then the 4 waves through LDS (fixed order: deterministic)
+      constexpr int RV = BM / 4;
+#pragma unroll
+      for (int o = 32; o >= RV && o >= 1; o >>= 1) {
+        qsum[0] += __shfl_xor(qsum[0], o, 64); qsum[1] += __shfl_xor(qsum[1], o, 64);
+        qsum[2] += __shfl_xor(qsum[2], o, 64); qsum[3] += __shfl_xor(qsum[3], o, 64);
+      }
+      float* red = smem;   // [4 waves][BM]; the tile images are dead after the last barrier of the main loop
+      if (lane < RV && lane < 64) *reinterpret_cast<f32x4*>(&red[wave * BM + 4 * lane]) = qsum;
+      __syncthreads();
+      if (tid < BM) {
+        const int m = m0 + tid;
+        if (m < g.M) {
+          const float t = ((red[tid] + red[BM + tid]) + red[2 * BM + tid]) + red[3 * BM + tid];
+          if (g.colsum_out) g.colsum_out[m] = (g.colsum_beta != 0.f) ? t + g.colsum_beta * g.colsum_out[m] : t;
+          else g.colsum_part[(int64_t)z * g.M + m] = t;
+        }
+      }
+    }
   }
 
   // ---- accumulator map: which (m, n) this lane's acc[a][b][e] is.

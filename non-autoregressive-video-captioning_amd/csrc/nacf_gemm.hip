@@ -64,55 +64,26 @@ __global__ void splitk_reduce_rows_kernel(const float* __restrict__ slabs, int64
   }
 }
 
-// dst[i] = beta*dst[i] + sum_z slab[z][i], fixed z order (deterministic split-K combine)
+// dst[i] = beta*dst[i] + sum_z slab[z][i], fixed z order (deterministic split-K combine); optionally the same
+// for the bias-gradient partials the dW GEMM left in part[z][n] (db[n] = beta*db[n] + sum_z part[z][n])
 __global__ void splitk_reduce_kernel(const float* __restrict__ slabs, int64_t slab_stride, int splits,
-                                     float* __restrict__ dst, int64_t ldd, int rows, int cols, float beta) {
+                                     float* __restrict__ dst, int64_t ldd, int rows, int cols, float beta,
+                                     const float* __restrict__ part, float* __restrict__ db) {
   const int64_t total = (int64_t)rows * cols;
-  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
-       idx += (int64_t)gridDim.x * blockDim.x) {
+  const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  for (int64_t idx = gid; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
     const int r = (int)(idx / cols), c = (int)(idx % cols);
     float acc = 0.f;
     for (int zz = 0; zz < splits; ++zz) acc += slabs[(int64_t)zz * slab_stride + idx];
     float* d = dst + (int64_t)r * ldd + c;
     *d = (beta != 0.f) ? acc + beta * (*d) : acc;
   }
-}
-
-// column sums of dZ[M,N] (optionally only over a live-row list): stage 1 -> part[S][N], stage 2 -> db
-__global__ void colsum_partial_kernel(const float* __restrict__ dz, int64_t ld, int M, int N, int rows_per,
-                                      const int* __restrict__ rows, const int* __restrict__ count,
-                                      float* __restrict__ part) {
-  __shared__ float red[4][64];
-  const int c = blockIdx.x * 64 + (threadIdx.x & 63);
-  const int rl = threadIdx.x >> 6;
-  const int Meff = count ? min(M, *count) : M;
-  const int r0 = blockIdx.y * rows_per;
-  const int r1 = min(Meff, r0 + rows_per);
-  float acc = 0.f;
-  if (c < N) {
-#pragma unroll 4
-    for (int r = r0 + rl; r < r1; r += 4) acc += dz[(int64_t)(rows ? rows[r] : r) * ld + c];
-  }
-  red[rl][threadIdx.x & 63] = acc;
-  __syncthreads();
-  if (rl == 0 && c < N)
-    part[(int64_t)blockIdx.y * N + c] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
-}
-// 64 columns per workgroup, 4 lanes of partials each; fixed combine order (s ascending within a lane, lanes 0..3)
-__global__ void colsum_final_kernel(const float* __restrict__ part, int S, int N, float* __restrict__ db, float beta) {
-  __shared__ float red[4][64];
-  const int c = blockIdx.x * 64 + (threadIdx.x & 63);
-  const int rl = threadIdx.x >> 6;
-  float acc = 0.f;
-  if (c < N) {
-#pragma unroll 4
-    for (int s = rl; s < S; s += 4) acc += part[(int64_t)s * N + c];
-  }
-  red[rl][threadIdx.x & 63] = acc;
-  __syncthreads();
-  if (rl == 0 && c < N) {
-    const float t = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
-    db[c] = (beta != 0.f) ? t + beta * db[c] : t;
+  if (db) {
+    for (int64_t n = gid; n < rows; n += (int64_t)gridDim.x * blockDim.x) {
+      float acc = 0.f;
+      for (int zz = 0; zz < splits; ++zz) acc += part[(int64_t)zz * rows + n];
+      db[n] = (beta != 0.f) ? acc + beta * db[n] : acc;
+    }
   }
 }
 
@@ -219,7 +190,7 @@ int nacf_linear_fwd(const float* X, int64_t ldx, const float* W, int64_t ldw, fl
   // the interior-tile epilogue wants a float4-addressable bias and (for dropout) 4-aligned Philox groups
   const bool no_drop = !(epi.ep.p_drop1 > 0.f) && !(epi.ep.p_drop2 > 0.f);
   epi.vec_bias = ((!epi.ep.bias || aligned16(epi.ep.bias)) && (no_drop || N % 4 == 0)) ? 1 : 0;
-  GemmShape g;
+  GemmShape g = {};
   g.Q = X; g.P = W; g.ldq = ldx; g.ldp = ldw; g.M = M; g.N = N; g.K = K;
   g.k_per_split = cdiv(K, 16) * 16;
   set_rows(g, rs);
@@ -267,7 +238,7 @@ int nacf_linear_bwd_data(const float* dZ, int64_t lddz, const float* W, int64_t 
   NACF_CHECK(splits == 1 || (ws && ws_bytes >= nacf_linear_bwd_data_workspace(M, N, K) && aligned16(ws)), NACF_EWORKSPACE,
              "nacf_linear_bwd_data: workspace too small / misaligned");
   hipStream_t s = as_hip(stream);
-  GemmShape g;
+  GemmShape g = {};
   g.Q = dZ; g.P = W; g.ldq = lddz; g.ldp = ldw; g.M = M; g.N = K; g.K = N;
   g.k_per_split = cdiv(cdiv(N, splits), 16) * 16;
   set_rows(g, rs);
@@ -339,7 +310,7 @@ int nacf_linear_bwd_weight(const float* dZ, int64_t lddz, const float* X, int64_
   hipStream_t s = as_hip(stream);
   // dW[n][k] = sum_m dZ[m][n] X[m][k]: output rows = n (Q = dZ, MC: element (n, m) at dZ[m*lddz + n]),
   // output cols = k (P = X, MC: element (k, m) at X[m*ldx + k]), reduce = m (through the live-row list if given)
-  GemmShape g;
+  GemmShape g = {};
   g.Q = dZ; g.P = X; g.ldq = lddz; g.ldp = ldx; g.M = N; g.N = K; g.K = M;
   g.k_per_split = cdiv(cdiv(M, splits), 16) * 16;
   set_rows(g, rs);
@@ -353,25 +324,19 @@ int nacf_linear_bwd_weight(const float* dZ, int64_t lddz, const float* X, int64_
     epi.C = dW; epi.ldc = lddw; epi.beta = beta; epi.slab_stride = 0;
     epi.vec_out = ((lddw % 4 == 0) && aligned16(dW)) ? 1 : 0;
   }
+  float* part = slabs + (splits > 1 ? (size_t)splits * N * K : 0);   // [real_splits][N] bias-gradient partials
+  if (db) {
+    if (real_splits > 1) g.colsum_part = part;
+    else { g.colsum_out = db; g.colsum_beta = beta; }
+  }
   launch_gemm<false, false, EpiStore>(g, epi, real_splits, tile, vec, s);
   NACF_LAUNCH_CHECK("nacf_linear_bwd_weight(gemm)");
   if (real_splits > 1) {
     const int64_t total = (int64_t)N * K;
     const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
     hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, s, slabs, (int64_t)N * K, real_splits, dW,
-                       lddw, N, K, beta);
+                       lddw, N, K, beta, db ? part : nullptr, db);
     NACF_LAUNCH_CHECK("nacf_linear_bwd_weight(reduce)");
-  }
-  if (db) {
-    float* part = slabs + (splits > 1 ? (size_t)splits * N * K : 0);
-    int S = cdiv(M, 128);
-    if (S > 64) S = 64;
-    const int rows_per = cdiv(M, S);
-    S = cdiv(M, rows_per);
-    hipLaunchKernelGGL(colsum_partial_kernel, dim3(cdiv(N, 64), S), dim3(256), 0, s, dZ, lddz, M, N, rows_per,
-                       rs ? rs->rows : nullptr, rs ? rs->count : nullptr, part);
-    hipLaunchKernelGGL(colsum_final_kernel, dim3(cdiv(N, 64)), dim3(256), 0, s, part, S, N, db, beta);
-    NACF_LAUNCH_CHECK("nacf_linear_bwd_weight(bias)");
   }
   return NACF_OK;
 }
@@ -420,7 +385,7 @@ int nacf_vocab_argmax(const float* hidden, int64_t ldh, const float* W, int64_t 
   epi.pmax = reinterpret_cast<float*>(ws);
   epi.psum = epi.pmax + (size_t)tn * rows;
   epi.pidx = reinterpret_cast<int*>(epi.psum + (size_t)tn * rows);
-  GemmShape g;
+  GemmShape g = {};
   g.Q = hidden; g.P = W; g.ldq = ldh; g.ldp = ldw; g.M = rows; g.N = V; g.K = K;
   g.k_per_split = cdiv(K, 16) * 16;
   set_rows(g, rs);
