@@ -139,14 +139,32 @@ __global__ __launch_bounds__(EMB_THREADS) void embed_ln_bwd_kernel(
     }
   }
 }
-__global__ void embed_ln_bwd_final_kernel(const float* __restrict__ part, int nblk, int D, float* __restrict__ dln_w,
-                                          float* __restrict__ dln_b, float beta) {
-  const int d = blockIdx.x * blockDim.x + threadIdx.x;
-  if (d >= D) return;
+// combine the per-block LayerNorm weight / bias gradient partials part[k][{w,b}][D]: a workgroup owns 16 columns and
+// splits the k walk over 16 groups (group gq sums k = gq, gq+16, ...), then folds the groups in fixed order
+__global__ __launch_bounds__(256) void embed_ln_bwd_final_kernel(const float* __restrict__ part, int nblk, int D,
+                                                                 float* __restrict__ dln_w, float* __restrict__ dln_b, float beta) {
+  __shared__ float red[2][16][17];
+  const int c = threadIdx.x & 15, gq = threadIdx.x >> 4;
+  const int d = blockIdx.x * 16 + c;
   float a = 0.f, b = 0.f;
-  for (int k = 0; k < nblk; ++k) { a += part[((int64_t)k * 2 + 0) * D + d]; b += part[((int64_t)k * 2 + 1) * D + d]; }
-  if (dln_w) dln_w[d] = (beta != 0.f) ? a + beta * dln_w[d] : a;
-  if (dln_b) dln_b[d] = (beta != 0.f) ? b + beta * dln_b[d] : b;
+  if (d < D) {
+#pragma unroll 4
+    for (int k = gq; k < nblk; k += 16) {
+      a += part[((int64_t)k * 2 + 0) * D + d];
+      b += part[((int64_t)k * 2 + 1) * D + d];
+    }
+  }
+  red[0][gq][c] = a;
+  red[1][gq][c] = b;
+  __syncthreads();
+  if (threadIdx.x < 32) {
+    const int which = threadIdx.x >> 4;
+    float t = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) t += red[which][i][c];
+    float* dst = which ? dln_b : dln_w;
+    if (dst && d < D) dst[d] = (beta != 0.f) ? t + beta * dst[d] : t;
+  }
 }
 
 // ------------------------------------------------------------------ generic LayerNorm (with_layernorm / norm_type=ln)
@@ -663,7 +681,7 @@ int nacf_embed_ln_bwd(const float* dOut, const float* xhat, const float* rstd, c
   hipStream_t s = as_hip(stream);
   hipLaunchKernelGGL(embed_ln_bwd_kernel, dim3(nblk), dim3(EMB_THREADS), 0, s, dOut, xhat, rstd, ln_w, dE, part, rows, D,
                      p_drop, salt, rng_state);
-  hipLaunchKernelGGL(embed_ln_bwd_final_kernel, dim3(cdiv(D, 256)), dim3(256), 0, s, part, nblk, D, dln_w, dln_b, beta);
+  hipLaunchKernelGGL(embed_ln_bwd_final_kernel, dim3(cdiv(D, 16)), dim3(256), 0, s, part, nblk, D, dln_w, dln_b, beta);
   NACF_LAUNCH_CHECK("nacf_embed_ln_bwd");
   return NACF_OK;
 }
@@ -700,7 +718,7 @@ int nacf_layernorm_bwd(const float* dOut, const float* xhat, const float* rstd, 
   hipStream_t s = as_hip(stream);
   hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(nblk), dim3(EMB_THREADS), 0, s, dOut, xhat, rstd, ln_w, dX, part, rows, D,
                      seg_in, seg_out, seg_off, p_drop, salt, rng_state, row_tokens);
-  hipLaunchKernelGGL(embed_ln_bwd_final_kernel, dim3(cdiv(D, 256)), dim3(256), 0, s, part, nblk, D, dln_w, dln_b, beta);
+  hipLaunchKernelGGL(embed_ln_bwd_final_kernel, dim3(cdiv(D, 16)), dim3(256), 0, s, part, nblk, D, dln_w, dln_b, beta);
   NACF_LAUNCH_CHECK("nacf_layernorm_bwd");
   return NACF_OK;
 }

@@ -46,6 +46,45 @@ __global__ void highway_mix_bwd_kernel(const float* __restrict__ dOut, const flo
   }
 }
 
+// float4 variants (D % 4 == 0, 16-byte aligned buffers): one Philox call per 4 elements instead of per element
+__global__ void highway_mix_fwd_v4_kernel(const float* __restrict__ H, const float* __restrict__ TG,
+                                          float* __restrict__ out, int rows, int D, float p, uint32_t salt,
+                                          const uint64_t* __restrict__ rng_state) {
+  const int D4 = D >> 2;
+  const int64_t total = (int64_t)rows * D4;
+  DropRng rng;
+  if (p > 0.f) rng.init(rng_state);
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+    const int r = (int)(e / D4), d = (int)(e % D4) * 4;
+    const f32x4 h = *reinterpret_cast<const f32x4*>(H + (int64_t)r * D + d);
+    const f32x4 t = *reinterpret_cast<const f32x4*>(TG + (int64_t)r * 2 * D + d);
+    const f32x4 g = *reinterpret_cast<const f32x4*>(TG + (int64_t)r * 2 * D + D + d);
+    f32x4 o = g * h + (1.f - g) * t;
+    if (p > 0.f) o *= rng.keep4((uint64_t)e, salt, p);
+    *reinterpret_cast<f32x4*>(out + (int64_t)r * D + d) = o;
+  }
+}
+__global__ void highway_mix_bwd_v4_kernel(const float* __restrict__ dOut, const float* __restrict__ H,
+                                          const float* __restrict__ TG, float* __restrict__ dH,
+                                          float* __restrict__ dP, int rows, int D, float p, uint32_t salt,
+                                          const uint64_t* __restrict__ rng_state) {
+  const int D4 = D >> 2;
+  const int64_t total = (int64_t)rows * D4;
+  DropRng rng;
+  if (p > 0.f) rng.init(rng_state);
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+    const int r = (int)(e / D4), d = (int)(e % D4) * 4;
+    f32x4 g0 = *reinterpret_cast<const f32x4*>(dOut + (int64_t)r * D + d);
+    if (p > 0.f) g0 *= rng.keep4((uint64_t)e, salt, p);
+    const f32x4 h = *reinterpret_cast<const f32x4*>(H + (int64_t)r * D + d);
+    const f32x4 t = *reinterpret_cast<const f32x4*>(TG + (int64_t)r * 2 * D + d);
+    const f32x4 g = *reinterpret_cast<const f32x4*>(TG + (int64_t)r * 2 * D + D + d);
+    *reinterpret_cast<f32x4*>(dH + (int64_t)r * D + d) = g0 * g;
+    *reinterpret_cast<f32x4*>(dP + (int64_t)r * 2 * D + d) = g0 * (1.f - g) * (1.f - t * t);
+    *reinterpret_cast<f32x4*>(dP + (int64_t)r * 2 * D + D + d) = g0 * (h - t) * g * (1.f - g);
+  }
+}
+
 // ------------------------------------------------------------------ BatchNorm + concat
 // stage A: part_sum[s][d] over a slab of rows
 __global__ void bn_partial_sum_kernel(const float* __restrict__ x, int rows, int D, int rows_per,
@@ -180,8 +219,184 @@ __global__ void bn_bwd_apply_kernel(const float* __restrict__ dOut, const float*
   }
 }
 
+// ---- float4 variants of the five BatchNorm kernels (D % 4 == 0, 16-byte aligned buffers): a workgroup is 16 float4
+// columns x 16 row groups (group rg walks rows r0+rg, r0+rg+16, ...), partials folded through LDS in fixed order.
+// Same two-pass statistics as above; ~4x fewer, 4x wider loads per thread.
+__device__ __forceinline__ f32x4 bn_fold16(f32x4 v, f32x4 (*red)[16], int rg, int c4) {
+  red[rg][c4] = v;
+  __syncthreads();
+  f32x4 t = red[0][c4];
+#pragma unroll
+  for (int i = 1; i < 16; ++i) t += red[i][c4];
+  __syncthreads();
+  return t;   // every thread gets the column's total
+}
+__device__ __forceinline__ f32x4 bn_sum_parts(const float* __restrict__ part, int S, int D, int c) {
+  f32x4 t = {0.f, 0.f, 0.f, 0.f};
+  for (int s = 0; s < S; ++s) t += *reinterpret_cast<const f32x4*>(part + (int64_t)s * D + c);
+  return t;
+}
+__global__ __launch_bounds__(256) void bn_partial_sum_v4_kernel(const float* __restrict__ x, int rows, int D, int rows_per,
+                                                                float* __restrict__ part) {
+  __shared__ f32x4 red[16][16];
+  const int c4 = threadIdx.x & 15, rg = threadIdx.x >> 4;
+  const int c = blockIdx.x * 64 + c4 * 4;
+  const int r0 = blockIdx.y * rows_per, r1 = min(rows, r0 + rows_per);
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  if (c < D) {
+#pragma unroll 4
+    for (int r = r0 + rg; r < r1; r += 16) acc += *reinterpret_cast<const f32x4*>(x + (int64_t)r * D + c);
+  }
+  const f32x4 t = bn_fold16(acc, red, rg, c4);
+  if (rg == 0 && c < D) *reinterpret_cast<f32x4*>(part + (int64_t)blockIdx.y * D + c) = t;
+}
+__global__ __launch_bounds__(256) void bn_partial_sqdev_v4_kernel(const float* __restrict__ x, int rows, int D, int rows_per, int S,
+                                                                  const float* __restrict__ part_sum, float* __restrict__ part_sq) {
+  __shared__ f32x4 red[16][16];
+  const int c4 = threadIdx.x & 15, rg = threadIdx.x >> 4;
+  const int c = blockIdx.x * 64 + c4 * 4;
+  const int r0 = blockIdx.y * rows_per, r1 = min(rows, r0 + rows_per);
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  if (c < D) {
+    const f32x4 mean = bn_sum_parts(part_sum, S, D, c) / (float)rows;
+#pragma unroll 4
+    for (int r = r0 + rg; r < r1; r += 16) {
+      const f32x4 dv = *reinterpret_cast<const f32x4*>(x + (int64_t)r * D + c) - mean;
+      acc += dv * dv;
+    }
+  }
+  const f32x4 t = bn_fold16(acc, red, rg, c4);
+  if (rg == 0 && c < D) *reinterpret_cast<f32x4*>(part_sq + (int64_t)blockIdx.y * D + c) = t;
+}
+__global__ __launch_bounds__(256) void bn_apply_v4_kernel(const float* __restrict__ x, float* __restrict__ out, int B, int F, int D,
+                                                          int M_total, int f_off, const float* __restrict__ w,
+                                                          const float* __restrict__ b, float* __restrict__ running_mean,
+                                                          float* __restrict__ running_var, int64_t* __restrict__ nbt,
+                                                          float* __restrict__ save_mean, float* __restrict__ save_invstd,
+                                                          int training, float momentum, float eps, int S,
+                                                          const float* __restrict__ part_sum, const float* __restrict__ part_sq,
+                                                          int rows_per) {
+  const int c4 = threadIdx.x & 15, rg = threadIdx.x >> 4;
+  const int c = blockIdx.x * 64 + c4 * 4;
+  const int rows = B * F;
+  const int r0 = blockIdx.y * rows_per, r1 = min(rows, r0 + rows_per);
+  if (c >= D) return;
+  f32x4 mean, invstd;
+  if (training) {
+    const f32x4 sm = bn_sum_parts(part_sum, S, D, c), sq = bn_sum_parts(part_sq, S, D, c);
+    mean = sm / (float)rows;
+    const f32x4 var_b = sq / (float)rows;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) invstd[e] = 1.0f / sqrtf(var_b[e] + eps);
+    if (blockIdx.y == 0 && rg == 0) {
+      const f32x4 var_u = sq / (float)(rows > 1 ? rows - 1 : 1);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        if (running_mean) running_mean[c + e] = (1.f - momentum) * running_mean[c + e] + momentum * mean[e];
+        if (running_var) running_var[c + e] = (1.f - momentum) * running_var[c + e] + momentum * var_u[e];
+        if (save_mean) save_mean[c + e] = mean[e];
+        if (save_invstd) save_invstd[c + e] = invstd[e];
+      }
+      if (nbt && c == 0) nbt[0] += 1;
+    }
+  } else {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { mean[e] = running_mean[c + e]; invstd[e] = 1.0f / sqrtf(running_var[c + e] + eps); }
+  }
+  f32x4 ww = {1.f, 1.f, 1.f, 1.f}, bb = {0.f, 0.f, 0.f, 0.f};
+  if (w) ww = *reinterpret_cast<const f32x4*>(w + c);
+  if (b) bb = *reinterpret_cast<const f32x4*>(b + c);
+#pragma unroll 4
+  for (int r = r0 + rg; r < r1; r += 16) {
+    const int bi = r / F, f = r % F;
+    const f32x4 v = *reinterpret_cast<const f32x4*>(x + (int64_t)r * D + c);
+    *reinterpret_cast<f32x4*>(out + ((int64_t)bi * M_total + f_off + f) * D + c) = (v - mean) * invstd * ww + bb;
+  }
+}
+__global__ __launch_bounds__(256) void bn_bwd_partial_v4_kernel(const float* __restrict__ dOut, const float* __restrict__ x, int B,
+                                                                int F, int D, int M_total, int f_off,
+                                                                const float* __restrict__ save_mean,
+                                                                const float* __restrict__ save_invstd, int rows_per,
+                                                                float* __restrict__ part_dy, float* __restrict__ part_dyx) {
+  __shared__ f32x4 red[16][16];
+  const int c4 = threadIdx.x & 15, rg = threadIdx.x >> 4;
+  const int c = blockIdx.x * 64 + c4 * 4;
+  const int rows = B * F;
+  const int r0 = blockIdx.y * rows_per, r1 = min(rows, r0 + rows_per);
+  f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
+  if (c < D) {
+    const f32x4 mean = *reinterpret_cast<const f32x4*>(save_mean + c), invstd = *reinterpret_cast<const f32x4*>(save_invstd + c);
+#pragma unroll 4
+    for (int r = r0 + rg; r < r1; r += 16) {
+      const int bi = r / F, f = r % F;
+      const f32x4 dy = *reinterpret_cast<const f32x4*>(dOut + ((int64_t)bi * M_total + f_off + f) * D + c);
+      a0 += dy;
+      a1 += dy * (*reinterpret_cast<const f32x4*>(x + (int64_t)r * D + c) - mean) * invstd;
+    }
+  }
+  const f32x4 t0 = bn_fold16(a0, red, rg, c4);
+  const f32x4 t1 = bn_fold16(a1, red, rg, c4);
+  if (rg == 0 && c < D) {
+    *reinterpret_cast<f32x4*>(part_dy + (int64_t)blockIdx.y * D + c) = t0;
+    *reinterpret_cast<f32x4*>(part_dyx + (int64_t)blockIdx.y * D + c) = t1;
+  }
+}
+__global__ __launch_bounds__(256) void bn_bwd_apply_v4_kernel(const float* __restrict__ dOut, const float* __restrict__ x,
+                                                              float* __restrict__ dx, int B, int F, int D, int M_total, int f_off,
+                                                              const float* __restrict__ w, const float* __restrict__ save_mean,
+                                                              const float* __restrict__ save_invstd, float* __restrict__ dweight,
+                                                              float* __restrict__ dbias, float beta, int S, int rows_per,
+                                                              const float* __restrict__ part_dy, const float* __restrict__ part_dyx) {
+  const int c4 = threadIdx.x & 15, rg = threadIdx.x >> 4;
+  const int c = blockIdx.x * 64 + c4 * 4;
+  const int rows = B * F;
+  const int r0 = blockIdx.y * rows_per, r1 = min(rows, r0 + rows_per);
+  if (c >= D) return;
+  const f32x4 sdy = bn_sum_parts(part_dy, S, D, c), sdyx = bn_sum_parts(part_dyx, S, D, c);
+  if (blockIdx.y == 0 && rg == 0) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      if (dweight) dweight[c + e] = (beta != 0.f) ? sdyx[e] + beta * dweight[c + e] : sdyx[e];
+      if (dbias) dbias[c + e] = (beta != 0.f) ? sdy[e] + beta * dbias[c + e] : sdy[e];
+    }
+  }
+  const f32x4 mean = *reinterpret_cast<const f32x4*>(save_mean + c), invstd = *reinterpret_cast<const f32x4*>(save_invstd + c);
+  f32x4 ww = {1.f, 1.f, 1.f, 1.f};
+  if (w) ww = *reinterpret_cast<const f32x4*>(w + c);
+  const float invn = 1.f / (float)rows;
+#pragma unroll 4
+  for (int r = r0 + rg; r < r1; r += 16) {
+    const int bi = r / F, f = r % F;
+    const f32x4 dy = *reinterpret_cast<const f32x4*>(dOut + ((int64_t)bi * M_total + f_off + f) * D + c);
+    const f32x4 xh = (*reinterpret_cast<const f32x4*>(x + (int64_t)r * D + c) - mean) * invstd;
+    *reinterpret_cast<f32x4*>(dx + (int64_t)r * D + c) = ww * invstd * (dy - sdy * invn - xh * sdyx * invn);
+  }
+}
+
 // ------------------------------------------------------------------ time mean
-__global__ void mean_time_fwd_kernel(const float* __restrict__ x, float* __restrict__ out, int T, int D) {
+// block = 32 float4 columns x 8 time groups; group tg sums t = tg, tg+8, ...; the 8 partials are combined in
+// fixed order through LDS
+__global__ __launch_bounds__(256) void mean_time_fwd_kernel(const float* __restrict__ x, float* __restrict__ out, int T, int D) {
+  __shared__ f32x4 red[8][32];
+  const int b = blockIdx.x;
+  const int c4 = blockIdx.y * 32 + (threadIdx.x & 31);   // float4 column
+  const int tg = threadIdx.x >> 5;
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  if (c4 * 4 < D) {
+    const float* p = x + (int64_t)b * T * D + c4 * 4;
+#pragma unroll 4
+    for (int t = tg; t < T; t += 8) acc += *reinterpret_cast<const f32x4*>(p + (int64_t)t * D);
+  }
+  red[tg][threadIdx.x & 31] = acc;
+  __syncthreads();
+  if (tg == 0 && c4 * 4 < D) {
+    f32x4 s = red[0][threadIdx.x];
+#pragma unroll
+    for (int i = 1; i < 8; ++i) s += red[i][threadIdx.x];
+    *reinterpret_cast<f32x4*>(out + (int64_t)b * D + c4 * 4) = s / (float)T;
+  }
+}
+__global__ void mean_time_fwd_scalar_kernel(const float* __restrict__ x, float* __restrict__ out, int T, int D) {
   const int b = blockIdx.x;
   for (int d = blockIdx.y * blockDim.x + threadIdx.x; d < D; d += gridDim.y * blockDim.x) {
     float acc = 0.f;
@@ -266,6 +481,34 @@ __global__ void epilogue_bwd_kernel(const float* __restrict__ dY, int64_t lddy, 
     if (ep.p_drop1 > 0.f) g *= rng.keep1((uint64_t)e, ep.salt1, ep.p_drop1);
     if (ep.act != NACF_ACT_NONE) g *= act_grad(ep.act, ep.preact[(int64_t)m * ep.ld_preact + n], n, ep.act_split);
     dZ[(int64_t)m * lddz + n] = g;
+  }
+}
+
+// float4 variant (N % 4 == 0, 16-byte aligned rows): one Philox call covers the 4 elements it was drawn for
+__global__ void epilogue_bwd_v4_kernel(const float* __restrict__ dY, int64_t lddy, float* __restrict__ dZ, int64_t lddz,
+                                       float* __restrict__ dR, int64_t lddr, int accumulate_dR, int M, int N,
+                                       nacf_epilogue ep) {
+  const int N4 = N >> 2;
+  const int64_t total = (int64_t)M * N4;
+  const bool any_drop = ep.p_drop1 > 0.f || ep.p_drop2 > 0.f;
+  DropRng rng;
+  if (any_drop) rng.init(ep.rng_state);
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+    const int m = (int)(e / N4), n = (int)(e % N4) * 4;
+    f32x4 g = *reinterpret_cast<const f32x4*>(dY + (int64_t)m * lddy + n);
+    if (ep.row_tokens && ep.row_tokens[m] == NACF_PAD) g = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (ep.p_drop2 > 0.f) g *= rng.keep4((uint64_t)e, ep.salt2, ep.p_drop2);
+    if (dR) {
+      f32x4* r = reinterpret_cast<f32x4*>(dR + (int64_t)m * lddr + n);
+      *r = accumulate_dR ? *r + g : g;
+    }
+    if (ep.p_drop1 > 0.f) g *= rng.keep4((uint64_t)e, ep.salt1, ep.p_drop1);
+    if (ep.act != NACF_ACT_NONE) {
+      const f32x4 z = *reinterpret_cast<const f32x4*>(ep.preact + (int64_t)m * ep.ld_preact + n);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) g[i] *= act_grad(ep.act, z[i], n + i, ep.act_split);
+    }
+    *reinterpret_cast<f32x4*>(dZ + (int64_t)m * lddz + n) = g;
   }
 }
 
@@ -412,6 +655,12 @@ inline int grid_for(int64_t total, int block = 256, int cap = 8192) {
   return (int)b;
 }
 
+template <class... P>
+inline bool bn_aligned16(P... ptrs) {
+  uintptr_t acc = 0;
+  ((acc |= reinterpret_cast<uintptr_t>(ptrs)), ...);   // null pointers (absent operands) are fine
+  return (acc & 15) == 0;
+}
 inline void bn_split(int rows, int* S, int* rows_per) {
   int s = cdiv(rows, 64);
   if (s > 32) s = 32;
@@ -428,8 +677,12 @@ int nacf_highway_mix_fwd(const float* H, const float* TG, float* out, int rows, 
                          uint32_t salt, const uint64_t* rng_state, nacf_stream_t stream) {
   NACF_CHECK(H && TG && out && rows > 0 && D > 0, NACF_EINVAL, "nacf_highway_mix_fwd: bad argument");
   NACF_CHECK(p_drop < 1.f && !(p_drop > 0.f && !rng_state), NACF_EINVAL, "nacf_highway_mix_fwd: dropout needs rng_state, p<1");
-  hipLaunchKernelGGL(highway_mix_fwd_kernel, dim3(grid_for((int64_t)rows * D)), dim3(256), 0, as_hip(stream), H, TG, out,
-                     rows, D, p_drop, salt, rng_state);
+  if (D % 4 == 0 && bn_aligned16(H, TG, out))
+    hipLaunchKernelGGL(highway_mix_fwd_v4_kernel, dim3(grid_for((int64_t)rows * (D / 4))), dim3(256), 0, as_hip(stream), H, TG,
+                       out, rows, D, p_drop, salt, rng_state);
+  else
+    hipLaunchKernelGGL(highway_mix_fwd_kernel, dim3(grid_for((int64_t)rows * D)), dim3(256), 0, as_hip(stream), H, TG, out,
+                       rows, D, p_drop, salt, rng_state);
   NACF_LAUNCH_CHECK("nacf_highway_mix_fwd");
   return NACF_OK;
 }
@@ -438,8 +691,12 @@ int nacf_highway_mix_bwd(const float* dOut, const float* H, const float* TG, flo
                          float p_drop, uint32_t salt, const uint64_t* rng_state, nacf_stream_t stream) {
   NACF_CHECK(dOut && H && TG && dH && dP && rows > 0 && D > 0, NACF_EINVAL, "nacf_highway_mix_bwd: bad argument");
   NACF_CHECK(p_drop < 1.f && !(p_drop > 0.f && !rng_state), NACF_EINVAL, "nacf_highway_mix_bwd: dropout needs rng_state, p<1");
-  hipLaunchKernelGGL(highway_mix_bwd_kernel, dim3(grid_for((int64_t)rows * D)), dim3(256), 0, as_hip(stream), dOut, H, TG,
-                     dH, dP, rows, D, p_drop, salt, rng_state);
+  if (D % 4 == 0 && bn_aligned16(dOut, H, TG, dH, dP))
+    hipLaunchKernelGGL(highway_mix_bwd_v4_kernel, dim3(grid_for((int64_t)rows * (D / 4))), dim3(256), 0, as_hip(stream), dOut, H,
+                       TG, dH, dP, rows, D, p_drop, salt, rng_state);
+  else
+    hipLaunchKernelGGL(highway_mix_bwd_kernel, dim3(grid_for((int64_t)rows * D)), dim3(256), 0, as_hip(stream), dOut, H, TG,
+                       dH, dP, rows, D, p_drop, salt, rng_state);
   NACF_LAUNCH_CHECK("nacf_highway_mix_bwd");
   return NACF_OK;
 }
@@ -464,13 +721,24 @@ int nacf_bn_concat_fwd(const float* x, float* out, int B, int F, int D, int M_to
   float* part_sq = part_sum + (size_t)32 * D;
   hipStream_t s = as_hip(stream);
   dim3 grid(cdiv(D, 64), S);
-  if (training) {
-    hipLaunchKernelGGL(bn_partial_sum_kernel, grid, dim3(256), 0, s, x, rows, D, rows_per, part_sum);
-    hipLaunchKernelGGL(bn_partial_sqdev_kernel, grid, dim3(256), 0, s, x, rows, D, rows_per, S, part_sum, part_sq);
+  const bool v4 = (D % 4 == 0) && bn_aligned16(x, out, weight, bias, save_mean, save_invstd, ws);
+  if (v4) {
+    if (training) {
+      hipLaunchKernelGGL(bn_partial_sum_v4_kernel, grid, dim3(256), 0, s, x, rows, D, rows_per, part_sum);
+      hipLaunchKernelGGL(bn_partial_sqdev_v4_kernel, grid, dim3(256), 0, s, x, rows, D, rows_per, S, part_sum, part_sq);
+    }
+    hipLaunchKernelGGL(bn_apply_v4_kernel, grid, dim3(256), 0, s, x, out, B, F, D, M_total, f_off, weight, bias, running_mean,
+                       running_var, num_batches_tracked, save_mean, save_invstd, training, momentum, eps, S, part_sum,
+                       part_sq, rows_per);
+  } else {
+    if (training) {
+      hipLaunchKernelGGL(bn_partial_sum_kernel, grid, dim3(256), 0, s, x, rows, D, rows_per, part_sum);
+      hipLaunchKernelGGL(bn_partial_sqdev_kernel, grid, dim3(256), 0, s, x, rows, D, rows_per, S, part_sum, part_sq);
+    }
+    hipLaunchKernelGGL(bn_apply_kernel, grid, dim3(256), 0, s, x, out, B, F, D, M_total, f_off, weight, bias, running_mean,
+                       running_var, num_batches_tracked, save_mean, save_invstd, training, momentum, eps, S, part_sum,
+                       part_sq, rows_per);
   }
-  hipLaunchKernelGGL(bn_apply_kernel, grid, dim3(256), 0, s, x, out, B, F, D, M_total, f_off, weight, bias, running_mean,
-                     running_var, num_batches_tracked, save_mean, save_invstd, training, momentum, eps, S, part_sum,
-                     part_sq, rows_per);
   NACF_LAUNCH_CHECK("nacf_bn_concat_fwd");
   return NACF_OK;
 }
@@ -488,17 +756,27 @@ int nacf_bn_concat_bwd(const float* dOut, const float* x, float* dx, int B, int 
   float* part_dyx = part_dy + (size_t)32 * D;
   hipStream_t s = as_hip(stream);
   dim3 grid(cdiv(D, 64), S);
-  hipLaunchKernelGGL(bn_bwd_partial_kernel, grid, dim3(256), 0, s, dOut, x, B, F, D, M_total, f_off, save_mean,
-                     save_invstd, rows_per, part_dy, part_dyx);
-  hipLaunchKernelGGL(bn_bwd_apply_kernel, grid, dim3(256), 0, s, dOut, x, dx, B, F, D, M_total, f_off, weight, save_mean,
-                     save_invstd, dweight, dbias, beta, S, rows_per, part_dy, part_dyx);
+  if ((D % 4 == 0) && bn_aligned16(dOut, x, dx, weight, save_mean, save_invstd, ws)) {
+    hipLaunchKernelGGL(bn_bwd_partial_v4_kernel, grid, dim3(256), 0, s, dOut, x, B, F, D, M_total, f_off, save_mean,
+                       save_invstd, rows_per, part_dy, part_dyx);
+    hipLaunchKernelGGL(bn_bwd_apply_v4_kernel, grid, dim3(256), 0, s, dOut, x, dx, B, F, D, M_total, f_off, weight, save_mean,
+                       save_invstd, dweight, dbias, beta, S, rows_per, part_dy, part_dyx);
+  } else {
+    hipLaunchKernelGGL(bn_bwd_partial_kernel, grid, dim3(256), 0, s, dOut, x, B, F, D, M_total, f_off, save_mean,
+                       save_invstd, rows_per, part_dy, part_dyx);
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, grid, dim3(256), 0, s, dOut, x, dx, B, F, D, M_total, f_off, weight, save_mean,
+                       save_invstd, dweight, dbias, beta, S, rows_per, part_dy, part_dyx);
+  }
   NACF_LAUNCH_CHECK("nacf_bn_concat_bwd");
   return NACF_OK;
 }
 
 int nacf_mean_time_fwd(const float* x, float* out, int B, int T, int D, nacf_stream_t stream) {
   NACF_CHECK(x && out && B > 0 && T > 0 && D > 0, NACF_EINVAL, "nacf_mean_time_fwd: bad argument");
-  hipLaunchKernelGGL(mean_time_fwd_kernel, dim3(B, cdiv(D, 256)), dim3(256), 0, as_hip(stream), x, out, T, D);
+  if (D % 4 == 0 && ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(out)) & 15) == 0)
+    hipLaunchKernelGGL(mean_time_fwd_kernel, dim3(B, cdiv(D, 128)), dim3(256), 0, as_hip(stream), x, out, T, D);
+  else
+    hipLaunchKernelGGL(mean_time_fwd_scalar_kernel, dim3(B, cdiv(D, 256)), dim3(256), 0, as_hip(stream), x, out, T, D);
   NACF_LAUNCH_CHECK("nacf_mean_time_fwd");
   return NACF_OK;
 }
@@ -540,8 +818,14 @@ int nacf_epilogue_bwd(const float* dY, int64_t lddy, float* dZ, int64_t lddz, fl
   NACF_CHECK(!(ep->act != NACF_ACT_NONE && !ep->preact), NACF_EINVAL, "nacf_epilogue_bwd: activation backward needs preact");
   NACF_CHECK(!((ep->p_drop1 > 0.f || ep->p_drop2 > 0.f) && !ep->rng_state), NACF_EINVAL,
              "nacf_epilogue_bwd: dropout needs rng_state");
-  hipLaunchKernelGGL(epilogue_bwd_kernel, dim3(grid_for((int64_t)M * N)), dim3(256), 0, as_hip(stream), dY, lddy, dZ, lddz,
-                     dR, lddr, accumulate_dR, M, N, *ep);
+  const bool v4 = (N % 4 == 0) && (lddy % 4 == 0) && (lddz % 4 == 0) && (!dR || lddr % 4 == 0) &&
+                  (!ep->preact || ep->ld_preact % 4 == 0) && bn_aligned16(dY, dZ, dR, ep->preact);
+  if (v4)
+    hipLaunchKernelGGL(epilogue_bwd_v4_kernel, dim3(grid_for((int64_t)M * (N / 4))), dim3(256), 0, as_hip(stream), dY, lddy,
+                       dZ, lddz, dR, lddr, accumulate_dR, M, N, *ep);
+  else
+    hipLaunchKernelGGL(epilogue_bwd_kernel, dim3(grid_for((int64_t)M * N)), dim3(256), 0, as_hip(stream), dY, lddy, dZ, lddz,
+                       dR, lddr, accumulate_dR, M, N, *ep);
   NACF_LAUNCH_CHECK("nacf_epilogue_bwd");
   return NACF_OK;
 }
