@@ -54,6 +54,7 @@ struct GemmShape {
   int tiles_m, tiles_n;
   const int* rows;   // optional live-row list (see "Row sets" above)
   const int* count;  // device int: number of valid entries of `rows`
+  int zero_dead;     // NT / NN with a row list: rows[count..M) are the dead rows; their output rows are zero-filled
   // TN only (dW = dZ^T X): the bias gradient db[n] = sum_m dZ[m][n] is the row sum of the Q operand this GEMM
   // stages anyway.  The workgroups of column tile 0 add up what they stage: straight into `colsum_out`
   // (= beta * old + sum) without a reduce split, else into colsum_part[z][n] for the split-K combine kernel.
@@ -194,6 +195,15 @@ struct EpiStore {
         if (e < nv) p[e] = (beta != 0.f) ? v[e] + beta * p[e] : v[e];
     }
   }
+  // dead-row fill (see nacf_rowset.zero_dead): columns [n, n + 4) of physical row mp
+  __device__ __forceinline__ void zero4(int mp, int n, int N) const {
+    if (beta != 0.f || slab_stride != 0) return;   // accumulate: dead rows contribute nothing
+    float* p = C + (int64_t)mp * ldc + n;
+    if (vec_out && n + 4 <= N) *reinterpret_cast<f32x4*>(p) = f32x4{0.f, 0.f, 0.f, 0.f};
+    else
+      for (int e = 0; e < 4; ++e)
+        if (n + e < N) p[e] = 0.f;
+  }
   // interior tile (every row < M, every column group < N, float4-addressable): all loads are issued
   // before the first store, nothing is guarded.  The per-call path above serialises one load -> wait ->
   // store chain per 16x16 sub-tile, which made the epilogue of a 128x128 tile cost ~8 % of a K=512 GEMM.
@@ -292,6 +302,18 @@ struct EpiLinear {
         if (e < nv) y[e] = v[e];
     }
   }
+  // dead-row fill (see nacf_rowset.zero_dead): Y and the saved pre-activation
+  __device__ __forceinline__ void zero4(int mp, int n, int N) const {
+    float* y = Y + (int64_t)mp * ldy + n;
+    float* z = ep.preact ? ep.preact + (int64_t)mp * ep.ld_preact + n : nullptr;
+    if (vec_out && n + 4 <= N) {
+      *reinterpret_cast<f32x4*>(y) = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (z) *reinterpret_cast<f32x4*>(z) = f32x4{0.f, 0.f, 0.f, 0.f};
+    } else {
+      for (int e = 0; e < 4; ++e)
+        if (n + e < N) { y[e] = 0.f; if (z) z[e] = 0.f; }
+    }
+  }
   // interior tile: bias / residual / row-token loads are all issued up front (see EpiStore::tile_fast)
   __device__ __forceinline__ bool fast_ok() const { return vec_out != 0 && vec_bias != 0; }
   template <int TM, int TN, bool PKC>
@@ -352,6 +374,7 @@ struct EpiArgmax {
   int* pidx;     // [tiles_n][M]
   static constexpr bool kArgmax = true;
   __device__ __forceinline__ void operator()(int, int, int, f32x4, int, int, int) const {}
+  __device__ __forceinline__ void zero4(int, int, int) const {}
 };
 
 template <int IDX, int TM, int TN, bool PKC, class Epi>
@@ -401,7 +424,22 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmShape g, Epi epi) {
   const int tiles_m_live = (Meff + BM - 1) / BM;
   const int nwg = tiles_m_live * g.tiles_n;
   const int bid = blockIdx.x;
-  if (bid >= nwg) return;
+  if (bid >= nwg) {
+    // workgroups past the live tiles: nothing to multiply.  With zero_dead they zero-fill the dead rows
+    // (rows[Meff .. M)) of the output instead, BM rows x BN columns each, so no memset is needed.
+    if constexpr (!ROWS_ARE_K) {
+      if (g.zero_dead && g.rows && blockIdx.z == 0) {
+        const int dt = bid - nwg;
+        const int j0 = (dt / g.tiles_n) * BM, c0 = (dt % g.tiles_n) * BN;
+        const int n_dead = g.M - Meff;
+        for (int q = tid; q < BM * (BN / 4); q += 256) {
+          const int j = j0 + q / (BN / 4), n = c0 + (q % (BN / 4)) * 4;
+          if (j < n_dead && n < g.N) epi.zero4(g.rows[Meff + j], n, g.N);
+        }
+      }
+    }
+    return;
+  }
   const int xq = nwg >> 3, xr = nwg & 7;
   const int xcd = bid & 7, slot = bid >> 3;
   const int logical = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + slot;

@@ -30,13 +30,14 @@ void launch_gemm(const GemmShape& g0, const Epi& epi, int splits, int tile, bool
   if (tile == 0) {
     g.tiles_m = cdiv(g.M, 128);
     g.tiles_n = cdiv(g.N, 128);
-    dim3 grid(g.tiles_m * g.tiles_n, 1, splits);
+    // live row tiles + dead row tiles can be one more than the dense count (both partly filled)
+    dim3 grid((g.tiles_m + (g.zero_dead ? 1 : 0)) * g.tiles_n, 1, splits);
     if (vec) hipLaunchKernelGGL((gemm_f32_kernel<128, 128, 2, 2, QKC, PKC, true, Epi>), grid, dim3(256), 0, s, g, epi);
     else hipLaunchKernelGGL((gemm_f32_kernel<128, 128, 2, 2, QKC, PKC, false, Epi>), grid, dim3(256), 0, s, g, epi);
   } else {
     g.tiles_m = cdiv(g.M, 64);
     g.tiles_n = cdiv(g.N, 64);
-    dim3 grid(g.tiles_m * g.tiles_n, 1, splits);
+    dim3 grid((g.tiles_m + (g.zero_dead ? 1 : 0)) * g.tiles_n, 1, splits);
     if (vec) hipLaunchKernelGGL((gemm_f32_kernel<64, 64, 2, 2, QKC, PKC, true, Epi>), grid, dim3(256), 0, s, g, epi);
     else hipLaunchKernelGGL((gemm_f32_kernel<64, 64, 2, 2, QKC, PKC, false, Epi>), grid, dim3(256), 0, s, g, epi);
   }
@@ -45,21 +46,25 @@ void launch_gemm(const GemmShape& g0, const Epi& epi, int splits, int tile, bool
 inline void set_rows(GemmShape& g, const nacf_rowset* rs) {
   g.rows = rs ? rs->rows : nullptr;
   g.count = rs ? rs->count : nullptr;
+  g.zero_dead = (rs && rs->zero_dead) ? 1 : 0;
 }
 
-// dst[rows[r]][c] = beta*dst + sum_z slab[z][rows[r]][c] over the live rows only (split-K combine of dX)
+// dst[rows[r]][c] = beta*dst + sum_z slab[z][rows[r]][c] over the live rows only (split-K combine of dX);
+// zero_dead: the rows listed after the live ones get zeros (beta == 0) in the same pass
 __global__ void splitk_reduce_rows_kernel(const float* __restrict__ slabs, int64_t slab_stride, int splits,
                                           float* __restrict__ dst, int64_t ldd, int rows, int cols, float beta,
-                                          const int* __restrict__ live, const int* __restrict__ count) {
+                                          const int* __restrict__ live, const int* __restrict__ count, int zero_dead) {
   const int n_live = count ? min(rows, *count) : rows;
-  const int64_t total = (int64_t)n_live * cols;
+  const int n_do = (zero_dead && live && beta == 0.f) ? rows : n_live;
+  const int64_t total = (int64_t)n_do * cols;
   for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
        idx += (int64_t)gridDim.x * blockDim.x) {
     const int r = (int)(idx / cols), c = (int)(idx % cols);
     const int pr = live ? live[r] : r;
+    float* d = dst + (int64_t)pr * ldd + c;
+    if (r >= n_live) { *d = 0.f; continue; }
     float acc = 0.f;
     for (int zz = 0; zz < splits; ++zz) acc += slabs[(int64_t)zz * slab_stride + (int64_t)pr * cols + c];
-    float* d = dst + (int64_t)pr * ldd + c;
     *d = (beta != 0.f) ? acc + beta * (*d) : acc;
   }
 }
@@ -125,7 +130,8 @@ __global__ void argmax_merge_kernel(const float* __restrict__ pmax, const float*
   }
 }
 
-// stable compaction: rows[] = ascending i with (tokens ? tokens[i] != PAD) && (flags ? flags[i] != 0); one workgroup
+// stable partition: rows[0..count) = ascending i with (tokens ? tokens[i] != PAD) && (flags ? flags[i] != 0),
+// rows[count..n) = the other slots, ascending; one workgroup, two sweeps
 __global__ __launch_bounds__(1024) void rowset_build_kernel(const int64_t* __restrict__ tokens,
                                                              const uint8_t* __restrict__ flags, int n,
                                                              int* __restrict__ rows, int* __restrict__ count) {
@@ -134,27 +140,30 @@ __global__ __launch_bounds__(1024) void rowset_build_kernel(const int64_t* __res
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   if (threadIdx.x == 0) base_s = 0;
   __syncthreads();
-  for (int c0 = 0; c0 < n; c0 += 1024) {
-    const int i = c0 + threadIdx.x;
-    bool live = i < n;
-    if (live && tokens) live = tokens[i] != NACF_PAD;
-    if (live && flags) live = flags[i] != 0;
-    const unsigned long long bal = __ballot(live);
-    const int pre = __popcll(bal & ((1ull << lane) - 1ull));
-    if (lane == 0) wsum[wave] = __popcll(bal);
-    __syncthreads();
-    int off = base_s;
-    for (int w = 0; w < wave; ++w) off += wsum[w];
-    if (live) rows[off + pre] = i;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-      int t = 0;
-      for (int w = 0; w < 16; ++w) t += wsum[w];
-      base_s += t;
+  for (int pass = 0; pass < 2; ++pass) {
+    for (int c0 = 0; c0 < n; c0 += 1024) {
+      const int i = c0 + threadIdx.x;
+      bool live = i < n;
+      if (live && tokens) live = tokens[i] != NACF_PAD;
+      if (live && flags) live = flags[i] != 0;
+      const bool take = (i < n) && (pass == 0 ? live : !live);
+      const unsigned long long bal = __ballot(take);
+      const int pre = __popcll(bal & ((1ull << lane) - 1ull));
+      if (lane == 0) wsum[wave] = __popcll(bal);
+      __syncthreads();
+      int off = base_s;
+      for (int w = 0; w < wave; ++w) off += wsum[w];
+      if (take) rows[off + pre] = i;
+      __syncthreads();
+      if (threadIdx.x == 0) {
+        int t = 0;
+        for (int w = 0; w < 16; ++w) t += wsum[w];
+        base_s += t;
+      }
+      __syncthreads();
     }
-    __syncthreads();
+    if (pass == 0 && threadIdx.x == 0) count[0] = base_s;
   }
-  if (threadIdx.x == 0) count[0] = base_s;
 }
 
 }  // namespace
@@ -248,6 +257,7 @@ int nacf_linear_bwd_data(const float* dZ, int64_t lddz, const float* W, int64_t 
   if (real_splits > 1) {
     epi.C = reinterpret_cast<float*>(ws); epi.ldc = K; epi.beta = 0.f; epi.slab_stride = (int64_t)M * K;
     epi.vec_out = (K % 4 == 0) ? 1 : 0;
+    g.zero_dead = 0;   // the combine kernel zeroes the dead rows of dX, not the GEMM those of the slabs
   } else {
     epi.C = dX; epi.ldc = lddx; epi.beta = beta; epi.slab_stride = 0;
     epi.vec_out = ((lddx % 4 == 0) && aligned16(dX)) ? 1 : 0;
@@ -258,7 +268,7 @@ int nacf_linear_bwd_data(const float* dZ, int64_t lddz, const float* W, int64_t 
     const int64_t total = (int64_t)M * K;
     const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
     hipLaunchKernelGGL(splitk_reduce_rows_kernel, dim3(blocks), dim3(256), 0, s, epi.C, (int64_t)M * K, real_splits, dX,
-                       lddx, M, K, beta, rs ? rs->rows : nullptr, rs ? rs->count : nullptr);
+                       lddx, M, K, beta, rs ? rs->rows : nullptr, rs ? rs->count : nullptr, (rs && rs->zero_dead) ? 1 : 0);
     NACF_LAUNCH_CHECK("nacf_linear_bwd_data(reduce)");
   }
   return NACF_OK;

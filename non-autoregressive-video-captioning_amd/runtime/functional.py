@@ -235,8 +235,8 @@ class LinearFn(Function):
         training = cfg.get("training", False)
         act = cfg.get("act", L.ACT_NONE)
         need_bwd = any(ctx.needs_input_grad)
-        rows = cfg.get("rows")      # live-row list: dead (<pad>) slots are neither computed nor written
-        mk = _zeros if rows is not None else _new
+        rows = cfg.get("rows")      # live-row list: dead (<pad>) slots are not computed; the GEMM zero-fills them
+        mk = _new
         pre = mk((M, N), x) if (act != L.ACT_NONE and need_bwd) else None
         res = _c2d(residual, M, N) if residual is not None else None
         epi = ops.Epi(bias=pk.b, act=act, preact=pre,
@@ -244,7 +244,7 @@ class LinearFn(Function):
                       residual=res, p2=cfg.get("p2", 0.0) if training else 0.0, salt2=cfg.get("salt2", 0),
                       row_tokens=cfg.get("row_tokens"), rng=cfg.get("rng"))
         out = mk((M, N), x)
-        ops.linear_fwd(x, pk.w, out, epi, rows)
+        ops.linear_fwd(x, pk.w, out, epi, rows, zero_dead=True)
         ctx.cfg, ctx.epi, ctx.x, ctx.rows = cfg, epi, x, rows
         ctx.has_res = residual is not None
         return out
@@ -270,8 +270,8 @@ class LinearFn(Function):
         dx = None
         rows = ctx.rows
         if ctx.needs_input_grad[0]:
-            dx = (_zeros if rows is not None else _new)((M, K), dy)
-            ops.linear_bwd_data(dz, pk.w, dx, rows=rows)
+            dx = _new((M, K), dy)
+            ops.linear_bwd_data(dz, pk.w, dx, rows=rows, zero_dead=True)
         if pk.gw is not None:
             ops.linear_bwd_weight(dz, ctx.x, pk.gw, pk.gb, beta=1.0, rows=rows)
         ctx.x = None
@@ -415,8 +415,8 @@ class FusedVocabXentFn(Function):
         rows, V = ctx.logp.shape
         dstats = dstats.contiguous()
         ops.xent_bwd(ctx.logp, ctx.logp, V, ctx.labels, dstats, 1.0, skip_pad_rows=True)  # in place: logp -> dlogits
-        dh = torch.zeros_like(ctx.h)
-        ops.linear_bwd_data(ctx.logp, pk.w, dh, rows=ctx.live)
+        dh = torch.empty_like(ctx.h)
+        ops.linear_bwd_data(ctx.logp, pk.w, dh, rows=ctx.live, zero_dead=True)
         ops.linear_bwd_weight(ctx.logp, ctx.h, pk.gw, pk.gb, beta=1.0, rows=ctx.live)
         ctx.h = ctx.logp = ctx.live = None
         return (dh, None, None, None) + (None,) * (len(ctx.needs_input_grad) - 4)

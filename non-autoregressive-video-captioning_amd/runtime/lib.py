@@ -31,7 +31,7 @@ class Epilogue(ctypes.Structure):
 
 class RowSet(ctypes.Structure):
     """struct nacf_rowset."""
-    _fields_ = [("rows", c_void_p), ("count", c_void_p)]
+    _fields_ = [("rows", c_void_p), ("count", c_void_p), ("zero_dead", ctypes.c_int32)]
 
 
 _P, _I, _L, _F, _U, _S = c_void_p, c_int, c_int64, c_float, c_uint32, c_size_t

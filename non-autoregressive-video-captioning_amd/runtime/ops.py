@@ -130,14 +130,14 @@ class RowSet:
     def __init__(self, rows: Tensor, count: Tensor):
         self.rows, self.count = rows, count
 
-    def c(self):
+    def c(self, zero_dead: bool = False):
         r = L.RowSet()
-        r.rows, r.count = self.rows.data_ptr(), self.count.data_ptr()
+        r.rows, r.count, r.zero_dead = self.rows.data_ptr(), self.count.data_ptr(), int(zero_dead)
         return ctypes.byref(r)
 
 
-def _rs(rows: Optional["RowSet"]):
-    return rows.c() if rows is not None else None
+def _rs(rows: Optional["RowSet"], zero_dead: bool = False):
+    return rows.c(zero_dead) if rows is not None else None
 
 
 def rowset_build(tokens: Optional[Tensor] = None, flags: Optional[Tensor] = None) -> RowSet:
@@ -178,8 +178,10 @@ class Epi:
         return e
 
 
-def linear_fwd(x: Tensor, w: Tensor, out: Tensor, epi: Optional[Epi] = None, rows: Optional[RowSet] = None) -> Tensor:
-    """out[M,N] = epilogue(x[M,K] @ w[N,K]^T)."""
+def linear_fwd(x: Tensor, w: Tensor, out: Tensor, epi: Optional[Epi] = None, rows: Optional[RowSet] = None,
+               zero_dead: bool = False) -> Tensor:
+    """out[M,N] = epilogue(x[M,K] @ w[N,K]^T).  With a row set only the live rows are computed; zero_dead also
+    writes zeros to the other rows of `out` (and of epi.preact), so `out` needs no initialisation."""
     _chk_f32(x, w, out)
     M, K, ldx = _rows2d(x)
     N, K2, ldw = _rows2d(w)
@@ -187,12 +189,13 @@ def linear_fwd(x: Tensor, w: Tensor, out: Tensor, epi: Optional[Epi] = None, row
     ep = epi.cstruct() if epi is not None else L.Epilogue()
     tok = PROFILER.begin(0, M, N, K, "EpiLinear", rows)
     L.check(L.load().nacf_linear_fwd(_ptr(x), ldx, _ptr(w), ldw, _ptr(out), out.stride(0), M, N, K,
-                                     ctypes.byref(ep), _rs(rows), _stream()), "nacf_linear_fwd")
+                                     ctypes.byref(ep), _rs(rows, zero_dead), _stream()), "nacf_linear_fwd")
     PROFILER.end(tok)
     return out
 
 
-def linear_bwd_data(dz: Tensor, w: Tensor, dx: Tensor, beta: float = 0.0, rows: Optional[RowSet] = None) -> Tensor:
+def linear_bwd_data(dz: Tensor, w: Tensor, dx: Tensor, beta: float = 0.0, rows: Optional[RowSet] = None,
+                    zero_dead: bool = False) -> Tensor:
     _chk_f32(dz, w, dx)
     M, N, lddz = _rows2d(dz)
     N2, K, ldw = _rows2d(w)
@@ -201,7 +204,8 @@ def linear_bwd_data(dz: Tensor, w: Tensor, dx: Tensor, beta: float = 0.0, rows: 
     ws = WORKSPACE.get(lib.nacf_linear_bwd_data_workspace(M, N, K), dz.device)
     tok = PROFILER.begin(1, M, N, K, "EpiStore", rows)
     L.check(lib.nacf_linear_bwd_data(_ptr(dz), lddz, _ptr(w), ldw, _ptr(dx), dx.stride(0), M, N, K,
-                                     float(beta), _ptr(ws), ws.numel(), _rs(rows), _stream()), "nacf_linear_bwd_data")
+                                     float(beta), _ptr(ws), ws.numel(), _rs(rows, zero_dead), _stream()),
+            "nacf_linear_bwd_data")
     PROFILER.end(tok)
     return dx
 

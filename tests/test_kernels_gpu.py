@@ -189,6 +189,40 @@ def test_live_row_gemms(dev, M, N, K, tile, monkeypatch):
     assert float(dw.abs().max()) == 0
 
 
+@pytest.mark.parametrize("M,N,K,tile", [(300, 136, 72, "64"), (1000, 512, 256, "128"), (130, 101, 64, "128"),
+                                        (2560, 4100, 64, "64")])
+def test_live_row_gemms_zero_fill_dead_rows(dev, M, N, K, tile, monkeypatch):
+    """zero_dead: the workgroups of the dead row tiles write zeros, outputs need no memset (NaN-poisoned here)"""
+    ops, L = _ops()
+    monkeypatch.setenv("NACF_GEMM_TILE", tile)
+    g = torch.Generator().manual_seed(1)
+    tok = torch.randint(0, 3, (M,), generator=g)
+    live = tok.ne(PAD)
+    rs = ops.rowset_build(tokens=tok.to(dev))
+    n_live = int(rs.count)
+    assert torch.equal(rs.rows[:n_live].cpu().long(), live.nonzero().squeeze(1))
+    assert torch.equal(rs.rows[n_live:].cpu().long(), (~live).nonzero().squeeze(1))      # the dead slots follow
+    x, w, b = rnd(M, K, seed=1), rnd(N, K, seed=2), rnd(N, seed=3)
+    y = torch.full((M, N), float("nan"), device=dev)
+    pre = torch.full((M, N), float("nan"), device=dev)
+    ops.linear_fwd(x.to(dev), w.to(dev), y, ops.Epi(bias=b.to(dev), act=L.ACT_RELU, preact=pre), rows=rs, zero_dead=True)
+    z = x.double() @ w.double().t() + b.double()
+    assert err(y[live.to(dev)], z.clamp_min(0)[live]) < 1e-4 and err(pre[live.to(dev)], z[live]) < 1e-4
+    assert float(y[~live.to(dev)].abs().max()) == 0 and float(pre[~live.to(dev)].abs().max()) == 0
+    dz = rnd(M, N, seed=5)
+    dx = torch.full((M, K), float("nan"), device=dev)
+    ops.linear_bwd_data(dz.to(dev), w.to(dev), dx, rows=rs, zero_dead=True)      # N = 4100: the split-K route
+    assert err(dx[live.to(dev)], (dz.double() @ w.double())[live]) < 2e-4
+    assert float(dx[~live.to(dev)].abs().max()) == 0
+    # every slot dead / every slot live
+    for toks in (torch.zeros(M, dtype=torch.int64), torch.ones(M, dtype=torch.int64)):
+        rs2 = ops.rowset_build(tokens=toks.to(dev))
+        y.fill_(float("nan"))
+        ops.linear_fwd(x.to(dev), w.to(dev), y, ops.Epi(bias=b.to(dev)), rows=rs2, zero_dead=True)
+        want = z if int(toks[0]) else torch.zeros_like(z)
+        assert err(y, want) < 1e-4
+
+
 def test_vocab_argmax_live_rows(dev):
     ops, _ = _ops()
     rows, V, K = 200, 333, 64
