@@ -20,4 +20,4 @@ for grp in "GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCL
   t=$(find /tmp/pmc_gemm_$i -name "*kernel_trace.csv" | head -1)
   [ -n "$t" ] && cp $t $OUT/trace_$i.csv
 done
-python $ROOT/tools/pmc_gemm_summary.py $OUT/counters_*.csv
+python $ROOT/tools/pmc_gemm_summary.py $OUT
