@@ -292,6 +292,17 @@ int nacf_masked_mean_fwd(const float* y, const int64_t* tokens, float* out, int 
 int nacf_vocab_logsoftmax_fwd(float* logits, int64_t ld, int rows, int V,
                               const int64_t* labels, float* lse, int64_t* argmax,
                               float* label_logp, int skip_pad_rows, nacf_stream_t stream);
+/* Criterion tail, misc/crit.py:40-45,107-121: the weighted total and the running meters in ONE launch.
+ *   total[0]          = sum_t coef[t] * slab[t * stride]                    (t < n_terms)
+ *   meters[m_dst[j]] += m_scale[j] * slab[m_src[j]]                         (j < n_meters, in order)
+ * `slab` holds the per-term result vectors side by side (e.g. the 5 outputs of nacf_nll_reduce per
+ * pass, the KL scalar).  Backward: gslab[t * stride] = coef[t] * gtotal[0], every other entry 0. */
+int nacf_loss_combine(const float* slab, int n_terms, int stride, const float* coef, float* total,
+                      const int32_t* m_dst, const int32_t* m_src, const float* m_scale, int n_meters,
+                      float* meters, nacf_stream_t stream);
+int nacf_loss_combine_bwd(const float* gtotal, const float* coef, int n_terms, int stride, float* gslab,
+                          nacf_stream_t stream);
+
 /* Reduce per-row results to the scalars the criterion reports:
  * out[0] = -sum_{label!=PAD} logp[label]      (token-SUM NLL, misc/crit.py:82)
  * out[1] = #(argmax == label) over the accuracy set, out[2] = |accuracy set|

@@ -461,6 +461,23 @@ __global__ void kldiv_mean_kernel(const float* __restrict__ x, const float* __re
   if (threadIdx.x == 0 && loss_out) loss_out[0] = acc * inv;
 }
 
+// ------------------------------------------------------------------ criterion tail
+__global__ void loss_combine_kernel(const float* __restrict__ slab, int n_terms, int stride, const float* __restrict__ coef,
+                                    float* __restrict__ total, const int* __restrict__ m_dst, const int* __restrict__ m_src,
+                                    const float* __restrict__ m_scale, int n_meters, float* __restrict__ meters) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;   // a dozen scalars: one lane, fixed order
+  float t = 0.f;
+  for (int i = 0; i < n_terms; ++i) t += coef[i] * slab[(int64_t)i * stride];
+  total[0] = t;
+  for (int j = 0; j < n_meters; ++j) meters[m_dst[j]] += m_scale[j] * slab[m_src[j]];
+}
+__global__ void loss_combine_bwd_kernel(const float* __restrict__ gtotal, const float* __restrict__ coef, int n_terms,
+                                        int stride, float* __restrict__ gslab) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_terms * stride) return;
+  gslab[i] = (i % stride == 0) ? coef[i / stride] * gtotal[0] : 0.f;
+}
+
 // ------------------------------------------------------------------ epilogue backward
 __global__ void epilogue_bwd_kernel(const float* __restrict__ dY, int64_t lddy, float* __restrict__ dZ, int64_t lddz,
                                     float* __restrict__ dR, int64_t lddr, int accumulate_dR, int M, int N,
@@ -809,6 +826,26 @@ int nacf_kldiv_mean(const float* x, const float* t, float* loss_out, float* dX, 
   hipLaunchKernelGGL(kldiv_mean_kernel, dim3(1), dim3(256), 0, as_hip(stream), x, t, loss_out, dX, gscale, scale,
                      rows * N);
   NACF_LAUNCH_CHECK("nacf_kldiv_mean");
+  return NACF_OK;
+}
+
+int nacf_loss_combine(const float* slab, int n_terms, int stride, const float* coef, float* total,
+                      const int32_t* m_dst, const int32_t* m_src, const float* m_scale, int n_meters,
+                      float* meters, nacf_stream_t stream) {
+  NACF_CHECK(slab && coef && total && n_terms > 0 && stride > 0, NACF_EINVAL, "nacf_loss_combine: bad argument");
+  NACF_CHECK(n_meters == 0 || (m_dst && m_src && m_scale && meters), NACF_EINVAL, "nacf_loss_combine: incomplete meter table");
+  hipLaunchKernelGGL(loss_combine_kernel, dim3(1), dim3(64), 0, as_hip(stream), slab, n_terms, stride, coef, total, m_dst,
+                     m_src, m_scale, n_meters, meters);
+  NACF_LAUNCH_CHECK("nacf_loss_combine");
+  return NACF_OK;
+}
+
+int nacf_loss_combine_bwd(const float* gtotal, const float* coef, int n_terms, int stride, float* gslab,
+                          nacf_stream_t stream) {
+  NACF_CHECK(gtotal && coef && gslab && n_terms > 0 && stride > 0, NACF_EINVAL, "nacf_loss_combine_bwd: bad argument");
+  hipLaunchKernelGGL(loss_combine_bwd_kernel, dim3(cdiv(n_terms * stride, 64)), dim3(64), 0, as_hip(stream), gtotal, coef,
+                     n_terms, stride, gslab);
+  NACF_LAUNCH_CHECK("nacf_loss_combine_bwd");
   return NACF_OK;
 }
 

@@ -70,18 +70,33 @@ __global__ void splitk_reduce_rows_kernel(const float* __restrict__ slabs, int64
 }
 
 // dst[i] = beta*dst[i] + sum_z slab[z][i], fixed z order (deterministic split-K combine); optionally the same
-// for the bias-gradient partials the dW GEMM left in part[z][n] (db[n] = beta*db[n] + sum_z part[z][n])
+// for the bias-gradient partials the dW GEMM left in part[z][n] (db[n] = beta*db[n] + sum_z part[z][n]).
+// VEC: cols % 4 == 0 and 16-byte aligned rows -> float4 per thread.
+template <bool VEC>
 __global__ void splitk_reduce_kernel(const float* __restrict__ slabs, int64_t slab_stride, int splits,
                                      float* __restrict__ dst, int64_t ldd, int rows, int cols, float beta,
                                      const float* __restrict__ part, float* __restrict__ db) {
-  const int64_t total = (int64_t)rows * cols;
   const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  for (int64_t idx = gid; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
-    const int r = (int)(idx / cols), c = (int)(idx % cols);
-    float acc = 0.f;
-    for (int zz = 0; zz < splits; ++zz) acc += slabs[(int64_t)zz * slab_stride + idx];
-    float* d = dst + (int64_t)r * ldd + c;
-    *d = (beta != 0.f) ? acc + beta * (*d) : acc;
+  if constexpr (VEC) {
+    const int c4n = cols >> 2;
+    const int64_t total = (int64_t)rows * c4n;
+    for (int64_t idx = gid; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+      const int r = (int)(idx / c4n), c = (int)(idx % c4n) * 4;
+      const float* sp = slabs + (int64_t)r * cols + c;
+      f32x4 acc = *reinterpret_cast<const f32x4*>(sp);
+      for (int zz = 1; zz < splits; ++zz) acc += *reinterpret_cast<const f32x4*>(sp + (int64_t)zz * slab_stride);
+      f32x4* d = reinterpret_cast<f32x4*>(dst + (int64_t)r * ldd + c);
+      *d = (beta != 0.f) ? acc + beta * (*d) : acc;
+    }
+  } else {
+    const int64_t total = (int64_t)rows * cols;
+    for (int64_t idx = gid; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+      const int r = (int)(idx / cols), c = (int)(idx % cols);
+      float acc = 0.f;
+      for (int zz = 0; zz < splits; ++zz) acc += slabs[(int64_t)zz * slab_stride + idx];
+      float* d = dst + (int64_t)r * ldd + c;
+      *d = (beta != 0.f) ? acc + beta * (*d) : acc;
+    }
   }
   if (db) {
     for (int64_t n = gid; n < rows; n += (int64_t)gridDim.x * blockDim.x) {
@@ -342,10 +357,15 @@ int nacf_linear_bwd_weight(const float* dZ, int64_t lddz, const float* X, int64_
   launch_gemm<false, false, EpiStore>(g, epi, real_splits, tile, vec, s);
   NACF_LAUNCH_CHECK("nacf_linear_bwd_weight(gemm)");
   if (real_splits > 1) {
-    const int64_t total = (int64_t)N * K;
-    const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
-    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, s, slabs, (int64_t)N * K, real_splits, dW,
-                       lddw, N, K, beta, db ? part : nullptr, db);
+    const bool v4 = (K % 4 == 0) && (lddw % 4 == 0) && aligned16(dW) && aligned16(slabs);
+    const int64_t total = (int64_t)N * (v4 ? K / 4 : K);
+    const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+    if (v4)
+      hipLaunchKernelGGL(splitk_reduce_kernel<true>, dim3(blocks), dim3(256), 0, s, slabs, (int64_t)N * K, real_splits, dW,
+                         lddw, N, K, beta, db ? part : nullptr, db);
+    else
+      hipLaunchKernelGGL(splitk_reduce_kernel<false>, dim3(blocks), dim3(256), 0, s, slabs, (int64_t)N * K, real_splits, dW,
+                         lddw, N, K, beta, db ? part : nullptr, db);
     NACF_LAUNCH_CHECK("nacf_linear_bwd_weight(reduce)");
   }
   return NACF_OK;

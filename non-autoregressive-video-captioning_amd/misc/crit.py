@@ -19,7 +19,7 @@ import math
 import torch
 
 from ..config import Constants
-from ..runtime.functional import FusedVocabXentFn, KLDivMeanFn
+from ..runtime.functional import FusedVocabXentFn, KLDivMeanFn, LossCombineFn
 
 
 class Criterion(object):
@@ -42,6 +42,13 @@ class Criterion(object):
         self._loss_cnt = [0] * len(self.crit)
         self._acc = None      # device [n_pass, 2] (hits, count)
         self._ppl = None      # device [2] (sum logp, count)
+        if getattr(self, '_meters', None) is not None:
+            self._meters.zero_()      # in place: a captured hipGraph keeps writing this very buffer
+        else:
+            self._meters = None       # fused form: device [n_crit | 2*n_pass | 2] running sums, see _fused_plan
+            self._meter_plan = None
+        if not hasattr(self, '_plans'):
+            self._plans = {}
 
     @staticmethod
     def _acc_add(cur, new):
@@ -89,7 +96,82 @@ class Criterion(object):
             self._ppl = self._acc_add(self._ppl, ppl)
         return loss, B
 
+    # ---- fused form: every term lands in one device slab, ONE kernel forms the total and updates the meters
+    _STRIDE = 8
+
+    def _fused_plan(self, B, n_pass, n_len, device):
+        key = (B, n_pass, n_len, str(device))
+        plan = self._plans.get(key)
+        if plan is not None:
+            return plan
+        weights = self.weights if self.weights is not None else [1.0] * n_pass
+        assert len(weights) == n_pass
+        n_crit = len(self.crit)
+        acc_base = n_crit
+        ppl_base = n_crit + 2 * n_pass
+        coef, m_dst, m_src, m_scale, slots = [], [], [], [], []
+        t = 0
+        for ci, name in enumerate(self.crit):
+            if name == 'lang':
+                for i in range(n_pass):
+                    coef.append(self.scales[ci] * weights[i] / B)
+                    m_dst.append(ci); m_src.append(t * self._STRIDE); m_scale.append(weights[i])     # loss sum (li * B)
+                    m_dst += [acc_base + 2 * i, acc_base + 2 * i + 1]
+                    m_src += [t * self._STRIDE + 1, t * self._STRIDE + 2]; m_scale += [1.0, 1.0]
+                    if i == n_pass - 1:        # perplexity: the last pass that does not exclude <mask> labels
+                        m_dst += [ppl_base, ppl_base + 1]
+                        m_src += [t * self._STRIDE + 3, t * self._STRIDE + 4]; m_scale += [1.0, 1.0]
+                    slots.append(('lang', i, t))
+                    t += 1
+            elif name == 'length':
+                coef.append(self.scales[ci])
+                m_dst.append(ci); m_src.append(t * self._STRIDE); m_scale.append(float(n_len))
+                slots.append(('length', 0, t))
+                t += 1
+            else:
+                raise NotImplementedError('criterion %s' % name)
+        f = lambda v, dt: torch.tensor(v, dtype=dt, device=device)
+        plan = dict(n_terms=t, slots=slots, coef=f(coef, torch.float32), m_dst=f(m_dst, torch.int32),
+                    m_src=f(m_src, torch.int32), m_scale=f(m_scale, torch.float32), n_pass=n_pass,
+                    acc_base=acc_base, ppl_base=ppl_base)
+        self._plans[key] = plan
+        return plan
+
+    def _get_loss_fused(self, results):
+        hidden = results['_nacf_hidden']
+        pack, params = results['_nacf_vocab']
+        labels = results[Constants.mapping['lang'][1]]
+        n_pass = len(hidden)
+        if not isinstance(labels, (list, tuple)):
+            labels = [labels] * n_pass
+        dev = hidden[0].device
+        B = hidden[0].shape[0]
+        pred = results.get(Constants.mapping['length'][0]) if 'length' in self.crit else None
+        plan = self._fused_plan(B, n_pass, pred.shape[0] if pred is not None else 0, dev)
+        if self._meters is None:
+            self._meters = torch.zeros(plan['ppl_base'] + 2, dtype=torch.float32, device=dev)
+            self._meter_plan = plan
+        S = self._STRIDE
+        slab = torch.empty(plan['n_terms'] * S, dtype=torch.float32, device=dev)
+        terms = []
+        for kind, i, t in plan['slots']:
+            if kind == 'lang':
+                h, lab = hidden[i], labels[i].contiguous()
+                assert h.shape[1] == lab.shape[1]
+                terms.append(FusedVocabXentFn.apply(h.reshape(-1, h.shape[-1]), dict(pack=pack, out=slab[t * S:t * S + 5]),
+                                                    lab, (i == 0 and self.vw), *params))
+            else:
+                terms.append(KLDivMeanFn.apply(pred, results[Constants.mapping['length'][1]].to(pred.dtype),
+                                               slab[t * S:t * S + 1]))
+        for ci, name in enumerate(self.crit):
+            self._loss_cnt[ci] += B if name == 'lang' else pred.shape[0]
+        cfg = dict(slab=slab, stride=S, coef=plan['coef'], m_dst=plan['m_dst'], m_src=plan['m_src'],
+                   m_scale=plan['m_scale'], meters=self._meters)
+        return LossCombineFn.apply(cfg, *terms)
+
     def get_loss(self, results, **kwargs):
+        if '_nacf_hidden' in results and 'lang' in self.crit:
+            return self._get_loss_fused(results)
         total = None
         for i, name in enumerate(self.crit):
             if name == 'lang':
@@ -112,14 +194,24 @@ class Criterion(object):
 
     def get_loss_info(self):
         names = list(self.names)
-        info = [float(s) / max(c, 1) if s is not None else 0.0 for s, c in zip(self._loss_sum, self._loss_cnt)]
-        if self._acc is not None:
-            acc = self._acc.tolist()
+        sums = [float(s) if s is not None else 0.0 for s in self._loss_sum]
+        acc = self._acc.tolist() if self._acc is not None else None
+        ppl = self._ppl.tolist() if self._ppl is not None else None
+        if self._meters is not None:         # fused form: one read-back of the meter vector
+            m, pl = self._meters.tolist(), self._meter_plan
+            for ci in range(len(self.crit)):
+                sums[ci] += m[ci]
+            a = [[m[pl['acc_base'] + 2 * i], m[pl['acc_base'] + 2 * i + 1]] for i in range(pl['n_pass'])]
+            acc = a if acc is None else [[x[0] + y[0], x[1] + y[1]] for x, y in zip(acc, a)]
+            p = [m[pl['ppl_base']], m[pl['ppl_base'] + 1]]
+            ppl = p if ppl is None else [ppl[0] + p[0], ppl[1] + p[1]]
+        info = [s / max(c, 1) for s, c in zip(sums, self._loss_cnt)]
+        if acc is not None:
             for i, (h, c) in enumerate(acc):
                 names.append('Word Acc%d' % i)
                 info.append(h / c if c > 0 else 0.0)   # the reference divides by zero here
-        if self._ppl is not None:
-            s, c = self._ppl.tolist()
+        if ppl is not None:
+            s, c = ppl
             names.append('Perplexity')
             info.append(math.exp(-s / c) if c > 0 else float('nan'))
         return names, info

@@ -404,7 +404,9 @@ class FusedVocabXentFn(Function):
         label_logp = _new((rows,), h)
         argmax = _new((rows,), h, torch.int64)
         ops.vocab_logsoftmax_fwd(logits, V, labels, None, argmax, label_logp, skip_pad_rows=True)
-        stats = _new((5,), h)
+        stats = cfg.get("out")          # optional slot of the criterion's term slab (LossCombineFn)
+        if stats is None:
+            stats = _new((5,), h)
         ops.nll_reduce(label_logp, argmax, labels, exclude_mask, stats)
         ctx.cfg, ctx.h, ctx.logp, ctx.labels, ctx.live = cfg, h, logits, labels, live
         return stats
@@ -426,9 +428,10 @@ class KLDivMeanFn(Function):
     """legacy nn.KLDivLoss() ('mean' over all elements), misc/crit.py:223."""
 
     @staticmethod
-    def forward(ctx, x, t):
+    def forward(ctx, x, t, out=None):
         x, t = x.contiguous(), t.contiguous()
-        out = _new((1,), x)
+        if out is None:                 # else: a 1-element slot of the criterion's term slab (LossCombineFn)
+            out = _new((1,), x)
         ops.kldiv_mean(x, t, out, None)
         ctx.x, ctx.t = x, t
         return out.view(())
@@ -437,7 +440,36 @@ class KLDivMeanFn(Function):
     def backward(ctx, dout):
         dx = torch.empty_like(ctx.x)
         ops.kldiv_mean(ctx.x, ctx.t, None, dx, gscale=dout.reshape(1).contiguous())
-        return dx, None
+        return dx, None, None
+
+
+class LossCombineFn(Function):
+    """Criterion tail (misc/crit.py:40-45,107-121) in one launch each way: total = sum_t coef[t] * term_t[0], and the
+    running meters (loss sums, accuracy hits/counts, perplexity sums) accumulate in the same kernel.  The terms were
+    written by their producers straight into cfg['slab'] (slot t = slab[t*stride:(t+1)*stride])."""
+
+    @staticmethod
+    def forward(ctx, cfg, *terms):
+        slab, coef = cfg["slab"], cfg["coef"]
+        total = _new((1,), slab)
+        ops.loss_combine(slab, len(terms), cfg["stride"], coef, total, cfg.get("m_dst"), cfg.get("m_src"),
+                         cfg.get("m_scale"), cfg.get("meters"))
+        ctx.cfg, ctx.shapes = cfg, [t.shape for t in terms]
+        return total.view(())
+
+    @staticmethod
+    def backward(ctx, g):
+        cfg, stride = ctx.cfg, ctx.cfg["stride"]
+        n = len(ctx.shapes)
+        gslab = _new((n * stride,), cfg["slab"])
+        ops.loss_combine_bwd(g.reshape(1).contiguous(), cfg["coef"], n, stride, gslab)
+        grads = []
+        for t, shp in enumerate(ctx.shapes):
+            k = 1
+            for d in shp:
+                k *= d
+            grads.append(gslab[t * stride:t * stride + k].view(shp))
+        return (None,) + tuple(grads)
 
 
 class LayerNormFn(Function):

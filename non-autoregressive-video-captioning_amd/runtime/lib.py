@@ -52,6 +52,8 @@ SIGNATURES = {
     "nacf_gemm_config": (c_int, [_I, _I, _I, _I, _P, _P]),
     "nacf_linear_bwd_weight": (c_int, [_P, _L, _P, _L, _P, _L, _P, _I, _I, _I, _F, _P, _S, _RS, _P]),
     "nacf_epilogue_bwd": (c_int, [_P, _L, _P, _L, _P, _L, _I, _I, _I, _EP, _P]),
+    "nacf_loss_combine": (c_int, [_P, _I, _I, _P, _P, _P, _P, _P, _I, _P, _P]),
+    "nacf_loss_combine_bwd": (c_int, [_P, _P, _I, _I, _P, _P]),
     "nacf_highway_mix_fwd": (c_int, [_P, _P, _P, _I, _I, _F, _U, _P, _P]),
     "nacf_highway_mix_bwd": (c_int, [_P, _P, _P, _P, _P, _I, _I, _F, _U, _P, _P]),
     "nacf_bn_workspace": (_S, [_I, _I]),

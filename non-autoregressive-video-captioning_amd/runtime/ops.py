@@ -226,6 +226,18 @@ def linear_bwd_weight(dz: Tensor, x: Tensor, dw: Tensor, db: Optional[Tensor], b
     PROFILER.end(tok)
 
 
+def loss_combine(slab: Tensor, n_terms: int, stride: int, coef: Tensor, total: Tensor, m_dst: Optional[Tensor],
+                 m_src: Optional[Tensor], m_scale: Optional[Tensor], meters: Optional[Tensor]) -> None:
+    n_m = 0 if m_dst is None else m_dst.numel()
+    L.check(L.load().nacf_loss_combine(_ptr(slab), n_terms, stride, _ptr(coef), _ptr(total), _ptr(m_dst), _ptr(m_src),
+                                       _ptr(m_scale), n_m, _ptr(meters), _stream()), "nacf_loss_combine")
+
+
+def loss_combine_bwd(gtotal: Tensor, coef: Tensor, n_terms: int, stride: int, gslab: Tensor) -> None:
+    L.check(L.load().nacf_loss_combine_bwd(_ptr(gtotal), _ptr(coef), n_terms, stride, _ptr(gslab), _stream()),
+            "nacf_loss_combine_bwd")
+
+
 def epilogue_bwd(dy: Tensor, dz: Tensor, dr: Optional[Tensor], epi: Epi, accumulate_dr: bool = False) -> None:
     _chk_f32(dy, dz, dr)
     M, N, lddy = _rows2d(dy)
