@@ -19,7 +19,7 @@ import torch
 import torch.nn as nn
 
 from ..runtime import ops
-from ..runtime.functional import MeanTimeFn
+from ..runtime.functional import HalvesFn, MeanTimeFn
 from .bert import BertEmbeddings, BertLayer
 
 __all__ = ('BertDecoder', 'BertDecoderDisentangled')
@@ -171,5 +171,6 @@ class BertDecoderDisentangled(nn.Module):
             both = torch.cat([tgt_seq[0], tgt_seq[1]], dim=0)
             kwargs = dict(kwargs, row_map=('mod', enc_output.shape[0]))
             hidden, embs = self.forward_(both, enc_output, category, **kwargs)[:2]
-            return ([hidden[:B], hidden[B:]], embs[B:],)
+            h0, h1 = HalvesFn.apply(hidden)
+            return ([h0, h1], embs[B:],)
         return self.forward_(tgt_seq, enc_output, category, **kwargs)

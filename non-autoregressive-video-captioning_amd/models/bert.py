@@ -17,6 +17,7 @@ eight launches-with-fused-epilogues on the MI355X:
 Reference quirks kept: mask fill is -1e7 (not -inf); scaling happens after
 QK^T; PAD *queries* are not masked, their rows are zeroed by non_pad_mask.
 """
+import torch
 import torch.nn as nn
 
 from ..config import Constants
@@ -162,17 +163,22 @@ class BertLayer(nn.Module):
         s = self._salts
         if self.with_layernorm:
             return self._run_layernorm(x2, tokens, causal, memory_kv, M, vdiv, vmod, training, want_probs, rows)
-        qkv = LinearFn.apply(x2, None, dict(pack=pk['qkv'], rows=rows), *P)
+        # each block input (x2, a, c) feeds a Linear AND the residual add of the block's output Linear.  The output
+        # Linear's backward runs first (it is downstream), parks its residual gradient in h*, and the input Linear's
+        # dX GEMM accumulates onto it (LinearFn: res_sink / dx_acc) -- only wired when both gradients will exist.
+        link = torch.is_grad_enabled() and x2.requires_grad
+        h1, h2, h3 = ({}, {}, {}) if link else (None, None, None)
+        qkv = LinearFn.apply(x2, None, dict(pack=pk['qkv'], rows=rows, dx_acc=h1), *P)
         att, p_self = SelfAttentionFn.apply(qkv, tokens, int(causal), self.H, want_probs)
         a = LinearFn.apply(att, x2, dict(pack=pk['so'], p1=self.p, salt1=s[0], row_tokens=tok_flat, rng=rng,
-                                         training=training, rows=rows), *P)
-        q = LinearFn.apply(a, None, dict(pack=pk['cq'], rows=rows), *P)
+                                         training=training, rows=rows, res_sink=h1), *P)
+        q = LinearFn.apply(a, None, dict(pack=pk['cq'], rows=rows, dx_acc=h2), *P)
         catt, p_cross = CrossAttentionFn.apply(q, memory_kv, self.H, Lq, M, vdiv, vmod, want_probs)
         c = LinearFn.apply(catt, a, dict(pack=pk['co'], p1=self.p, salt1=s[1], row_tokens=tok_flat, rng=rng,
-                                         training=training, rows=rows), *P)
-        u = LinearFn.apply(c, None, dict(pack=pk['f1'], act=self.act, rows=rows), *P)
+                                         training=training, rows=rows, res_sink=h2), *P)
+        u = LinearFn.apply(c, None, dict(pack=pk['f1'], act=self.act, rows=rows, dx_acc=h3), *P)
         y = LinearFn.apply(u, c, dict(pack=pk['f2'], p1=self.p, salt1=s[2], p2=self.p, salt2=s[3], row_tokens=tok_flat,
-                                      rng=rng, training=training, rows=rows), *P)
+                                      rng=rng, training=training, rows=rows, res_sink=h3), *P)
         return y, (p_self, p_cross)
 
     def _run_layernorm(self, x2, tokens, causal, memory_kv, M, vdiv, vmod, training, want_probs, rows):

@@ -269,14 +269,48 @@ class LinearFn(Function):
             epi.residual = None
         dx = None
         rows = ctx.rows
+        # residual-gradient hand-over (cfg['res_sink'] / cfg['dx_acc'], see BertLayer.run): when x feeds both this
+        # Linear and the residual input of a LATER Linear, that one parks its residual gradient in the shared holder
+        # and this dX GEMM accumulates onto it (beta = 1): no separate gradient-add kernel, x gets the sum.
+        sink = cfg.get("res_sink")
+        if sink is not None and dr is not None and ctx.needs_input_grad[1]:
+            sink["dr"] = dr
+            dr = None
+        acc = cfg.get("dx_acc")
         if ctx.needs_input_grad[0]:
-            dx = _new((M, K), dy)
-            ops.linear_bwd_data(dz, pk.w, dx, rows=rows, zero_dead=True)
+            parked = acc.pop("dr", None) if acc is not None else None
+            if parked is not None:
+                dx = parked
+                ops.linear_bwd_data(dz, pk.w, dx, beta=1.0, rows=rows)
+            else:
+                dx = _new((M, K), dy)
+                ops.linear_bwd_data(dz, pk.w, dx, rows=rows, zero_dead=True)
         if pk.gw is not None:
             ops.linear_bwd_weight(dz, ctx.x, pk.gw, pk.gb, beta=1.0, rows=rows)
         ctx.x = None
         epi.preact = None
         return (dx, dr if ctx.needs_input_grad[1] else None, None) + (None,) * (len(ctx.needs_input_grad) - 3)
+
+
+class HalvesFn(Function):
+    """x[2B, ...] -> (x[:B], x[B:]) (the two decoding passes that were batched into one set of rows).  Backward
+    writes both gradients into ONE buffer; plain slicing costs two zero-fills, two copies and an add."""
+
+    @staticmethod
+    def forward(ctx, x):
+        B = x.shape[0] // 2
+        ctx.shape = x.shape
+        return x[:B], x[B:]
+
+    @staticmethod
+    def backward(ctx, g0, g1):
+        B = ctx.shape[0] // 2
+        g = torch.empty(ctx.shape, dtype=(g0 if g0 is not None else g1).dtype, device=(g0 if g0 is not None else g1).device)
+        if g0 is not None: g[:B].copy_(g0)
+        else: g[:B].zero_()
+        if g1 is not None: g[B:].copy_(g1)
+        else: g[B:].zero_()
+        return g
 
 
 class SelfAttentionFn(Function):
