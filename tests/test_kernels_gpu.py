@@ -747,3 +747,28 @@ def test_layernorm_dropout_mask_replays_in_backward(dev):
     dx, dw, db = torch.empty(rows, D, device=dev), torch.zeros(D, device=dev), torch.zeros(D, device=dev)
     ops.layernorm_bwd(torch.ones(rows, D, device=dev), xhat, rstd, w, dx, dw, db, rows, rows, 0, p, 9, rng, None)
     assert err(dx, xr.grad) < 5e-5
+
+
+def test_loss_combine_fwd_bwd(dev):
+    """criterion tail: weighted total + meter accumulation in one launch, and its gradient slab"""
+    ops, _ = _ops()
+    S, n = 8, 3
+    slab = rnd(n * S, seed=1).to(dev)
+    coef = torch.tensor([0.25, 1.5, -2.0], device=dev)
+    total = torch.empty(1, device=dev)
+    m_dst = torch.tensor([0, 0, 1, 2, 3], dtype=torch.int32, device=dev)
+    m_src = torch.tensor([0, S, 1, 2, 2 * S], dtype=torch.int32, device=dev)
+    m_scale = torch.tensor([0.8, 1.0, 1.0, 1.0, 64.0], device=dev)
+    meters = torch.tensor([10.0, 20.0, 30.0, 40.0], device=dev)
+    ops.loss_combine(slab, n, S, coef, total, m_dst, m_src, m_scale, meters)
+    sl = slab.cpu().double()
+    assert abs(float(total) - float(0.25 * sl[0] + 1.5 * sl[S] - 2.0 * sl[2 * S])) < 1e-6
+    want = [10 + 0.8 * sl[0] + sl[S], 20 + sl[1], 30 + sl[2], 40 + 64 * sl[2 * S]]
+    assert err(meters, torch.tensor([float(w) for w in want])) < 1e-5
+    ops.loss_combine(slab, n, S, coef, total, None, None, None, None)      # no meter table
+    g = torch.tensor([3.0], device=dev)
+    gslab = torch.full((n * S,), float("nan"), device=dev)
+    ops.loss_combine_bwd(g, coef, n, S, gslab)
+    ref = torch.zeros(n * S)
+    ref[0], ref[S], ref[2 * S] = 0.75, 4.5, -6.0
+    assert torch.equal(gslab.cpu(), ref)
