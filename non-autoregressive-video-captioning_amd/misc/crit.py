@@ -19,7 +19,7 @@ import math
 import torch
 
 from ..config import Constants
-from ..runtime.functional import FusedVocabXentFn, KLDivMeanFn, LossCombineFn
+from ..runtime.functional import FusedVocabXentFn, FusedVocabXentMultiFn, KLDivMeanFn, LossCombineFn
 
 
 class Criterion(object):
@@ -154,8 +154,18 @@ class Criterion(object):
         S = self._STRIDE
         slab = torch.empty(plan['n_terms'] * S, dtype=torch.float32, device=dev)
         terms = []
+        both = getattr(hidden, 'both', None)      # the passes are halves of one tensor: project them in one go
+        lang_terms = None
+        if both is not None and all(labels[i].shape == labels[0].shape for i in range(n_pass)):
+            lang_slots = [t for kind, _, t in plan['slots'] if kind == 'lang']
+            lab_all = torch.cat([labels[i].reshape(-1) for i in range(n_pass)])
+            lang_terms = FusedVocabXentMultiFn.apply(
+                both.reshape(-1, both.shape[-1]), dict(pack=pack, outs=[slab[t * S:t * S + 5] for t in lang_slots]),
+                lab_all, tuple((i == 0 and self.vw) for i in range(n_pass)), *params)
         for kind, i, t in plan['slots']:
-            if kind == 'lang':
+            if kind == 'lang' and lang_terms is not None:
+                terms.append(lang_terms[i])
+            elif kind == 'lang':
                 h, lab = hidden[i], labels[i].contiguous()
                 assert h.shape[1] == lab.shape[1]
                 terms.append(FusedVocabXentFn.apply(h.reshape(-1, h.shape[-1]), dict(pack=pack, out=slab[t * S:t * S + 5]),

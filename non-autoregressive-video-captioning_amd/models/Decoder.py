@@ -19,7 +19,7 @@ import torch
 import torch.nn as nn
 
 from ..runtime import ops
-from ..runtime.functional import HalvesFn, MeanTimeFn
+from ..runtime.functional import BatchedPasses, HalvesFn, MeanTimeFn
 from .bert import BertEmbeddings, BertLayer
 
 __all__ = ('BertDecoder', 'BertDecoderDisentangled')
@@ -172,5 +172,5 @@ class BertDecoderDisentangled(nn.Module):
             kwargs = dict(kwargs, row_map=('mod', enc_output.shape[0]))
             hidden, embs = self.forward_(both, enc_output, category, **kwargs)[:2]
             h0, h1 = HalvesFn.apply(hidden)
-            return ([h0, h1], embs[B:],)
+            return (BatchedPasses([h0, h1], hidden), embs[B:],)
         return self.forward_(tgt_seq, enc_output, category, **kwargs)

@@ -458,6 +458,64 @@ class FusedVocabXentFn(Function):
         return (dh, None, None, None) + (None,) * (len(ctx.needs_input_grad) - 4)
 
 
+class BatchedPasses(list):
+    """[pass0 hidden, pass1 hidden] that are the two halves of ONE [2B, L, D] tensor (`.both`): consumers that can
+    work on the batch (the fused vocabulary loss) take `.both`, everything else sees a plain list."""
+
+    def __init__(self, parts, both):
+        super().__init__(parts)
+        self.both = both
+
+
+class FusedVocabXentMultiFn(Function):
+    """FusedVocabXentFn over several passes that share tgt_word_prj and sit back to back in one [S*rows, D]
+    tensor: ONE projection GEMM, one log-softmax, one dX and one dW GEMM for all of them (the two NACF passes
+    are 821 + 1490 live rows at B=128: one launch has fewer ragged tiles than two).  Per-pass statistics and
+    per-pass upstream gradients are kept apart by row range.  cfg: pack, outs (optional slab slots)."""
+
+    @staticmethod
+    def forward(ctx, h, cfg, labels, excludes, *params):
+        pk: Pack = cfg["pack"]
+        rows, D = h.shape
+        S = len(excludes)
+        rp = rows // S
+        V = pk.w.shape[0]
+        h = _c2d(h, rows, D)
+        labels = labels.reshape(-1).contiguous()
+        live = ops.rowset_build(tokens=labels)
+        buf = _new((rows, ops.vocab_ld(V)), h)
+        logits = buf[:, :V]
+        ops.linear_fwd(h, pk.w, logits, ops.Epi(bias=pk.b), live)
+        label_logp = _new((rows,), h)
+        argmax = _new((rows,), h, torch.int64)
+        ops.vocab_logsoftmax_fwd(logits, V, labels, None, argmax, label_logp, skip_pad_rows=True)
+        outs = cfg.get("outs")
+        stats = []
+        for i in range(S):
+            st = outs[i] if outs is not None else _new((5,), h)
+            sl = slice(i * rp, (i + 1) * rp)
+            ops.nll_reduce(label_logp[sl], argmax[sl], labels[sl], excludes[i], st)
+            stats.append(st)
+        ctx.cfg, ctx.h, ctx.logp, ctx.labels, ctx.live, ctx.S = cfg, h, logits, labels, live, S
+        return tuple(stats)
+
+    @staticmethod
+    def backward(ctx, *dstats):
+        pk: Pack = ctx.cfg["pack"]
+        rows, V = ctx.logp.shape
+        rp = rows // ctx.S
+        for i, g in enumerate(dstats):
+            sl = slice(i * rp, (i + 1) * rp)
+            if g is None:
+                g = torch.zeros(5, dtype=ctx.logp.dtype, device=ctx.logp.device)
+            ops.xent_bwd(ctx.logp[sl], ctx.logp[sl], V, ctx.labels[sl], g.contiguous(), 1.0, skip_pad_rows=True)
+        dh = torch.empty_like(ctx.h)
+        ops.linear_bwd_data(ctx.logp, pk.w, dh, rows=ctx.live, zero_dead=True)
+        ops.linear_bwd_weight(ctx.logp, ctx.h, pk.gw, pk.gb, beta=1.0, rows=ctx.live)
+        ctx.h = ctx.logp = ctx.live = None
+        return (dh, None, None, None) + (None,) * (len(ctx.needs_input_grad) - 4)
+
+
 class KLDivMeanFn(Function):
     """legacy nn.KLDivLoss() ('mean' over all elements), misc/crit.py:223."""
 
