@@ -100,17 +100,17 @@ typedef struct nacf_epilogue {
  * (gathering operands / scattering results through the list; dW reduces over them) and tiles
  * beyond `count` do no arithmetic.  Buffers keep their dense layout, shapes stay static, the host
  * never reads the count (hipGraph-safe).  NULL = all rows.
- * Rows outside the list: nacf_rowset_build also lists them, after the live ones (rows[count .. n)),
+ * Rows outside the list: nacf_rowset_build also lists them, after the live ones (rows[count .. n), any order),
  * and a call made with zero_dead != 0 has the otherwise idle workgroups of the dead row tiles write
  * zeros to those rows of the outputs (Y and preact of linear_fwd, dX of linear_bwd_data), so the
  * output is fully defined without a separate memset.  With zero_dead == 0 dead rows are left untouched. */
 typedef struct nacf_rowset {
-  const int32_t* rows;   /* [n_slots]: count live slot indices ascending, then the dead ones ascending */
+  const int32_t* rows;   /* [n_slots]: count live slot indices ascending, then the dead ones (any order) */
   const int32_t* count;  /* device int32[1] */
   int32_t zero_dead;     /* != 0: zero the dead rows of the outputs (requires rows from nacf_rowset_build) */
 } nacf_rowset;
 /* live = { i : (tokens == NULL || tokens[i] != PAD) && (flags == NULL || flags[i] != 0) }:
- * rows[0 .. count) = live ascending, rows[count .. n) = the rest ascending, count[0] = |live| */
+ * rows[0 .. count) = live ascending, rows[count .. n) = the rest (descending), count[0] = |live| */
 int nacf_rowset_build(const int64_t* tokens, const uint8_t* flags, int64_t n, int32_t* rows,
                       int32_t* count, nacf_stream_t stream);
 

@@ -145,8 +145,9 @@ __global__ void argmax_merge_kernel(const float* __restrict__ pmax, const float*
   }
 }
 
-// stable partition: rows[0..count) = ascending i with (tokens ? tokens[i] != PAD) && (flags ? flags[i] != 0),
-// rows[count..n) = the other slots, ascending; one workgroup, two sweeps
+// partition: rows[0..count) = ascending i with (tokens ? tokens[i] != PAD) && (flags ? flags[i] != 0); the other
+// slots fill rows[count..n) from the END (so they come out descending -- their order is irrelevant, the GEMMs only
+// zero-fill them).  One workgroup, ONE sweep, 4 consecutive slots per thread, wave scans by shuffle.
 __global__ __launch_bounds__(1024) void rowset_build_kernel(const int64_t* __restrict__ tokens,
                                                              const uint8_t* __restrict__ flags, int n,
                                                              int* __restrict__ rows, int* __restrict__ count) {
@@ -155,30 +156,47 @@ __global__ __launch_bounds__(1024) void rowset_build_kernel(const int64_t* __res
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   if (threadIdx.x == 0) base_s = 0;
   __syncthreads();
-  for (int pass = 0; pass < 2; ++pass) {
-    for (int c0 = 0; c0 < n; c0 += 1024) {
-      const int i = c0 + threadIdx.x;
-      bool live = i < n;
-      if (live && tokens) live = tokens[i] != NACF_PAD;
-      if (live && flags) live = flags[i] != 0;
-      const bool take = (i < n) && (pass == 0 ? live : !live);
-      const unsigned long long bal = __ballot(take);
-      const int pre = __popcll(bal & ((1ull << lane) - 1ull));
-      if (lane == 0) wsum[wave] = __popcll(bal);
-      __syncthreads();
-      int off = base_s;
-      for (int w = 0; w < wave; ++w) off += wsum[w];
-      if (take) rows[off + pre] = i;
-      __syncthreads();
-      if (threadIdx.x == 0) {
-        int t = 0;
-        for (int w = 0; w < 16; ++w) t += wsum[w];
-        base_s += t;
-      }
-      __syncthreads();
+  for (int c0 = 0; c0 < n; c0 += 4096) {
+    const int i0 = c0 + threadIdx.x * 4;
+    bool live[4];
+    int c = 0;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int i = i0 + e;
+      bool l = i < n;
+      if (l && tokens) l = tokens[i] != NACF_PAD;
+      if (l && flags) l = flags[i] != 0;
+      live[e] = l;
+      c += l ? 1 : 0;
     }
-    if (pass == 0 && threadIdx.x == 0) count[0] = base_s;
+    int incl = c;                       // inclusive scan of the per-thread live counts inside the wave
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const int t = __shfl_up(incl, o, 64);
+      if (lane >= o) incl += t;
+    }
+    if (lane == 63) wsum[wave] = incl;
+    __syncthreads();
+    int off = base_s;
+    for (int w = 0; w < wave; ++w) off += wsum[w];
+    int lpos = off + incl - c;          // live slots before this thread's first element
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int i = i0 + e;
+      if (i < n) {
+        if (live[e]) rows[lpos++] = i;
+        else rows[n - 1 - (i - lpos)] = i;     // i - lpos = dead slots before i
+      }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      int t = 0;
+      for (int w = 0; w < 16; ++w) t += wsum[w];
+      base_s += t;
+    }
+    __syncthreads();
   }
+  if (threadIdx.x == 0) count[0] = base_s;
 }
 
 }  // namespace
