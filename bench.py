@@ -64,8 +64,12 @@ def main():
     assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    # NACF_BENCH_FORCE_DIST=1: run the N>1 code path (staged backward, bucketed RCCL all-reduce on its own stream,
+    # separate Adam graph) with a 1-rank process group -- the mechanics can be exercised on a 1-GPU box
+    force_dist = os.environ.get("NACF_BENCH_FORCE_DIST") == "1"
+    if world > 1 or force_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29531")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     import nacf_amd
@@ -82,8 +86,9 @@ def main():
     model = nacf_amd.get_model(opt)
     model.load_state_dict({k: v.clone() for k, v in sd.items()})
     model.to(dev).train()
-    ddp = DataParallel(model)
+    ddp = DataParallel(model, force_collectives=force_dist)
     ddp.broadcast_parameters()
+    multi = world > 1 or force_dist
     crit = get_criterion(model.opt)
     optim = get_optimizer(model.opt, model)
     n_params = sum(p.numel() for p in model.parameters())
@@ -106,9 +111,38 @@ def main():
         loss.backward()
         loss_buf.copy_(loss.detach())
 
+    # N > 1: backward in two stages so the decoder-side gradient bucket (61 of 74 MB) is all-reduced while the
+    # encoder's backward still runs (runtime/ddp.py)
+    staged = multi and ddp.bucket_split() is not None
+    hold = {}
+
+    def stage1():
+        optim.zero_grad()
+        res = model(feats=feats, tgt_tokens=tokens, category=category)
+        res["tgt_word_labels"] = labels
+        res["tgt_length"] = tgt_length
+        loss = crit.get_loss(res)
+        hold["cut"], hold["grads"] = ddp.backward_to_cut(loss)
+        loss_buf.copy_(loss.detach())
+
+    def stage2():
+        ddp.backward_from_cut(hold["cut"], hold["grads"])
+
+    def reduce_and_wait(after_stage2):
+        w1 = ddp.all_reduce_bucket(0)
+        after_stage2()
+        w2 = ddp.all_reduce_bucket(1)
+        for w in (w1, w2):
+            if w is not None:
+                w.wait()
+
     def step_eager():
-        fwd_bwd()
-        ddp.all_reduce_gradients()
+        if staged:
+            stage1()
+            reduce_and_wait(stage2)
+        else:
+            fwd_bwd()
+            ddp.all_reduce_gradients()
         optim.step(grad_scale=ddp.grad_scale)
 
     for _ in range(max(args.warmup, 2)):          # untimed warm-up (also grows workspaces before capture)
@@ -116,7 +150,7 @@ def main():
     torch.cuda.synchronize()
 
     use_graph = args.graph != "off"
-    g_main = g_opt = None
+    g_main = g_enc = g_opt = None
     if use_graph:
         try:
             side = torch.cuda.Stream()
@@ -124,12 +158,20 @@ def main():
             with torch.cuda.stream(side):
                 g_main = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(g_main, stream=side):
-                    fwd_bwd()
-                    if world == 1:
-                        optim.step(grad_scale=1.0)
-                if world > 1:
+                    if staged:
+                        stage1()
+                    else:
+                        fwd_bwd()
+                        if not multi:
+                            optim.step(grad_scale=1.0)
+                if staged:      # second half of backward: same memory pool, the autograd graph is still alive
+                    g_enc = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(g_enc, stream=side, pool=g_main.pool()):
+                        stage2()
+                    hold.clear()
+                if multi:
                     g_opt = torch.cuda.CUDAGraph()
-                    with torch.cuda.graph(g_opt, stream=side):
+                    with torch.cuda.graph(g_opt, stream=side, pool=g_main.pool()):
                         optim.step(grad_scale=ddp.grad_scale)
             torch.cuda.current_stream().wait_stream(side)
             torch.cuda.synchronize()
@@ -138,7 +180,8 @@ def main():
                 raise
             print("[bench] hipGraph capture failed (%s: %s); timing eager launches" % (type(e).__name__, e),
                   file=sys.stderr)
-            g_main = g_opt = None
+            g_main = g_enc = g_opt = None
+            hold.clear()
             use_graph = False
             torch.cuda.synchronize()
 
@@ -147,7 +190,10 @@ def main():
             step_eager()
         else:
             g_main.replay()
-            if world > 1:
+            if staged:
+                reduce_and_wait(g_enc.replay)
+                g_opt.replay()
+            elif multi:
                 ddp.all_reduce_gradients()
                 g_opt.replay()
 
@@ -155,7 +201,7 @@ def main():
         step()
 
     def barrier():
-        if world > 1:
+        if multi:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -165,7 +211,7 @@ def main():
         step()
     barrier()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if multi:
         tt = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt)
@@ -300,15 +346,23 @@ def main():
                "config": {"workload": "NACF train step, MSRVTT-shape (configs[2]/[3]): %d videos/GPU, 2x60x2048 fp32 "
                                       "feats, seq_len %d, V=%d, dropout 0.5, Adam" % (B, L, V),
                           "global_batch": B * world, "seq_len": L, "vocab": V, "params": n_params,
-                          "parallelism": "dp%d" % world, "hipgraph": bool(use_graph), "live_row_gemms": True},
+                          "parallelism": "dp%d" % world, "hipgraph": bool(use_graph), "live_row_gemms": True,
+                          "overlapped_allreduce": bool(staged)},
                "roofline": roofline, "cpu_baseline": cpu, "decode": decode, "config5_ar_vs_na": compare,
                "final_loss": round(final_loss, 4),
                "gemm_kernels": gemm_table}
-    if world > 1:
+    if multi:
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
-        print(json.dumps(out))
+        # RCCL writes a version banner to the C-level stdout; flush it first so the JSON line is the LAST line
+        import ctypes
+        sys.stdout.flush()
+        try:
+            ctypes.CDLL(None).fflush(None)
+        except OSError:
+            pass
+        print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":

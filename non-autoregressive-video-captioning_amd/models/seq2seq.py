@@ -66,6 +66,12 @@ class Seq2Seq(nn.Module):
         self._flatten()  # .to()/.cuda() re-homes the tensors: rebuild the flat views on the new device
         return out
 
+    def late_parameters(self):
+        """parameters whose gradients are complete once backward has reached the encoder output
+        (length head + decoder + vocabulary projection): the first bucket of the overlapped all-reduce"""
+        aux = list(self.auxiliary_task_predictor.parameters()) if self.auxiliary_task_predictor is not None else []
+        return aux + list(self.decoder.parameters()) + list(self.tgt_word_prj.parameters())
+
     def zero_grad(self, set_to_none=False):
         self.flat.attach_grads(zero=True)
 
@@ -121,6 +127,12 @@ class Seq2Seq(nn.Module):
             self.rt.rng(feats[0].device)
             self.rt.advance()
         results = self.encode(feats)
+        if self.training:
+            # the encoder/decoder boundary, for the staged backward of runtime/ddp.py: every path from the loss to an
+            # encoder / fusion parameter goes through enc_output (the pooled memory and the length head hang off it),
+            # so the gradients of everything downstream are complete before the encoder's backward starts
+            eo = results['enc_output']
+            self._cut = [t for t in (eo if isinstance(eo, (list, tuple)) else [eo]) if t.requires_grad]
         inputs_for_decoder = self.prepare_inputs_for_decoder(results, category)
         hidden_states, embs, *_ = self.decoder(tgt_tokens, decoding_type=decoding_type,
                                                pooled_memory=results['_pooled_memory'], **inputs_for_decoder)

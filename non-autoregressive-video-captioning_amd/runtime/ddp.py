@@ -10,6 +10,12 @@ clip(+-5) follows the reduce exactly as misc/run.py:258-261 orders them.
 Per-rank losses are normalised by the LOCAL batch (misc/crit.py:40), so the
 mean of rank gradients equals the global-batch gradient.  BatchNorm statistics
 are per-rank (documented deviation; the fusion layer sees 7 680 rows per rank).
+
+Overlap: the flat buffer is laid out encoder | fusion | length head | decoder | vocabulary projection, and backward
+finishes the decoder side first.  `backward_to_cut` / `backward_from_cut` split the backward pass at the encoder
+outputs; the all-reduce of the decoder-side bucket (61 of 74 MB) is launched between the two and runs on
+torch.distributed's own stream while the encoder's backward (~1 ms of GEMMs) executes.  xGMI is point-to-point, so
+at 2 GPUs a 74 MB ring step crosses ONE link: hiding it matters most at small N.
 """
 import torch
 import torch.distributed as dist
@@ -23,18 +29,20 @@ def shard_range(global_batch: int, rank: int, world: int):
 
 
 class DataParallel(object):
-    def __init__(self, model, process_group=None):
+    def __init__(self, model, process_group=None, force_collectives=False):
         self.model = model
         self.group = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(process_group) if dist.is_initialized() else 0
+        # issue the collectives even for a 1-rank group (exercises the N>1 launch sequence on one GPU)
+        self.force = bool(force_collectives) and dist.is_initialized()
 
     @property
     def grad_scale(self):
         return 1.0 / self.world
 
     def broadcast_parameters(self, src=0):
-        if self.world == 1:
+        if self.world == 1 and not self.force:
             return
         dist.broadcast(self.model.flat.data, src, group=self.group)
         for b in self.model.buffers():
@@ -42,6 +50,45 @@ class DataParallel(object):
 
     def all_reduce_gradients(self):
         """sum-all-reduce of the single flat gradient bucket"""
-        if self.world == 1:
+        if self.world == 1 and not self.force:
             return
         dist.all_reduce(self.model.flat.grad, op=dist.ReduceOp.SUM, group=self.group)
+
+    # ---- overlapped variant: two buckets, the big one travels while the encoder's backward still runs ----
+    def bucket_split(self):
+        """Offset `s` such that flat.grad[s:] holds exactly the gradients of model.late_parameters() (decoder +
+        vocabulary projection, ~80 % of the bytes) and flat.grad[:s] the rest (encoder, fusion, length head);
+        None when the flat layout does not separate them."""
+        flat = self.model.flat
+        late = {id(p) for p in self.model.late_parameters()}
+        lo = min(flat.offset[i] for i in late)
+        for p in flat.params:
+            if (flat.offset[id(p)] >= lo) != (id(p) in late):
+                return None
+        return lo
+
+    def backward_to_cut(self, loss):
+        """Stage 1: backward from the loss down to the encoder outputs (model._cut).  The decoder-side parameters are
+        listed as inputs too so that every Function that only leads to parameters (e.g. an embedding lookup) still
+        runs -- the kernels write parameter gradients as a side effect and return None for them."""
+        cut = list(self.model._cut)
+        late = [p for p in self.model.late_parameters() if p.requires_grad]
+        grads = torch.autograd.grad(loss, cut + late, allow_unused=True)
+        return cut, list(grads[:len(cut)])
+
+    @staticmethod
+    def backward_from_cut(cut, grads):
+        """Stage 2: the encoder side."""
+        pairs = [(t, g) for t, g in zip(cut, grads) if g is not None]
+        torch.autograd.backward([t for t, _ in pairs], [g for _, g in pairs])
+
+    def all_reduce_bucket(self, which, async_op=True):
+        """which = 0: flat.grad[split:] (complete after stage 1), 1: flat.grad[:split].  Returns the Work handle
+        (None for a single process): torch.distributed runs it on its own stream, ordered after the work already
+        queued on the current stream, so the caller can keep launching stage 2."""
+        if self.world == 1 and not self.force:
+            return None
+        s = self.bucket_split()
+        g = self.model.flat.grad
+        view = g[s:] if which == 0 else g[:s]
+        return dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group, async_op=async_op)

@@ -58,12 +58,25 @@ def _worker(rank, world, port, out):
         p.grad.copy_(g[k])                               # local gradients land in the flat bucket
     ddp.all_reduce_gradients()
     reduced = {k: p.grad.clone() * ddp.grad_scale for k, p in model.named_parameters()}
+    # the overlapped variant: two buckets (decoder side first), together they must equal the single bucket
+    one_bucket = model.flat.grad.clone()
+    model.zero_grad()
+    for k, p in model.named_parameters():
+        p.grad.copy_(g[k])
+    split = ddp.bucket_split()
+    late = {id(p) for p in model.late_parameters()}
+    layout_ok = (split is not None and 0 < split < model.flat.total and
+                 all((model.flat.offset[id(p)] >= split) == (id(p) in late) for p in model.flat.params))
+    works = [ddp.all_reduce_bucket(0), ddp.all_reduce_bucket(1)]
+    for w in works:
+        w.wait()
+    buckets_ok = bool(torch.equal(model.flat.grad, one_bucket)) and layout_ok
     if rank == 0:
         full = _grads(sd, opt, batch, 0, G)
         err = max(float((reduced[k] - full[k]).abs().max()) for k in full)
-        out.put((same, (lo, hi), err))
+        out.put((same and buckets_ok, (lo, hi), err))
     else:
-        out.put((same, (lo, hi), 0.0))
+        out.put((same and buckets_ok, (lo, hi), 0.0))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -79,7 +92,7 @@ def test_two_rank_gloo_allreduce_equals_global_batch_gradient():
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    assert all(r[0] for r in res), "broadcast did not make the replicas identical"
+    assert all(r[0] for r in res), "replicas differ after broadcast, or the two-bucket all-reduce != the single bucket"
     assert sorted(r[1] for r in res) == [(0, 4), (4, 8)]
     assert max(r[2] for r in res) < 2e-6
 

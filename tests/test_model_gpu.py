@@ -264,3 +264,42 @@ def test_dropout_training_step_is_finite_and_replayable(dev):
         assert torch.isfinite(loss) and torch.isfinite(model.flat.grad).all()
         grads.append(model.flat.grad.clone())
     assert torch.equal(grads[0], grads[1])
+
+
+def test_staged_backward_matches_single_pass(dev):
+    """runtime/ddp.py: backward split at the encoder outputs (the overlap point of the bucketed all-reduce)
+    leaves the same gradients in the flat buffer as loss.backward(), and the flat layout separates the buckets"""
+    import nacf_amd
+    from nacf_amd.misc.crit import get_criterion
+    from nacf_amd.runtime.ddp import DataParallel
+    from nacf_amd import synthetic as S
+    g = load_gold("tiny_nacf_train")
+    opt = dict(gold_opt(g), fused_loss=True)
+    b = gold_batch(g)
+    grads = []
+    for staged in (False, True):
+        model = nacf_amd.get_model(opt)
+        model.load_state_dict(S.init_state_dict(opt, seed=0))
+        model.to(dev).train()
+        crit = get_criterion(model.opt)
+        ddp = DataParallel(model)
+        model.zero_grad()
+        res = model(feats=[f.to(dev) for f in b["feats"]], tgt_tokens=[b["tokens_1"].to(dev), b["tokens"].to(dev)],
+                    category=b["category"].to(dev))
+        res["tgt_word_labels"] = [b["labels_1"].to(dev), b["labels"].to(dev)]
+        res["tgt_length"] = b["tgt_length"].to(dev)
+        loss = crit.get_loss(res)
+        if staged:
+            split = ddp.bucket_split()
+            assert split is not None and 0 < split < model.flat.total
+            cut, gr = ddp.backward_to_cut(loss)
+            late = model.flat.grad[split:].clone()
+            early_before = float(model.flat.grad[:split].abs().max())
+            ddp.backward_from_cut(cut, gr)
+            assert early_before == 0.0                                    # stage 1 left the encoder side untouched
+            assert torch.equal(late, model.flat.grad[split:])             # stage 2 left the decoder side untouched
+        else:
+            loss.backward()
+        grads.append(model.flat.grad.clone())
+    assert float(grads[0].abs().max()) > 0
+    assert float((grads[0] - grads[1]).abs().max()) <= 1e-6 * float(grads[0].abs().max())
