@@ -18,6 +18,7 @@ stored.  SURVEY.md section 8c lists the cases.
 """
 import copy
 import io
+import json
 import os
 import sys
 import contextlib
@@ -325,8 +326,44 @@ def full_shape_case(name="full_nacf", B=4, V=10547, L=20, F_=60):
 EOS_BOOST = float(os.environ.get("EOS_BOOST", "8.0"))
 
 
+def checkpoint_case():
+    """a checkpoint written by the REFERENCE (misc/utils.py:195-202 layout, run.py:334-339 keys)
+    plus what the reference's own loaders make of it: load_model_and_opt (utils.py:54-63) and the teacher-init remap
+    load_satisfied_weights(..., {'decoder.bert.': 'decoder.'}) (run.py:275-283) into a NACF student."""
+    opt_t = ref_opt("ARB", "MSRVTT", TINY + ["-wc"]); opt_t["vocab_size"] = 101
+    teacher = ref_model(opt_t, O.init_state_dict(opt_t, seed=5))
+    os.chdir(REF)
+    from misc.utils import load_model_and_opt, load_satisfied_weights, save_checkpoint
+    os.chdir(ROOT)
+    path = os.path.join(GOLD, "tiny_arb_checkpoint.pth.tar")
+    save_checkpoint({"epoch": 7, "state_dict": teacher.state_dict(), "validate_result": {"CIDEr": 0.5, "loss": 1.25},
+                     "settings": opt_t}, False, filepath=GOLD, filename="tiny_arb_checkpoint.pth.tar")
+    model, opt_l, other = load_model_and_opt(path, "cpu", return_other_info=True)
+    assert sorted(other) == ["epoch", "settings", "validate_result"]
+    batch = O.synth_batch(opt_t, 3, 6, seed=2)
+    model.eval()
+    with torch.no_grad():
+        enc = model.encoder(batch["feats"])
+    opt_s = ref_opt("NACF", "MSRVTT", TINY + ["-wc"]); opt_s["vocab_size"] = 101
+    student = ref_model(opt_s, O.init_state_dict(opt_s, seed=6))
+    before = {k: v.clone() for k, v in student.state_dict().items()}
+    student = load_satisfied_weights(student, path, str_mapping={"decoder.bert.": "decoder."})
+    after = student.state_dict()
+    names = list(after.keys())
+    taken = np.array([not torch.equal(after[k], before[k]) for k in names])
+    np.savez_compressed(os.path.join(GOLD, "tiny_checkpoint.npz"),
+                        teacher_opt_json=json.dumps(opt_t), student_opt_json=json.dumps(opt_s),
+                        names=np.array(names), taken=taken,
+                        sums=np.array([float(after[k].double().sum()) for k in names]),
+                        epoch=7, n_taken=int(taken.sum()))
+    print("[checkpoint] ok: %d/%d student tensors taken from the ARB checkpoint" % (int(taken.sum()), len(names)))
+
+
 def main():
     torch.manual_seed(0)
+    if os.environ.get("ONLY_CKPT"):
+        checkpoint_case()
+        return
     if os.environ.get("ONLY_LN"):
         train_case("tiny_nacf_ln_train", "NACF", ["-wc", "--with_layernorm", "--norm_type", "ln"], V=101, B=3, F_=6)
         return
@@ -351,6 +388,7 @@ def main():
                                                   "--enhance_input", "0", "--no_encoder_bn", "-tie"],
                V=101, B=3, F_=6, dataset="Youtube2Text", beta=(0.0, 1.0))
     train_case("tiny_nacf_ln_train", "NACF", ["-wc", "--with_layernorm", "--norm_type", "ln"], V=101, B=3, F_=6)
+    checkpoint_case()
     # NA decode: all paradigms, +-ct, per-iteration tokens/probs
     decode_case("tiny_nacf_decode", "NACF", ["-wc"], V=101, B=4, F_=6, variants={
         "mp_ct": dict(paradigm="mp", use_ct=True, iterations=5, length_beam_size=6, beam_alpha=1.35),

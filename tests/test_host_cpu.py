@@ -113,3 +113,45 @@ def test_num_mask_lut_matches_torch_float_semantics():
     for c in range(T):
         lens = torch.arange(Lp + 1)
         assert torch.equal(lut[c].long(), (lens.float() * (1.0 - (c / T))).long())
+
+
+def test_reference_checkpoint_contract(tmp_path):
+    """a checkpoint file WRITTEN BY THE REFERENCE (tests/golden/tiny_arb_checkpoint.pth.tar, made by
+    oracle/make_golden.py with the reference's save_checkpoint) loads through the mirrored helpers, and the teacher-init
+    remap takes exactly the tensors the reference's load_satisfied_weights took (misc/utils.py:54-63,158-192)."""
+    import os
+    import numpy as np
+    from nacf_amd.misc.utils import load_model_and_opt, load_satisfied_weights, save_checkpoint
+    from util import GOLD
+    g = np.load(os.path.join(GOLD, "tiny_checkpoint.npz"))
+    path = os.path.join(GOLD, "tiny_arb_checkpoint.pth.tar")
+    model, opt, other = load_model_and_opt(path, "cpu", return_other_info=True)
+    assert sorted(other) == ["epoch", "settings", "validate_result"] and other["epoch"] == int(g["epoch"])
+    assert opt["method"] == "ARB" and type(model.decoder).__name__ == "BertDecoder"
+    raw = torch.load(path, map_location="cpu", weights_only=False)["state_dict"]
+    sd = model.state_dict()
+    assert set(sd) == set(raw) and all(torch.equal(sd[k], raw[k]) for k in raw)
+    # teacher init of a NACF student: 'decoder.bert.X' <- 'decoder.X'
+    import json
+    s_opt = json.loads(str(g["student_opt_json"]))
+    student = nacf_amd.get_model(s_opt)
+    from nacf_amd import synthetic as S
+    student.load_state_dict(S.init_state_dict(s_opt, seed=6))
+    before = {k: v.clone() for k, v in student.state_dict().items()}
+    load_satisfied_weights(student, path, str_mapping={"decoder.bert.": "decoder."})
+    after = student.state_dict()
+    names = [str(n) for n in g["names"]]
+    assert names == list(after.keys())
+    taken = [not torch.equal(after[k], before[k]) for k in names]
+    assert taken == [bool(x) for x in g["taken"]] and sum(taken) == int(g["n_taken"])
+    np.testing.assert_allclose([float(after[k].double().sum()) for k in names], g["sums"], rtol=0, atol=1e-9)
+    for k in names:
+        if k.startswith("decoder.bert.") and k.replace("decoder.bert.", "decoder.") in raw:
+            assert torch.equal(after[k], raw[k.replace("decoder.bert.", "decoder.")]), k
+    with pytest.raises(AssertionError):
+        load_satisfied_weights(nacf_amd.get_model(s_opt), path, strict=True)          # no remap: decoder.bert.* missing
+    # round trip through save_checkpoint (same dict layout as misc/run.py:334-339)
+    save_checkpoint({"epoch": 1, "state_dict": student.state_dict(), "validate_result": {}, "settings": s_opt}, True,
+                    filepath=str(tmp_path), filename="c.pth.tar")
+    m2, o2 = load_model_and_opt(os.path.join(str(tmp_path), "best.pth.tar"), "cpu")
+    assert all(torch.equal(v, after[k]) for k, v in m2.state_dict().items())
