@@ -43,6 +43,68 @@ def make_opt(nacf_amd, L, V):
                                   beam_alpha=1.35, paradigm="mp")
 
 
+def bench_loader(args, nacf_amd, opt, dev, B, L, V, F_, static, graph):
+    """Train-step throughput when every batch comes from nacf_amd.data.ShardLoader (synthetic shards written to a
+    temp dir): per step the loader's tensors are copied into the graph's static input buffers and the captured step is
+    replayed.  Reports the three placements of the shards: HBM-resident (no PCIe per step), pinned host memory (one
+    DMA per clip, PCIe-inclusive) and memory-mapped file (host-thread gather into pinned staging + upload)."""
+    import shutil
+    import tempfile
+    import numpy as np
+    from nacf_amd.data import CaptionTable, FeatureShard, ShardLoader, write_feature_shard
+    tmp = tempfile.mkdtemp(prefix="nacf_shards_")
+    try:
+        N = max(args.loader_videos, B)
+        rs = np.random.RandomState(0)
+        shards = []
+        for m in "mi":
+            path = os.path.join(tmp, "feats_%s.nacf" % m)
+            write_feature_shard(path, rs.standard_normal((N, F_, 2048)).astype(np.float32))
+            shards.append(FeatureShard(path))
+        caps, tags, li = {}, {}, {}
+        for v in range(N):
+            n = int(rs.randint(4, L))
+            caps["video%d" % v] = [[2] + rs.randint(6, V, size=n).tolist() + [3]]
+            tags["video%d" % v] = [[2] + rs.randint(6, 12, size=n).tolist() + [3]]
+            h = [0] * (L + 2)
+            h[n] = 1
+            li["video%d" % v] = h
+        names = ["<pad>", "<unk>", "<bos>", "<eos>", "<mask>", "<vis>", "NOUN", "VERB", "DET", "ADJ", "ADP", "PRON"]
+        info = dict(itow={i: "w%d" % i for i in range(V)}, itop=dict(enumerate(names)), itoc={v: v % 20 for v in range(N)},
+                    length_info=li)
+        lopt = dict(opt, n_frames=F_, load_feats_type=1)
+        table, vids = CaptionTable.from_corpus(caps, tags, info, list(range(N)), lopt, "train")
+        out = {"videos_in_shards": N, "shard_bytes": sum(s.nbytes for s in shards), "batch": B}
+        for mode, placement in (("resident_hbm", "hbm"), ("pinned_host", "host"), ("mmap", "mmap")):
+            ld = ShardLoader(shards, table, vids, lopt, batch_size=B, device=dev, mode="train", seed=1, placement=placement,
+                             drop_last=True)
+
+            def run(n_epochs):
+                steps = 0
+                for _ in range(n_epochs):
+                    for b in ld:
+                        for dst, src in zip(static["feats"], b["feats"]):
+                            dst.copy_(src)
+                        static["tokens"][0].copy_(b["tokens_1"]); static["tokens"][1].copy_(b["tokens"])
+                        static["labels"][0].copy_(b["labels_1"]); static["labels"][1].copy_(b["labels"])
+                        static["category"].copy_(b["category"].view_as(static["category"]))
+                        static["tgt_length"].copy_(b["length_target"])
+                        graph.replay()
+                        steps += 1
+                return steps
+            run(1)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            steps = run(max(1, 24 // max(1, len(ld))))
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+            out[mode] = {"videos_per_s": round(B * steps / dt, 1), "ms_per_step": round(dt / steps * 1e3, 3), "steps": steps}
+            del ld
+        return out
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -56,6 +118,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--decode-batches", type=int, default=5)
     ap.add_argument("--no-compare", action="store_true", help="skip the ARB2 beam-5 vs NACF decode comparison (config 5)")
+    ap.add_argument("--no-loader", action="store_true", help="skip the shard-loader leg (SURVEY 8f row 1)")
+    ap.add_argument("--loader-videos", type=int, default=1024, help="videos in the synthetic feature shards")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -281,6 +345,14 @@ def main():
                       "paradigm": "mp+ct", "iterations": 5, "length_beam_size": 6, "width": int(hyp.shape[1])}
             model.train()
 
+        # ---- the same step fed by the shard loader (features gathered / frame-sampled / masked on
+        # the device) instead of one resident synthetic batch; "streaming" includes the PCIe upload of every batch
+        loader_leg = None
+        if not args.no_loader and g_main is not None and not multi:
+            loader_leg = bench_loader(args, nacf_amd, model.opt, dev, B, L, V, F_,
+                                      dict(feats=feats, tokens=tokens, labels=labels, category=category, tgt_length=tgt_length),
+                                      g_main)
+
         # ---- BASELINE.json configs[4]: ARB2 beam-5 autoregressive decode vs NACF parallel decode, batch 256
         compare = None
         if not args.no_compare and not args.no_decode:
@@ -349,6 +421,7 @@ def main():
                           "parallelism": "dp%d" % world, "hipgraph": bool(use_graph), "live_row_gemms": True,
                           "overlapped_allreduce": bool(staged)},
                "roofline": roofline, "cpu_baseline": cpu, "decode": decode, "config5_ar_vs_na": compare,
+               "loader_fed": loader_leg,
                "final_loss": round(final_loss, 4),
                "gemm_kernels": gemm_table}
     if multi:

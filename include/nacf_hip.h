@@ -63,6 +63,33 @@ int nacf_version(void);
 /* number of exported compute entry points (used by the loader self-check) */
 int nacf_abi_count(void);
 
+/* ---- batch construction (reference: dataloader.py) ----------------------------------------
+ * The reference assembles every sample in Python on the host.  Here the feature shards sit in HBM (a whole split of
+ * MSRVTT is 9.8 GB of fp32 [N, 60, 2048] rows) or pass through a pinned staging buffer, and two launches build a batch.
+ *
+ * nacf_sample_frames: out[b, i, :] = src[video[b], frame(b, i), :]           (video == NULL: b; src_len == NULL: T)
+ *   mode 0 'equally_sampling': middle of segment i of n_frames equal segments of the clip (dataloader.py:24-37);
+ *   mode 1 'segment_random'  : one uniform draw per segment (Philox, device {seed, step} + salt);
+ *   a clip shorter than n_frames is stretched: round-half-even(i * (S-1) / (n_frames-1))      (dataloader.py:20-21,305)
+ *   frame_ids (optional) receives the chosen indices [B, n_frames]. */
+int nacf_sample_frames(const float* src, const int32_t* video, const int32_t* src_len, int B, int T, int D,
+                       int n_frames, int mode, uint32_t salt, const uint64_t* rng_state, float* out,
+                       int32_t* frame_ids, nacf_stream_t stream);
+/* nacf_build_targets: the decoder inputs / labels of B captions, dataloader.py:317-425.
+ *   caps[b, 0..cap_len[b]) = <bos> w1 .. wn <eos> (int32, row pitch ld_caps), pos_tags alike.
+ *   narformer != 0: masked-LM pair (:346-380).  train: a uniformly random subset of the n word slots (size uniform
+ *     in [max(int(n*beta_low),1), max(int(n*beta_high),1)) -- widened by one when empty) is <mask> in `tokens` and
+ *     keeps its word in `labels`, all other labels are <pad>; eval: every word is <mask>, labels = the sentence.
+ *   narformer == 0: tokens = labels = the caption padded / cut to max_len with a closing <eos> (:333-337).
+ *   visual_word && train: tokens_1 = <vis> per slot, labels_1 = the word where tag_demanded[tag] && !word_is_be[word],
+ *     else <mask> (AR form: wrapped in <bos> .. <eos>)  (:382-425).
+ *   All outputs are int64 [B, max_len]. */
+int nacf_build_targets(const int32_t* caps, int ld_caps, const int32_t* cap_len, const int32_t* pos_tags,
+                       const uint8_t* tag_demanded, const uint8_t* word_is_be, int B, int max_len, int narformer,
+                       int visual_word, int train, double beta_low, double beta_high, uint32_t salt,
+                       const uint64_t* rng_state, int64_t* tokens, int64_t* labels, int64_t* tokens_1,
+                       int64_t* labels_1, nacf_stream_t stream);
+
 /* ------------------------------------------------------------------------
  * RNG state: device uint64[2] = {seed, step}.
  * ---------------------------------------------------------------------- */

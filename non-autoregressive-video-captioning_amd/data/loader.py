@@ -1,0 +1,179 @@
+"""Batch iterator over feature shards + a caption table.
+
+Replaces `DataLoader(VideoDataset(...), batch_size, shuffle)` of the reference (dataloader.py:40-425,
+misc/run.py:92-96) with the same batch dictionary -- feats (one [B, n_frames, D] tensor per modality), tokens, labels,
+tokens_1 / labels_1 (visual-word pass), length_target, category -- built ON THE DEVICE:
+
+  * resident mode (default when the shards fit `hbm_budget_bytes`): the whole [N, T, D] arrays are uploaded once; a
+    batch is one gather+frame-sampling launch per modality driven by a device index vector.  No PCIe traffic per step.
+  * host mode (shards that exceed the HBM budget but fit pinned host memory): the shard is read once into pinned RAM;
+    a batch is one asynchronous DMA per clip (T*D*4 contiguous bytes) from there straight into one of two device
+    staging buffers on a side stream while the previous batch trains -- no host-side gather copy at all.
+  * mmap mode (larger than host memory): the batch's clips are copied from the memory-mapped shard into one of two
+    pinned staging buffers by a few host threads and uploaded on the side stream (double buffering).
+    In both streaming modes frame sampling then runs on the staged rows.
+  * decoder inputs / labels (masked-LM pairs, visual-word targets, AR pairs) come from `nacf_build_targets`; the
+    masks are drawn with the device Philox stream {seed, step}, so an epoch is reproducible from `seed`.
+
+There is no CPU fallback: construction raises without the HIP library / a HIP device.
+"""
+import numpy as np
+import torch
+
+from ..runtime import ops
+
+
+class ShardLoader:
+    def __init__(self, shards, table, video_index, opt, batch_size, device, mode="train", shuffle=None, seed=0,
+                 resident=None, hbm_budget_bytes=64 << 30, drop_last=False, placement=None, host_budget_bytes=64 << 30):
+        """shards: one FeatureShard per modality character of opt['modality'] (same video ids); table / video_index:
+        CaptionTable.from_corpus(...) output (video_index = corpus ids of the table's video rows)."""
+        self.shards, self.table, self.opt = list(shards), table, opt
+        self.B, self.dev, self.mode = int(batch_size), torch.device(device), mode
+        self.train = mode == "train"
+        self.shuffle = self.train if shuffle is None else bool(shuffle)
+        self.drop_last = drop_last
+        if opt.get("load_feats_type", 1) not in (1, 2):
+            raise NotImplementedError("nacf_amd: load_feats_type 0 (one shared frame-id draw per sample) is not built")
+        random_type = opt.get("random_type", "segment_random") if self.train else "equally_sampling"
+        if random_type not in ("segment_random", "equally_sampling"):
+            raise NotImplementedError("nacf_amd: random_type %s is not built" % random_type)
+        self.frame_mode = 1 if random_type == "segment_random" else 0
+        self.n_frames = [s.T if opt.get("load_feats_type", 1) == 2 else opt["n_frames"] for s in self.shards]
+        self.rows = [s.row_of(video_index) for s in self.shards]          # table video row -> shard row
+        total = sum(s.nbytes for s in self.shards)
+        if placement is None:        # where the shards live: "hbm" | "host" (pinned RAM) | "mmap" (page cache / disk)
+            if resident is not None:
+                placement = "hbm" if resident else "mmap"
+            else:
+                placement = "hbm" if total <= hbm_budget_bytes else ("host" if total <= host_budget_bytes else "mmap")
+        if placement not in ("hbm", "host", "mmap"):
+            raise ValueError("placement must be hbm | host | mmap")
+        self.placement = placement
+        self.resident = placement == "hbm"
+        self.rng = ops.RngState(seed, self.dev)
+        self.gen = torch.Generator().manual_seed(seed)
+        t = table
+        up = lambda a, dt: torch.from_numpy(np.ascontiguousarray(a)).to(self.dev, dtype=dt)
+        self.d_caps, self.d_len, self.d_tags = up(t.caps, torch.int32), up(t.cap_len, torch.int32), up(t.pos_tags, torch.int32)
+        self.d_video, self.d_cat = up(t.video, torch.int64), up(t.category, torch.int64)
+        self.d_lt = up(t.length_target, torch.float32)
+        self.d_dem, self.d_be = up(t.tag_demanded, torch.uint8), up(t.word_is_be, torch.uint8)
+        self.d_srclen = [up(s.lengths, torch.int32) for s in self.shards]
+        if self.resident:
+            self.d_feats = [self._upload(s) for s in self.shards]
+            self.d_rows = [up(r, torch.int32) for r in self.rows]
+        else:
+            self.copy_stream = torch.cuda.Stream(device=self.dev)
+            if placement == "host":
+                self.host_feats = []
+                for s in self.shards:
+                    h = torch.empty(s.N, s.T, s.D, dtype=torch.float32).pin_memory()
+                    np.copyto(h.numpy(), s.array)
+                    self.host_feats.append(h)
+                self.pinned = None
+            else:
+                self.pinned = [[torch.empty(self.B, s.T, s.D, dtype=torch.float32).pin_memory() for s in self.shards]
+                               for _ in range(2)]
+            self.staged = [[torch.empty(self.B, s.T, s.D, dtype=torch.float32, device=self.dev) for s in self.shards] for _ in range(2)]
+            self.staged_len = [[torch.empty(self.B, dtype=torch.int32, device=self.dev) for _ in self.shards] for _ in range(2)]
+            self.pinned_len = [[torch.empty(self.B, dtype=torch.int32).pin_memory() for _ in self.shards] for _ in range(2)]
+            self._slot_event = [None, None]
+            from concurrent.futures import ThreadPoolExecutor
+            self._pool = ThreadPoolExecutor(max_workers=int(opt.get("loader_threads", 32)))
+
+    def _upload(self, shard, chunk_bytes=256 << 20):
+        """whole shard -> HBM: large sequential reads of the memory-mapped file into two alternating pinned buffers,
+        asynchronous H2D copies behind them"""
+        dst = torch.empty(shard.N, shard.T, shard.D, dtype=torch.float32, device=self.dev)
+        per = max(1, chunk_bytes // (shard.T * shard.D * 4))
+        pins = [torch.empty(min(per, shard.N), shard.T, shard.D, dtype=torch.float32).pin_memory() for _ in range(2)]
+        evs = [None, None]
+        for k, lo in enumerate(range(0, shard.N, per)):
+            hi, slot = min(shard.N, lo + per), k & 1
+            if evs[slot] is not None:
+                evs[slot].synchronize()
+            np.copyto(pins[slot].numpy()[:hi - lo], shard.array[lo:hi])
+            dst[lo:hi].copy_(pins[slot][:hi - lo], non_blocking=True)
+            evs[slot] = torch.cuda.Event()
+            evs[slot].record()
+        torch.cuda.current_stream(self.dev).synchronize()
+        return dst
+
+    def __len__(self):
+        n = len(self.table)
+        return n // self.B if self.drop_last else (n + self.B - 1) // self.B
+
+    # ---- host side of streaming mode: gather the batch's clips into pinned memory, start the upload
+    def _stage(self, slot, vids_host):
+        n = len(vids_host)
+        prev = self._slot_event[slot]
+        if prev is not None:
+            prev.synchronize()              # the upload that last read this pinned slot has finished
+        # the frame-sampling kernels that read this staging slot two batches ago were launched on the compute stream
+        self.copy_stream.wait_stream(torch.cuda.current_stream(self.dev))
+        with torch.cuda.stream(self.copy_stream):
+            for m, s in enumerate(self.shards):
+                rows = self.rows[m][vids_host]
+                if self.placement == "host":               # one DMA per clip, pinned RAM -> device staging
+                    src, dst = self.host_feats[m], self.staged[slot][m]
+                    for j, r in enumerate(rows.tolist()):
+                        dst[j].copy_(src[r], non_blocking=True)
+                    self.pinned_len[slot][m][:n] = torch.from_numpy(s.lengths[rows])
+                    self.staged_len[slot][m][:n].copy_(self.pinned_len[slot][m][:n], non_blocking=True)
+                    continue
+                buf = self.pinned[slot][m].numpy()
+                # one memcpy per clip (T*D*4 bytes, contiguous in the shard) straight into pinned memory, spread over a
+                # few host threads (numpy drops the GIL for plain copies); no intermediate gather buffer
+                list(self._pool.map(lambda jr: np.copyto(buf[jr[0]], s.array[jr[1]]), enumerate(rows)))
+                self.staged[slot][m][:n].copy_(self.pinned[slot][m][:n], non_blocking=True)
+                self.pinned_len[slot][m][:n] = torch.from_numpy(s.lengths[rows])
+                self.staged_len[slot][m][:n].copy_(self.pinned_len[slot][m][:n], non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record(self.copy_stream)
+        self._slot_event[slot] = ev
+        return ev
+
+    def _build(self, idx_dev, vids_dev, feats_src):
+        opt, n = self.opt, idx_dev.numel()
+        batch = {"feats": []}
+        for m, s in enumerate(self.shards):
+            out = torch.empty(n, self.n_frames[m], s.D, dtype=torch.float32, device=self.dev)
+            src, video, src_len = feats_src(m, vids_dev)
+            ops.sample_frames(src, video, src_len, self.n_frames[m], self.frame_mode, out, salt=0x5EED0000 + m, rng=self.rng)
+            batch["feats"].append(out)
+        caps, lens = self.d_caps.index_select(0, idx_dev), self.d_len.index_select(0, idx_dev)
+        tags = self.d_tags.index_select(0, idx_dev)
+        narformer = opt["decoding_type"] == "NARFormer"
+        batch.update(ops.build_targets(caps, lens, tags, self.d_dem, self.d_be, opt["max_len"], narformer,
+                                       opt.get("visual_word_generation", False), self.train, opt.get("beta", [0, 1]),
+                                       salt=0x7A26E7, rng=self.rng))
+        batch["length_target"] = self.d_lt.index_select(0, vids_dev)
+        batch["category"] = self.d_cat.index_select(0, vids_dev).unsqueeze(1)
+        batch["sample_index"] = idx_dev
+        self.rng.advance()
+        return batch
+
+    def __iter__(self):
+        n = len(self.table)
+        order = torch.randperm(n, generator=self.gen) if self.shuffle else torch.arange(n)
+        nb = len(self)
+        chunks = [order[i * self.B:min(n, (i + 1) * self.B)] for i in range(nb)]
+        if self.resident:
+            for ch in chunks:
+                idx = ch.to(self.dev)
+                vids = self.d_video.index_select(0, idx)
+                yield self._build(idx, vids, lambda m, v: (self.d_feats[m], self.d_rows[m].index_select(0, v), self.d_srclen[m]))
+            return
+        vid_host = self.table.video
+        pending = self._stage(0, vid_host[chunks[0].numpy()]) if nb else None
+        for i, ch in enumerate(chunks):
+            slot = i & 1
+            ev = pending
+            if i + 1 < nb:                                                 # start the next upload before this batch is used
+                pending = self._stage(1 - slot, vid_host[chunks[i + 1].numpy()])
+            torch.cuda.current_stream(self.dev).wait_event(ev)
+            idx = ch.to(self.dev)
+            vids = self.d_video.index_select(0, idx)
+            k = idx.numel()
+            yield self._build(idx, vids, lambda m, v: (self.staged[slot][m][:k], None, self.staged_len[slot][m][:k]))

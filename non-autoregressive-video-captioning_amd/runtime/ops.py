@@ -523,3 +523,37 @@ def beam_step(logp2d, V, t, max_len, want, seqs, scores, fin_scores, fin_len, fi
     L.check(L.load().nacf_beam_step(_ptr(logp2d), logp2d.stride(0), B, n_bm, V, int(t), int(max_len), int(want),
                                     _ptr(seqs), _ptr(scores), _ptr(fin_scores), _ptr(fin_len), _ptr(fin_tokens),
                                     _ptr(fin_count), _ptr(done), _ptr(n_active), _stream()), "nacf_beam_step")
+
+
+# ---------------------------------------------------------------- batch construction
+def sample_frames(src: Tensor, video: Optional[Tensor], src_len: Optional[Tensor], n_frames: int, mode: int,
+                  out: Tensor, salt: int = 0, rng: Optional[RngState] = None, frame_ids: Optional[Tensor] = None) -> Tensor:
+    """out[b, i] = src[video[b], frame(b, i)]; mode 0 equally_sampling, 1 segment_random (dataloader.py:24-37)"""
+    _chk_f32(src, out)
+    B = out.shape[0]
+    T, D = src.shape[-2], src.shape[-1]
+    assert src.is_contiguous() and out.is_contiguous() and out.shape == (B, n_frames, D)
+    L.check(L.load().nacf_sample_frames(_ptr(src), _ptr(video), _ptr(src_len), B, T, D, n_frames, int(mode),
+                                        int(salt) & 0xFFFFFFFF, _ptr(rng.state) if rng else None, _ptr(out),
+                                        _ptr(frame_ids), _stream()), "nacf_sample_frames")
+    return out
+
+
+def build_targets(caps: Tensor, cap_len: Tensor, pos_tags: Optional[Tensor], tag_demanded: Optional[Tensor],
+                  word_is_be: Optional[Tensor], max_len: int, narformer: bool, visual_word: bool, train: bool,
+                  beta=(0.0, 1.0), salt: int = 0, rng: Optional[RngState] = None):
+    """decoder inputs / labels of a batch of captions (dataloader.py:317-425) -> dict of int64 [B, max_len]"""
+    assert caps.dtype == torch.int32 and caps.dim() == 2 and caps.stride(1) == 1 and cap_len.dtype == torch.int32
+    B = caps.shape[0]
+    mk = lambda: torch.empty(B, max_len, dtype=torch.int64, device=caps.device)
+    out = {"tokens": mk(), "labels": mk()}
+    vw = bool(visual_word and train)
+    if vw:
+        out["tokens_1"], out["labels_1"] = mk(), mk()
+    L.check(L.load().nacf_build_targets(_ptr(caps), caps.stride(0), _ptr(cap_len), _ptr(pos_tags), _ptr(tag_demanded),
+                                        _ptr(word_is_be), B, max_len, int(narformer), int(vw), int(train),
+                                        float(beta[0]), float(beta[1]), int(salt) & 0xFFFFFFFF,
+                                        _ptr(rng.state) if rng else None, _ptr(out["tokens"]), _ptr(out["labels"]),
+                                        _ptr(out.get("tokens_1")), _ptr(out.get("labels_1")), _stream()),
+            "nacf_build_targets")
+    return out

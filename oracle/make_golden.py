@@ -359,8 +359,132 @@ def checkpoint_case():
     print("[checkpoint] ok: %d/%d student tensors taken from the ARB checkpoint" % (int(taken.sum()), len(names)))
 
 
+def _reference_dataset_class():
+    """The reference's VideoDataset with its real method bodies.  dataloader.py imports h5py (absent here) at module
+    level for the HDF5 reads this fixture does not exercise, so the module source is executed without that one line;
+    nothing else is changed and no stand-in is provided."""
+    src = open(os.path.join(REF, "dataloader.py")).read().replace("import h5py\n", "")
+    ns = {"__name__": "reference_dataloader"}
+    cwd = os.getcwd()
+    os.chdir(REF)
+    if REF not in sys.path:
+        sys.path.insert(0, REF)
+    try:
+        exec(compile(src, os.path.join(REF, "dataloader.py"), "exec"), ns)
+    finally:
+        os.chdir(cwd)
+    return ns
+
+
+def data_case():
+    """the reference's batch construction on a synthetic corpus (dataloader.py:24-37,166-175,
+    296-327,329-425), oracle/nacf_data_oracle.py asserted equal, everything saved as arrays."""
+    from oracle import nacf_data_oracle as D
+    ns = _reference_dataset_class()
+    VD = ns["VideoDataset"]
+    rs = np.random.RandomState(123)
+    tags = ["NOUN", "VERB", "DET", "ADJ", "ADP", "PRON"]
+    itop = {i: t for i, t in enumerate(["<pad>", "<unk>", "<bos>", "<eos>", "<mask>", "<vis>"] + tags)}
+    V = 101
+    itow = {i: "w%d" % i for i in range(V)}
+    for i, w in enumerate(D.BE_VERBS):
+        itow[6 + i] = w
+    demand = ["VERB", "NOUN"]
+    demanded = np.array([itop[i] in demand for i in range(len(itop))])
+    is_be = np.array([itow[i] in D.BE_VERBS for i in range(V)])
+    caps, poss = [], []
+    for n in [1, 2, 3, 5, 8, 9, 12, 17, 20, 28, 33]:              # words per caption (max_len 10 / 30 cut some)
+        words = rs.randint(6, V, size=n).tolist()
+        caps.append([D.BOS] + words + [D.EOS])
+        poss.append([2] + rs.randint(6, 6 + len(tags), size=n).tolist() + [3])
+    out = {}
+    for dt, vw, max_len, beta in [("NARFormer", True, 10, [0.35, 0.9]), ("NARFormer", False, 30, [0.0, 1.0]),
+                                  ("ARFormer", True, 10, [0, 1]), ("ARFormer", False, 30, [0, 1])]:
+        for mode in ("train", "validate"):
+            opt = dict(decoding_type=dt, visual_word_generation=vw, max_len=max_len, beta=beta, demand=demand, seed=7)
+            ds = object.__new__(VD)                       # no corpus / HDF5 files: only the pure methods are used
+            ds.opt, ds.mode, ds.itow, ds.itop = opt, mode, itow, itop
+            ds.random = np.random.RandomState(opt["seed"])
+            mine = np.random.RandomState(opt["seed"])
+            key = "%s.%s.%d.%s" % (dt, "vw" if vw else "plain", max_len, mode)
+            rows = {k: [] for k in ("tokens", "labels", "tokens_1", "labels_1")}
+            for c, p in zip(caps, poss):
+                if dt == "NARFormer" or True:
+                    ref = ds._make_source_target(list(c), list(p))
+                got = D.make_source_target(c, p, opt, demanded, is_be, mode == "train", rng=mine)
+                pairs = [("tokens", "dec_source"), ("labels", "dec_target")]
+                if vw:
+                    pairs += [("tokens_1", "dec_source_1"), ("labels_1", "dec_target_1")]
+                for mk, rk in pairs:
+                    assert list(got[mk]) == list(ref[rk]), (key, mk, got[mk], ref[rk])
+                    rows[mk].append(list(ref[rk]))
+            for mk, v in rows.items():
+                if v and len({len(r) for r in v}) == 1:
+                    out[key + "." + mk] = np.array(v, dtype=np.int64)
+    # frame sampling + resampling + length targets
+    fr = []
+    for total, n in [(60, 8), (60, 60), (28, 8), (9, 8), (100, 12), (8, 8)]:
+        ref = ns["get_frame_ids"](total, n, "equally_sampling")
+        assert ref == D.get_frame_ids(total, n, "equally_sampling")
+        fr.append((total, n, ref))
+    np.random.seed(11)
+    seg_ref = [ns["get_frame_ids"](60, 8, "segment_random") for _ in range(4)]
+    mine = np.random.RandomState(11)
+    assert seg_ref == [D.get_frame_ids(60, 8, "segment_random", mine) for _ in range(4)]
+    rsmp = [(s, t_, ns["resampling"](s, t_)) for s, t_ in [(5, 8), (3, 60), (59, 60), (2, 8)]]
+    for s_, t_, r in rsmp:
+        assert r == D.resampling(s_, t_)
+    lens = [[0, 0, 3, 5, 0, 2], [1] + [0] * 40, [0, 4]]
+    lt = []
+    for li in lens:
+        for max_len in (10, 4):
+            ref = list(li)[:max_len]
+            ref += [0] * (max_len - len(ref))
+            ref = np.array(ref) / sum(ref)                  # dataloader.py:170-175, verbatim arithmetic
+            assert np.array_equal(ref, D.length_target(li, max_len))
+            lt.append(ref)
+    # sample enumeration (_make_infoset, dataloader.py:146-199) on a 6-video corpus
+    corpus_caps, corpus_tags, length_info = {}, {}, {}
+    for v in range(6):
+        k = 3 + v % 3
+        corpus_caps["video%d" % v] = [[D.BOS] + rs.randint(6, V, size=rs.randint(2, 9)).tolist() + [D.EOS] for _ in range(k)]
+        corpus_tags["video%d" % v] = [[2] + rs.randint(6, 6 + len(tags), size=len(c) - 2).tolist() + [3] for c in corpus_caps["video%d" % v]]
+        hist = [0] * 12
+        for c in corpus_caps["video%d" % v]:
+            hist[len(c) - 2] += 1
+        length_info["video%d" % v] = hist
+    itoc = {v: (v * 7) % 20 for v in range(6)}
+    splits = {"train": [4, 0, 2, 5], "validate": [1], "test": [3]}
+    info_rows = {}
+    for mode, ncap in [("train", 0), ("train", 2), ("validate", 0)]:
+        opt = dict(max_len=10, n_caps_per_video=ncap, seed=3, dataset="x")
+        ds = object.__new__(VD)
+        ds.opt, ds.mode, ds.specific = opt, mode, -1
+        ds.captions, ds.pos_tags, ds.itoc, ds.length_info, ds.splits = corpus_caps, corpus_tags, itoc, length_info, splits
+        ds.random = np.random.RandomState(opt["seed"])
+        ds.n_caps_per_video = ncap if mode == "train" else 1
+        with contextlib.redirect_stdout(io.StringIO()):
+            infoset = ds._make_infoset()
+        info_rows["%s.%d" % (mode, ncap)] = [[int(it["vid"][5:]), int(it["cap_id"]), int(it["category"])] +
+                                            [float(x) for x in it["length_target"]] for it in infoset]
+    np.savez_compressed(os.path.join(GOLD, "tiny_data.npz"),
+                        corpus_json=json.dumps(dict(captions=corpus_caps, pos_tags=corpus_tags, length_info=length_info,
+                                                    itoc={str(k): v for k, v in itoc.items()}, splits=splits,
+                                                    itow={str(k): v for k, v in itow.items()},
+                                                    itop={str(k): v for k, v in itop.items()})),
+                        infoset_json=json.dumps(info_rows),
+                        caps=np.array([c + [-1] * (40 - len(c)) for c in caps]), poss=np.array([p + [-1] * (40 - len(p)) for p in poss]),
+                        cap_len=np.array([len(c) for c in caps]), demanded=demanded, is_be=is_be,
+                        frames_json=json.dumps(fr), seg_random_json=json.dumps(seg_ref), resampling_json=json.dumps(rsmp),
+                        length_info_json=json.dumps(lens), **out)
+    print("[data] ok:", len(out), "token/label tables,", len(fr), "frame-id cases")
+
+
 def main():
     torch.manual_seed(0)
+    if os.environ.get("ONLY_DATA"):
+        data_case()
+        return
     if os.environ.get("ONLY_CKPT"):
         checkpoint_case()
         return
@@ -389,6 +513,7 @@ def main():
                V=101, B=3, F_=6, dataset="Youtube2Text", beta=(0.0, 1.0))
     train_case("tiny_nacf_ln_train", "NACF", ["-wc", "--with_layernorm", "--norm_type", "ln"], V=101, B=3, F_=6)
     checkpoint_case()
+    data_case()
     # NA decode: all paradigms, +-ct, per-iteration tokens/probs
     decode_case("tiny_nacf_decode", "NACF", ["-wc"], V=101, B=4, F_=6, variants={
         "mp_ct": dict(paradigm="mp", use_ct=True, iterations=5, length_beam_size=6, beam_alpha=1.35),
