@@ -326,7 +326,7 @@ def main():
 
         # ---- NA decode throughput (captions/s incl. encode), same model in eval mode
         decode = None
-        if not args.no_decode:
+        if not args.no_decode and world == 1:
             model.eval()
             tr = Translator(model, dict(model.opt), device=dev)
             def dec_once():
@@ -355,7 +355,7 @@ def main():
 
         # ---- BASELINE.json configs[4]: ARB2 beam-5 autoregressive decode vs NACF parallel decode, batch 256
         compare = None
-        if not args.no_compare and not args.no_decode:
+        if not args.no_compare and not args.no_decode and world == 1:
             CB = 256
             cb = O.synth_batch(opt, CB, F_, seed=7)
             cfeats = [f.to(dev) for f in cb["feats"]]
@@ -391,7 +391,7 @@ def main():
 
         # ---- CPU baseline: the oracle (plain eager PyTorch fp32 restatement) on this box's host cores
         cpu = None
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:      # reported at N=1 only (the other ranks would sit in a barrier)
             from oracle import nacf_oracle as ORACLE   # the CPU checker: imported for THIS leg only, never measured as product
             cb = 32
             cbatch = O.synth_batch(opt, cb, F_, seed=1)
