@@ -332,38 +332,52 @@ __global__ __launch_bounds__(EMB_THREADS) void embed_scatter_word_kernel(const f
 // chunks, then a fixed-order combine.  grid = (n_chunks, SPECIAL_N)
 constexpr int SPECIAL_N = 5;          // ids 1..5
 constexpr int SCATTER_CHUNK = 128;
-__global__ __launch_bounds__(EMB_THREADS) void embed_scatter_special_partial_kernel(
+__global__ __launch_bounds__(4 * EMB_THREADS) void embed_scatter_special_partial_kernel(
     const float* __restrict__ dE, const int64_t* __restrict__ tokens, float* __restrict__ part, int n_rows, int D) {
+  // 4 * EMB_THREADS threads: the first EMB_THREADS list the chunk's rows that hold this token (ascending); group gq
+  // then adds list entries gq, gq+4, ... and the 4 partials fold through LDS in fixed order
   __shared__ int list[SCATTER_CHUNK];
   __shared__ int wcnt[2];
+  __shared__ f32x4 red[4][EMB_MAXJ][EMB_THREADS];
   const int chunk = blockIdx.x;
   const int64_t tok = blockIdx.y + 1;
+  const int t = threadIdx.x % EMB_THREADS, gq = threadIdx.x / EMB_THREADS;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int idx = chunk * SCATTER_CHUNK + threadIdx.x;
-  const bool match = idx < n_rows && tokens[idx] == tok;
-  const unsigned long long bal = __ballot(match);
-  const int pre = __popcll(bal & ((1ull << lane) - 1ull));
-  if (lane == 0) wcnt[wave] = __popcll(bal);
+  bool match = false;
+  int pre = 0;
+  if (gq == 0) {
+    const int idx = chunk * SCATTER_CHUNK + t;
+    match = idx < n_rows && tokens[idx] == tok;
+    const unsigned long long bal = __ballot(match);
+    pre = __popcll(bal & ((1ull << lane) - 1ull));
+    if (lane == 0) wcnt[wave] = __popcll(bal);
+  }
   __syncthreads();
-  const int off = (wave == 0) ? 0 : wcnt[0];
   const int n = wcnt[0] + wcnt[1];
-  if (match) list[off + pre] = idx;
+  if (gq == 0 && match) list[((wave == 0) ? 0 : wcnt[0]) + pre] = chunk * SCATTER_CHUNK + t;
   __syncthreads();
   f32x4 acc[EMB_MAXJ];
 #pragma unroll
   for (int j = 0; j < EMB_MAXJ; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
-  for (int i = 0; i < n; ++i) {
+  for (int i = gq; i < n; i += 4) {
     const int64_t src = (int64_t)list[i] * D;
 #pragma unroll
     for (int j = 0; j < EMB_MAXJ; ++j) {
-      const int d = (threadIdx.x + EMB_THREADS * j) * 4;
+      const int d = (t + EMB_THREADS * j) * 4;
       if (d < D) acc[j] += *reinterpret_cast<const f32x4*>(dE + src + d);
     }
   }
 #pragma unroll
-  for (int j = 0; j < EMB_MAXJ; ++j) {
-    const int d = (threadIdx.x + EMB_THREADS * j) * 4;
-    if (d < D) *reinterpret_cast<f32x4*>(part + ((int64_t)chunk * SPECIAL_N + blockIdx.y) * D + d) = acc[j];
+  for (int j = 0; j < EMB_MAXJ; ++j) red[gq][j][t] = acc[j];
+  __syncthreads();
+  if (gq == 0) {
+#pragma unroll
+    for (int j = 0; j < EMB_MAXJ; ++j) {
+      const int d = (t + EMB_THREADS * j) * 4;
+      if (d < D)
+        *reinterpret_cast<f32x4*>(part + ((int64_t)chunk * SPECIAL_N + blockIdx.y) * D + d) =
+            ((red[0][j][t] + red[1][j][t]) + red[2][j][t]) + red[3][j][t];
+    }
   }
 }
 
@@ -377,6 +391,7 @@ __global__ __launch_bounds__(EMB_THREADS) void embed_scatter_combine_kernel(cons
     const int d = (threadIdx.x + EMB_THREADS * j) * 4;
     if (d < D) {
       f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
       for (int c = 0; c < n_parts; ++c) acc += *reinterpret_cast<const f32x4*>(part + ((int64_t)c * n_items + item) * D + d);
       float* o = dst + (int64_t)(row0 + item) * D + d;
       if (accumulate) acc += *reinterpret_cast<const f32x4*>(o);
@@ -409,29 +424,38 @@ __global__ __launch_bounds__(EMB_THREADS) void embed_scatter_pos_partial_kernel(
   }
 }
 
-// vsum[v] = sum over the decoder rows of video v and all positions   grid = n_video
-__global__ __launch_bounds__(EMB_THREADS) void embed_scatter_video_kernel(const float* __restrict__ dE,
-                                                                           float* __restrict__ vsum, int R, int L, int D,
-                                                                           int vdiv, int vmod) {
+// vsum[v] = sum over the decoder rows of video v and all positions   grid = n_video, 4 * EMB_THREADS threads:
+// position group gq walks l = gq, gq+4, ... of every matching row; the 4 partials fold through LDS in fixed order
+constexpr int SCAT_GROUPS = 4;
+__global__ __launch_bounds__(SCAT_GROUPS * EMB_THREADS) void embed_scatter_video_kernel(const float* __restrict__ dE,
+                                                                                         float* __restrict__ vsum, int R,
+                                                                                         int L, int D, int vdiv, int vmod) {
+  __shared__ f32x4 red[SCAT_GROUPS][EMB_MAXJ][EMB_THREADS];
   const int me = blockIdx.x;
+  const int t = threadIdx.x % EMB_THREADS, gq = threadIdx.x / EMB_THREADS;
   f32x4 acc[EMB_MAXJ];
 #pragma unroll
   for (int j = 0; j < EMB_MAXJ; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
   for (int r = 0; r < R; ++r) {
     if ((r / vdiv) % vmod != me) continue;
-    for (int l = 0; l < L; ++l) {
+    for (int l = gq; l < L; l += SCAT_GROUPS) {
       const int64_t src = ((int64_t)r * L + l) * D;
 #pragma unroll
       for (int j = 0; j < EMB_MAXJ; ++j) {
-        const int d = (threadIdx.x + EMB_THREADS * j) * 4;
+        const int d = (t + EMB_THREADS * j) * 4;
         if (d < D) acc[j] += *reinterpret_cast<const f32x4*>(dE + src + d);
       }
     }
   }
 #pragma unroll
-  for (int j = 0; j < EMB_MAXJ; ++j) {
-    const int d = (threadIdx.x + EMB_THREADS * j) * 4;
-    if (d < D) *reinterpret_cast<f32x4*>(vsum + (int64_t)me * D + d) = acc[j];
+  for (int j = 0; j < EMB_MAXJ; ++j) red[gq][j][t] = acc[j];
+  __syncthreads();
+  if (gq == 0) {
+#pragma unroll
+    for (int j = 0; j < EMB_MAXJ; ++j) {
+      const int d = (t + EMB_THREADS * j) * 4;
+      if (d < D) *reinterpret_cast<f32x4*>(vsum + (int64_t)me * D + d) = ((red[0][j][t] + red[1][j][t]) + red[2][j][t]) + red[3][j][t];
+    }
   }
 }
 
@@ -752,7 +776,7 @@ int nacf_embed_scatter_bwd(const float* dE, const int64_t* tokens, const int64_t
   if (dword) {
     const int n_special = V - 1 < SPECIAL_N ? V - 1 : SPECIAL_N;   // tiny vocabularies
     if (n_special > 0) {
-      hipLaunchKernelGGL(embed_scatter_special_partial_kernel, dim3(chunks, n_special), dim3(EMB_THREADS), 0, s, dE, tokens,
+      hipLaunchKernelGGL(embed_scatter_special_partial_kernel, dim3(chunks, n_special), dim3(4 * EMB_THREADS), 0, s, dE, tokens,
                          part_special, rows, D);
       // partial layout is [chunk][SPECIAL_N][D]: combine with n_items = SPECIAL_N, only the first n_special used
       hipLaunchKernelGGL(embed_scatter_combine_kernel, dim3(n_special), dim3(EMB_THREADS), 0, s, part_special, chunks,
@@ -771,7 +795,8 @@ int nacf_embed_scatter_bwd(const float* dE, const int64_t* tokens, const int64_t
   }
   if (dcat || dadd) {
     float* vs = dadd ? dadd : vsum_ws;
-    hipLaunchKernelGGL(embed_scatter_video_kernel, dim3(n_video), dim3(EMB_THREADS), 0, s, dE, vs, R, L, D, vdiv, vmod);
+    hipLaunchKernelGGL(embed_scatter_video_kernel, dim3(n_video), dim3(SCAT_GROUPS * EMB_THREADS), 0, s, dE, vs, R, L, D, vdiv,
+                       vmod);
     if (dcat)
       hipLaunchKernelGGL(embed_scatter_cat_kernel, dim3(n_cat), dim3(EMB_THREADS), 0, s, vs, category, dcat, n_video, D);
   }

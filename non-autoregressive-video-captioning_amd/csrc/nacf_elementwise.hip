@@ -231,10 +231,14 @@ __device__ __forceinline__ f32x4 bn_fold16(f32x4 v, f32x4 (*red)[16], int rg, in
   __syncthreads();
   return t;   // every thread gets the column's total
 }
-__device__ __forceinline__ f32x4 bn_sum_parts(const float* __restrict__ part, int S, int D, int c) {
+// column totals of the S slab partials: row group rg adds slabs rg, rg+16, ..., the 16 groups fold through LDS
+// (a 32-long chain of dependent loads at the start of every workgroup cost more than the workgroup's own rows)
+__device__ __forceinline__ f32x4 bn_sum_parts(const float* __restrict__ part, int S, int D, int c, bool valid,
+                                              f32x4 (*red)[16], int rg, int c4) {
   f32x4 t = {0.f, 0.f, 0.f, 0.f};
-  for (int s = 0; s < S; ++s) t += *reinterpret_cast<const f32x4*>(part + (int64_t)s * D + c);
-  return t;
+  if (valid)
+    for (int s = rg; s < S; s += 16) t += *reinterpret_cast<const f32x4*>(part + (int64_t)s * D + c);
+  return bn_fold16(t, red, rg, c4);
 }
 __global__ __launch_bounds__(256) void bn_partial_sum_v4_kernel(const float* __restrict__ x, int rows, int D, int rows_per,
                                                                 float* __restrict__ part) {
@@ -257,8 +261,8 @@ __global__ __launch_bounds__(256) void bn_partial_sqdev_v4_kernel(const float* _
   const int c = blockIdx.x * 64 + c4 * 4;
   const int r0 = blockIdx.y * rows_per, r1 = min(rows, r0 + rows_per);
   f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  const f32x4 mean = bn_sum_parts(part_sum, S, D, c, c < D, red, rg, c4) / (float)rows;
   if (c < D) {
-    const f32x4 mean = bn_sum_parts(part_sum, S, D, c) / (float)rows;
 #pragma unroll 4
     for (int r = r0 + rg; r < r1; r += 16) {
       const f32x4 dv = *reinterpret_cast<const f32x4*>(x + (int64_t)r * D + c) - mean;
@@ -278,12 +282,17 @@ __global__ __launch_bounds__(256) void bn_apply_v4_kernel(const float* __restric
                                                           int rows_per) {
   const int c4 = threadIdx.x & 15, rg = threadIdx.x >> 4;
   const int c = blockIdx.x * 64 + c4 * 4;
+  __shared__ f32x4 red[16][16];
   const int rows = B * F;
   const int r0 = blockIdx.y * rows_per, r1 = min(rows, r0 + rows_per);
+  f32x4 sm = {0.f, 0.f, 0.f, 0.f}, sq = {0.f, 0.f, 0.f, 0.f};
+  if (training) {            // block-uniform: every thread takes part in the folds
+    sm = bn_sum_parts(part_sum, S, D, c, c < D, red, rg, c4);
+    sq = bn_sum_parts(part_sq, S, D, c, c < D, red, rg, c4);
+  }
   if (c >= D) return;
   f32x4 mean, invstd;
   if (training) {
-    const f32x4 sm = bn_sum_parts(part_sum, S, D, c), sq = bn_sum_parts(part_sq, S, D, c);
     mean = sm / (float)rows;
     const f32x4 var_b = sq / (float)rows;
 #pragma unroll
@@ -351,8 +360,10 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_v4_kernel(const float* __res
   const int c = blockIdx.x * 64 + c4 * 4;
   const int rows = B * F;
   const int r0 = blockIdx.y * rows_per, r1 = min(rows, r0 + rows_per);
+  __shared__ f32x4 red[16][16];
+  const f32x4 sdy = bn_sum_parts(part_dy, S, D, c, c < D, red, rg, c4);
+  const f32x4 sdyx = bn_sum_parts(part_dyx, S, D, c, c < D, red, rg, c4);
   if (c >= D) return;
-  const f32x4 sdy = bn_sum_parts(part_dy, S, D, c), sdyx = bn_sum_parts(part_dyx, S, D, c);
   if (blockIdx.y == 0 && rg == 0) {
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
@@ -678,9 +689,10 @@ inline bool bn_aligned16(P... ptrs) {
   ((acc |= reinterpret_cast<uintptr_t>(ptrs)), ...);   // null pointers (absent operands) are fine
   return (acc & 15) == 0;
 }
+constexpr int BN_MAX_SLABS = 32;   // row slabs of the BatchNorm reductions (partials: [BN_MAX_SLABS][D] per statistic)
 inline void bn_split(int rows, int* S, int* rows_per) {
   int s = cdiv(rows, 64);
-  if (s > 32) s = 32;
+  if (s > BN_MAX_SLABS) s = BN_MAX_SLABS;
   if (s < 1) s = 1;
   *rows_per = cdiv(rows, s);
   *S = cdiv(rows, *rows_per);
@@ -720,7 +732,7 @@ int nacf_highway_mix_bwd(const float* dOut, const float* H, const float* TG, flo
 
 size_t nacf_bn_workspace(int rows, int D) {
   (void)rows;
-  return (size_t)2 * 32 * D * sizeof(float) + 256;
+  return (size_t)2 * BN_MAX_SLABS * D * sizeof(float) + 256;
 }
 
 int nacf_bn_concat_fwd(const float* x, float* out, int B, int F, int D, int M_total, int f_off, const float* weight,
@@ -735,7 +747,7 @@ int nacf_bn_concat_fwd(const float* x, float* out, int B, int F, int D, int M_to
   int S, rows_per;
   bn_split(rows, &S, &rows_per);
   float* part_sum = reinterpret_cast<float*>(ws);
-  float* part_sq = part_sum + (size_t)32 * D;
+  float* part_sq = part_sum + (size_t)BN_MAX_SLABS * D;
   hipStream_t s = as_hip(stream);
   dim3 grid(cdiv(D, 64), S);
   const bool v4 = (D % 4 == 0) && bn_aligned16(x, out, weight, bias, save_mean, save_invstd, ws);
@@ -770,7 +782,7 @@ int nacf_bn_concat_bwd(const float* dOut, const float* x, float* dx, int B, int 
   int S, rows_per;
   bn_split(rows, &S, &rows_per);
   float* part_dy = reinterpret_cast<float*>(ws);
-  float* part_dyx = part_dy + (size_t)32 * D;
+  float* part_dyx = part_dy + (size_t)BN_MAX_SLABS * D;
   hipStream_t s = as_hip(stream);
   dim3 grid(cdiv(D, 64), S);
   if ((D % 4 == 0) && bn_aligned16(dOut, x, dx, weight, save_mean, save_invstd, ws)) {
