@@ -436,15 +436,20 @@ __global__ __launch_bounds__(SCAT_GROUPS * EMB_THREADS) void embed_scatter_video
   f32x4 acc[EMB_MAXJ];
 #pragma unroll
   for (int j = 0; j < EMB_MAXJ; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
-  for (int r = 0; r < R; ++r) {
-    if ((r / vdiv) % vmod != me) continue;
-    for (int l = gq; l < L; l += SCAT_GROUPS) {
-      const int64_t src = ((int64_t)r * L + l) * D;
+  // the rows of video `me` are r = (q * vmod + me) * vdiv + j  (j < vdiv, q = 0, 1, ...): walk the (row, position)
+  // pairs directly, group gq takes pairs gq, gq+4, ...
+  const int per_q = vdiv * L;
+  const int n_q = (R / vdiv - me + vmod - 1) / vmod;          // number of q with (q*vmod + me) < R/vdiv
+  const int n_pairs = (n_q > 0 ? n_q : 0) * per_q;
+#pragma unroll 2
+  for (int pidx = gq; pidx < n_pairs; pidx += SCAT_GROUPS) {
+    const int q = pidx / per_q, rem = pidx % per_q;
+    const int r = (q * vmod + me) * vdiv + rem / L, l = rem % L;
+    const int64_t src = ((int64_t)r * L + l) * D;
 #pragma unroll
-      for (int j = 0; j < EMB_MAXJ; ++j) {
-        const int d = (t + EMB_THREADS * j) * 4;
-        if (d < D) acc[j] += *reinterpret_cast<const f32x4*>(dE + src + d);
-      }
+    for (int j = 0; j < EMB_MAXJ; ++j) {
+      const int d = (t + EMB_THREADS * j) * 4;
+      if (d < D) acc[j] += *reinterpret_cast<const f32x4*>(dE + src + d);
     }
   }
 #pragma unroll
@@ -686,7 +691,7 @@ int nacf_embed_ln_fwd(const int64_t* tokens, const int64_t* category, const floa
   return NACF_OK;
 }
 
-static int embed_bwd_blocks(int rows) { return rows < 256 ? rows : 256; }
+static int embed_bwd_blocks(int rows) { return rows < 1024 ? rows : 1024; }   // row slabs of the LayerNorm backward (weight/bias gradient partials)
 
 size_t nacf_embed_ln_bwd_workspace(int R, int L, int D) {
   return (size_t)embed_bwd_blocks(R * L) * 2 * D * sizeof(float) + 256;
