@@ -273,6 +273,11 @@ __device__ __forceinline__ void tile_to_lds(float* T, int pitch, const f32x4 (&p
       *reinterpret_cast<f32x4*>(&T[(tm * 16 + i) * pitch + tn * 16 + g * 4]) = p[tm][tn];
 }
 
+// Backward.  An "item" is one (key/value row set, head): all sequences that attend to the same memory (both NACF passes
+// of a video; one sequence for self-attention) contribute to the same dK / dV.  `wpi` waves share an item: wave `sub`
+// takes the sequences k = sub, sub + wpi, ... of the item.  Everything up to dQ runs in parallel; the dK / dV updates
+// (read-modify-write of the same global rows) are then applied one wave at a time in sequence order, separated by
+// workgroup barriers -- deterministic, and with two sequences per video twice the waves are in flight.
 template <int NKT, int DK16>
 __global__ __launch_bounds__(256) void bwd_kernel(const float* __restrict__ Q, int64_t ldq, const float* __restrict__ K,
                                                    int64_t ldk, const float* __restrict__ V, int64_t ldv,
@@ -280,75 +285,84 @@ __global__ __launch_bounds__(256) void bwd_kernel(const float* __restrict__ Q, i
                                                    int64_t lddq, float* __restrict__ dK, int64_t lddk,
                                                    float* __restrict__ dV, int64_t lddv,
                                                    const int64_t* __restrict__ key_tokens, int causal, int R, int n_kv,
-                                                   int H, int Lq, int Lk, int kv_div, int kv_mod) {
+                                                   int H, int Lq, int Lk, int kv_div, int kv_mod, int wpi, int rounds) {
   constexpr int DK = 16 * DK16;
   constexpr int PITCH = NKT * 16 + 16;          // = 16 mod 32 dwords: the q = 4*st + g rows of a read land 16 banks apart
   constexpr int TKC = NKT < 4 ? NKT : 4;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   float* T = smem + wave * 32 * PITCH;
-  const int item = blockIdx.x * 4 + wave;
-  if (item >= n_kv * H) return;
-  const int kvr = item / H, h = item % H;
+  const int item = (blockIdx.x * 4 + wave) / wpi, sub = wave % wpi;
+  const bool active = item < n_kv * H;          // inactive waves still take part in the barriers
+  const int kvr = active ? item / H : 0, h = active ? item % H : 0;
   const int i = lane & 15, g = lane >> 4;
   const float sq = sqrtf((float)DK);
   const float* Kb = K + (int64_t)kvr * Lk * ldk + h * DK;
   const float* Vb = V + (int64_t)kvr * Lk * ldv + h * DK;
   float* dKb = dK + (int64_t)kvr * Lk * lddk + h * DK;
   float* dVb = dV + (int64_t)kvr * Lk * lddv + h * DK;
-  bool seen = false;
-  for (int r = 0; r < R; ++r) {
-    if ((r / kv_div) % kv_mod != kvr) continue;
-    const float* Qb = Q + (int64_t)r * Lq * ldq + h * DK;
-    const float* dOb = dO + (int64_t)r * Lq * lddo + h * DK;
+  for (int round = 0; round < rounds; ++round) {
+    // the k-th sequence of this memory row set: r = (q * kv_mod + kvr) * kv_div + j with k = q * kv_div + j
+    const int k = round * wpi + sub;
+    const int r = ((k / kv_div) * kv_mod + kvr) * kv_div + k % kv_div;
+    const bool has = active && r < R && (k / kv_div) * kv_mod + kvr < (R + kv_div - 1) / kv_div;
+    const float* Qb = Q + (int64_t)(has ? r : 0) * Lq * ldq + h * DK;
+    const float* dOb = dO + (int64_t)(has ? r : 0) * Lq * lddo + h * DK;
     f32x4 p[2][NKT], dp[2][NKT];
-#pragma unroll
-    for (int tm = 0; tm < 2; ++tm)
-#pragma unroll
-      for (int tn = 0; tn < NKT; ++tn) { p[tm][tn] = f32x4{0.f, 0.f, 0.f, 0.f}; dp[tm][tn] = f32x4{0.f, 0.f, 0.f, 0.f}; }
-    {
-      f32x4 qf[2][DK16];
-#pragma unroll
-      for (int tm = 0; tm < 2; ++tm) load_row_frag<DK16>(qf[tm], Qb, ldq, tm * 16 + i, Lq, g);
-      contract_d<NKT, DK16>(p, Kb, ldk, Lk, qf, i, g);
-    }
-    softmax_rows<NKT>(p, sq, key_tokens ? key_tokens + (int64_t)r * Lk : nullptr, causal, Lk, i, g);
-    {
-      f32x4 gf[2][DK16];
-#pragma unroll
-      for (int tm = 0; tm < 2; ++tm) load_row_frag<DK16>(gf[tm], dOb, lddo, tm * 16 + i, Lq, g);
-      contract_d<NKT, DK16>(dp, Vb, ldv, Lk, gf, i, g);   // dP = dO V^T
-    }
-    // dS = P * (dP - rowsum(P * dP)) / sqrt(dk)
-#pragma unroll
-    for (int tm = 0; tm < 2; ++tm) {
-      float dot = 0.f;
-#pragma unroll
-      for (int tn = 0; tn < NKT; ++tn)
-#pragma unroll
-        for (int rr = 0; rr < 4; ++rr) dot += p[tm][tn][rr] * dp[tm][tn][rr];
-      dot += __shfl_xor(dot, 16, 64);
-      dot += __shfl_xor(dot, 32, 64);
-#pragma unroll
-      for (int tn = 0; tn < NKT; ++tn)
-#pragma unroll
-        for (int rr = 0; rr < 4; ++rr) dp[tm][tn][rr] = p[tm][tn][rr] * (dp[tm][tn][rr] - dot) / sq;
-    }
-    {
-      f32x4 o[2][DK16];
+    if (has) {
 #pragma unroll
       for (int tm = 0; tm < 2; ++tm)
 #pragma unroll
-        for (int td = 0; td < DK16; ++td) o[tm][td] = f32x4{0.f, 0.f, 0.f, 0.f};
-      contract_key<NKT, DK16>(o, dp, Kb, ldk, Lk, i, g);   // dQ = dS K
-      store_rows<DK16>(o, dQ + (int64_t)r * Lq * lddq + h * DK, lddq, Lq, i, g);
+        for (int tn = 0; tn < NKT; ++tn) { p[tm][tn] = f32x4{0.f, 0.f, 0.f, 0.f}; dp[tm][tn] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+      {
+        f32x4 qf[2][DK16];
+#pragma unroll
+        for (int tm = 0; tm < 2; ++tm) load_row_frag<DK16>(qf[tm], Qb, ldq, tm * 16 + i, Lq, g);
+        contract_d<NKT, DK16>(p, Kb, ldk, Lk, qf, i, g);
+      }
+      softmax_rows<NKT>(p, sq, key_tokens ? key_tokens + (int64_t)r * Lk : nullptr, causal, Lk, i, g);
+      {
+        f32x4 gf[2][DK16];
+#pragma unroll
+        for (int tm = 0; tm < 2; ++tm) load_row_frag<DK16>(gf[tm], dOb, lddo, tm * 16 + i, Lq, g);
+        contract_d<NKT, DK16>(dp, Vb, ldv, Lk, gf, i, g);   // dP = dO V^T
+      }
+      // dS = P * (dP - rowsum(P * dP)) / sqrt(dk)
+#pragma unroll
+      for (int tm = 0; tm < 2; ++tm) {
+        float dot = 0.f;
+#pragma unroll
+        for (int tn = 0; tn < NKT; ++tn)
+#pragma unroll
+          for (int rr = 0; rr < 4; ++rr) dot += p[tm][tn][rr] * dp[tm][tn][rr];
+        dot += __shfl_xor(dot, 16, 64);
+        dot += __shfl_xor(dot, 32, 64);
+#pragma unroll
+        for (int tn = 0; tn < NKT; ++tn)
+#pragma unroll
+          for (int rr = 0; rr < 4; ++rr) dp[tm][tn][rr] = p[tm][tn][rr] * (dp[tm][tn][rr] - dot) / sq;
+      }
+      {
+        f32x4 o[2][DK16];
+#pragma unroll
+        for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+          for (int td = 0; td < DK16; ++td) o[tm][td] = f32x4{0.f, 0.f, 0.f, 0.f};
+        contract_key<NKT, DK16>(o, dp, Kb, ldk, Lk, i, g);   // dQ = dS K
+        store_rows<DK16>(o, dQ + (int64_t)r * Lq * lddq + h * DK, lddq, Lq, i, g);
+      }
     }
-    // reductions over q: transpose dS / P through the wave-private LDS tile
-    tile_to_lds<NKT>(T, PITCH, dp, i, g);
-    contract_q<NKT, DK16, TKC>(T, PITCH, Qb, ldq, Lq, dKb, lddk, Lk, seen, i, g);    // dK (+)= dS^T Q
-    tile_to_lds<NKT>(T, PITCH, p, i, g);
-    contract_q<NKT, DK16, TKC>(T, PITCH, dOb, lddo, Lq, dVb, lddv, Lk, seen, i, g);  // dV (+)= P^T dO
-    seen = true;
+    // reductions over q: transpose dS / P through the wave-private LDS tile; one wave of the item at a time
+    for (int turn = 0; turn < wpi; ++turn) {
+      if (has && turn == sub) {
+        const bool seen = k > 0;
+        tile_to_lds<NKT>(T, PITCH, dp, i, g);
+        contract_q<NKT, DK16, TKC>(T, PITCH, Qb, ldq, Lq, dKb, lddk, Lk, seen, i, g);    // dK (+)= dS^T Q
+        tile_to_lds<NKT>(T, PITCH, p, i, g);
+        contract_q<NKT, DK16, TKC>(T, PITCH, dOb, lddo, Lq, dVb, lddv, Lk, seen, i, g);  // dV (+)= P^T dO
+      }
+      if (wpi > 1) __syncthreads();
+    }
   }
 }
 

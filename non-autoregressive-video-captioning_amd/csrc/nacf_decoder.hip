@@ -864,7 +864,15 @@ int nacf_attention_bwd(const float* Q, int64_t ldq, const float* K, int64_t ldk,
   NACF_CHECK(!(causal && Lq != Lk), NACF_EINVAL, "nacf_attention_bwd: causal mask needs Lq == Lk");
   if (attn_mfma_ok(Lq, Lk, dk) && attn_aligned(Q, ldq) && attn_aligned(K, ldk) && attn_aligned(V, ldv) &&
       attn_aligned(dO, lddo) && attn_aligned(dQ, lddq) && attn_aligned(dK, lddk) && attn_aligned(dV, lddv)) {
-    const dim3 grid(cdiv(n_kv * H, 4));
+    // sequences per memory row set (upper bound) -> waves per item (1, 2 or 4) and rounds of the item loop
+    const int groups = cdiv(R, kv_div);
+    const int nseq_max = kv_div * cdiv(groups, kv_mod);
+    // measured on MI355X (NACF train step, 2 sequences per video): 1 wave per item 144 us, 2 waves 187 us -- the ordered
+    // dK / dV turns and their barriers cost more than the extra waves hide; NACF_ATTN_WPI=2|4 keeps the variant testable
+    int wpi = 1;
+    { const char* e = getenv("NACF_ATTN_WPI"); if (e && (atoi(e) == 2 || atoi(e) == 4) && nseq_max >= atoi(e)) wpi = atoi(e); }
+    const int rounds = cdiv(nseq_max, wpi);
+    const dim3 grid(cdiv(n_kv * H * wpi, 4));
     hipStream_t s = as_hip(stream);
     const int nkt = Lk <= 32 ? 2 : 8;
     const size_t lds_m = (size_t)4 * 32 * (nkt * 16 + 16) * sizeof(float);   // one transpose tile per wave
@@ -877,7 +885,7 @@ int nacf_attention_bwd(const float* Q, int64_t ldq, const float* K, int64_t ldk,
       set_##NKT##_##DK16 = true;                                                                                      \
     }                                                                                                                 \
     hipLaunchKernelGGL((attn::bwd_kernel<NKT, DK16>), grid, dim3(256), lds_m, s, Q, ldq, K, ldk, V, ldv, dO, lddo, dQ,  \
-                       lddq, dK, lddk, dV, lddv, key_tokens, causal, R, n_kv, H, Lq, Lk, kv_div, kv_mod);              \
+                       lddq, dK, lddk, dV, lddv, key_tokens, causal, R, n_kv, H, Lq, Lk, kv_div, kv_mod, wpi, rounds);  \
   } while (0)
     if (nkt == 2) { if (dk == 64) NACF_ATTN_BWD(2, 4); else NACF_ATTN_BWD(2, 1); }
     else { if (dk == 64) NACF_ATTN_BWD(8, 4); else NACF_ATTN_BWD(8, 1); }

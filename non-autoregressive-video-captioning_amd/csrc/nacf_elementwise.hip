@@ -689,10 +689,21 @@ __global__ __launch_bounds__(256) void xent_bwd_kernel(const float* __restrict__
   const float g = (gscale ? gscale[0] : 1.f) * scale;
   const float* p = logp + (int64_t)row * ld;
   float* d = dlogits + (int64_t)row * ldd;
+  // float4 body when both rows are 16-byte aligned (ld % 4 == 0: vocab_ld), scalar tail / fallback otherwise
+  const bool vec = ((ld | ldd) & 3) == 0 && ((reinterpret_cast<uintptr_t>(logp) | reinterpret_cast<uintptr_t>(dlogits)) & 15) == 0;
+  const int V4 = vec ? (V >> 2) : 0;
   if (lab == NACF_PAD) {
-    for (int i = threadIdx.x; i < V; i += 256) d[i] = 0.f;
+    for (int i = threadIdx.x; i < V4; i += 256) reinterpret_cast<f32x4*>(d)[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int i = 4 * V4 + threadIdx.x; i < V; i += 256) d[i] = 0.f;
   } else {
-    for (int i = threadIdx.x; i < V; i += 256) {
+    for (int i = threadIdx.x; i < V4; i += 256) {
+      const f32x4 lp = reinterpret_cast<const f32x4*>(p)[i];
+      f32x4 o;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[e] = (expf(lp[e]) - ((4 * i + e) == lab ? 1.f : 0.f)) * g;
+      reinterpret_cast<f32x4*>(d)[i] = o;
+    }
+    for (int i = 4 * V4 + threadIdx.x; i < V; i += 256) {
       const float sm = expf(p[i]);
       d[i] = (sm - (i == lab ? 1.f : 0.f)) * g;
     }

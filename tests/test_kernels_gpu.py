@@ -463,8 +463,10 @@ def test_self_attention_fwd_bwd(dev, R, Lq, H, dk, causal):
     assert err(dqkv, qd.grad) < 5e-5
 
 
+@pytest.mark.parametrize("wpi", ["1", "2"])
 @pytest.mark.parametrize("mode", ["mod", "div"])
-def test_cross_attention_shared_memory_fwd_bwd(dev, mode):
+def test_cross_attention_shared_memory_fwd_bwd(dev, mode, wpi, monkeypatch):
+    monkeypatch.setenv("NACF_ATTN_WPI", wpi)      # waves per memory row set in the backward kernel (default 1)
     ops, _ = _ops()
     Bv, k_, Lq, Lk, H, dk = 3, 2, 6, 12, 4, 16
     D, R = H * dk, Bv * k_
