@@ -190,7 +190,7 @@ def test_shard_loader_resident_equals_streaming_and_feeds_a_train_step(dev, tmp_
     bound = D.frame_bounds(60, 8)
     for b in range(n):
         corpus_vid = int(vids[table.video[idx[b]]])
-        clip = torch.from_numpy(np.ascontiguousarray(shards[0].array[shards[0].row_of(np.array([corpus_vid]))[0]])).to(dev)
+        clip = torch.from_numpy(np.array(shards[0].array[shards[0].row_of(np.array([corpus_vid]))[0]])).to(dev)
         for i in range(8):
             hit = (clip[bound[i]:bound[i + 1]] == first["feats"][0][b, i]).all(1)
             assert int(hit.sum()) >= 1

@@ -510,7 +510,7 @@ def test_attention_generic_lds_kernels(dev, R, Lq, H, dk, causal, monkeypatch):
     """the LDS/VALU attention kernels (shapes the MFMA path does not cover) stay correct"""
     monkeypatch.setenv("NACF_ATTN_VALU", "1")
     test_self_attention_fwd_bwd(dev, R, Lq, H, dk, causal)
-    test_cross_attention_shared_memory_fwd_bwd(dev, "mod")
+    test_cross_attention_shared_memory_fwd_bwd(dev, "mod", "1", monkeypatch)
     test_cross_attention_shared_memory_fwd_bwd(dev, "div")
 
 
