@@ -511,7 +511,7 @@ def test_attention_generic_lds_kernels(dev, R, Lq, H, dk, causal, monkeypatch):
     monkeypatch.setenv("NACF_ATTN_VALU", "1")
     test_self_attention_fwd_bwd(dev, R, Lq, H, dk, causal)
     test_cross_attention_shared_memory_fwd_bwd(dev, "mod", "1", monkeypatch)
-    test_cross_attention_shared_memory_fwd_bwd(dev, "div")
+    test_cross_attention_shared_memory_fwd_bwd(dev, "div", "1", monkeypatch)
 
 
 def test_attention_odd_head_dim_uses_generic_path(dev):
