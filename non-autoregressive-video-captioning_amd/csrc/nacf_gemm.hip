@@ -14,10 +14,14 @@ int forced_tile() {
   return e ? (atoi(e) == 64 ? 1 : (atoi(e) == 128 ? 0 : -1)) : -1;
 }
 
-int pick_tile(int M, int N, int splits, bool has_rows = false) {
+int pick_tile(int M, int N, int splits, bool has_rows = false, bool heavy_epilogue = false) {
   const int forced = forced_tile();
   if (forced >= 0) return forced;
   const long big = (long)cdiv(M, 128) * cdiv(N, 128) * splits;
+  // a transcendental activation in the epilogue (gelu: one tanh per output) keeps the VALU busy for a long time per
+  // tile; with only 2 big-tile workgroups per CU the matrix pipe idles meanwhile, 5-6 small-tile workgroups overlap it
+  // (decode FFN 14592x2048x512 with gelu_new: 69.7 TF on 128x128, 94.9 TF on 64x64)
+  if (heavy_epilogue) return big >= 8192 ? 0 : 1;
   // >= 3 workgroups per CU with the big tile, else go small (tools/gemm_bench.py: 64x64 wins or ties up to
   // 640 big tiles, 128x128 wins from 960).  With a live-row list the host does not know how many row tiles
   // survive (typically 40-60 %), so ask for twice the tiles.
@@ -237,7 +241,9 @@ int nacf_linear_fwd(const float* X, int64_t ldx, const float* W, int64_t ldw, fl
   g.k_per_split = cdiv(K, 16) * 16;
   set_rows(g, rs);
   const bool vec = (ldx % 4 == 0) && (ldw % 4 == 0) && aligned16(X) && aligned16(W);
-  launch_gemm<true, true, EpiLinear>(g, epi, 1, pick_tile(M, N, 1, rs != nullptr), vec, as_hip(stream));
+  const bool heavy = epi.ep.act == NACF_ACT_GELU_NEW || epi.ep.act == NACF_ACT_GELU_ERF || epi.ep.act == NACF_ACT_TANH ||
+                     epi.ep.act == NACF_ACT_SIGMOID || epi.ep.act == NACF_ACT_TANH_SIGMOID;
+  launch_gemm<true, true, EpiLinear>(g, epi, 1, pick_tile(M, N, 1, rs != nullptr, heavy), vec, as_hip(stream));
   NACF_LAUNCH_CHECK("nacf_linear_fwd");
   return NACF_OK;
 }
