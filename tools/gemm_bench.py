@@ -54,13 +54,15 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--only", type=str, default="")
+    ap.add_argument("--tiles", type=str, default="64,128", help="NACF_GEMM_TILE values to compare")
     ap.add_argument("--shapes", type=str, default="", help="extra shapes 'kind:M:N:K,...' (kind 0 fwd, 1 dX, 2 dW)")
     ap.add_argument("--pad", type=int, default=0, help="extra floats of row pitch on the K-contiguous fwd operands")
     args = ap.parse_args()
     global PAD
     PAD = args.pad
     dev = torch.device("cuda:0")
-    print("%-12s %-26s %10s %10s %10s %10s" % ("gemm", "M,N,K", "ms@64", "TF@64", "ms@128", "TF@128"))
+    tiles = args.tiles.split(",")
+    print("%-12s %-26s " % ("gemm", "M,N,K") + " ".join("%10s %10s" % ("ms@" + t, "TF@" + t) for t in tiles))
     shapes = SHAPES
     if args.shapes:
         shapes = [("custom k%s" % t.split(":")[0],) + tuple(int(v) for v in t.split(":")) for t in args.shapes.split(",")]
@@ -68,11 +70,10 @@ def main():
         if args.only and args.only not in label:
             continue
         res = []
-        for tile in ("64", "128"):
+        for tile in tiles:
             os.environ["NACF_GEMM_TILE"] = tile
             res.append(run(kind, M, N, K, args.iters, dev))
-        print("%-12s %-26s %10.3f %10.1f %10.3f %10.1f" % (label, "%d,%d,%d" % (M, N, K), res[0][0], res[0][1],
-                                                           res[1][0], res[1][1]))
+        print("%-12s %-26s " % (label, "%d,%d,%d" % (M, N, K)) + " ".join("%10.3f %10.1f" % r for r in res))
 
 
 if __name__ == "__main__":
