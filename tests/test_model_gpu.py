@@ -303,3 +303,33 @@ def test_staged_backward_matches_single_pass(dev):
         grads.append(model.flat.grad.clone())
     assert float(grads[0].abs().max()) > 0
     assert float((grads[0] - grads[1]).abs().max()) <= 1e-6 * float(grads[0].abs().max())
+
+
+def test_live_row_path_equals_dense_path_at_model_width(dev):
+    """size-independent property of the <pad>-skipping GEMMs: at the real model width (d=512, V=10547, F=60) the step with
+    live-row lists (default) and the step that multiplies every slot (pack_rows=False) give the same loss and the same
+    gradients -- the skipped rows only ever held exact zeros"""
+    import nacf_amd
+    from nacf_amd.misc.crit import get_criterion
+    from nacf_amd import synthetic as S
+    outs = []
+    for pack in (True, False):
+        opt = nacf_amd.opts.make_opt("NACF", "MSRVTT", with_category=True, max_len=20, vocab_size=10547, fused_loss=True,
+                                     hidden_dropout_prob=0.0, encoder_dropout=0.0, pack_rows=pack)
+        b = S.synth_batch(opt, 16, 60, seed=4)
+        model = nacf_amd.get_model(opt)
+        model.load_state_dict(S.init_state_dict(opt, seed=1))
+        model.to(dev).train()
+        crit = get_criterion(model.opt)
+        model.zero_grad()
+        res = model(feats=[f.to(dev) for f in b["feats"]], tgt_tokens=[b["tokens_1"].to(dev), b["tokens"].to(dev)],
+                    category=b["category"].to(dev))
+        res["tgt_word_labels"] = [b["labels_1"].to(dev), b["labels"].to(dev)]
+        res["tgt_length"] = b["tgt_length"].to(dev)
+        loss = crit.get_loss(res)
+        loss.backward()
+        outs.append((float(loss.detach()), model.flat.grad.clone()))
+    (l0, g0), (l1, g1) = outs
+    assert abs(l0 - l1) <= 1e-5 * abs(l1)
+    scale = float(g1.abs().max())
+    assert scale > 0 and float((g0 - g1).abs().max()) <= 2e-5 * scale
