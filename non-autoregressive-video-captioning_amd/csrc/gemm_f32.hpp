@@ -502,7 +502,10 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmShape g, Epi epi) {
 
   // ---- global -> register staging of one k-tile.  Interior k-tiles (block-uniform test) use plain
   // 16-byte loads with no per-lane guards; the last partial k-tile and ragged row tiles use the checked loaders.
-  f32x4 qreg[BM / 64], preg[BN / 64];
+  // TWO staging register sets: set (t & 1) carries tile t+2 into iteration t and is refilled with tile t+4 there, so
+  // two k-tiles of global loads are in flight per workgroup (bytes in flight / latency is what bounds the global->LDS
+  // rate: with one 16 KB tile in flight per 128x128 workgroup every K=512 shape sat at ~3.2 TB/s of loads = 100 TFLOP/s)
+  f32x4 qreg[2][BM / 64], preg[2][BN / 64];
   // row-list dW GEMMs walk the reduce dimension through `kmap`: the indices of the NEXT staged k-tile are
   // fetched one iteration ahead (kq / kp), so the data loads never wait on an index load issued just before them
   int kq[BM / 64], kp[BN / 64];
@@ -516,47 +519,50 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmShape g, Epi epi) {
       }
     }
   };
-  auto load_fast = [&](int k0, bool idx_ready) {
+  auto load_fast = [&](auto set_c, int k0, bool idx_ready) {
+    constexpr int S = decltype(set_c)::value;
 #pragma unroll
     for (int u = 0; u < BM / 64; ++u) {
       if constexpr (QKC) {
-        qreg[u] = *reinterpret_cast<const f32x4*>(qfast[u] + k0);
+        qreg[S][u] = *reinterpret_cast<const f32x4*>(qfast[u] + k0);
       } else {
         const int gk = k0 + (tid + 256 * u) / (BM / 4);
         const int pk = kmap ? (idx_ready ? kq[u] : kmap[gk]) : gk;
-        qreg[u] = *reinterpret_cast<const f32x4*>(qfast[u] + (int64_t)pk * g.ldq);
+        qreg[S][u] = *reinterpret_cast<const f32x4*>(qfast[u] + (int64_t)pk * g.ldq);
       }
     }
 #pragma unroll
     for (int u = 0; u < BN / 64; ++u) {
       if constexpr (PKC) {
-        preg[u] = *reinterpret_cast<const f32x4*>(pfast[u] + k0);
+        preg[S][u] = *reinterpret_cast<const f32x4*>(pfast[u] + k0);
       } else {
         const int gk = k0 + (tid + 256 * u) / (BN / 4);
         const int pk = kmap ? (idx_ready ? kp[u] : kmap[gk]) : gk;
-        preg[u] = *reinterpret_cast<const f32x4*>(pfast[u] + (int64_t)pk * g.ldp);
+        preg[S][u] = *reinterpret_cast<const f32x4*>(pfast[u] + (int64_t)pk * g.ldp);
       }
     }
   };
-  auto load_tiles = [&](int k0) {
+  auto load_tiles = [&](auto set_c, int k0) {
+    constexpr int S = decltype(set_c)::value;
     if (VEC && q_full && p_full && (k0 + BK <= kend)) {
-      load_fast(k0, false);
+      load_fast(set_c, k0, false);
     } else {
-      if constexpr (QKC) tile_load_kc<BM, VEC>(qreg, g.Q, g.ldq, qrow, k0, kend, tid);
-      else tile_load_mc<BM, VEC>(qreg, g.Q, g.ldq, m0, Meff, k0, kend, kmap, tid);
-      if constexpr (PKC) tile_load_kc<BN, VEC>(preg, g.P, g.ldp, prow, k0, kend, tid);
-      else tile_load_mc<BN, VEC>(preg, g.P, g.ldp, n0, g.N, k0, kend, kmap, tid);
+      if constexpr (QKC) tile_load_kc<BM, VEC>(qreg[S], g.Q, g.ldq, qrow, k0, kend, tid);
+      else tile_load_mc<BM, VEC>(qreg[S], g.Q, g.ldq, m0, Meff, k0, kend, kmap, tid);
+      if constexpr (PKC) tile_load_kc<BN, VEC>(preg[S], g.P, g.ldp, prow, k0, kend, tid);
+      else tile_load_mc<BN, VEC>(preg[S], g.P, g.ldp, n0, g.N, k0, kend, kmap, tid);
     }
   };
   const bool do_colsum = ROWS_ARE_K && (g.colsum_part || g.colsum_out) && tile_n == 0;
   f32x4 qsum = {0.f, 0.f, 0.f, 0.f};   // running row sums of the staged Q vectors (every k-tile is stored exactly once)
-  auto store_tiles = [&](float* buf) {
-    tile_store<BM, QKC>(buf, qreg, tid);
-    tile_store<BN, PKC>(buf + QSZ, preg, tid);
+  auto store_tiles = [&](auto set_c, float* buf) {
+    constexpr int S = decltype(set_c)::value;
+    tile_store<BM, QKC>(buf, qreg[S], tid);
+    tile_store<BN, PKC>(buf + QSZ, preg[S], tid);
     if constexpr (ROWS_ARE_K) {
       if (do_colsum) {
 #pragma unroll
-        for (int u = 0; u < BM / 64; ++u) qsum += qreg[u];
+        for (int u = 0; u < BM / 64; ++u) qsum += qreg[S][u];
       }
     }
   };
@@ -583,10 +589,12 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmShape g, Epi epi) {
   auto read_p_kc = [&](const float* buf, int set, int b) { pf[set][b] = frag_load_kc<BN>(buf + QSZ, wn * WTN + b * 16, li, lg); };
   auto read_q_mc = [&](const float* buf, int s) { qv[s] = frag_load_mc<BM, TM>(buf, wm * WTM, li, lg, s); };
   auto read_p_mc = [&](const float* buf, int s) { pv[s] = frag_load_mc<BN, TN>(buf + QSZ, wn * WTN, li, lg, s); };
+  using S0 = std::integral_constant<int, 0>;
+  using S1 = std::integral_constant<int, 1>;
   if (nk > 0) {
-    load_tiles(kbeg);
-    store_tiles(smem);
-    if (nk > 1) load_tiles(kbeg + BK);
+    load_tiles(S0{}, kbeg);
+    store_tiles(S0{}, smem);
+    if (nk > 1) load_tiles(S1{}, kbeg + BK);
   }
   __syncthreads();
   if (nk > 0) {
@@ -604,32 +612,33 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmShape g, Epi epi) {
       for (int b = 0; b < TN; ++b) read_p_kc(smem, 0, b);
     }
     if (nk > 1) {
-      store_tiles(smem + BUF);
-      if (nk > 2) load_tiles(kbeg + 2 * BK);
+      store_tiles(S1{}, smem + BUF);
+      if (nk > 2) load_tiles(S0{}, kbeg + 2 * BK);
+      if (nk > 3) load_tiles(S1{}, kbeg + 3 * BK);
     }
   }
   __syncthreads();
 
   // STEADY iterations are straight-line code (no guards: tile kt+3 exists and is an interior tile of fully
   // populated row tiles), so the scheduler is free to interleave the LDS / global traffic with the MFMAs.
-  // The loop is deliberately NOT unrolled by two (double-buffered fragments are rotated with register moves
-  // instead): with both parities in one body the optimiser sinks G(kt+3) down to its consumer W(kt+3)
-  // in the second half and every other k-tile eats a full memory latency.
-  auto iteration = [&](auto steady, int kt) {
+  // The loop body holds both parities (the staging set index must be a compile-time constant); every load is
+  // consumed in the NEXT trip (G(kt+4) -> W(kt+4) two iterations later), so the optimiser cannot sink it to its use.
+  // Double-buffered fragments are still rotated with register moves.
+  auto iteration = [&](auto steady, auto set_c, int kt) {     // set_c = kt & 1 (compile time): the staging set of this parity
     constexpr bool STEADY = decltype(steady)::value;
     const float* nbuf = smem + ((kt + 1) & 1) * BUF;   // image of tile kt+1
     float* wbuf = smem + (kt & 1) * BUF;               // image of tile kt, about to become tile kt+2
-    const bool has1 = STEADY || kt + 1 < nk, has2 = STEADY || kt + 2 < nk, has3 = STEADY || kt + 3 < nk;
-    auto stage_ahead = [&]() {   // W(kt+2), G(kt+3)
-      if (has2) store_tiles(wbuf);
+    const bool has1 = STEADY || kt + 1 < nk, has2 = STEADY || kt + 2 < nk, has4 = STEADY || kt + 4 < nk;
+    auto stage_ahead = [&]() {   // W(kt+2) out of this parity's staging set, then G(kt+4) into it
+      if (has2) store_tiles(set_c, wbuf);
       if constexpr (STEADY) {
-        load_fast(kbeg + (kt + 3) * BK, true);
-        load_kidx(kbeg + (kt + 4) * BK);
-        // keep W(kt+2) / G(kt+3) up here, a whole k-tile of MFMAs ahead of their consumers
+        load_fast(set_c, kbeg + (kt + 4) * BK, true);
+        load_kidx(kbeg + (kt + 5) * BK);
+        // keep W(kt+2) / G(kt+4) up here, ahead of their consumers
         // (MFMA, VALU, SALU and LDS reads may still be scheduled across; VMEM and LDS writes may not)
         __builtin_amdgcn_sched_barrier(0x10E);
-      } else if (has3) {
-        load_tiles(kbeg + (kt + 3) * BK);
+      } else if (has4) {
+        load_tiles(set_c, kbeg + (kt + 4) * BK);
       }
     };
     if constexpr (!GROUP_BY_S) {
@@ -684,15 +693,25 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmShape g, Epi epi) {
     __syncthreads();
   };
   {
-    // number of leading iterations whose G(kt+3) is an unguarded interior tile
+    // number of leading iterations whose G(kt+4) is an unguarded interior tile (even: the loop handles both parities
+    // per trip so that the staging set index is a compile-time constant)
     int n_steady = 0;
-    if (VEC && q_full && p_full) n_steady = min(nk - 3, (kend - kbeg) / BK - 3);
+    if (VEC && q_full && p_full) n_steady = min(nk - 4, (kend - kbeg) / BK - 4);
+    if (n_steady < 0) n_steady = 0;
+    n_steady &= ~1;
     int kt = 0;
-    if (n_steady > 0) load_kidx(kbeg + 3 * BK);
+    if (n_steady > 0) load_kidx(kbeg + 4 * BK);
 #pragma nounroll
-    for (; kt < n_steady; ++kt) iteration(std::true_type{}, kt);
+    for (; kt < n_steady; kt += 2) {
+      iteration(std::true_type{}, S0{}, kt);
+      iteration(std::true_type{}, S1{}, kt + 1);
+    }
 #pragma nounroll
-    for (; kt < nk; ++kt) iteration(std::false_type{}, kt);
+    for (; kt + 1 < nk; kt += 2) {
+      iteration(std::false_type{}, S0{}, kt);
+      iteration(std::false_type{}, S1{}, kt + 1);
+    }
+    if (kt < nk) iteration(std::false_type{}, S0{}, kt);
   }
 
   if constexpr (ROWS_ARE_K) {
