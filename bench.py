@@ -43,6 +43,66 @@ def make_opt(nacf_amd, L, V):
                                   beam_alpha=1.35, paradigm="mp")
 
 
+def bench_nab(nacf_amd, dev, B, L, V, F_):
+    """train-step and decode throughput of NAB (BASELINE.json configs[1]) with the step captured in a hipGraph"""
+    from nacf_amd.misc.crit import get_criterion
+    from nacf_amd.misc.optim import get_optimizer
+    from nacf_amd.models.Translator import Translator
+    from nacf_amd import synthetic as O
+    opt = nacf_amd.opts.make_opt("NAB", "MSRVTT", with_category=True, max_len=L, vocab_size=V, n_frames=60, fused_loss=True,
+                                 beta=[0.35, 0.9], iterations=5, length_beam_size=6, beam_alpha=1.35, paradigm="mp")
+    model = nacf_amd.get_model(opt)
+    model.load_state_dict({k: v.clone() for k, v in O.init_state_dict(opt, seed=0).items()})
+    model.to(dev).train()
+    crit, optim = get_criterion(model.opt), get_optimizer(model.opt, model)
+    b = O.synth_batch(opt, B, F_, seed=3)
+    feats = [f.to(dev) for f in b["feats"]]
+    tokens, labels = b["tokens"].to(dev), b["labels"].to(dev)
+    category, tgt_length = b["category"].to(dev), b["tgt_length"].to(dev)
+
+    def step():
+        optim.zero_grad()
+        res = model(feats=feats, tgt_tokens=tokens, category=category)
+        res["tgt_word_labels"] = labels
+        res["tgt_length"] = tgt_length
+        crit.get_loss(res).backward()
+        optim.step(grad_scale=1.0)
+    for _ in range(3):
+        step()
+    torch.cuda.synchronize()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=side):
+            step()
+    torch.cuda.current_stream().wait_stream(side)
+    for _ in range(3):
+        graph.replay()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    n = 30
+    for _ in range(n):
+        graph.replay()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / n
+    model.eval()
+    tr = Translator(model, dict(model.opt), device=dev)
+
+    def dec():
+        with torch.no_grad():
+            return tr.translate_batch(model.encode(feats=feats), category, None, None)
+    dec(); dec()
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    for _ in range(5):
+        dec()
+    torch.cuda.synchronize()
+    ddt = (time.perf_counter() - t1) / 5
+    return {"batch": B, "train_videos_per_s": round(B / dt, 1), "train_ms_per_step": round(dt * 1e3, 3),
+            "decode_captions_per_s": round(B / ddt, 1), "decode_ms_per_batch": round(ddt * 1e3, 2), "dtype": "f32"}
+
+
 def bench_loader(args, nacf_amd, opt, dev, B, L, V, F_, static, graph):
     """Train-step throughput when every batch comes from nacf_amd.data.ShardLoader (synthetic shards written to a
     temp dir): per step the loader's tensors are copied into the graph's static input buffers and the captured step is
@@ -389,6 +449,12 @@ def main():
             del amodel
             model.train()
 
+        # ---- BASELINE.json configs[1]: NAB (single-pass masked-LM decoder), MSRVTT-shape, batch 64, seq_len 20 --
+        # the same engine on the other NA model family (fp32 here: see DESIGN.md on bf16 and greedy-token parity)
+        nab = None
+        if not args.no_compare and world == 1:
+            nab = bench_nab(nacf_amd, dev, 64, L, V, F_)
+
         # ---- CPU baseline: the oracle (plain eager PyTorch fp32 restatement) on this box's host cores
         cpu = None
         if not args.no_cpu_baseline and world == 1:      # reported at N=1 only (the other ranks would sit in a barrier)
@@ -421,7 +487,7 @@ def main():
                           "parallelism": "dp%d" % world, "hipgraph": bool(use_graph), "live_row_gemms": True,
                           "overlapped_allreduce": bool(staged)},
                "roofline": roofline, "cpu_baseline": cpu, "decode": decode, "config5_ar_vs_na": compare,
-               "loader_fed": loader_leg,
+               "loader_fed": loader_leg, "config1_nab": nab,
                "final_loss": round(final_loss, 4),
                "gemm_kernels": gemm_table}
     if multi:
