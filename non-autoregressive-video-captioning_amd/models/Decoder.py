@@ -106,6 +106,10 @@ class BertDecoder(nn.Module):
             additional = kwargs.get('pooled_memory')
             if additional is None:
                 additional = MeanTimeFn.apply(enc_output)
+        pos2 = None
+        if self.pos_attention:      # Decoder.py:144-146: the embedding gets no additional features in this mode
+            additional = None
+            pos2 = self.embedding.run_pos(R, Lq, training, tgt_seq.device)
         hidden = self.embedding.run(tgt_seq, category, additional, vdiv, vmod, training)
         memory_kv = kwargs.get('memory_kv')
         # live-row list of the [R, L] slot grid: by default every non-<pad> slot of tgt_seq; the NA
@@ -119,7 +123,7 @@ class BertDecoder(nn.Module):
         for i, layer in enumerate(self.layer):
             kv = memory_kv[i] if memory_kv is not None else layer.project_memory(enc_output)
             x2, att = layer.run(x2, tgt_seq, decoding_type == 'ARFormer', kv, M, vdiv, vmod, training,
-                                output_attentions, rows)
+                                output_attentions, rows, pos2)
             if output_attentions:
                 all_attentions = all_attentions + (att,)
         hidden = x2.view(R, Lq, D)

@@ -22,7 +22,8 @@ import torch.nn as nn
 
 from ..config import Constants
 from ..runtime import lib as L
-from ..runtime.functional import CrossAttentionFn, EmbedLNFn, LayerNormFn, LinearFn, SelfAttentionFn
+from ..runtime.functional import (CrossAttentionFn, EmbedLNFn, LayerNormFn, LinearFn, QKVAttentionFn,
+                                  SelfAttentionFn)
 
 
 class BertEmbeddings(nn.Module):
@@ -36,6 +37,8 @@ class BertEmbeddings(nn.Module):
         self.position_embeddings = nn.Embedding(config.max_len, config.dim_hidden)
         self.category_embeddings = nn.Embedding(config.num_category, config.dim_hidden) if config.with_category else None
         self.LayerNorm = nn.LayerNorm(config.dim_hidden, eps=config.layer_norm_eps)
+        # pos_attention (opts.py:33): the normalised position embeddings are a second output (bert.py:63-65,97-108)
+        self.pos_LN = nn.LayerNorm(config.dim_hidden, eps=config.layer_norm_eps) if config.pos_attention else None
         self.p = config.hidden_dropout_prob
         self.eps = config.layer_norm_eps
 
@@ -43,7 +46,10 @@ class BertEmbeddings(nn.Module):
         g = [[self.word_embeddings.weight], [self.position_embeddings.weight]]
         if self.category_embeddings is not None:
             g.append([self.category_embeddings.weight])
-        return g + [[self.LayerNorm.weight], [self.LayerNorm.bias]]
+        g += [[self.LayerNorm.weight], [self.LayerNorm.bias]]
+        if self.pos_LN is not None:
+            g += [[self.pos_LN.weight], [self.pos_LN.bias]]
+        return g
 
     def nacf_bind(self, flat, rt):
         self._rt = rt
@@ -52,7 +58,16 @@ class BertEmbeddings(nn.Module):
                          cat=flat.pack([cat.weight]) if cat is not None else None,
                          ln=flat.pack([self.LayerNorm.weight], [self.LayerNorm.bias]), p=self.p, eps=self.eps,
                          salt=rt.next_salt(), train_word=self.word_embeddings.weight.requires_grad)
+        if self.pos_LN is not None:
+            self._ln_pos = flat.pack([self.pos_LN.weight], [self.pos_LN.bias])
+            self._salt_pos = rt.next_salt()
         self._params = [p for p in self.parameters()]
+
+    def run_pos(self, R, Lq, training, device):
+        """pos_dropout(pos_LN(position_embeddings)) for every slot: [R*Lq, D]  (bert.py:105)"""
+        rows = self.position_embeddings.weight[:Lq].repeat(R, 1)
+        cfg = dict(ln=self._ln_pos, eps=self.eps, p=self.p, salt=self._salt_pos, rng=self._rt.rng(device), training=training)
+        return LayerNormFn.apply(rows, cfg, *self._params)
 
     def run(self, tokens, category, additional, vdiv, vmod, training):
         cfg = dict(self._cfg, vdiv=vdiv, vmod=vmod, training=training, rng=self._rt.rng(tokens.device))
@@ -98,14 +113,17 @@ class _Dense(nn.Module):
 class BertLayer(nn.Module):
     def __init__(self, config, is_decoder_layer=True):
         super().__init__()
-        if config.pos_attention or getattr(config, 'parallel_mlm', False):
-            raise NotImplementedError('nacf_amd: pos_attention / parallel_mlm variants are not built '
-                                      '(reference defaults are off, opts.py:34-35)')
+        if getattr(config, 'parallel_mlm', False):
+            raise NotImplementedError('nacf_amd: the parallel_mlm variant is not built (reference default off, opts.py:35)')
+        if config.pos_attention and config.with_layernorm:
+            raise NotImplementedError('nacf_amd: pos_attention together with with_layernorm is not built')
         if config.attention_probs_dropout_prob != 0.0:
             raise NotImplementedError('nacf_amd: attention_probs_dropout_prob must be 0 (reference default, opts.py:29)')
         if config.hidden_act not in L.ACT_BY_NAME:
             raise NotImplementedError('nacf_amd: hidden_act %s is not built' % config.hidden_act)
         self.attention = BertAttention(config)
+        # registration order = the reference's (bert.py:254-260): state_dict order and default-init RNG consumption
+        self.pos_attention = BertAttention(config) if (config.pos_attention and is_decoder_layer) else None
         self.attend_to_enc_output = BertAttention(config)
         self.intermediate = _Dense(config.dim_hidden, config.intermediate_size)
         self.output = _Dense(config.intermediate_size, config.dim_hidden, config.with_layernorm, config.layer_norm_eps)
@@ -127,7 +145,10 @@ class BertLayer(nn.Module):
             [self.intermediate.dense.weight], [self.intermediate.dense.bias],
             [self.output.dense.weight], [self.output.dense.bias],
         ] + ([[m.LayerNorm.weight] for m in (a.output, c.output, self.output)] +
-             [[m.LayerNorm.bias] for m in (a.output, c.output, self.output)] if self.with_layernorm else [])
+             [[m.LayerNorm.bias] for m in (a.output, c.output, self.output)] if self.with_layernorm else []) + \
+            ([[pa.self.query.weight, pa.self.key.weight], [pa.self.query.bias, pa.self.key.bias],
+              [pa.self.value.weight], [pa.self.value.bias], [pa.output.dense.weight], [pa.output.dense.bias]]
+             if (pa := self.pos_attention) is not None else [])
 
     def nacf_bind(self, flat, rt):
         self._rt = rt
@@ -145,6 +166,12 @@ class BertLayer(nn.Module):
             for key, m in (('ln_so', a.output), ('ln_co', c.output), ('ln_f2', self.output)):
                 self._pk[key] = flat.pack([m.LayerNorm.weight], [m.LayerNorm.bias])
         self._salts = [rt.next_salt() for _ in range(4)]
+        pa = self.pos_attention
+        if pa is not None:
+            self._pk['pqk'] = flat.pack([pa.self.query.weight, pa.self.key.weight], [pa.self.query.bias, pa.self.key.bias])
+            self._pk['pv'] = flat.pack([pa.self.value.weight], [pa.self.value.bias])
+            self._pk['po'] = flat.pack([pa.output.dense.weight], [pa.output.dense.bias])
+            self._salt_pos = rt.next_salt()
         self._params = [p for p in self.parameters()]
 
     def project_memory(self, enc_output):
@@ -152,7 +179,7 @@ class BertLayer(nn.Module):
         Bv, M, D = enc_output.shape
         return LinearFn.apply(enc_output.reshape(Bv * M, D), None, dict(pack=self._pk['ckv']), *self._params)
 
-    def run(self, x2, tokens, causal, memory_kv, M, vdiv, vmod, training, want_probs, rows=None):
+    def run(self, x2, tokens, causal, memory_kv, M, vdiv, vmod, training, want_probs, rows=None, pos2=None):
         """x2: [R*L, D] hidden rows; tokens: [R, L]; memory_kv: [Bv*M, 2D]; rows: live (non-<pad>)
         slot list -- the row-wise GEMMs skip <pad> slots, whose outputs are exact zeros anyway."""
         R, Lq = tokens.shape
@@ -163,6 +190,8 @@ class BertLayer(nn.Module):
         s = self._salts
         if self.with_layernorm:
             return self._run_layernorm(x2, tokens, causal, memory_kv, M, vdiv, vmod, training, want_probs, rows)
+        if self.pos_attention is not None:
+            return self._run_pos(x2, pos2, tokens, causal, memory_kv, M, vdiv, vmod, training, want_probs, rows)
         # each block input (x2, a, c) feeds a Linear AND the residual add of the block's output Linear.  The output
         # Linear's backward runs first (it is downstream), parks its residual gradient in h*, and the input Linear's
         # dX GEMM accumulates onto it (LinearFn: res_sink / dx_acc) -- only wired when both gradients will exist.
@@ -203,4 +232,29 @@ class BertLayer(nn.Module):
         u = LinearFn.apply(c, None, dict(pack=pk['f1'], act=self.act, rows=rows), *P)
         y = LinearFn.apply(u, c, dict(pack=pk['f2'], p1=self.p, salt1=s[2], rng=rng, training=training, rows=rows), *P)
         y = LayerNormFn.apply(y, ln('ln_f2', self.p, s[3]), *P)
+        return y, (p_self, p_cross)
+
+    def _run_pos(self, x2, pos2, tokens, causal, memory_kv, M, vdiv, vmod, training, want_probs, rows):
+        """pos_attention=True (opts.py:33, bert.py:274-281): between the self- and the cross-attention block sits a
+        third attention whose queries AND keys come from the (normalised) position embeddings, whose values come from
+        the hidden states, and whose residual is the query input, i.e. the position embeddings:
+            a' = (dropout(dense(softmax(Qp Kp^T / sqrt(dk), mask) V(a))) + pos) * non_pad"""
+        assert pos2 is not None, 'pos_attention layers need the position embeddings'
+        R, Lq = tokens.shape
+        rng = self._rt.rng(x2.device)
+        tok_flat = tokens.reshape(-1)
+        P, pk, s = self._params, self._pk, self._salts
+        common = dict(row_tokens=tok_flat, rng=rng, training=training, rows=rows)
+        qkv = LinearFn.apply(x2, None, dict(pack=pk['qkv'], rows=rows), *P)
+        att, p_self = SelfAttentionFn.apply(qkv, tokens, int(causal), self.H, want_probs)
+        a = LinearFn.apply(att, x2, dict(pack=pk['so'], p1=self.p, salt1=s[0], **common), *P)
+        pqk = LinearFn.apply(pos2, None, dict(pack=pk['pqk'], rows=rows), *P)
+        pv = LinearFn.apply(a, None, dict(pack=pk['pv'], rows=rows), *P)
+        patt = QKVAttentionFn.apply(pqk, pv, tokens, int(causal), self.H)
+        a = LinearFn.apply(patt, pos2, dict(pack=pk['po'], p1=self.p, salt1=self._salt_pos, **common), *P)
+        q = LinearFn.apply(a, None, dict(pack=pk['cq'], rows=rows), *P)
+        catt, p_cross = CrossAttentionFn.apply(q, memory_kv, self.H, Lq, M, vdiv, vmod, want_probs)
+        c = LinearFn.apply(catt, a, dict(pack=pk['co'], p1=self.p, salt1=s[1], **common), *P)
+        u = LinearFn.apply(c, None, dict(pack=pk['f1'], act=self.act, rows=rows), *P)
+        y = LinearFn.apply(u, c, dict(pack=pk['f2'], p1=self.p, salt1=s[2], p2=self.p, salt2=s[3], **common), *P)
         return y, (p_self, p_cross)

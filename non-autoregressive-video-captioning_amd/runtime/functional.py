@@ -346,6 +346,35 @@ class SelfAttentionFn(Function):
         return dqkv, None, None, None, None
 
 
+class QKVAttentionFn(Function):
+    """self-attention geometry with q|k taken from one packed [rows, 2D] tensor and v from another [rows, D] tensor
+    (the position attention of models/bert.py:274-281: queries and keys from the position embeddings, values from
+    the hidden states)."""
+
+    @staticmethod
+    def forward(ctx, qk, v, tokens, causal, H):
+        R, Lq = tokens.shape
+        D = v.shape[1]
+        dk = D // H
+        out = _new((R * Lq, D), v)
+        ops.attention_fwd(qk[:, :D], qk[:, D:], v, out, tokens, causal, None, R, H, Lq, Lq, dk, 1, R)
+        ctx.qk, ctx.v, ctx.tokens, ctx.causal, ctx.H = qk, v, tokens, causal, H
+        return out
+
+    @staticmethod
+    def backward(ctx, do):
+        qk, v, tokens = ctx.qk, ctx.v, ctx.tokens
+        R, Lq = tokens.shape
+        D = v.shape[1]
+        dk = D // ctx.H
+        do = _c2d(do, R * Lq, D)
+        dqk, dv = torch.empty_like(qk), torch.empty_like(v)
+        ops.attention_bwd(qk[:, :D], qk[:, D:], v, do, dqk[:, :D], dqk[:, D:], dv, tokens, ctx.causal, R, R, ctx.H, Lq, Lq,
+                          dk, 1, R)
+        ctx.qk = ctx.v = None
+        return dqk, dv, None, None, None
+
+
 class CrossAttentionFn(Function):
     """decoder -> visual memory attention; K|V are the packed projection of the
     memory, computed once per video and shared by every row mapped to it."""

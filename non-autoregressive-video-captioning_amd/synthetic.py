@@ -54,16 +54,20 @@ def param_shapes(opt: dict) -> Dict[str, Tuple[int, ...]]:
     if opt["with_category"]:
         sh[p + "embedding.category_embeddings.weight"] = (opt["num_category"], d)
     sh[p + "embedding.LayerNorm.weight"] = (d,); sh[p + "embedding.LayerNorm.bias"] = (d,)
+    pos_att = bool(opt.get("pos_attention", False))
+    if pos_att:                                  # models/bert.py:63-65
+        sh[p + "embedding.pos_LN.weight"] = (d,); sh[p + "embedding.pos_LN.bias"] = (d,)
     for i in range(opt["num_hidden_layers_decoder"]):
         l = f"{p}layer.{i}."
-        for a in ("attention", "attend_to_enc_output"):
+        for a in (("attention", "pos_attention", "attend_to_enc_output") if pos_att else ("attention", "attend_to_enc_output")):
             for q in ("query", "key", "value"):
                 sh[f"{l}{a}.self.{q}.weight"] = (d, d); sh[f"{l}{a}.self.{q}.bias"] = (d,)
             sh[f"{l}{a}.output.dense.weight"] = (d, d); sh[f"{l}{a}.output.dense.bias"] = (d,)
         sh[l + "intermediate.dense.weight"] = (ff, d); sh[l + "intermediate.dense.bias"] = (ff,)
         sh[l + "output.dense.weight"] = (d, ff); sh[l + "output.dense.bias"] = (d,)
         if opt.get("with_layernorm", False):
-            for m in ("attention.output", "attend_to_enc_output.output", "output"):
+            for m in (("attention.output", "pos_attention.output") if pos_att else ("attention.output",)) + \
+                     ("attend_to_enc_output.output", "output"):
                 sh[f"{l}{m}.LayerNorm.weight"] = (d,); sh[f"{l}{m}.LayerNorm.bias"] = (d,)
     sh["tgt_word_prj.weight"] = (V, d)
     if opt.get("tie_weights", False):      # models/seq2seq.py:30-33: shared with the word embedding + a bias
@@ -91,9 +95,9 @@ def init_state_dict(opt: dict, seed: int = 0) -> SD:
             sd[name] = torch.ones(shape)
         elif "embedding.LayerNorm.bias" in name or (".bn" in name and name.endswith("bias")):
             sd[name] = torch.zeros(shape)
-        elif "LayerNorm.weight" in name or (".ln" in name and name.endswith("weight")):
+        elif "LayerNorm.weight" in name or "pos_LN.weight" in name or (".ln" in name and name.endswith("weight")):
             sd[name] = 1.0 + 0.2 * (torch.rand(shape, generator=g) * 2 - 1)      # optional LayerNorms: non-trivial affine
-        elif "LayerNorm.bias" in name or (".ln" in name and name.endswith("bias")):
+        elif "LayerNorm.bias" in name or "pos_LN.bias" in name or (".ln" in name and name.endswith("bias")):
             sd[name] = 0.1 * (torch.rand(shape, generator=g) * 2 - 1)
         elif "embeddings.weight" in name:
             w = torch.randn(shape, generator=g)

@@ -488,6 +488,9 @@ def main():
     if os.environ.get("ONLY_CKPT"):
         checkpoint_case()
         return
+    if os.environ.get("ONLY_POS"):
+        train_case("tiny_nacf_pos_train", "NACF", ["-wc", "--pos_attention"], V=101, B=3, F_=6)
+        return
     if os.environ.get("ONLY_LN"):
         train_case("tiny_nacf_ln_train", "NACF", ["-wc", "--with_layernorm", "--norm_type", "ln"], V=101, B=3, F_=6)
         return
@@ -512,6 +515,7 @@ def main():
                                                   "--enhance_input", "0", "--no_encoder_bn", "-tie"],
                V=101, B=3, F_=6, dataset="Youtube2Text", beta=(0.0, 1.0))
     train_case("tiny_nacf_ln_train", "NACF", ["-wc", "--with_layernorm", "--norm_type", "ln"], V=101, B=3, F_=6)
+    train_case("tiny_nacf_pos_train", "NACF", ["-wc", "--pos_attention"], V=101, B=3, F_=6)
     checkpoint_case()
     data_case()
     # NA decode: all paradigms, +-ct, per-iteration tokens/probs

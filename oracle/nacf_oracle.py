@@ -166,8 +166,8 @@ def length_head(sd: SD, opt: dict, enc_output: Tensor, training: bool) -> Tensor
 # decoder: SURVEY.md section 8a rows 5-12
 # --------------------------------------------------------------------------
 def embeddings(sd: SD, pfx: str, opt: dict, ids: Tensor, category: Optional[Tensor],
-               additional: Optional[Tensor], training: bool) -> Tensor:
-    """BertEmbeddings.forward (return_pos=False branch), models/bert.py:70-96."""
+               additional: Optional[Tensor], training: bool, return_pos: bool = False):
+    """BertEmbeddings.forward, models/bert.py:70-108 (return_pos: also the normalised position embeddings, :97-108)."""
     L = ids.shape[1]
     # nn.Embedding(padding_idx=PAD): the PAD row never receives gradient from the lookup (bert.py:53-56)
     e = F.embedding(ids, sd[pfx + "embedding.word_embeddings.weight"], padding_idx=PAD) \
@@ -178,11 +178,17 @@ def embeddings(sd: SD, pfx: str, opt: dict, ids: Tensor, category: Optional[Tens
         e = e + additional
     e = F.layer_norm(e, (e.shape[-1],), sd[pfx + "embedding.LayerNorm.weight"],
                      sd[pfx + "embedding.LayerNorm.bias"], opt["layer_norm_eps"])
-    return _dropout(e, opt["hidden_dropout_prob"], training)
+    e = _dropout(e, opt["hidden_dropout_prob"], training)
+    if not return_pos:
+        return e
+    pos = sd[pfx + "embedding.position_embeddings.weight"][:L].unsqueeze(0).expand(ids.shape[0], -1, -1)
+    pos = F.layer_norm(pos, (pos.shape[-1],), sd[pfx + "embedding.pos_LN.weight"], sd[pfx + "embedding.pos_LN.bias"],
+                       opt["layer_norm_eps"])
+    return e, _dropout(pos, opt["hidden_dropout_prob"], training)
 
 
 def mha(sd: SD, pfx: str, opt: dict, q_in: Tensor, kv_in: Tensor, mask: Optional[Tensor],
-        training: bool) -> Tuple[Tensor, Tensor]:
+        training: bool, v_in: Optional[Tensor] = None) -> Tuple[Tensor, Tensor]:
     """BertSelfAttention.forward, models/bert.py:139-179.  ``mask`` is
     bool [B, Lq, Lk], True = masked (filled with -10e6, *not* -inf, :161);
     the 1/sqrt(d_k) scale is applied after QK^T (:157-158)."""
@@ -192,7 +198,8 @@ def mha(sd: SD, pfx: str, opt: dict, q_in: Tensor, kv_in: Tensor, mask: Optional
     dk = D // H
     q = F.linear(q_in, sd[pfx + "self.query.weight"], sd[pfx + "self.query.bias"]).view(B, Lq, H, dk).permute(0, 2, 1, 3)
     k = F.linear(kv_in, sd[pfx + "self.key.weight"], sd[pfx + "self.key.bias"]).view(B, Lk, H, dk).permute(0, 2, 1, 3)
-    v = F.linear(kv_in, sd[pfx + "self.value.weight"], sd[pfx + "self.value.bias"]).view(B, Lk, H, dk).permute(0, 2, 1, 3)
+    v = F.linear(kv_in if v_in is None else v_in, sd[pfx + "self.value.weight"],
+                 sd[pfx + "self.value.bias"]).view(B, Lk, H, dk).permute(0, 2, 1, 3)
     s = torch.matmul(q, k.transpose(-1, -2)) / math.sqrt(dk)
     if mask is not None:
         s = s.masked_fill(mask.unsqueeze(1), -10e6)
@@ -203,10 +210,11 @@ def mha(sd: SD, pfx: str, opt: dict, q_in: Tensor, kv_in: Tensor, mask: Optional
 
 
 def attention_block(sd: SD, pfx: str, opt: dict, q_in: Tensor, kv_in: Tensor,
-                    mask: Optional[Tensor], training: bool) -> Tuple[Tensor, Tensor]:
+                    mask: Optional[Tensor], training: bool, v_in: Optional[Tensor] = None) -> Tuple[Tensor, Tensor]:
     """BertAttention = BertSelfAttention + BertSelfOutput,
-    models/bert.py:182-215: dense -> dropout -> + query input (-> LN if enabled)."""
-    o, p = mha(sd, pfx, opt, q_in, kv_in, mask, training)
+    models/bert.py:182-215: dense -> dropout -> + query input (-> LN if enabled).  v_in: a separate value input
+    (the position attention: queries and keys from the position embeddings, values from the hidden states)."""
+    o, p = mha(sd, pfx, opt, q_in, kv_in, mask, training, v_in)
     o = F.linear(o, sd[pfx + "output.dense.weight"], sd[pfx + "output.dense.bias"])
     o = _dropout(o, opt["hidden_dropout_prob"], training) + q_in
     if opt["with_layernorm"]:
@@ -216,10 +224,13 @@ def attention_block(sd: SD, pfx: str, opt: dict, q_in: Tensor, kv_in: Tensor,
 
 
 def bert_layer(sd: SD, pfx: str, opt: dict, x: Tensor, non_pad: Tensor, self_mask: Tensor,
-               enc_output: Tensor, training: bool):
-    """BertLayer.forward, models/bert.py:262-303 (pos_attention off)."""
+               enc_output: Tensor, training: bool, pos: Optional[Tensor] = None):
+    """BertLayer.forward, models/bert.py:262-303."""
     a, p_self = attention_block(sd, pfx + "attention.", opt, x, x, self_mask, training)
     a = a * non_pad
+    if pos is not None:     # bert.py:274-281: q = k = position embeddings, v = hidden; the residual is the query input
+        a, _ = attention_block(sd, pfx + "pos_attention.", opt, pos, pos, self_mask, training, v_in=a)
+        a = a * non_pad
     c, p_cross = attention_block(sd, pfx + "attend_to_enc_output.", opt, a, enc_output, None, training)
     c = c * non_pad
     u = ACT[opt["hidden_act"]](F.linear(c, sd[pfx + "intermediate.dense.weight"], sd[pfx + "intermediate.dense.bias"]))
@@ -256,12 +267,15 @@ def decoder_forward(sd: SD, opt: dict, tgt_seq: Tensor, enc_output: Tensor, cate
             additional = enc_output.mean(1).unsqueeze(1).expand(-1, L, -1)
         else:
             assert opt["enhance_input"] == 0, "enhance_input=1 crashes upstream (SURVEY 8a row 11)"
-    assert not opt["pos_attention"]
-    h = embeddings(sd, pfx, opt, tgt_seq, category, additional, training)
+    pos = None
+    if opt["pos_attention"]:                                            # Decoder.py:144-146: no additional feats here
+        h, pos = embeddings(sd, pfx, opt, tgt_seq, category, None, training, return_pos=True)
+    else:
+        h = embeddings(sd, pfx, opt, tgt_seq, category, additional, training)
     attns = []
     embs = None
     for i in range(opt["num_hidden_layers_decoder"]):
-        h, embs, att = bert_layer(sd, f"{pfx}layer.{i}.", opt, h, non_pad, self_mask, enc_output, training)
+        h, embs, att = bert_layer(sd, f"{pfx}layer.{i}.", opt, h, non_pad, self_mask, enc_output, training, pos)
         attns.append(att)
     return h, embs, attns
 

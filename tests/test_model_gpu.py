@@ -31,7 +31,7 @@ def _tok_labels(opt, b):
 
 
 TRAIN_CASES = ["tiny_nacf_train", "tiny_nab_train", "tiny_arb2_train", "tiny_arb_train", "tiny_nab_variants_train",
-               "tiny_nacf_ln_train"]
+               "tiny_nacf_ln_train", "tiny_nacf_pos_train"]
 
 
 @pytest.mark.parametrize("name", TRAIN_CASES)

@@ -16,7 +16,7 @@ def _tok_labels(opt, b):
 
 
 @pytest.mark.parametrize("name", ["tiny_nacf_train", "tiny_nab_train", "tiny_arb2_train", "tiny_arb_train",
-                                  "tiny_nab_variants_train", "tiny_nacf_ln_train"])
+                                  "tiny_nab_variants_train", "tiny_nacf_ln_train", "tiny_nacf_pos_train"])
 def test_train_step_matches_reference(name):
     g = load_gold(name)
     opt = gold_opt(g)
