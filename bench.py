@@ -60,30 +60,18 @@ def bench_nab(nacf_amd, dev, B, L, V, F_):
     tokens, labels = b["tokens"].to(dev), b["labels"].to(dev)
     category, tgt_length = b["category"].to(dev), b["tgt_length"].to(dev)
 
-    def step():
-        optim.zero_grad()
-        res = model(feats=feats, tgt_tokens=tokens, category=category)
-        res["tgt_word_labels"] = labels
-        res["tgt_length"] = tgt_length
-        crit.get_loss(res).backward()
-        optim.step(grad_scale=1.0)
-    for _ in range(3):
-        step()
-    torch.cuda.synchronize()
-    side = torch.cuda.Stream()
-    side.wait_stream(torch.cuda.current_stream())
-    with torch.cuda.stream(side):
-        graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph, stream=side):
-            step()
-    torch.cuda.current_stream().wait_stream(side)
-    for _ in range(3):
-        graph.replay()
+    from nacf_amd.misc.run import get_forword_results
+    from nacf_amd.runtime.engine import TrainStep
+    engine = TrainStep(model, crit, optim, lambda bb: get_forword_results(model.opt, model, bb, dev), graph="on")
+    engine({"feats": feats, "tokens": tokens, "labels": labels, "category": category, "length_target": tgt_length})
+    for _ in range(5):          # two more launch-by-launch steps, capture, replays
+        engine()
+    assert engine.captured
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     n = 30
     for _ in range(n):
-        graph.replay()
+        engine()
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / n
     model.eval()
@@ -103,15 +91,16 @@ def bench_nab(nacf_amd, dev, B, L, V, F_):
             "decode_captions_per_s": round(B / ddt, 1), "decode_ms_per_batch": round(ddt * 1e3, 2), "dtype": "f32"}
 
 
-def bench_loader(args, nacf_amd, opt, dev, B, L, V, F_, static, graph):
+def bench_loader(args, nacf_amd, opt, dev, B, L, V, F_, engine):
     """Train-step throughput when every batch comes from nacf_amd.data.ShardLoader (synthetic shards written to a
-    temp dir): per step the loader's tensors are copied into the graph's static input buffers and the captured step is
-    replayed.  Reports the three placements of the shards: HBM-resident (no PCIe per step), pinned host memory (one
+    temp dir): per step the engine copies the loader's tensors into the graph's static input buffers and replays the
+    captured step (runtime/engine.py -- the same object misc/run.py:run_train drives).  Reports the three placements of the shards: HBM-resident (no PCIe per step), pinned host memory (one
     DMA per clip, PCIe-inclusive) and memory-mapped file (host-thread gather into pinned staging + upload)."""
     import shutil
     import tempfile
     import numpy as np
     from nacf_amd.data import CaptionTable, FeatureShard, ShardLoader, write_feature_shard
+    from nacf_amd.runtime.engine import _signature
     tmp = tempfile.mkdtemp(prefix="nacf_shards_")
     try:
         N = max(args.loader_videos, B)
@@ -143,13 +132,9 @@ def bench_loader(args, nacf_amd, opt, dev, B, L, V, F_, static, graph):
                 steps = 0
                 for _ in range(n_epochs):
                     for b in ld:
-                        for dst, src in zip(static["feats"], b["feats"]):
-                            dst.copy_(src)
-                        static["tokens"][0].copy_(b["tokens_1"]); static["tokens"][1].copy_(b["tokens"])
-                        static["labels"][0].copy_(b["labels_1"]); static["labels"][1].copy_(b["labels"])
-                        static["category"].copy_(b["category"].view_as(static["category"]))
-                        static["tgt_length"].copy_(b["length_target"])
-                        graph.replay()
+                        b["category"] = b["category"].view(-1, 1)
+                        assert _signature(b) == engine.sig, "loader batch does not match the captured step"
+                        engine(b)
                         steps += 1
                 return steps
             run(1)
@@ -224,105 +209,26 @@ def main():
     labels = [batch["labels_1"].to(dev), batch["labels"].to(dev)]
     category = batch["category"].to(dev)
     tgt_length = batch["tgt_length"].to(dev)
-    loss_buf = torch.zeros((), device=dev)
+    from nacf_amd.misc.run import get_forword_results
+    from nacf_amd.runtime.engine import TrainStep
 
-    def fwd_bwd():
-        optim.zero_grad()
-        res = model(feats=feats, tgt_tokens=tokens, category=category)
-        res["tgt_word_labels"] = labels
-        res["tgt_length"] = tgt_length
-        loss = crit.get_loss(res)
-        loss.backward()
-        loss_buf.copy_(loss.detach())
-
-    # N > 1: backward in two stages so the decoder-side gradient bucket (61 of 74 MB) is all-reduced while the
-    # encoder's backward still runs (runtime/ddp.py)
-    staged = multi and ddp.bucket_split() is not None
-    hold = {}
-
-    def stage1():
-        optim.zero_grad()
-        res = model(feats=feats, tgt_tokens=tokens, category=category)
-        res["tgt_word_labels"] = labels
-        res["tgt_length"] = tgt_length
-        loss = crit.get_loss(res)
-        hold["cut"], hold["grads"] = ddp.backward_to_cut(loss)
-        loss_buf.copy_(loss.detach())
-
-    def stage2():
-        ddp.backward_from_cut(hold["cut"], hold["grads"])
-
-    def reduce_and_wait(after_stage2):
-        w1 = ddp.all_reduce_bucket(0)
-        after_stage2()
-        w2 = ddp.all_reduce_bucket(1)
-        for w in (w1, w2):
-            if w is not None:
-                w.wait()
-
-    def step_eager():
-        if staged:
-            stage1()
-            reduce_and_wait(stage2)
-        else:
-            fwd_bwd()
-            ddp.all_reduce_gradients()
-        optim.step(grad_scale=ddp.grad_scale)
-
-    for _ in range(max(args.warmup, 2)):          # untimed warm-up (also grows workspaces before capture)
-        step_eager()
+    # the step engine misc/run.py:run_train drives: launch-by-launch warm-up steps, then ONE hipGraph per step
+    # (N > 1: backward in two graphs so the decoder-side gradient bucket (61 of 74 MB) is all-reduced while the
+    # encoder's backward still runs, then the Adam graph -- runtime/engine.py, runtime/ddp.py)
+    n_eager = max(args.warmup, 2)
+    engine = TrainStep(model, crit, optim, lambda bb: get_forword_results(model.opt, model, bb, dev),
+                       ddp=ddp if multi else None, graph=args.graph, eager_steps=n_eager)
+    staged = engine.staged
+    engine({"feats": feats, "tokens_1": tokens[0], "tokens": tokens[1], "labels_1": labels[0], "labels": labels[1],
+            "category": category, "length_target": tgt_length})
+    for _ in range(n_eager - 1):                  # untimed warm-up (also grows workspaces before capture)
+        engine()
     torch.cuda.synchronize()
-
-    use_graph = args.graph != "off"
-    g_main = g_enc = g_opt = None
-    if use_graph:
-        try:
-            side = torch.cuda.Stream()
-            side.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(side):
-                g_main = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g_main, stream=side):
-                    if staged:
-                        stage1()
-                    else:
-                        fwd_bwd()
-                        if not multi:
-                            optim.step(grad_scale=1.0)
-                if staged:      # second half of backward: same memory pool, the autograd graph is still alive
-                    g_enc = torch.cuda.CUDAGraph()
-                    with torch.cuda.graph(g_enc, stream=side, pool=g_main.pool()):
-                        stage2()
-                    hold.clear()
-                if multi:
-                    g_opt = torch.cuda.CUDAGraph()
-                    with torch.cuda.graph(g_opt, stream=side, pool=g_main.pool()):
-                        optim.step(grad_scale=ddp.grad_scale)
-            torch.cuda.current_stream().wait_stream(side)
-            torch.cuda.synchronize()
-        except Exception as e:  # noqa: BLE001
-            if args.graph == "on":
-                raise
-            print("[bench] hipGraph capture failed (%s: %s); timing eager launches" % (type(e).__name__, e),
-                  file=sys.stderr)
-            g_main = g_enc = g_opt = None
-            hold.clear()
-            use_graph = False
-            torch.cuda.synchronize()
-
-    def step():
-        if g_main is None:
-            step_eager()
-        else:
-            g_main.replay()
-            if staged:
-                reduce_and_wait(g_enc.replay)
-                g_opt.replay()
-            elif multi:
-                ddp.all_reduce_gradients()
-                g_opt.replay()
-
-    for _ in range(2):
-        step()
+    for _ in range(3):                            # capture + first replays
+        engine()
+    use_graph = engine.captured
+    step = engine
+    loss_buf = engine.loss
 
     def barrier():
         if multi:
@@ -348,9 +254,10 @@ def main():
         # ---- live roofline: HIP events around every GEMM launch of a few eager steps
         ops.PROFILER.enabled = True
         n_prof = 3
-        for _ in range(n_prof):
-            fwd_bwd()
-            optim.step(grad_scale=1.0)
+        for _ in range(n_prof):                  # rank-local launch-by-launch steps (no collective: only rank 0 is here)
+            optim.zero_grad()
+            crit.get_loss(get_forword_results(model.opt, model, engine.static, dev)).backward()
+            optim._optimizer.step(grad_scale=1.0)
         torch.cuda.synchronize()
         ops.PROFILER.enabled = False
         summ = ops.PROFILER.summary()
@@ -408,10 +315,8 @@ def main():
         # ---- the same step fed by the shard loader (features gathered / frame-sampled / masked on
         # the device) instead of one resident synthetic batch; "streaming" includes the PCIe upload of every batch
         loader_leg = None
-        if not args.no_loader and g_main is not None and not multi:
-            loader_leg = bench_loader(args, nacf_amd, model.opt, dev, B, L, V, F_,
-                                      dict(feats=feats, tokens=tokens, labels=labels, category=category, tgt_length=tgt_length),
-                                      g_main)
+        if not args.no_loader and engine.captured and not multi:
+            loader_leg = bench_loader(args, nacf_amd, model.opt, dev, B, L, V, F_, engine)
 
         # ---- BASELINE.json configs[4]: ARB2 beam-5 autoregressive decode vs NACF parallel decode, batch 256
         compare = None

@@ -25,14 +25,20 @@ from ..runtime import ops
 
 class ShardLoader:
     def __init__(self, shards, table, video_index, opt, batch_size, device, mode="train", shuffle=None, seed=0,
-                 resident=None, hbm_budget_bytes=64 << 30, drop_last=False, placement=None, host_budget_bytes=64 << 30):
+                 resident=None, hbm_budget_bytes=64 << 30, drop_last=False, placement=None, host_budget_bytes=64 << 30,
+                 rank=0, world=1):
         """shards: one FeatureShard per modality character of opt['modality'] (same video ids); table / video_index:
-        CaptionTable.from_corpus(...) output (video_index = corpus ids of the table's video rows)."""
+        CaptionTable.from_corpus(...) output (video_index = corpus ids of the table's video rows).
+        rank / world: data-parallel sharding -- every rank draws the SAME permutation (same seed) and takes the
+        rank-th slice of `batch_size` samples out of each global batch of world*batch_size; the ragged tail is dropped
+        so that all ranks run the same number of steps."""
+        self.rank, self.world = int(rank), int(world)
+        assert 0 <= self.rank < self.world
         self.shards, self.table, self.opt = list(shards), table, opt
         self.B, self.dev, self.mode = int(batch_size), torch.device(device), mode
         self.train = mode == "train"
         self.shuffle = self.train if shuffle is None else bool(shuffle)
-        self.drop_last = drop_last
+        self.drop_last = drop_last or self.world > 1
         if opt.get("load_feats_type", 1) not in (1, 2):
             raise NotImplementedError("nacf_amd: load_feats_type 0 (one shared frame-id draw per sample) is not built")
         random_type = opt.get("random_type", "segment_random") if self.train else "equally_sampling"
@@ -101,8 +107,8 @@ class ShardLoader:
         return dst
 
     def __len__(self):
-        n = len(self.table)
-        return n // self.B if self.drop_last else (n + self.B - 1) // self.B
+        n, g = len(self.table), self.B * self.world
+        return n // g if self.drop_last else (n + g - 1) // g
 
     # ---- host side of streaming mode: gather the batch's clips into pinned memory, start the upload
     def _stage(self, slot, vids_host):
@@ -134,7 +140,7 @@ class ShardLoader:
         self._slot_event[slot] = ev
         return ev
 
-    def _build(self, idx_dev, vids_dev, feats_src):
+    def _build(self, idx_dev, vids_dev, feats_src, idx_host=None):
         opt, n = self.opt, idx_dev.numel()
         batch = {"feats": []}
         for m, s in enumerate(self.shards):
@@ -151,6 +157,7 @@ class ShardLoader:
         batch["length_target"] = self.d_lt.index_select(0, vids_dev)
         batch["category"] = self.d_cat.index_select(0, vids_dev).unsqueeze(1)
         batch["sample_index"] = idx_dev
+        batch["sample_index_host"] = idx_host       # numpy: lets the caller name the videos without a device sync
         self.rng.advance()
         return batch
 
@@ -158,12 +165,14 @@ class ShardLoader:
         n = len(self.table)
         order = torch.randperm(n, generator=self.gen) if self.shuffle else torch.arange(n)
         nb = len(self)
-        chunks = [order[i * self.B:min(n, (i + 1) * self.B)] for i in range(nb)]
+        g, lo = self.B * self.world, self.B * self.rank
+        chunks = [order[i * g + lo:min(n, i * g + lo + self.B)] for i in range(nb)]
         if self.resident:
             for ch in chunks:
                 idx = ch.to(self.dev)
                 vids = self.d_video.index_select(0, idx)
-                yield self._build(idx, vids, lambda m, v: (self.d_feats[m], self.d_rows[m].index_select(0, v), self.d_srclen[m]))
+                yield self._build(idx, vids, lambda m, v: (self.d_feats[m], self.d_rows[m].index_select(0, v), self.d_srclen[m]),
+                                  ch.numpy())
             return
         vid_host = self.table.video
         pending = self._stage(0, vid_host[chunks[0].numpy()]) if nb else None
@@ -176,4 +185,5 @@ class ShardLoader:
             idx = ch.to(self.dev)
             vids = self.d_video.index_select(0, idx)
             k = idx.numel()
-            yield self._build(idx, vids, lambda m, v: (self.staged[slot][m][:k], None, self.staged_len[slot][m][:k]))
+            yield self._build(idx, vids, lambda m, v: (self.staged[slot][m][:k], None, self.staged_len[slot][m][:k]),
+                              ch.numpy())

@@ -68,3 +68,82 @@ def save_checkpoint(state, is_best, filepath='./', filename='checkpoint.pth.tar'
     torch.save(state, target)
     if is_best:
         shutil.copyfile(target, os.path.join(filepath, best_model_name))
+
+
+# ---- text helpers used by run_eval (reference: misc/utils.py:11-147) ----------------------------------------------
+def set_seed(seed=2019):
+    import random
+    import numpy as np
+    random.seed(seed)
+    os.environ['PYTHONHASHSEED'] = str(seed)
+    np.random.seed(seed)
+    torch.manual_seed(seed)
+
+
+def to_sentence(hyp, vocab, break_words=(3, 0), skip_words=()):
+    """ids -> words joined by blanks, up to the first <eos>(3) / <pad>(0)  (misc/utils.py:21-30)"""
+    words = []
+    for wid in hyp:
+        if wid in skip_words:
+            continue
+        if wid in break_words:
+            break
+        words.append(vocab[wid])
+    return ' '.join(words)
+
+
+def remove_repeat_n_grame(sent, n):
+    """Drop ONE immediate repetition of an n-gram (second copy adjacent to, or one word after, the FIRST occurrence
+    of that n-gram; the in-between word goes too) and return (words, False); (sent, True) when nothing repeats
+    (misc/utils.py:66-81)."""
+    first_at = {}
+    for i in range(len(sent) - n + 1):
+        gram = ' '.join(sent[i:i + n])
+        if gram not in first_at:
+            first_at[gram] = i
+            continue
+        gap = i - first_at[gram] - n
+        if gap == 0 or gap == 1:
+            return sent[:i - gap] + sent[i + n:], False
+    return sent, True
+
+
+def duplicate(sent):
+    """de-duplication post-process of NA captions, 4-grams first (misc/utils.py:84-98): returns (sentence, report)"""
+    words = sent.split(' ')
+    removed = {}
+    for n in (4, 3, 2, 1):
+        while True:
+            words, clean = remove_repeat_n_grame(words, n)
+            if clean:
+                break
+            removed[n] = removed.get(n, 0) + 1
+    return ' '.join(words), '\t'.join('%d-gram: %d' % (n, removed.get(n, 0)) for n in (1, 2, 3, 4))
+
+
+def _count_ngrams(sentences, n):
+    grams = {}
+    for words in sentences:
+        for j in range(len(words) - n + 1):
+            g = ' '.join(words[j:j + n])
+            grams[g] = grams.get(g, 0) + 1
+    return grams
+
+
+def analyze_length_novel_unique(gt_data, data, vocab, splits, n=1, calculate_novel=True):
+    """(average length, novel ratio, unique ratio, vocabulary usage, n-gram counts, #distinct 4-grams) of predicted
+    captions `data` = {vid: [{'caption': str}, ...]}; novel = not among the training captions (misc/utils.py:101-146)"""
+    hyps = [item['caption'] for k in data for item in data[k]]
+    split_hyps = [h.split(' ') for h in hyps]
+    count = len(hyps)
+    distinct = set(hyps)
+    novel = 0
+    if calculate_novel:
+        train = set()
+        for i in splits['train']:
+            for cap in gt_data['video%d' % int(i)]:
+                train.add(' '.join(vocab[w] for w in cap[1:-1]))
+        novel = sum(1 for s in distinct if s not in train)
+    grams = _count_ngrams(split_hyps, n)
+    return (sum(len(w) for w in split_hyps) / count, novel / count, len(distinct) / count, len(grams), grams,
+            len(_count_ngrams(split_hyps, 4)))

@@ -1,0 +1,197 @@
+"""One optimisation step as a replayable launch sequence (used by misc/run.py:run_train and bench.py).
+
+The reference's step is five host statements (misc/run.py:254-261): zero_grad, forward, get_loss, backward,
+clip_grad_value_ + optimizer.step.  On an MI355X that step is ~4 ms of device work behind ~350 kernel launches, so the
+host must not be in the loop: `TrainStep` runs the first `eager_steps` steps launch by launch (they are real steps:
+workspaces and the criterion's fused plan are created there), then captures the sequence ONCE into hipGraphs whose
+inputs are static device buffers, and afterwards every step is: copy the batch into the static buffers, bump the
+learning rate / host-side meters, replay.
+
+Everything data dependent stays on the device inside the captured sequence: live-row lists (count in device memory),
+dropout and masking seeds (Philox {seed, step} advanced by a kernel), Adam's step counter and learning rate
+(`FusedAdam.step_dev / lr_dev`), the criterion's meters (`Criterion._meters`).
+
+N > 1 ranks (runtime/ddp.py): the backward pass is split at the encoder outputs into two graphs; the decoder-side
+gradient bucket is all-reduced (RCCL, torch.distributed's own stream -- never captured) while the encoder-side graph
+replays, the rest after it, then the Adam graph.
+
+A batch whose shapes differ from the captured ones (the ragged tail of an epoch) runs launch by launch.
+"""
+import sys
+
+import torch
+
+
+BATCH_KEYS = ('feats', 'feats_a', 'feats_m', 'feats_i', 'tokens', 'tokens_1', 'labels', 'labels_1', 'category',
+              'length_target')         # what misc/run.py:get_forword_results reads from a batch
+
+
+def _tensors(batch, keys=BATCH_KEYS):
+    """(key, index) -> tensor for the tensor / list-of-tensors entries of a batch dictionary the forward consumes"""
+    out = {}
+    for k in sorted(batch):
+        if keys is not None and k not in keys:
+            continue
+        v = batch[k]
+        if torch.is_tensor(v):
+            out[(k, None)] = v
+        elif isinstance(v, (list, tuple)) and len(v) and all(torch.is_tensor(x) for x in v):
+            for i, x in enumerate(v):
+                out[(k, i)] = x
+    return out
+
+
+def _signature(batch, keys=BATCH_KEYS):
+    return tuple((k, tuple(t.shape), t.dtype) for k, t in _tensors(batch, keys).items())
+
+
+class TrainStep(object):
+    def __init__(self, model, crit, optimizer, forward, ddp=None, graph='auto', eager_steps=2, keys=BATCH_KEYS):
+        """forward(batch) -> the results dictionary `crit.get_loss` consumes (labels included);
+        optimizer: misc.optim.ScheduledOptim (or a bare FusedAdam); graph: 'auto' | 'on' | 'off';
+        keys: the batch entries `forward` reads (they get static device buffers; everything else rides along)."""
+        self.keys = keys
+        assert graph in ('auto', 'on', 'off')
+        self.model, self.crit, self.forward, self.ddp = model, crit, forward, ddp
+        self.sched = optimizer if hasattr(optimizer, 'step_update_learning_rate') else None
+        self.adam = optimizer._optimizer if self.sched is not None else optimizer
+        self.graph_mode, self.eager_steps = graph, int(eager_steps)
+        self.multi = ddp is not None and (ddp.world > 1 or ddp.force)
+        self.staged = self.multi and ddp.bucket_split() is not None
+        self.grad_scale = ddp.grad_scale if self.multi else 1.0
+        self.static = self.sig = None
+        self.loss = None                    # device scalar: the last step's loss
+        self.n_steps = 0
+        self.graphs = None                  # (front, encoder-side backward | None, adam | None)
+        self.count_delta = None
+        self._hold = {}
+
+    # ---- the launch sequence -------------------------------------------------------------------------------------
+    def _front(self, b):
+        self.adam.zero_grad()
+        loss = self.crit.get_loss(self.forward(b))
+        if self.staged:
+            self._hold['cut'], self._hold['grads'] = self.ddp.backward_to_cut(loss)
+        else:
+            loss.backward()
+        self.loss.copy_(loss.detach())
+
+    def _back(self):
+        self.ddp.backward_from_cut(self._hold['cut'], self._hold['grads'])
+
+    def _update(self):
+        self.adam.step(grad_scale=self.grad_scale)
+
+    def _reduce_around(self, second_stage):
+        w1 = self.ddp.all_reduce_bucket(0)
+        second_stage()
+        w2 = self.ddp.all_reduce_bucket(1)
+        for w in (w1, w2):
+            if w is not None:
+                w.wait()
+
+    def _eager(self, b):
+        self._front(b)
+        if self.staged:
+            self._reduce_around(self._back)
+            self._hold.clear()
+        elif self.multi:
+            self.ddp.all_reduce_gradients()
+        self._update()
+
+    def _capture(self):
+        dev = self.loss.device
+        before = list(self.crit._loss_cnt)
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):
+            front = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(front, stream=side):
+                self._front(self.static)
+                if not self.multi:
+                    self._update()
+            back = upd = None
+            if self.staged:                 # same memory pool: the autograd graph of `front` is still alive
+                back = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(back, stream=side, pool=front.pool()):
+                    self._back()
+                self._hold.clear()
+            if self.multi:
+                upd = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(upd, stream=side, pool=front.pool()):
+                    self._update()
+        torch.cuda.current_stream(dev).wait_stream(side)
+        # capturing ran the host side of get_loss once without executing anything: take its sample-count increments
+        # as the per-replay delta and undo them
+        self.count_delta = [a - b for a, b in zip(self.crit._loss_cnt, before)]
+        self.crit._loss_cnt = before
+        self.graphs = (front, back, upd)
+
+    def _replay(self):
+        front, back, upd = self.graphs
+        front.replay()
+        if self.staged:
+            self._reduce_around(back.replay)
+        elif self.multi:
+            self.ddp.all_reduce_gradients()
+        if upd is not None:
+            upd.replay()
+        self.crit._loss_cnt = [c + d for c, d in zip(self.crit._loss_cnt, self.count_delta)]
+
+    def _graph_ready(self):
+        """the criterion must keep ALL its running sums in the in-place device meter vector (fused form)"""
+        c = self.crit
+        return getattr(c, '_meters', None) is not None and all(s is None for s in c._loss_sum) \
+            and c._acc is None and c._ppl is None
+
+    # ---- one step ------------------------------------------------------------------------------------------------
+    def __call__(self, batch=None):
+        """batch=None: step again on the contents of the static buffers (bench: one resident synthetic batch)"""
+        if self.static is None:
+            assert batch is not None
+            self.static = dict(batch)
+            for (k, i), t in _tensors(batch, self.keys).items():
+                if i is None:
+                    self.static[k] = t.clone()
+                else:
+                    self.static[k] = list(self.static[k])
+                    self.static[k][i] = t.clone()
+            self.sig = _signature(batch, self.keys)
+            self.loss = torch.zeros((), device=next(iter(_tensors(batch, self.keys).values())).device)
+        self.n_steps += 1
+        if self.sched is not None:
+            self.sched.step_update_learning_rate()      # host counter + one fill of the device-side learning rate
+        if batch is not None and _signature(batch, self.keys) != self.sig:
+            return self._eager(batch)                   # ragged tail of an epoch
+        if batch is not None:
+            dst = _tensors(self.static, self.keys)
+            for key, src in _tensors(batch, self.keys).items():
+                if dst[key].data_ptr() != src.data_ptr():
+                    dst[key].copy_(src)
+            for k, v in batch.items():                  # everything else (video ids, sample indices ...) rides along
+                if (k, None) not in dst and (k, 0) not in dst:
+                    self.static[k] = v
+        if self.graphs is None and self.graph_mode != 'off' and self.n_steps > self.eager_steps:
+            if self._graph_ready():
+                try:
+                    self._capture()
+                except Exception as e:  # noqa: BLE001
+                    if self.graph_mode == 'on':
+                        raise
+                    print('[nacf_amd] hipGraph capture failed (%s: %s); stepping launch by launch'
+                          % (type(e).__name__, e), file=sys.stderr)
+                    self.graphs, self.graph_mode = None, 'off'
+                    self._hold.clear()
+                    torch.cuda.synchronize()
+            elif self.graph_mode == 'on':
+                raise RuntimeError('nacf_amd: hipGraph capture needs the fused criterion (opt["fused_loss"])')
+            else:
+                self.graph_mode = 'off'
+        if self.graphs is not None:
+            self._replay()
+        else:
+            self._eager(self.static)
+
+    @property
+    def captured(self):
+        return self.graphs is not None

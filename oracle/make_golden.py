@@ -77,7 +77,7 @@ TINY = ["--dim_hidden", "64", "--num_attention_heads", "4", "--intermediate_size
 
 
 def keep(opt):
-    ks = list(O.DEFAULT_OPT.keys()) + ["vocab_size", "grad_clip", "weight_decay", "learning_rate", "crit"]
+    ks = list(O.DEFAULT_OPT.keys()) + ["vocab_size", "grad_clip", "weight_decay", "learning_rate", "crit", "minimum_learning_rate", "decay", "optim"]
     return {k: opt[k] for k in ks if k in opt}
 
 
@@ -480,8 +480,188 @@ def data_case():
     print("[data] ok:", len(out), "token/label tables,", len(fr), "frame-id cases")
 
 
+def trajectory_case(name="tiny_nacf_trajectory", method="NACF", extra=("-wc",), V=101, B=4, F_=6, epochs=2, steps=3):
+    """the reference's epoch loop (run_train, misc/run.py:249-269, called from train_network_all
+    :312-318) for `epochs` x `steps` iterations on seeded batches: zero_grad, forward, get_loss, backward,
+    clip_grad_value_, ScheduledOptim.step; the per-epoch loss record and epoch_update_learning_rate between epochs.
+    Stored: every batch, the loss of every step, the learning rate of every step, the loss-info of every epoch, the
+    final weights, and per parameter the entries whose reference gradient stayed above round-off in every step (Adam
+    normalises the others to +-lr steps of arbitrary sign, in the reference too).  The oracle replays the same
+    trajectory as the pin."""
+    opt = ref_opt(method, "MSRVTT", TINY + list(extra))
+    opt["vocab_size"] = V
+    sd = O.init_state_dict(opt, seed=0)
+    model = ref_model(opt, sd)
+    os.chdir(REF)
+    from misc.crit import get_criterion
+    from misc.optim import get_optimizer
+    os.chdir(ROOT)
+    crit = get_criterion(opt)
+    optim = get_optimizer(opt, model)
+    vw = opt["visual_word_generation"]
+    sd_o, st_o = {k: v.clone() for k, v in sd.items()}, {}
+    out = {"opt_json": opt_blob(opt), "B": B, "F": F_, "epochs": epochs, "steps": steps}
+    losses, lrs, infos, solid = [], [], [], None
+    seed = 10
+    lr_o = opt["learning_rate"]
+    for ep in range(epochs):
+        model.train()
+        crit.reset_loss_recorder()
+        for it in range(steps):
+            seed += 1
+            batch = O.synth_batch(opt, B, F_, seed=seed)
+            tokens = [batch["tokens_1"], batch["tokens"]] if vw else batch["tokens"]
+            labels = [batch["labels_1"], batch["labels"]] if vw else batch["labels"]
+            optim.zero_grad()
+            results = model(feats=[f.clone() for f in batch["feats"]], tgt_tokens=tokens, category=batch["category"])
+            results["tgt_length"] = batch["tgt_length"]
+            results["tgt_word_labels"] = labels
+            loss = crit.get_loss(results, epoch=ep)
+            loss.backward()
+            torch.nn.utils.clip_grad_value_(model.parameters(), opt["grad_clip"])
+            big = {k: p.grad.abs() > 2e-6 for k, p in model.named_parameters()}
+            solid = big if solid is None else {k: solid[k] & big[k] for k in big}
+            optim.step()
+            losses.append(float(loss))
+            lrs.append(optim._optimizer.param_groups[0]["lr"])
+            o_loss, _, _ = O.train_step(sd_o, opt, batch["feats"], tokens, batch["category"], labels, batch["tgt_length"],
+                                        st_o, lr=lr_o)
+            check(o_loss, loss.detach(), 5e-5, "trajectory loss %d/%d" % (ep, it))
+            k = "b%d." % (ep * steps + it)
+            for kk, v in batch.items():
+                if kk == "feats":
+                    for i, f in enumerate(v):
+                        out[k + "feats%d" % i] = f
+                else:
+                    out[k + kk] = v
+        names, info = crit.get_loss_info()
+        infos.append(info)
+        optim.epoch_update_learning_rate()
+        lr_o = max(opt["minimum_learning_rate"], opt["decay"] * lr_o)
+        assert abs(lr_o - optim.get_lr()) < 1e-12
+    worst = 0.0
+    for k, v in model.state_dict().items():
+        out["after." + k] = v
+        if k in solid:
+            out["solid." + k] = solid[k]
+            if solid[k].any():
+                worst = max(worst, float((sd_o[k] - v).abs()[solid[k]].max()))
+    assert worst < 3e-4, worst
+    out.update(losses=np.array(losses), lrs=np.array(lrs), loss_names=np.array(names),
+               loss_info=np.array(infos, dtype=np.float64), final_lr=optim.get_lr())
+    np.savez_compressed(os.path.join(GOLD, name + ".npz"), **npz(out))
+    print(f"[{name}] ok  losses {losses[0]:.4f} -> {losses[-1]:.4f}  oracle-vs-reference weights {worst:.2e}")
+
+
+def host_case():
+    """SURVEY 8f rows 3-4, host side: what the reference's k-best queue (misc/logger.py:81-211), text helpers
+    (misc/utils.py:21-147) and Python caption scorers (coco-caption/pycocoevalcap/{bleu,rouge,cider}) return on seeded
+    inputs.  Stored as JSON (inputs + expected outputs)."""
+    import shutil
+    import tempfile
+    os.chdir(REF)
+    if REF not in sys.path:
+        sys.path.insert(0, REF)
+    from misc.logger import k_PriorityQueue
+    from misc.utils import analyze_length_novel_unique, duplicate, to_sentence
+    sys.path.insert(0, os.path.join(REF, "coco-caption"))
+    from pycocoevalcap.bleu.bleu import Bleu
+    from pycocoevalcap.cider.cider import Cider
+    from pycocoevalcap.rouge.rouge import Rouge
+    os.chdir(ROOT)
+    rs = np.random.RandomState(7)
+    words = ["a", "man", "woman", "is", "are", "playing", "cooking", "the", "guitar", "dog", "running", "on", "in", "stage",
+             "kitchen", "and", "singing", "with", "cat", "ball", "two", "people", "talking", "car", "driving"]
+
+    def sentence(lo, hi):
+        return " ".join(words[i] for i in rs.randint(0, len(words), size=rs.randint(lo, hi)))
+    out = {}
+    # --- metrics
+    gts, res = {}, {}
+    for v in range(14):
+        vid = "video%d" % v
+        gts[vid] = [sentence(3, 11) for _ in range(rs.randint(2, 6))]
+        base = gts[vid][0].split(" ")
+        hyp = [w if rs.rand() > 0.3 else words[rs.randint(len(words))] for w in base][:rs.randint(2, len(base) + 1)]
+        res[vid] = [" ".join(hyp)]
+    res["video3"] = [gts["video3"][1]]                      # an exact match
+    res["video5"] = ["zebra xylophone"]                     # nothing in common
+    with contextlib.redirect_stdout(io.StringIO()):
+        b, b_each = Bleu(4).compute_score(gts, res)
+        r, r_each = Rouge().compute_score(gts, res)
+        c, c_each = Cider().compute_score(gts, res)
+    out["metrics"] = dict(gts=gts, res=res, bleu=list(b), bleu_each=[list(x) for x in b_each], rouge=float(r),
+                          rouge_each=[float(x) for x in r_each], cider=float(c), cider_each=[float(x) for x in c_each])
+    # --- text helpers
+    dups = []
+    for _ in range(60):
+        w = sentence(4, 12).split(" ")
+        for _ in range(rs.randint(0, 3)):                   # plant adjacent / one-apart repeats
+            n = rs.randint(1, 4)
+            i = rs.randint(0, max(1, len(w) - n))
+            gap = [words[rs.randint(len(words))]] if rs.rand() < 0.4 else []
+            w = w[:i + n] + gap + w[i:i + n] + w[i + n:]
+        s_in = " ".join(w)
+        s_out, rep = duplicate(s_in)
+        dups.append([s_in, s_out, rep])
+    out["duplicate"] = dups
+    vocab = {i: w for i, w in enumerate(["<pad>", "<unk>", "<bos>", "<eos>", "<mask>", "<vis>"] + words)}
+    hyps = [[int(x) for x in rs.randint(0, len(vocab), size=9)] for _ in range(20)]
+    out["to_sentence"] = [[h, to_sentence(h, vocab)] for h in hyps]
+    gt_data = {"video%d" % v: [[2] + [int(x) for x in rs.randint(6, len(vocab), size=rs.randint(2, 6))] + [3] for _ in range(3)]
+               for v in range(8)}
+    preds = {"video%d" % v: [{"caption": " ".join(vocab[w] for w in gt_data["video%d" % (v % 8)][v % 3][1:-1]) if v % 2 else sentence(2, 7)}]
+             for v in range(12)}
+    splits = {"train": [0, 1, 2, 3, 4], "validate": [5, 6], "test": [7]}
+    a = analyze_length_novel_unique(gt_data, preds, vocab, splits, n=1)
+    out["analyze"] = dict(gt_data=gt_data, preds=preds, splits=splits, vocab={str(k): v for k, v in vocab.items()},
+                          ave_length=a[0], novel=a[1], unique=a[2], usage=a[3], grams=a[4], gram4=a[5])
+    # --- k-best queue
+    runs = []
+    for k_best, standard, tol in ((1, ["METEOR", "CIDEr"], 3), (3, ["METEOR", "CIDEr"], 4), (2, ["CIDEr"], 2)):
+        tmp = tempfile.mkdtemp()
+        try:
+            opt = {"checkpoint_path": tmp, "tolerence": tol}
+            folder = os.path.join(tmp, "tmp_models")
+            q = k_PriorityQueue(k_best_model=k_best, folder_path=folder, standard=standard)
+            trace, base = [], 0.2
+            for ep in range(14):
+                base += 0.03 if ep < 5 else -0.004
+                res_ep = {"Bleu_4": float(base + 0.02 * rs.rand()), "METEOR": float(0.5 * base + 0.02 * rs.rand()),
+                          "ROUGE_L": float(base + 0.1 + 0.02 * rs.rand()), "CIDEr": float(1.5 * base + 0.05 * rs.rand()),
+                          "epoch": ep}
+                if ep in (7, 8):
+                    res_ep["CIDEr"] = trace[6]["res"]["CIDEr"]         # ties
+                given = dict(res_ep)
+                with open(os.path.join(tmp, "checkpoint.pth.tar"), "w") as f:
+                    f.write("epoch %d" % ep)
+                name = "model_%04d.pth.tar" % ep
+                ok, info = q.check(res_ep, opt, os.path.join(folder, name), name)
+                kept = sorted(os.listdir(folder)) if k_best > 1 else []
+                best_file = open(os.path.join(tmp, "best.pth.tar")).read() if k_best == 1 else None
+                trace.append(dict(res=given, ok=bool(ok), info=info, failed=q.continuous_failed_count, kept=kept,
+                                  best_file=best_file, sum=float(res_ep["Sum"]), best_epoch=q.best_res.get("epoch", -1),
+                                  qsize=q.qsize()))
+                if not ok:
+                    break
+            runs.append(dict(k_best=k_best, standard=standard, tolerence=tol, trace=trace))
+        finally:
+            shutil.rmtree(tmp)
+    out["kbest"] = runs
+    with open(os.path.join(GOLD, "tiny_host.json"), "w") as f:
+        json.dump(out, f, indent=0, sort_keys=True)
+    print("[host] ok: %d videos scored, %d duplicate cases, %d k-best runs (%s steps)" % (
+        len(gts), len(dups), len(runs), [len(r["trace"]) for r in runs]))
+
+
 def main():
     torch.manual_seed(0)
+    if os.environ.get("ONLY_HOST"):
+        host_case()
+        return
+    if os.environ.get("ONLY_TRAJ"):
+        trajectory_case()
+        return
     if os.environ.get("ONLY_DATA"):
         data_case()
         return
@@ -518,6 +698,8 @@ def main():
     train_case("tiny_nacf_pos_train", "NACF", ["-wc", "--pos_attention"], V=101, B=3, F_=6)
     checkpoint_case()
     data_case()
+    trajectory_case()
+    host_case()
     # NA decode: all paradigms, +-ct, per-iteration tokens/probs
     decode_case("tiny_nacf_decode", "NACF", ["-wc"], V=101, B=4, F_=6, variants={
         "mp_ct": dict(paradigm="mp", use_ct=True, iterations=5, length_beam_size=6, beam_alpha=1.35),
