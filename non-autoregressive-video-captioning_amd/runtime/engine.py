@@ -102,23 +102,27 @@ class TrainStep(object):
     def _capture(self):
         dev = self.loss.device
         before = list(self.crit._loss_cnt)
+        # drain first: RCCL's watchdog thread polls the events of unfinished collectives, which is illegal while a
+        # capture is open in another thread ("thread_local" below keeps unrelated threads out of it as well)
+        torch.cuda.synchronize(dev)
+        mode = dict(capture_error_mode='thread_local')
         side = torch.cuda.Stream(device=dev)
         side.wait_stream(torch.cuda.current_stream(dev))
         with torch.cuda.stream(side):
             front = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(front, stream=side):
+            with torch.cuda.graph(front, stream=side, **mode):
                 self._front(self.static)
                 if not self.multi:
                     self._update()
             back = upd = None
             if self.staged:                 # same memory pool: the autograd graph of `front` is still alive
                 back = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(back, stream=side, pool=front.pool()):
+                with torch.cuda.graph(back, stream=side, pool=front.pool(), **mode):
                     self._back()
                 self._hold.clear()
             if self.multi:
                 upd = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(upd, stream=side, pool=front.pool()):
+                with torch.cuda.graph(upd, stream=side, pool=front.pool(), **mode):
                     self._update()
         torch.cuda.current_stream(dev).wait_stream(side)
         # capturing ran the host side of get_loss once without executing anything: take its sample-count increments

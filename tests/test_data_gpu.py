@@ -180,7 +180,7 @@ def test_shard_loader_resident_equals_streaming_and_feeds_a_train_step(dev, tmp_
             assert set(a) == set(b)
             for k in a:
                 xs, ys = (a[k], b[k]) if isinstance(a[k], list) else ([a[k]], [b[k]])
-                assert all(torch.equal(x, y) for x, y in zip(xs, ys)), (other, k)
+                assert all(torch.equal(torch.as_tensor(x), torch.as_tensor(y)) for x, y in zip(xs, ys)), (other, k)
     first = batches[True][0]
     n = first["tokens"].shape[0]
     assert first["feats"][0].shape == (n, 8, 32) and first["tokens"].shape == (n, 10) and first["category"].shape == (n, 1)
