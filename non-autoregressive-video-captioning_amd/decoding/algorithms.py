@@ -28,16 +28,19 @@ class DecodeContext(object):
         self.vocab_b = model.tgt_word_prj.bias
         self.row_set = None     # live slots of the canvas (set by the algorithm once the canvas exists)
 
-    def hidden(self, tokens, decoding_type='NARFormer', output_attentions=False, row_set='canvas'):
+    def hidden(self, tokens, decoding_type='NARFormer', output_attentions=False, row_set='canvas', out_row_set=None):
         out = self.model.decoder(tokens, enc_output=self.enc_output, category=self.category,
                                  decoding_type=decoding_type, row_map=('div', self.lbs),
                                  memory_kv=self.memory_kv, pooled_memory=self.pooled,
                                  output_attentions=output_attentions,
-                                 row_set=self.row_set if row_set == 'canvas' else row_set)
+                                 row_set=self.row_set if row_set == 'canvas' else row_set, out_row_set=out_row_set)
         h = out[0]
         if isinstance(h, list):
             h = h[-1]
         return h, (out[2] if output_attentions else None)
+
+
+_LUT_CACHE = {}      # (ratios, width, device) -> device table; module level so that a captured decode never uploads
 
 
 class Algorithm_Base(object):
@@ -50,7 +53,6 @@ class Algorithm_Base(object):
         self.masking_decision = opt.get('masking_decision', False)
         self.no_candidate_decision = opt.get('no_candidate_decision', False)
         self.vocab = tgt_vocab
-        self._lut_cache = {}
 
     # ------------------------------------------------------------ helpers
     def collect_data(self, tokens, probs, is_last=False):
@@ -74,11 +76,12 @@ class Algorithm_Base(object):
             ctx.row_set = ops.rowset_build(tokens=pad_tokens.reshape(-1))
             if out_probs is None:
                 ops.init_probs(pad_tokens.reshape(-1), probs.reshape(-1))   # <pad> slots: (PAD, 1.0) for good
-        h, _ = ctx.hidden(tokens)
-        R, Lp, D = h.shape
-        # project only the slots this pass may change: live canvas slots, and within them the re-masked ones
+        # only the slots this pass may change are read from the decoder and projected: live canvas slots, and within
+        # them the re-masked ones (keys / values of the self-attention still cover every live slot)
         live = ctx.row_set if update_mask is None else ops.rowset_build(tokens=pad_tokens.reshape(-1),
                                                                         flags=update_mask.reshape(-1))
+        h, _ = ctx.hidden(tokens, out_row_set=None if update_mask is None else live)
+        R, Lp, D = h.shape
         ops.vocab_argmax(h.reshape(R * Lp, D), ctx.vocab_w, ctx.vocab_b, pad_tokens.reshape(-1), zero_mask_prob,
                          update_mask.reshape(-1) if update_mask is not None else None,
                          (out_tokens if out_tokens is not None else tokens).reshape(-1),
@@ -88,11 +91,11 @@ class Algorithm_Base(object):
         """floor(len * ratio) exactly as `(seq_lens.float() * ratio).long()` computes it
         (algorithms.py:256), tabulated per length so the kernel needs no float math."""
         key = (tuple(ratios), Lp, str(device))
-        if key not in self._lut_cache:
+        if key not in _LUT_CACHE:
             lens = torch.arange(Lp + 1, dtype=torch.float32)
             rows = [(lens * r).long() for r in ratios]
-            self._lut_cache[key] = torch.stack(rows, 0).to(torch.int32).to(device)
-        return self._lut_cache[key]
+            _LUT_CACHE[key] = torch.stack(rows, 0).to(torch.int32).to(device)
+        return _LUT_CACHE[key]
 
     def scoring_by_teacher(self, teacher_ctx, tokens, pad_tokens, is_last=False):
         """algorithms.py:169-204: p(y_t | y_<t) under an autoregressive teacher."""

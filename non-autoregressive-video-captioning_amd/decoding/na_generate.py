@@ -6,7 +6,9 @@ best-candidate gather are device kernels, the visual memory is addressed by
 `row // lbs` instead of being repeated lbs times (misc/utils.py:205-229), and
 its cross-attention K|V projection is computed once per video.  The single host
 read per batch is the canvas width (`beam.max().item()`, na_generate.py:37),
-kept so the returned hypotheses have exactly the reference's shape.
+kept so the returned hypotheses have exactly the reference's shape; for
+mask-predict it moves behind the work, which replays from one hipGraph
+(`_generate_graphed`, opt['decode_graph'] = 'auto' | 'on' | 'off').
 """
 import torch
 
@@ -25,6 +27,96 @@ def generate(opt, model, teacher_model, encoder_outputs, teacher_encoder_outputs
         raise NotImplementedError('nacf_amd: load_generated_captions (gold length beam) is not built')
     if kwargs.get('output_attentions', False) or opt.get('example', ''):
         raise NotImplementedError('nacf_amd: attention collection / example mode of generate() is not built')
+    mode = opt.get('decode_graph', 'auto')
+    assert mode in ('auto', 'on', 'off')
+    # mask-predict has a fixed launch sequence once the canvas width is fixed: replay it from a hipGraph
+    # ('l2r' / 'ef' read a slot count on the host between passes; a vocabulary remap table is uploaded per call)
+    if mode != 'off' and paradigm == 'mp' and not dict_mapping:
+        out = _generate_graphed(opt, model, teacher_model, encoder_outputs, teacher_encoder_outputs, category,
+                                tgt_vocab, length_bias, mode)
+        if out is not None:
+            return out
+    hyp, lprobs, _ = _generate(opt, model, teacher_model, encoder_outputs, teacher_encoder_outputs, category, tgt_vocab,
+                               dict_mapping, length_bias, None)
+    return hyp, lprobs
+
+
+def _enc_tensors(enc):
+    e = enc['enc_output']
+    return e[0] if isinstance(e, list) else e, enc.get('pred_length'), enc.get('_pooled_memory')
+
+
+def _generate_graphed(opt, model, teacher_model, enc, t_enc, category, tgt_vocab, length_bias, mode):
+    """The whole decode of one batch -- length beam, canvas, T(+1) decoder passes with fused projection/argmax,
+    re-masking, optional teacher scoring, candidate selection -- as ONE hipGraph replay over static inputs.  Inside
+    the graph the canvas is max_len-1 slots wide (the length beam's upper clamp, na_generate.py:133): the extra
+    slots are <pad> in every candidate, so they are skipped by the live-row GEMMs and change no value; the result
+    is cut back to the reference's width (`beam.max()`) with the single host read the reference performs too.
+    mode 'auto': a batch geometry is captured the second time it is seen (a one-off decode or the ragged last batch
+    of an evaluation never pays for a capture); 'on': at once."""
+    e, pl, pooled = _enc_tensors(enc)
+    if not e.is_cuda:
+        return None
+    te = _enc_tensors(t_enc) if (teacher_model is not None and t_enc is not None) else None
+    keys = ('paradigm', 'use_ct', 'iterations', 'length_beam_size', 'beam_alpha', 'masking_decision',
+            'no_candidate_decision', 'collect_best_candidate_iterative_results', 'collect_last',
+            'not_only_best_candidate')
+    flat = getattr(model, 'flat', None)          # the graph holds raw pointers into the parameter buffer
+    key = (None if flat is None else flat.data.data_ptr(), tuple(e.shape), tuple(pl.shape), None if category is None else tuple(category.shape), int(length_bias),
+           id(teacher_model) if te is not None else None, None if te is None else tuple(te[0].shape),
+           tuple(str(opt.get(k)) for k in keys))
+    cache = model.__dict__.setdefault('_nacf_decode_graphs', {})
+    entry = cache.get(key)
+    if entry is None:
+        if mode == 'auto' and not cache.setdefault(('seen', key), False):
+            cache[('seen', key)] = True
+            return None
+        W = pl.shape[1] - 1
+        st = dict(e=e.clone(), pl=pl.clone(), pooled=None if pooled is None else pooled.clone(),
+                  cat=None if category is None else category.clone(),
+                  te=None if te is None else [None if x is None else x.clone() for x in te])
+
+        def run():
+            s_enc = {'enc_output': st['e'], 'pred_length': st['pl']}
+            if st['pooled'] is not None:
+                s_enc['_pooled_memory'] = st['pooled']
+            s_t = None
+            if st['te'] is not None:
+                s_t = {'enc_output': st['te'][0]}
+                if st['te'][2] is not None:
+                    s_t['_pooled_memory'] = st['te'][2]
+            return _generate(opt, model, teacher_model, s_enc, s_t, st['cat'], tgt_vocab, {}, length_bias, W)
+        run()                                   # launch by launch once: workspaces, mask-count tables
+        dev = e.device
+        torch.cuda.synchronize(dev)
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.stream(side):
+            with torch.cuda.graph(graph, stream=side, capture_error_mode='thread_local'):
+                outs = run()
+        torch.cuda.current_stream(dev).wait_stream(side)
+        entry = cache[key] = (graph, st, outs)
+    graph, st, (hyp, lprobs, beam_max) = entry
+    st['e'].copy_(e)
+    st['pl'].copy_(pl)
+    if pooled is not None:
+        st['pooled'].copy_(pooled)
+    if category is not None:
+        st['cat'].copy_(category)
+    if te is not None:
+        for dst, src in zip(st['te'], te):
+            if src is not None:
+                dst.copy_(src)
+    graph.replay()
+    Lp = int(beam_max.item())                   # the reference's one host read (na_generate.py:37), after the work
+    out_l = None if lprobs is None else tuple(x[..., :Lp].clone() for x in lprobs)
+    return hyp[:, :Lp].clone(), out_l
+
+
+def _generate(opt, model, teacher_model, encoder_outputs, teacher_encoder_outputs, category, tgt_vocab, dict_mapping,
+              length_bias, fixed_width):
+    paradigm = opt.get('paradigm', 'mp')
     algorithm = algorithms_mapping[paradigm](opt, dict_mapping, tgt_vocab)
     lbs = opt['length_beam_size']
     beam_alpha = opt.get('beam_alpha', 1.0)
@@ -36,7 +128,7 @@ def generate(opt, model, teacher_model, encoder_outputs, teacher_encoder_outputs
     beam = torch.empty(B, lbs, dtype=torch.int32, device=dev)
     beam_max = torch.empty(1, dtype=torch.int32, device=dev)
     ops.length_beam(pred_length, lbs, int(length_bias), beam, beam_max)
-    Lp = int(beam_max.item())
+    Lp = int(beam_max.item()) if fixed_width is None else int(fixed_width)
     R = B * lbs
     tokens = torch.empty(R, Lp, dtype=torch.int64, device=dev)
     ops.canvas_init(beam, R, Lp, tokens)
@@ -70,4 +162,4 @@ def generate(opt, model, teacher_model, encoder_outputs, teacher_encoder_outputs
             sents = [s.view(B, lbs, Lp).gather(1, idx).squeeze(1) for s in sents]
             scores = [s.view(B, lbs, Lp).gather(1, idx).squeeze(1) for s in scores]
         lprobs = (torch.stack(sents, dim=1), torch.stack(scores, dim=1))
-    return hypotheses, lprobs
+    return hypotheses, lprobs, beam_max

@@ -10,7 +10,8 @@ and add three keyword-only accelerators the NA decoding loop uses:
         misc/utils.py:205-213);
     memory_kv=[...]: per-layer K|V projections of the memory (project_memory),
         computed once per video instead of once per pass;
-    pooled_memory: mean_t(enc_output) for enhance_input=2.
+    pooled_memory: mean_t(enc_output) for enhance_input=2;
+    out_row_set: (inference) the slots whose hidden state will be read -- the last layer computes only those.
 Masks are never materialised: kernels derive key-padding / causal masks from
 the token ids (models/Decoder.py:9-39).  The two NACF / ARB2 passes run as ONE
 batch of 2B rows that share weights and memory (models/Decoder.py:201-215).
@@ -118,17 +119,23 @@ class BertDecoder(nn.Module):
         rows = kwargs.get('row_set')
         if rows is None and self.pack_rows:
             rows = ops.rowset_build(tokens=tgt_seq.reshape(-1))
+        # inference only: the slots whose hidden state the caller will read (a subset of `rows`); the last layer
+        # restricts its query-side work to them and `embs` (a mean over ALL slots) is not produced
+        out_rows = kwargs.get('out_row_set') if not (training or torch.is_grad_enabled()) else None
         x2 = hidden.reshape(R * Lq, D)
         all_attentions = ()
         for i, layer in enumerate(self.layer):
             kv = memory_kv[i] if memory_kv is not None else layer.project_memory(enc_output)
+            last = i == len(self.layer) - 1
             x2, att = layer.run(x2, tgt_seq, decoding_type == 'ARFormer', kv, M, vdiv, vmod, training,
-                                output_attentions, rows, pos2)
+                                output_attentions, rows, pos2, out_rows if last else None)
             if output_attentions:
                 all_attentions = all_attentions + (att,)
         hidden = x2.view(R, Lq, D)
-        with torch.no_grad():
-            embs = ops.masked_mean_fwd(hidden.detach(), tgt_seq, torch.empty(R, D, device=hidden.device))
+        embs = None
+        if out_rows is None:
+            with torch.no_grad():
+                embs = ops.masked_mean_fwd(hidden.detach(), tgt_seq, torch.empty(R, D, device=hidden.device))
         outputs = ([hidden], embs,)
         if output_attentions:
             outputs = outputs + (all_attentions,)

@@ -22,7 +22,8 @@ import torch.nn as nn
 
 from ..config import Constants
 from ..runtime import lib as L
-from ..runtime.functional import (CrossAttentionFn, EmbedLNFn, LayerNormFn, LinearFn, QKVAttentionFn,
+from ..runtime import ops
+from ..runtime.functional import (CrossAttentionFn, EmbedLNFn, LayerNormFn, LinearFn, Pack, QKVAttentionFn,
                                   SelfAttentionFn)
 
 
@@ -179,7 +180,8 @@ class BertLayer(nn.Module):
         Bv, M, D = enc_output.shape
         return LinearFn.apply(enc_output.reshape(Bv * M, D), None, dict(pack=self._pk['ckv']), *self._params)
 
-    def run(self, x2, tokens, causal, memory_kv, M, vdiv, vmod, training, want_probs, rows=None, pos2=None):
+    def run(self, x2, tokens, causal, memory_kv, M, vdiv, vmod, training, want_probs, rows=None, pos2=None,
+            out_rows=None):
         """x2: [R*L, D] hidden rows; tokens: [R, L]; memory_kv: [Bv*M, 2D]; rows: live (non-<pad>)
         slot list -- the row-wise GEMMs skip <pad> slots, whose outputs are exact zeros anyway."""
         R, Lq = tokens.shape
@@ -192,6 +194,8 @@ class BertLayer(nn.Module):
             return self._run_layernorm(x2, tokens, causal, memory_kv, M, vdiv, vmod, training, want_probs, rows)
         if self.pos_attention is not None:
             return self._run_pos(x2, pos2, tokens, causal, memory_kv, M, vdiv, vmod, training, want_probs, rows)
+        if out_rows is not None and not torch.is_grad_enabled() and not training:
+            return self._run_subset(x2, tokens, causal, memory_kv, M, vdiv, vmod, want_probs, rows, out_rows)
         # each block input (x2, a, c) feeds a Linear AND the residual add of the block's output Linear.  The output
         # Linear's backward runs first (it is downstream), parks its residual gradient in h*, and the input Linear's
         # dX GEMM accumulates onto it (LinearFn: res_sink / dx_acc) -- only wired when both gradients will exist.
@@ -208,6 +212,35 @@ class BertLayer(nn.Module):
         u = LinearFn.apply(c, None, dict(pack=pk['f1'], act=self.act, rows=rows, dx_acc=h3), *P)
         y = LinearFn.apply(u, c, dict(pack=pk['f2'], p1=self.p, salt1=s[2], p2=self.p, salt2=s[3], row_tokens=tok_flat,
                                       rng=rng, training=training, rows=rows, res_sink=h3), *P)
+        return y, (p_self, p_cross)
+
+    def _run_subset(self, x2, tokens, causal, memory_kv, M, vdiv, vmod, want_probs, rows, out_rows):
+        """Inference, last layer: only the slots in `out_rows` are consumed downstream (mask-predict re-predicts just
+        the re-masked slots: decoding/algorithms.py:na_pass).  Keys and values are still projected for every live
+        slot, but the query projection and everything after the self-attention (output projections, the
+        cross-attention, the FFN -- 5/6 of the layer's GEMM flops) run on `out_rows` only.  Each kept row is
+        computed by the same instruction sequence as in `run`, so its values are bit-identical; the other rows of
+        the returned tensor are zeros."""
+        R, Lq = tokens.shape
+        D = x2.shape[1]
+        P, pk = self._params, self._pk
+        tok_flat = tokens.reshape(-1)
+        if 'q_only' not in pk:
+            full = pk['qkv']
+            pk['q_only'] = Pack(full.w[:D], full.b[:D], None, None)
+            pk['kv_only'] = Pack(full.w[D:], full.b[D:], None, None)
+        sub = dict(row_tokens=tok_flat, training=False, rows=out_rows)
+        q = LinearFn.apply(x2, None, dict(pack=pk['q_only'], rows=out_rows), *P)
+        kv = LinearFn.apply(x2, None, dict(pack=pk['kv_only'], rows=rows), *P)
+        att = torch.empty(R * Lq, D, dtype=x2.dtype, device=x2.device)
+        p_self = torch.empty(self.H, R, Lq, Lq, dtype=x2.dtype, device=x2.device) if want_probs else None
+        ops.attention_fwd(q, kv[:, :D], kv[:, D:], att, tokens, int(causal), p_self, R, self.H, Lq, Lq, D // self.H, 1, R)
+        a = LinearFn.apply(att, x2, dict(pack=pk['so'], **sub), *P)
+        cq = LinearFn.apply(a, None, dict(pack=pk['cq'], rows=out_rows), *P)
+        catt, p_cross = CrossAttentionFn.apply(cq, memory_kv, self.H, Lq, M, vdiv, vmod, want_probs)
+        c = LinearFn.apply(catt, a, dict(pack=pk['co'], **sub), *P)
+        u = LinearFn.apply(c, None, dict(pack=pk['f1'], act=self.act, rows=out_rows), *P)
+        y = LinearFn.apply(u, c, dict(pack=pk['f2'], **sub), *P)
         return y, (p_self, p_cross)
 
     def _run_layernorm(self, x2, tokens, causal, memory_kv, M, vdiv, vmod, training, want_probs, rows):

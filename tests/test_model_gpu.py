@@ -95,11 +95,11 @@ def test_train_step_vs_reference_golden(dev, name, fused):
         assert abs(mine[k] - v) < 1e-3 * max(1.0, abs(v)), (k, mine[k], v)
 
 
-def _run_decode(model, dec, b, dev, teacher=None, t_enc=None):
+def _run_decode(model, dec, b, dev, teacher=None, t_enc=None, graph="off"):
     from nacf_amd.models.Translator import Translator
     dopt = dict(model.opt)
     dopt.update(dec)
-    dopt.update(collect_best_candidate_iterative_results=True, not_only_best_candidate=True)
+    dopt.update(collect_best_candidate_iterative_results=True, not_only_best_candidate=True, decode_graph=graph)
     tr = Translator(model, dopt, device=dev, teacher_model=teacher)
     with torch.no_grad():
         enc = model.encode(feats=b["feats"])
@@ -107,8 +107,11 @@ def _run_decode(model, dec, b, dev, teacher=None, t_enc=None):
     return enc, hyp, extra
 
 
+@pytest.mark.parametrize("graph", ["off", "on"])
 @pytest.mark.parametrize("name", ["tiny_nacf_decode", "tiny_nab_decode"])
-def test_na_decode_tokens_bit_exact_vs_reference_golden(dev, name):
+def test_na_decode_tokens_bit_exact_vs_reference_golden(dev, name, graph):
+    """graph='on': mask-predict variants replay from one hipGraph on a max_len-1 wide canvas and must still return the
+    reference's tokens, per-iteration tokens / probabilities and shapes"""
     g = load_gold(name)
     opt = gold_opt(g)
     b = gold_batch(g, dev)
@@ -117,7 +120,15 @@ def test_na_decode_tokens_bit_exact_vs_reference_golden(dev, name):
     variants = sorted({k.split(".")[0] for k in g.files if k.endswith(".hyp")})
     for v in variants:
         dec = gold_json(g, v + ".dec_json")
-        enc, hyp, (it_tok, it_prob) = _run_decode(model, dec, b, dev)
+        enc, hyp, (it_tok, it_prob) = _run_decode(model, dec, b, dev, graph=graph)
+        if graph == "on" and dec.get("paradigm", "mp") == "mp":
+            assert len([k for k in model._nacf_decode_graphs if k[0] != "seen"]) >= 1
+            # a second batch through the SAME captured graph: permuted videos give permuted captions
+            perm = torch.arange(hyp.shape[0] - 1, -1, -1, device=dev)
+            b2 = dict(b, feats=[f[perm] for f in b["feats"]], category=b["category"][perm])
+            _, hyp2, _ = _run_decode(model, dec, b2, dev, graph=graph)
+            w = min(hyp.shape[1], hyp2.shape[1])
+            assert torch.equal(hyp2[:, :w], hyp[perm][:, :w])
         assert maxerr(enc["enc_output"], t(g["out.enc_output"])) < 2e-5
         assert maxerr(enc["pred_length"], t(g["out.pred_length"])) < 2e-5
         assert torch.equal(hyp.cpu(), t(g[v + ".hyp"])), v
@@ -133,11 +144,12 @@ def test_na_decode_with_ar_teacher_rescoring(dev):
     teacher = build(t_opt, O.init_state_dict(t_opt, seed=7), dev); teacher.eval()
     with torch.no_grad():
         t_enc = teacher.encode(feats=b["feats"])
-    for v in ("mp_ct", "mp_md"):
-        dec = gold_json(g, v + ".dec_json")
-        _, hyp, (it_tok, _) = _run_decode(model, dec, b, dev, teacher, t_enc)
-        assert torch.equal(hyp.cpu(), t(g[v + ".hyp"])), v
-        assert torch.equal(it_tok.cpu(), t(g[v + ".iter_tokens"]).long()), v
+    for graph in ("off", "on"):
+        for v in ("mp_ct", "mp_md"):
+            dec = gold_json(g, v + ".dec_json")
+            _, hyp, (it_tok, _) = _run_decode(model, dec, b, dev, teacher, t_enc, graph=graph)
+            assert torch.equal(hyp.cpu(), t(g[v + ".hyp"])), (graph, v)
+            assert torch.equal(it_tok.cpu(), t(g[v + ".iter_tokens"]).long()), (graph, v)
 
 
 @pytest.mark.parametrize("name", ["tiny_arb2_beam", "tiny_arb_beam", "tiny_arb_beam_eos", "tiny_arb2_beam_eos"])
@@ -333,3 +345,32 @@ def test_live_row_path_equals_dense_path_at_model_width(dev):
     assert abs(l0 - l1) <= 1e-5 * abs(l1)
     scale = float(g1.abs().max())
     assert scale > 0 and float((g0 - g1).abs().max()) <= 2e-5 * scale
+
+
+@pytest.mark.parametrize("layers", [1, 2])
+def test_decoder_query_subset_is_bit_identical_on_the_kept_slots(dev, layers):
+    """NA decoding reads the decoder's hidden state only at the re-masked slots: with `out_row_set` the last layer
+    computes just those rows (keys/values still span every live slot) and they equal the full pass bit for bit"""
+    import nacf_amd
+    from nacf_amd import synthetic as S
+    from nacf_amd.runtime import ops
+    opt = nacf_amd.opts.make_opt("NACF", "MSRVTT", with_category=True, max_len=20, vocab_size=1000, n_frames=8,
+                                 num_hidden_layers_decoder=layers)
+    model = nacf_amd.get_model(opt)
+    model.load_state_dict(S.init_state_dict(opt, seed=2))
+    model.to(dev).eval()
+    b = S.synth_batch(opt, 6, 8, seed=3)
+    feats, cat = [f.to(dev) for f in b["feats"]], b["category"].to(dev)
+    tokens = b["tokens"].to(dev)
+    g = torch.Generator().manual_seed(0)
+    keep = ((torch.rand(tokens.shape, generator=g) < 0.4).to(dev) & (tokens != 0))
+    with torch.no_grad():
+        enc = model.encode(feats=feats)["enc_output"]
+        full = model.decoder(tokens, enc_output=enc, category=cat)[0]
+        rows = ops.rowset_build(tokens=tokens.reshape(-1), flags=keep.reshape(-1).to(torch.uint8))
+        out = model.decoder(tokens, enc_output=enc, category=cat, out_row_set=rows)
+    full = full[-1] if isinstance(full, list) else full
+    sub = out[0][-1] if isinstance(out[0], list) else out[0]
+    assert out[1] is None and int(keep.sum()) > 10
+    assert torch.equal(sub[keep], full[keep])
+    assert float(sub[~keep].abs().max()) == 0.0           # everything else is zero-filled, never garbage
