@@ -174,20 +174,25 @@ __global__ __launch_bounds__(256) void fwd_kernel(const float* __restrict__ Q, i
                                                    float* __restrict__ O, int64_t ldo,
                                                    const int64_t* __restrict__ key_tokens, int causal,
                                                    float* __restrict__ probs, int R, int H, int Lq, int Lk, int kv_div,
-                                                   int kv_mod) {
+                                                   int kv_mod, int nqb) {
+  // item = (sequence, head, block of 32 queries); nqb = ceil(Lq / 32) > 1 only without a causal mask.  The blocks of
+  // one (sequence, head) are consecutive items, i.e. waves of ONE workgroup: they walk the same K / V rows together.
   constexpr int DK = 16 * DK16;
   const int lane = threadIdx.x & 63;
   const int item = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (item >= R * H) return;
-  const int r = item / H, h = item % H;
+  if (item >= R * H * nqb) return;
+  const int qb = item % nqb, rh = item / nqb;
+  const int r = rh / H, h = rh % H;
+  const int q0 = qb * 32;
+  const int nq = min(32, Lq - q0);
   const int kvr = (r / kv_div) % kv_mod;
   const int i = lane & 15, g = lane >> 4;
-  const float* Qb = Q + (int64_t)r * Lq * ldq + h * DK;
+  const float* Qb = Q + ((int64_t)r * Lq + q0) * ldq + h * DK;
   const float* Kb = K + (int64_t)kvr * Lk * ldk + h * DK;
   const float* Vb = V + (int64_t)kvr * Lk * ldv + h * DK;
   f32x4 qf[2][DK16];
 #pragma unroll
-  for (int tm = 0; tm < 2; ++tm) load_row_frag<DK16>(qf[tm], Qb, ldq, tm * 16 + i, Lq, g);
+  for (int tm = 0; tm < 2; ++tm) load_row_frag<DK16>(qf[tm], Qb, ldq, tm * 16 + i, nq, g);
   f32x4 s[2][NKT];
 #pragma unroll
   for (int tm = 0; tm < 2; ++tm)
@@ -199,13 +204,13 @@ __global__ __launch_bounds__(256) void fwd_kernel(const float* __restrict__ Q, i
 #pragma unroll
     for (int tm = 0; tm < 2; ++tm) {
       const int q = tm * 16 + i;
-      if (q < Lq) {
+      if (q < nq) {
 #pragma unroll
         for (int tn = 0; tn < NKT; ++tn)
 #pragma unroll
           for (int rr = 0; rr < 4; ++rr) {
             const int key = tn * 16 + g * 4 + rr;
-            if (key < Lk) probs[(((int64_t)h * R + r) * Lq + q) * Lk + key] = s[tm][tn][rr];
+            if (key < Lk) probs[(((int64_t)h * R + r) * Lq + q0 + q) * Lk + key] = s[tm][tn][rr];
           }
       }
     }
@@ -216,7 +221,7 @@ __global__ __launch_bounds__(256) void fwd_kernel(const float* __restrict__ Q, i
 #pragma unroll
     for (int td = 0; td < DK16; ++td) o[tm][td] = f32x4{0.f, 0.f, 0.f, 0.f};
   contract_key<NKT, DK16>(o, s, Vb, ldv, Lk, i, g);
-  store_rows<DK16>(o, O + (int64_t)r * Lq * ldo + h * DK, ldo, Lq, i, g);
+  store_rows<DK16>(o, O + ((int64_t)r * Lq + q0) * ldo + h * DK, ldo, nq, i, g);
 }
 
 // dst[key][d] (+)= sum_q T[q][key] * A[q][d]  for key tiles [tk0, tk0+TKC), T = wave-private LDS tile [32][PITCH]

@@ -823,14 +823,16 @@ int nacf_attention_fwd(const float* Q, int64_t ldq, const float* K, int64_t ldk,
   NACF_CHECK(R > 0 && H > 0 && Lq > 0 && Lk > 0 && dk > 0 && kv_div > 0 && kv_mod > 0, NACF_EINVAL,
              "nacf_attention_fwd: bad shape");
   NACF_CHECK(!(causal && Lq != Lk), NACF_EINVAL, "nacf_attention_fwd: causal mask needs Lq == Lk");
-  if (attn_mfma_ok(Lq, Lk, dk) && attn_aligned(Q, ldq) && attn_aligned(K, ldk) && attn_aligned(V, ldv) &&
-      attn_aligned(O, ldo)) {
-    // matrix-core path: one wave per (sequence, head), operands straight from HBM/L2 into MFMA fragments
-    const dim3 grid(cdiv(R * H, 4));
+  // more than 32 queries per sequence run as blocks of 32 (one wave each) when no causal mask ties a query to its index
+  if (attn_mfma_ok(causal ? Lq : min(Lq, 32), Lk, dk) && attn_aligned(Q, ldq) && attn_aligned(K, ldk) &&
+      attn_aligned(V, ldv) && attn_aligned(O, ldo)) {
+    // matrix-core path: one wave per (sequence, head, 32 queries), operands straight from HBM/L2 into MFMA fragments
+    const int nqb = cdiv(Lq, 32);
+    const dim3 grid(cdiv(R * H * nqb, 4));
     hipStream_t s = as_hip(stream);
 #define NACF_ATTN_FWD(NKT, DK16)                                                                                      \
   hipLaunchKernelGGL((attn::fwd_kernel<NKT, DK16>), grid, dim3(256), 0, s, Q, ldq, K, ldk, V, ldv, O, ldo, key_tokens, \
-                     causal, probs, R, H, Lq, Lk, kv_div, kv_mod)
+                     causal, probs, R, H, Lq, Lk, kv_div, kv_mod, nqb)
     if (Lk <= 32) { if (dk == 64) NACF_ATTN_FWD(2, 4); else NACF_ATTN_FWD(2, 1); }
     else { if (dk == 64) NACF_ATTN_FWD(8, 4); else NACF_ATTN_FWD(8, 1); }
 #undef NACF_ATTN_FWD

@@ -387,7 +387,13 @@ class CrossAttentionFn(Function):
         k, v = kv[:, :D], kv[:, D:]
         out = _new((R * Lq, D), q)
         probs = _new((H, R, Lq, Lk), q) if want_probs else None
-        ops.attention_fwd(q, k, v, out, None, 0, probs, R, H, Lq, Lk, dk, kv_div, kv_mod)
+        if kv_div > 1 and R == kv_div * kv_mod and not want_probs and not any(ctx.needs_input_grad):
+            # inference with the length beam: the kv_div candidates of a video are consecutive rows and nothing masks a
+            # query, so they are ONE sequence of kv_div*Lq queries over that video's memory -- 114 rows in blocks of
+            # 32 instead of 6 x (19 padded to 32), and the blocks share the K / V rows they stream
+            ops.attention_fwd(q, k, v, out, None, 0, None, kv_mod, H, Lq * kv_div, Lk, dk, 1, kv_mod)
+        else:
+            ops.attention_fwd(q, k, v, out, None, 0, probs, R, H, Lq, Lk, dk, kv_div, kv_mod)
         ctx.q, ctx.kv = q, kv
         ctx.dims = (R, H, Lq, Lk, dk, kv_div, kv_mod)
         if want_probs:

@@ -503,6 +503,13 @@ def test_attention_full_size_cross(dev):
     kvx = kv.to(dev)
     ops.attention_fwd(q.to(dev), kvx[:, :D], kvx[:, D:], out, None, 0, None, R, H, Lq, Lk, dk, lbs, Bv)
     assert err(out, o_ref.reshape(R * Lq, D)) < 5e-5
+    # the candidates of a video as ONE sequence of lbs*Lq queries (blocks of 32 queries per wave): same bits
+    out2 = torch.empty(R * Lq, D, device=dev)
+    ops.attention_fwd(q.to(dev), kvx[:, :D], kvx[:, D:], out2, None, 0, None, Bv, H, lbs * Lq, Lk, dk, 1, Bv)
+    assert torch.equal(out, out2)
+    probs = torch.empty(H, Bv, lbs * Lq, Lk, device=dev)
+    ops.attention_fwd(q.to(dev), kvx[:, :D], kvx[:, D:], out2, None, 0, probs, Bv, H, lbs * Lq, Lk, dk, 1, Bv)
+    assert torch.equal(out, out2) and float((probs.sum(-1) - 1).abs().max()) < 1e-5
 
 
 @pytest.mark.parametrize("R,Lq,H,dk,causal", [(5, 7, 4, 16, False), (3, 9, 4, 16, True), (2, 20, 8, 64, False)])
