@@ -75,6 +75,12 @@ int nacf_abi_count(void);
 int nacf_sample_frames(const float* src, const int32_t* video, const int32_t* src_len, int B, int T, int D,
                        int n_frames, int mode, uint32_t salt, const uint64_t* rng_state, float* out,
                        int32_t* frame_ids, nacf_stream_t stream);
+/* nacf_gather_clips_h2d: dst[j, :] = src_host[rows[j], :] for j < n, one asynchronous copy of `clip_bytes` per clip on
+ *   `stream` (pinned host memory -> device staging; replaces the reference's per-sample HDF5 read + DataLoader collate,
+ *   dataloader.py:222-239, when most frames of a clip are needed).  `rows` is a HOST array; src_host must be pinned for
+ *   the copies to overlap with kernels. */
+int nacf_gather_clips_h2d(void* dst, const void* src_host, const int32_t* rows, int n, size_t clip_bytes,
+                          nacf_stream_t stream);
 /* nacf_build_targets: the decoder inputs / labels of B captions, dataloader.py:317-425.
  *   caps[b, 0..cap_len[b]) = <bos> w1 .. wn <eos> (int32, row pitch ld_caps), pos_tags alike.
  *   narformer != 0: masked-LM pair (:346-380).  train: a uniformly random subset of the n word slots (size uniform

@@ -2,6 +2,8 @@
 // sample in Python on the host (HDF5 read, numpy frame sampling, per-caption masking) with 0 workers; here the
 // feature shards live in HBM (or arrive through a pinned staging buffer) and one launch per tensor family builds the
 // whole batch:  frame selection + gather (HBM-bound), and the token / label tables of all captions (integer work).
+#include <algorithm>
+
 #include "common.hpp"
 
 namespace {
@@ -20,29 +22,26 @@ __device__ __forceinline__ uint32_t rand_below(uint32_t r, uint32_t range) {   /
 // out[b, i, :] = src[video[b], frame(b, i), :]
 //   mode 0 'equally_sampling': middle of segment i;  mode 1 'segment_random': uniform in segment i
 //   (dataloader.py:24-37);  a clip shorter than n_frames is stretched: round-half-even(i * (S-1) / (n-1)) (:20-21,305)
+__device__ __forceinline__ int pick_frame(int b, int i, int S, int n_frames, int mode, uint32_t salt,
+                                          const uint64_t* __restrict__ rng_state) {
+  if (S < n_frames) return (n_frames > 1) ? (int)rint((double)(i * (S - 1)) / (double)(n_frames - 1)) : 0;
+  const int lo = seg_bound(i, S, n_frames), hi = seg_bound(i + 1, S, n_frames);
+  if (mode != 1) return (lo + hi) / 2;
+  if (hi <= lo + 1) return lo;
+  DropRng rng;
+  rng.init(rng_state);
+  const uint64_t e = (uint64_t)b * (uint64_t)n_frames + (uint64_t)i;
+  const uint4 r = philox4x32_10(make_uint4((uint32_t)e, salt ^ (uint32_t)(e >> 32), rng.step_lo, rng.step_hi), rng.key);
+  return lo + (int)rand_below(r.x, (uint32_t)(hi - lo));
+}
+
 __global__ __launch_bounds__(256) void sample_frames_kernel(const float* __restrict__ src, const int* __restrict__ video,
                                                             const int* __restrict__ src_len, int T, int D, int n_frames,
                                                             int mode, uint32_t salt, const uint64_t* __restrict__ rng_state,
                                                             float* __restrict__ out, int* __restrict__ ids_out) {
   const int b = blockIdx.x, i = blockIdx.y;
   const int S = src_len ? min(src_len[video ? video[b] : b], T) : T;
-  int f;
-  if (S >= n_frames) {
-    const int lo = seg_bound(i, S, n_frames), hi = seg_bound(i + 1, S, n_frames);
-    if (mode == 1 && hi > lo + 1) {
-      DropRng rng;
-      rng.init(rng_state);
-      const uint64_t e = (uint64_t)b * (uint64_t)n_frames + (uint64_t)i;
-      const uint4 r = philox4x32_10(make_uint4((uint32_t)e, salt ^ (uint32_t)(e >> 32), rng.step_lo, rng.step_hi), rng.key);
-      f = lo + (int)rand_below(r.x, (uint32_t)(hi - lo));
-    } else if (mode == 1) {
-      f = lo;
-    } else {
-      f = (lo + hi) / 2;
-    }
-  } else {
-    f = (n_frames > 1) ? (int)rint((double)(i * (S - 1)) / (double)(n_frames - 1)) : 0;
-  }
+  const int f = pick_frame(b, i, S, n_frames, mode, salt, rng_state);
   if (threadIdx.x == 0 && ids_out) ids_out[b * n_frames + i] = f;
   const int64_t v = video ? video[b] : b;
   const float* p = src + (v * T + f) * (int64_t)D;
@@ -51,6 +50,48 @@ __global__ __launch_bounds__(256) void sample_frames_kernel(const float* __restr
     for (int d = threadIdx.x * 4; d < D; d += 1024) *reinterpret_cast<f32x4*>(q + d) = *reinterpret_cast<const f32x4*>(p + d);
   } else {
     for (int d = threadIdx.x; d < D; d += 256) q[d] = p[d];
+  }
+}
+
+// The same gather when `src` is PINNED HOST memory read over PCIe (zero-copy): a few persistent workgroups instead of
+// one per row -- the link needs ~100 KB in flight, not thousands of resident waves that would take compute units
+// away from the training kernels running next to it -- and each thread keeps ROWS_IN_FLIGHT rows' loads outstanding
+// before it stores any of them.
+constexpr int ROWS_IN_FLIGHT = 4;
+__global__ __launch_bounds__(256) void sample_frames_pcie_kernel(const float* __restrict__ src, const int* __restrict__ video,
+                                                                 const int* __restrict__ src_len, int B, int T, int D,
+                                                                 int n_frames, int mode, uint32_t salt,
+                                                                 const uint64_t* __restrict__ rng_state,
+                                                                 float* __restrict__ out, int* __restrict__ ids_out) {
+  const int total = B * n_frames;
+  const int chunks = D / 1024;                      // f32x4 per thread per row (host guarantees D % 1024 == 0, <= 4 chunks)
+  for (int r0 = blockIdx.x * ROWS_IN_FLIGHT; r0 < total; r0 += gridDim.x * ROWS_IN_FLIGHT) {
+    f32x4 buf[ROWS_IN_FLIGHT][4];
+#pragma unroll
+    for (int k = 0; k < ROWS_IN_FLIGHT; ++k) {
+      const int r = r0 + k;
+      if (r < total) {
+        const int b = r / n_frames, i = r % n_frames;
+        const int64_t v = video ? video[b] : b;
+        const int S = src_len ? min(src_len[v], T) : T;
+        const int f = pick_frame(b, i, S, n_frames, mode, salt, rng_state);
+        if (threadIdx.x == 0 && ids_out) ids_out[r] = f;
+        const float* p = src + (v * T + f) * (int64_t)D;
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+          if (c < chunks) buf[k][c] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p + c * 1024 + threadIdx.x * 4));
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < ROWS_IN_FLIGHT; ++k) {
+      const int r = r0 + k;
+      if (r < total) {
+        float* q = out + (int64_t)r * D;
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+          if (c < chunks) *reinterpret_cast<f32x4*>(q + c * 1024 + threadIdx.x * 4) = buf[k][c];
+      }
+    }
   }
 }
 
@@ -153,9 +194,35 @@ int nacf_sample_frames(const float* src, const int32_t* video, const int32_t* sr
   NACF_CHECK(src && out && B > 0 && T > 0 && D > 0 && n_frames > 0, NACF_EINVAL, "nacf_sample_frames: bad argument");
   NACF_CHECK(mode == 0 || mode == 1, NACF_EINVAL, "nacf_sample_frames: mode must be 0 (equally_sampling) or 1 (segment_random)");
   NACF_CHECK(!(mode == 1 && !rng_state), NACF_EINVAL, "nacf_sample_frames: segment_random needs rng_state");
+  hipPointerAttribute_t attr;
+  const bool host_src = hipPointerGetAttributes(&attr, src) == hipSuccess && attr.type == hipMemoryTypeHost;
+  (void)hipGetLastError();          // an unregistered pointer is an error for the query only
+  if (host_src && D % 1024 == 0 && D <= 4096 && (reinterpret_cast<uintptr_t>(src) & 15) == 0 &&
+      (reinterpret_cast<uintptr_t>(out) & 15) == 0) {
+    const int total = B * n_frames;
+    const int grid = std::min(96, cdiv(total, ROWS_IN_FLIGHT));
+    hipLaunchKernelGGL(sample_frames_pcie_kernel, dim3(grid), dim3(256), 0, as_hip(stream), src, video, src_len, B, T, D,
+                       n_frames, mode, salt, rng_state, out, frame_ids);
+    NACF_LAUNCH_CHECK("nacf_sample_frames(pcie)");
+    return NACF_OK;
+  }
   hipLaunchKernelGGL(sample_frames_kernel, dim3(B, n_frames), dim3(256), 0, as_hip(stream), src, video, src_len, T, D,
                      n_frames, mode, salt, rng_state, out, frame_ids);
   NACF_LAUNCH_CHECK("nacf_sample_frames");
+  return NACF_OK;
+}
+
+int nacf_gather_clips_h2d(void* dst, const void* src_host, const int32_t* rows, int n, size_t clip_bytes,
+                          nacf_stream_t stream) {
+  NACF_CHECK(dst && src_host && rows && n >= 0 && clip_bytes > 0, NACF_EINVAL, "nacf_gather_clips_h2d: bad argument");
+  hipStream_t s = as_hip(stream);
+  for (int j = 0; j < n; ++j) {
+    NACF_CHECK(rows[j] >= 0, NACF_EINVAL, "nacf_gather_clips_h2d: negative row %d", rows[j]);
+    const hipError_t e = hipMemcpyAsync(static_cast<char*>(dst) + (size_t)j * clip_bytes,
+                                        static_cast<const char*>(src_host) + (size_t)rows[j] * clip_bytes, clip_bytes,
+                                        hipMemcpyHostToDevice, s);
+    NACF_CHECK(e == hipSuccess, NACF_ELAUNCH, "nacf_gather_clips_h2d: %s", hipGetErrorString(e));
+  }
   return NACF_OK;
 }
 

@@ -6,9 +6,14 @@ tokens_1 / labels_1 (visual-word pass), length_target, category -- built ON THE 
 
   * resident mode (default when the shards fit `hbm_budget_bytes`): the whole [N, T, D] arrays are uploaded once; a
     batch is one gather+frame-sampling launch per modality driven by a device index vector.  No PCIe traffic per step.
-  * host mode (shards that exceed the HBM budget but fit pinned host memory): the shard is read once into pinned RAM;
-    a batch is one asynchronous DMA per clip (T*D*4 contiguous bytes) from there straight into one of two device
-    staging buffers on a side stream while the previous batch trains -- no host-side gather copy at all.
+  * host mode (shards that exceed the HBM budget but fit pinned host memory): the shard is read once into pinned RAM.
+    While the current batch trains, the next one is fetched on a side stream, one of two ways:
+      - few frames per clip (n_frames <= T/3, e.g. the reference's 8 of 60): pinned memory is mapped into the device's
+        address space and the frame-sampling kernel itself pulls exactly the sampled rows over PCIe (zero-copy gather:
+        7.5x fewer bytes than copying clips, no host loop per clip; measured ~18 GB/s of kernel-issued PCIe reads);
+      - most frames needed: one asynchronous DMA per clip (T*D*4 contiguous bytes, ~56 GB/s; issued by a C loop,
+        `nacf_gather_clips_h2d`) into a device staging buffer, frame sampling then runs on the staged clips.  (The
+        copy engines do not compete with the training kernels for compute units; the gather kernel does.)
   * mmap mode (larger than host memory): the batch's clips are copied from the memory-mapped shard into one of two
     pinned staging buffers by a few host threads and uploaded on the side stream (double buffering).
     In both streaming modes frame sampling then runs on the staged rows.
@@ -17,6 +22,8 @@ tokens_1 / labels_1 (visual-word pass), length_target, category -- built ON THE 
 
 There is no CPU fallback: construction raises without the HIP library / a HIP device.
 """
+import os
+
 import numpy as np
 import torch
 
@@ -57,6 +64,7 @@ class ShardLoader:
             raise ValueError("placement must be hbm | host | mmap")
         self.placement = placement
         self.resident = placement == "hbm"
+        self.zero_copy = False
         self.rng = ops.RngState(seed, self.dev)
         self.gen = torch.Generator().manual_seed(seed)
         t = table
@@ -70,7 +78,8 @@ class ShardLoader:
             self.d_feats = [self._upload(s) for s in self.shards]
             self.d_rows = [up(r, torch.int32) for r in self.rows]
         else:
-            self.copy_stream = torch.cuda.Stream(device=self.dev)
+            self.copy_stream = torch.cuda.Stream(device=self.dev, priority=int(os.environ.get('NACF_LOADER_STREAM_PRIORITY', '0')))
+            self.zero_copy = False
             if placement == "host":
                 self.host_feats = []
                 for s in self.shards:
@@ -78,12 +87,27 @@ class ShardLoader:
                     np.copyto(h.numpy(), s.array)
                     self.host_feats.append(h)
                 self.pinned = None
+                zc = opt.get("loader_zero_copy")
+                if zc is None and os.environ.get("NACF_LOADER_ZERO_COPY", "") != "":
+                    zc = os.environ["NACF_LOADER_ZERO_COPY"] != "0"
+                self.zero_copy = bool(zc) if zc is not None else all(3 * nf <= s.T for nf, s in zip(self.n_frames, self.shards))
+                # per staging slot: the sampled batch, and a private {seed, step} so that the prefetch kernel draws
+                # the frames of batch k with step k no matter when it runs relative to the compute stream
+                self.sampled = [[torch.empty(self.B, nf, s.D, dtype=torch.float32, device=self.dev)
+                                 for nf, s in zip(self.n_frames, self.shards)] for _ in range(2)]
+                self.pref_rng = [ops.RngState(seed, self.dev) for _ in range(2)]
+                self.pref_state = [torch.tensor([seed, 0], dtype=torch.int64).pin_memory() for _ in range(2)]
+                self.pref_rows = [[torch.empty(self.B, dtype=torch.int32).pin_memory() for _ in self.shards] for _ in range(2)]
+                self.pref_rows_dev = [[torch.empty(self.B, dtype=torch.int32, device=self.dev) for _ in self.shards]
+                                      for _ in range(2)]
+                self.n_built = 0
             else:
                 self.pinned = [[torch.empty(self.B, s.T, s.D, dtype=torch.float32).pin_memory() for s in self.shards]
                                for _ in range(2)]
-            self.staged = [[torch.empty(self.B, s.T, s.D, dtype=torch.float32, device=self.dev) for s in self.shards] for _ in range(2)]
-            self.staged_len = [[torch.empty(self.B, dtype=torch.int32, device=self.dev) for _ in self.shards] for _ in range(2)]
-            self.pinned_len = [[torch.empty(self.B, dtype=torch.int32).pin_memory() for _ in self.shards] for _ in range(2)]
+            if placement == "mmap" or not self.zero_copy:
+                self.staged = [[torch.empty(self.B, s.T, s.D, dtype=torch.float32, device=self.dev) for s in self.shards] for _ in range(2)]
+                self.staged_len = [[torch.empty(self.B, dtype=torch.int32, device=self.dev) for _ in self.shards] for _ in range(2)]
+                self.pinned_len = [[torch.empty(self.B, dtype=torch.int32).pin_memory() for _ in self.shards] for _ in range(2)]
             self._slot_event = [None, None]
             from concurrent.futures import ThreadPoolExecutor
             self._pool = ThreadPoolExecutor(max_workers=int(opt.get("loader_threads", 32)))
@@ -111,7 +135,7 @@ class ShardLoader:
         return n // g if self.drop_last else (n + g - 1) // g
 
     # ---- host side of streaming mode: gather the batch's clips into pinned memory, start the upload
-    def _stage(self, slot, vids_host):
+    def _stage(self, slot, vids_host, batch_no=0):
         n = len(vids_host)
         prev = self._slot_event[slot]
         if prev is not None:
@@ -119,14 +143,22 @@ class ShardLoader:
         # the frame-sampling kernels that read this staging slot two batches ago were launched on the compute stream
         self.copy_stream.wait_stream(torch.cuda.current_stream(self.dev))
         with torch.cuda.stream(self.copy_stream):
+            if self.placement == "host" and self.zero_copy:
+                self.pref_state[slot][1] = batch_no
+                self.pref_rng[slot].state.copy_(self.pref_state[slot], non_blocking=True)
             for m, s in enumerate(self.shards):
                 rows = self.rows[m][vids_host]
-                if self.placement == "host":               # one DMA per clip, pinned RAM -> device staging
-                    src, dst = self.host_feats[m], self.staged[slot][m]
-                    for j, r in enumerate(rows.tolist()):
-                        dst[j].copy_(src[r], non_blocking=True)
+                if self.placement == "host" and not self.zero_copy:    # one DMA per clip, pinned RAM -> device staging
+                    ops.gather_clips_h2d(self.staged[slot][m], self.host_feats[m], rows)
                     self.pinned_len[slot][m][:n] = torch.from_numpy(s.lengths[rows])
                     self.staged_len[slot][m][:n].copy_(self.pinned_len[slot][m][:n], non_blocking=True)
+                    continue
+                if self.placement == "host":               # zero-copy gather: the kernel reads the pinned shard itself
+                    self.pref_rows[slot][m][:n] = torch.from_numpy(np.ascontiguousarray(rows, dtype=np.int32))
+                    self.pref_rows_dev[slot][m][:n].copy_(self.pref_rows[slot][m][:n], non_blocking=True)
+                    ops.sample_frames(self.host_feats[m], self.pref_rows_dev[slot][m][:n], self.d_srclen[m],
+                                      self.n_frames[m], self.frame_mode, self.sampled[slot][m][:n],
+                                      salt=0x5EED0000 + m, rng=self.pref_rng[slot])
                     continue
                 buf = self.pinned[slot][m].numpy()
                 # one memcpy per clip (T*D*4 bytes, contiguous in the shard) straight into pinned memory, spread over a
@@ -144,8 +176,11 @@ class ShardLoader:
         opt, n = self.opt, idx_dev.numel()
         batch = {"feats": []}
         for m, s in enumerate(self.shards):
-            out = torch.empty(n, self.n_frames[m], s.D, dtype=torch.float32, device=self.dev)
             src, video, src_len = feats_src(m, vids_dev)
+            if video is None and src_len is None:          # host placement: already sampled by the prefetch kernel
+                batch["feats"].append(src.clone())         # (the staging slot is overwritten two batches later)
+                continue
+            out = torch.empty(n, self.n_frames[m], s.D, dtype=torch.float32, device=self.dev)
             ops.sample_frames(src, video, src_len, self.n_frames[m], self.frame_mode, out, salt=0x5EED0000 + m, rng=self.rng)
             batch["feats"].append(out)
         caps, lens = self.d_caps.index_select(0, idx_dev), self.d_len.index_select(0, idx_dev)
@@ -175,15 +210,21 @@ class ShardLoader:
                                   ch.numpy())
             return
         vid_host = self.table.video
-        pending = self._stage(0, vid_host[chunks[0].numpy()]) if nb else None
+        host = self.placement == "host" and self.zero_copy
+        base = self.n_built if host else 0         # Philox step of a batch = number of batches built before it
+        pending = self._stage(0, vid_host[chunks[0].numpy()], base) if nb else None
         for i, ch in enumerate(chunks):
             slot = i & 1
             ev = pending
             if i + 1 < nb:                                                 # start the next upload before this batch is used
-                pending = self._stage(1 - slot, vid_host[chunks[i + 1].numpy()])
+                pending = self._stage(1 - slot, vid_host[chunks[i + 1].numpy()], base + i + 1)
             torch.cuda.current_stream(self.dev).wait_event(ev)
             idx = ch.to(self.dev)
             vids = self.d_video.index_select(0, idx)
             k = idx.numel()
-            yield self._build(idx, vids, lambda m, v: (self.staged[slot][m][:k], None, self.staged_len[slot][m][:k]),
-                              ch.numpy())
+            if host:
+                self.n_built += 1
+                yield self._build(idx, vids, lambda m, v: (self.sampled[slot][m][:k], None, None), ch.numpy())
+            else:
+                yield self._build(idx, vids, lambda m, v: (self.staged[slot][m][:k], None, self.staged_len[slot][m][:k]),
+                                  ch.numpy())

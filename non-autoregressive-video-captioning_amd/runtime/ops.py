@@ -528,8 +528,15 @@ def beam_step(logp2d, V, t, max_len, want, seqs, scores, fin_scores, fin_len, fi
 # ---------------------------------------------------------------- batch construction
 def sample_frames(src: Tensor, video: Optional[Tensor], src_len: Optional[Tensor], n_frames: int, mode: int,
                   out: Tensor, salt: int = 0, rng: Optional[RngState] = None, frame_ids: Optional[Tensor] = None) -> Tensor:
-    """out[b, i] = src[video[b], frame(b, i)]; mode 0 equally_sampling, 1 segment_random (dataloader.py:24-37)"""
-    _chk_f32(src, out)
+    """out[b, i] = src[video[b], frame(b, i)]; mode 0 equally_sampling, 1 segment_random (dataloader.py:24-37).
+    `src` may be a PINNED host tensor: pinned memory is mapped into the device's address space, so the kernel pulls
+    exactly the sampled rows over PCIe (zero-copy gather) -- no staging copy of whole clips."""
+    if src.is_cuda:
+        _chk_f32(src, out)
+    else:
+        if not src.is_pinned() or src.dtype != torch.float32:
+            raise L.NacfLibraryError("nacf_sample_frames: a host source must be pinned float32 memory")
+        _chk_f32(out)
     B = out.shape[0]
     T, D = src.shape[-2], src.shape[-1]
     assert src.is_contiguous() and out.is_contiguous() and out.shape == (B, n_frames, D)
@@ -537,6 +544,20 @@ def sample_frames(src: Tensor, video: Optional[Tensor], src_len: Optional[Tensor
                                         int(salt) & 0xFFFFFFFF, _ptr(rng.state) if rng else None, _ptr(out),
                                         _ptr(frame_ids), _stream()), "nacf_sample_frames")
     return out
+
+
+def gather_clips_h2d(dst: Tensor, src_host: Tensor, rows_host) -> None:
+    """dst[j] = src_host[rows_host[j]] (whole clips), one asynchronous DMA per clip issued from C on the current
+    stream; src_host: pinned [N, T, D] tensor, rows_host: int32 numpy array"""
+    import numpy as np
+    rows_host = np.ascontiguousarray(rows_host, dtype=np.int32)
+    n = int(rows_host.shape[0])
+    assert dst.is_cuda and dst.is_contiguous() and src_host.is_pinned() and src_host.is_contiguous()
+    assert dst.shape[0] >= n and dst.shape[1:] == src_host.shape[1:] and dst.dtype == src_host.dtype
+    assert n == 0 or (0 <= int(rows_host.min()) and int(rows_host.max()) < src_host.shape[0])
+    clip = src_host[0].numel() * src_host.element_size()
+    L.check(L.load().nacf_gather_clips_h2d(_ptr(dst), _ptr(src_host), ctypes.c_void_p(rows_host.ctypes.data), n, clip,
+                                           _stream()), "nacf_gather_clips_h2d")
 
 
 def build_targets(caps: Tensor, cap_len: Tensor, pos_tags: Optional[Tensor], tag_demanded: Optional[Tensor],
