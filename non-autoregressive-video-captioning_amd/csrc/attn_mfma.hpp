@@ -371,4 +371,234 @@ __global__ __launch_bounds__(256) void bwd_kernel(const float* __restrict__ Q, i
   }
 }
 
+// ---- key-block backward (cross-attention: no key mask, not causal, up to 128 keys) ------------------------------------
+// The kernel above gives one wave a whole (memory row set, head): 1024 waves for B=128 x 8 heads -- one per SIMD, each
+// walking 1280 MFMAs per sequence behind uncovered load latency.  Here the FOUR waves of a workgroup share the item and
+// split its keys into blocks of 32: a wave computes S, P, dP, dS only for its block, owns the dK / dV rows of that block
+// (accumulated in registers over the item's sequences: no read-modify-write of global rows, no ordering between
+// sequences), and the three quantities that span all keys are combined through LDS in a fixed wave order:
+//   row max / row sum of exp  (softmax statistics, flash-style rescaling),
+//   delta = rowsum(P * dP),
+//   dQ = sum over key blocks of dS_blk K_blk.
+template <int DK16>
+__device__ __forceinline__ void contract_q_acc(const float* T, int pitch, const float* __restrict__ A, int64_t lda,
+                                               int n_q, f32x4 (&acc)[DK16][2], int i, int g) {
+#pragma unroll
+  for (int st = 0; st < 8; ++st) {
+    const int q = st * 4 + g;
+    float af[DK16];
+#pragma unroll
+    for (int td = 0; td < DK16; ++td) af[td] = 0.f;
+    if (q < n_q) Ld<DK16>::ld(A + (int64_t)q * lda + DK16 * i, af);
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const float b = T[q * pitch + t * 16 + i];
+#pragma unroll
+      for (int td = 0; td < DK16; ++td) acc[td][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[td], b, acc[td][t], 0, 0, 0);
+    }
+  }
+}
+
+template <int DK16>
+__device__ __forceinline__ void store_key_rows(const f32x4 (&acc)[DK16][2], float* __restrict__ dst, int64_t ldd,
+                                               int n_keys, int i, int g) {
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    const int key = t * 16 + i;
+    if (key < n_keys) {
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr) {
+        float v[DK16];
+#pragma unroll
+        for (int td = 0; td < DK16; ++td) v[td] = acc[td][t][rr];
+        Ld<DK16>::st(dst + (int64_t)key * ldd + DK16 * (g * 4 + rr), v);
+      }
+    }
+  }
+}
+
+#ifndef NACF_ATTN_KB_WGS
+#define NACF_ATTN_KB_WGS 2
+#endif
+constexpr int KB_WGS = NACF_ATTN_KB_WGS;        // resident workgroups per CU the register budget is set for
+                                                // (measured: 1 -> 121 us, 2 -> 97 us, 3 spills 71 VGPRs -> 145 us)
+constexpr int KB_PITCH = 48;                     // transpose tile [32][48]: 2 key tiles + 16 (rows 16 banks apart)
+constexpr int KB_RED_PITCH = 68;                 // dQ partials [4][32][64 + 4]
+template <int DK16>
+__global__ __launch_bounds__(256, KB_WGS) void bwd_kb_kernel(const float* __restrict__ Q, int64_t ldq, const float* __restrict__ K,
+                                                      int64_t ldk, const float* __restrict__ V, int64_t ldv,
+                                                      const float* __restrict__ dO, int64_t lddo, float* __restrict__ dQ,
+                                                      int64_t lddq, float* __restrict__ dK, int64_t lddk,
+                                                      float* __restrict__ dV, int64_t lddv, int R, int n_kv, int H, int Lq,
+                                                      int Lk, int kv_div, int kv_mod, int rounds) {
+  constexpr int DK = 16 * DK16;
+  static_assert(DK <= 64, "dQ reduce buffer is sized for dk <= 64");
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float* ex = smem;                                             // [3][4][32]: block max, block sum, block delta
+  float* red = ex + 3 * 4 * 32;                                 // [4][32][KB_RED_PITCH] dQ partials ...
+  float* T = red + wave * 32 * KB_PITCH;                        // ... later reused as wave-private transpose tiles
+  const int item = blockIdx.x;
+  const int kvr = item / H, h = item % H;
+  const int i = lane & 15, g = lane >> 4;
+  const float sq = sqrtf((float)DK);
+  const int k0 = wave * 32;
+  const int nk = max(0, min(32, Lk - k0));                      // live keys of this wave's block
+  const float* Kb = K + ((int64_t)kvr * Lk + k0) * ldk + h * DK;
+  const float* Vb = V + ((int64_t)kvr * Lk + k0) * ldv + h * DK;
+  f32x4 accK[DK16][2], accV[DK16][2];
+#pragma unroll
+  for (int td = 0; td < DK16; ++td)
+#pragma unroll
+    for (int t = 0; t < 2; ++t) { accK[td][t] = f32x4{0.f, 0.f, 0.f, 0.f}; accV[td][t] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+
+  for (int k = 0; k < rounds; ++k) {
+    // the k-th sequence of this memory row set (same enumeration as bwd_kernel); uniform over the workgroup
+    const int r = ((k / kv_div) * kv_mod + kvr) * kv_div + k % kv_div;
+    if (!(r < R && (k / kv_div) * kv_mod + kvr < (R + kv_div - 1) / kv_div)) continue;
+    const float* Qb = Q + (int64_t)r * Lq * ldq + h * DK;
+    const float* dOb = dO + (int64_t)r * Lq * lddo + h * DK;
+    f32x4 p[2][2], dp[2][2];
+#pragma unroll
+    for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+      for (int t = 0; t < 2; ++t) { p[tm][t] = f32x4{0.f, 0.f, 0.f, 0.f}; dp[tm][t] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+    float bm[2] = {-3.0e38f, -3.0e38f}, bl[2] = {0.f, 0.f};
+    if (nk > 0) {
+      {
+        f32x4 qf[2][DK16];
+#pragma unroll
+        for (int tm = 0; tm < 2; ++tm) load_row_frag<DK16>(qf[tm], Qb, ldq, tm * 16 + i, Lq, g);
+        contract_d<2, DK16>(p, Kb, ldk, nk, qf, i, g);            // S block
+      }
+      {
+        f32x4 gf[2][DK16];
+#pragma unroll
+        for (int tm = 0; tm < 2; ++tm) load_row_frag<DK16>(gf[tm], dOb, lddo, tm * 16 + i, Lq, g);
+        contract_d<2, DK16>(dp, Vb, ldv, nk, gf, i, g);           // dP block = dO V_blk^T
+      }
+#pragma unroll
+      for (int tm = 0; tm < 2; ++tm) {
+        float mx = -3.0e38f;
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+          for (int rr = 0; rr < 4; ++rr) {
+            const int key = t * 16 + g * 4 + rr;
+            const float v = key < nk ? p[tm][t][rr] / sq : -3.0e38f;
+            p[tm][t][rr] = v;
+            mx = fmaxf(mx, v);
+          }
+        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        float sum = 0.f;
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+          for (int rr = 0; rr < 4; ++rr) {
+            const float e = expf(p[tm][t][rr] - mx);               // tile padding: exp(-3e38 - mx) = 0
+            p[tm][t][rr] = e;
+            sum += e;
+          }
+        sum += __shfl_xor(sum, 16, 64);
+        sum += __shfl_xor(sum, 32, 64);
+        bm[tm] = mx;
+        bl[tm] = sum;
+      }
+    }
+    if (g == 0) {
+#pragma unroll
+      for (int tm = 0; tm < 2; ++tm) {
+        ex[(0 * 4 + wave) * 32 + tm * 16 + i] = bm[tm];
+        ex[(1 * 4 + wave) * 32 + tm * 16 + i] = bl[tm];
+      }
+    }
+    __syncthreads();
+    float part[2] = {0.f, 0.f};
+#pragma unroll
+    for (int tm = 0; tm < 2; ++tm) {
+      const int q = tm * 16 + i;
+      float M = -3.0e38f;
+#pragma unroll
+      for (int w = 0; w < 4; ++w) M = fmaxf(M, ex[(0 * 4 + w) * 32 + q]);
+      float Lsum = 0.f;
+#pragma unroll
+      for (int w = 0; w < 4; ++w) Lsum += ex[(1 * 4 + w) * 32 + q] * expf(ex[(0 * 4 + w) * 32 + q] - M);
+      const float scale = expf(bm[tm] - M) / Lsum;
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+          p[tm][t][rr] *= scale;                                   // P block
+          part[tm] += p[tm][t][rr] * dp[tm][t][rr];
+        }
+      part[tm] += __shfl_xor(part[tm], 16, 64);
+      part[tm] += __shfl_xor(part[tm], 32, 64);
+    }
+    if (g == 0) {
+#pragma unroll
+      for (int tm = 0; tm < 2; ++tm) ex[(2 * 4 + wave) * 32 + tm * 16 + i] = part[tm];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int tm = 0; tm < 2; ++tm) {
+      const int q = tm * 16 + i;
+      float dot = 0.f;
+#pragma unroll
+      for (int w = 0; w < 4; ++w) dot += ex[(2 * 4 + w) * 32 + q];
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) dp[tm][t][rr] = p[tm][t][rr] * (dp[tm][t][rr] - dot) / sq;   // dS block
+    }
+    {
+      f32x4 o[2][DK16];
+#pragma unroll
+      for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+        for (int td = 0; td < DK16; ++td) o[tm][td] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (nk > 0) contract_key<2, DK16>(o, dp, Kb, ldk, nk, i, g);   // dQ partial = dS_blk K_blk
+      float* mine = red + wave * 32 * KB_RED_PITCH;
+#pragma unroll
+      for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+          float v[DK16];
+#pragma unroll
+          for (int td = 0; td < DK16; ++td) v[td] = o[tm][td][rr];
+          Ld<DK16>::st(mine + (tm * 16 + i) * KB_RED_PITCH + DK16 * (g * 4 + rr), v);
+        }
+    }
+    __syncthreads();
+    {
+      // 32 rows x DK columns summed over the 4 key blocks in wave order; thread -> (row, 8 columns)
+      constexpr int CPT = DK / 8;                                   // threads per row
+      const int q = threadIdx.x / CPT, d0 = (threadIdx.x % CPT) * 8;
+      if (q < 32 && q < Lq) {
+        f32x4 a0 = f32x4{0.f, 0.f, 0.f, 0.f}, a1 = a0;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+          const float* src = red + (w * 32 + q) * KB_RED_PITCH + d0;
+          const f32x4 x0 = *reinterpret_cast<const f32x4*>(src), x1 = *reinterpret_cast<const f32x4*>(src + 4);
+          a0 += x0; a1 += x1;
+        }
+        float* out = dQ + ((int64_t)r * Lq + q) * lddq + h * DK + d0;
+        *reinterpret_cast<f32x4*>(out) = a0;
+        *reinterpret_cast<f32x4*>(out + 4) = a1;
+      }
+    }
+    __syncthreads();                                            // the transpose tiles alias the dQ partials
+    if (nk > 0) {
+      tile_to_lds<2>(T, KB_PITCH, dp, i, g);
+      contract_q_acc<DK16>(T, KB_PITCH, Qb, ldq, Lq, accK, i, g);     // dK_blk += dS_blk^T Q
+      tile_to_lds<2>(T, KB_PITCH, p, i, g);
+      contract_q_acc<DK16>(T, KB_PITCH, dOb, lddo, Lq, accV, i, g);   // dV_blk += P_blk^T dO
+    }
+  }
+  if (nk > 0) {
+    store_key_rows<DK16>(accK, dK + ((int64_t)kvr * Lk + k0) * lddk + h * DK, lddk, nk, i, g);
+    store_key_rows<DK16>(accV, dV + ((int64_t)kvr * Lk + k0) * lddv + h * DK, lddv, nk, i, g);
+  }
+}
+
 }  // namespace attn

@@ -869,6 +869,25 @@ int nacf_attention_bwd(const float* Q, int64_t ldq, const float* K, int64_t ldk,
     // sequences per memory row set (upper bound) -> waves per item (1, 2 or 4) and rounds of the item loop
     const int groups = cdiv(R, kv_div);
     const int nseq_max = kv_div * cdiv(groups, kv_mod);
+    {
+      // cross-attention over a long memory (no key mask, not causal): the four waves of a workgroup split the keys of one
+      // (memory row set, head) -- attn_mfma.hpp:bwd_kb_kernel (NACF train step: 145 -> 97 us); NACF_ATTN_KB=0 keeps the
+      // one-wave-per-item kernel.
+      const char* e = getenv("NACF_ATTN_KB");
+      if (Lk > 32 && !key_tokens && !causal && dk == 64 && !(e && atoi(e) == 0)) {
+        const size_t lds_kb = (size_t)(3 * 4 * 32 + 4 * 32 * attn::KB_RED_PITCH) * sizeof(float);   // tiles alias the partials
+        static bool set_kb = false;
+        if (!set_kb) {
+          (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn::bwd_kb_kernel<4>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+          set_kb = true;
+        }
+        hipLaunchKernelGGL((attn::bwd_kb_kernel<4>), dim3(n_kv * H), dim3(256), lds_kb, as_hip(stream), Q, ldq, K, ldk, V,
+                           ldv, dO, lddo, dQ, lddq, dK, lddk, dV, lddv, R, n_kv, H, Lq, Lk, kv_div, kv_mod, nseq_max);
+        NACF_LAUNCH_CHECK("nacf_attention_bwd(mfma, key blocks)");
+        return NACF_OK;
+      }
+    }
     // measured on MI355X (NACF train step, 2 sequences per video): 1 wave per item 144 us, 2 waves 187 us -- the ordered
     // dK / dV turns and their barriers cost more than the extra waves hide; NACF_ATTN_WPI=2|4 keeps the variant testable
     int wpi = 1;

@@ -781,3 +781,31 @@ def test_loss_combine_fwd_bwd(dev):
     ref = torch.zeros(n * S)
     ref[0], ref[S], ref[2 * S] = 0.75, 4.5, -6.0
     assert torch.equal(gslab.cpu(), ref)
+
+
+@pytest.mark.parametrize("kb", ["1", "0"])
+@pytest.mark.parametrize("mode,Lk", [("mod", 120), ("div", 120), ("mod", 70), ("mod", 33)])
+def test_cross_attention_backward_model_width(dev, mode, Lk, kb, monkeypatch):
+    """dk = 64, memory of up to 128 keys: the key-block kernel (four waves split the keys of a (video, head); softmax
+    statistics, delta and dQ combined through LDS) and the one-wave-per-item kernel against float64 autograd"""
+    monkeypatch.setenv("NACF_ATTN_KB", kb)
+    ops, _ = _ops()
+    Bv, k_, Lq, H, dk = 5, 2, 20, 8, 64
+    D, R = H * dk, Bv * k_
+    q = rnd(R * Lq, D, seed=1)
+    kv = rnd(Bv * Lk, 2 * D, seed=2)
+    vid = (torch.arange(R) % Bv) if mode == "mod" else (torch.arange(R) // k_)
+    kv_div, kv_mod = (1, Bv) if mode == "mod" else (k_, Bv)
+    qd, kvd = q.double().requires_grad_(True), kv.double().requires_grad_(True)
+    o_ref, _ = _mha_ref(qd.view(R, Lq, D), kvd[:, :D].reshape(Bv, Lk, D)[vid], kvd[:, D:].reshape(Bv, Lk, D)[vid], H, None, False)
+    do = rnd(R * Lq, D, seed=3)
+    o_ref.backward(do.view(R, Lq, D).double())
+    qx, kvx = q.to(dev), kv.to(dev)
+    dq, dkv = torch.full_like(qx, float("nan")), torch.full_like(kvx, float("nan"))
+    ops.attention_bwd(qx, kvx[:, :D], kvx[:, D:], do.to(dev), dq, dkv[:, :D], dkv[:, D:], None, 0, R, Bv, H, Lq, Lk, dk,
+                      kv_div, kv_mod)
+    assert err(dq, qd.grad) < 5e-5 and err(dkv, kvd.grad) < 1e-4
+    again_q, again_kv = torch.empty_like(qx), torch.empty_like(kvx)
+    ops.attention_bwd(qx, kvx[:, :D], kvx[:, D:], do.to(dev), again_q, again_kv[:, :D], again_kv[:, D:], None, 0, R, Bv, H,
+                      Lq, Lk, dk, kv_div, kv_mod)
+    assert torch.equal(dq, again_q) and torch.equal(dkv, again_kv)        # fixed combination order: run to run identical
