@@ -187,6 +187,11 @@ def test_train_network_all_end_to_end(dev, tmp_path):
     again = run_eval(o2, m2, None, vl, vl.dataset.get_vocab(), dev, json_path=os.path.join(tmp, "pred"), json_name="p.json")
     assert again["CIDEr"] == pytest.approx(best["CIDEr"], abs=1e-9) and again["Bleu_4"] == pytest.approx(best["Bleu_4"], abs=1e-9)
     assert os.path.exists(os.path.join(tmp, "pred", "p.json"))
+    # the same evaluation with every decode replayed from a hipGraph (fixed-width canvas) scores identically
+    o3 = dict(o2, decode_graph="on")
+    graphed = run_eval(o3, m2, None, get_loader(o3, "validate", device=dev), vl.dataset.get_vocab(), dev)
+    assert graphed["CIDEr"] == again["CIDEr"] and graphed["Bleu_4"] == again["Bleu_4"]
+    assert any(k[0] != "seen" for k in m2._nacf_decode_graphs)
 
 
 def test_rank_sharded_loaders_partition_the_global_batch(dev, tmp_path):
