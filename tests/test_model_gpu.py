@@ -374,3 +374,44 @@ def test_decoder_query_subset_is_bit_identical_on_the_kept_slots(dev, layers):
     assert out[1] is None and int(keep.sum()) > 10
     assert torch.equal(sub[keep], full[keep])
     assert float(sub[~keep].abs().max()) == 0.0           # everything else is zero-filled, never garbage
+
+
+@pytest.mark.parametrize("B", [1, 64])
+def test_reference_default_shapes_train_and_decode(dev, B):
+    """the reference's own MSRVTT defaults (opts.py: max_len 30, n_frames 8 -> a 16-slot visual memory, batch 64) and
+    the batch-of-one latency setting (run.py:139-143): a training step is finite and moves every parameter group,
+    graph-replayed decoding equals launch-by-launch decoding, and hypotheses are well formed"""
+    import nacf_amd
+    from nacf_amd import synthetic as S
+    from nacf_amd.misc.crit import get_criterion
+    from nacf_amd.misc.optim import get_optimizer
+    from nacf_amd.models.Translator import Translator
+    opt = nacf_amd.opts.make_opt("NACF", "MSRVTT", default=True, vocab_size=10547, n_frames=8, fused_loss=True)
+    assert opt["max_len"] == 30 and opt["with_category"] and opt["length_beam_size"] == 6 and opt["use_ct"]
+    model = nacf_amd.get_model(opt)
+    model.load_state_dict(S.init_state_dict(opt, seed=0))
+    model.to(dev).train()
+    b = S.synth_batch(opt, B, 8, seed=5)
+    feats, cat = [f.to(dev) for f in b["feats"]], b["category"].to(dev)
+    crit, optim = get_criterion(model.opt), get_optimizer(model.opt, model)
+    before = model.flat.data.clone()
+    optim.zero_grad()
+    res = model(feats=feats, tgt_tokens=[b["tokens_1"].to(dev), b["tokens"].to(dev)], category=cat)
+    res["tgt_word_labels"] = [b["labels_1"].to(dev), b["labels"].to(dev)]
+    res["tgt_length"] = b["tgt_length"].to(dev)
+    loss = crit.get_loss(res)
+    loss.backward()
+    optim.step()
+    assert torch.isfinite(loss) and bool(torch.isfinite(model.flat.data).all())
+    assert float((model.flat.data - before).abs().max()) > 0
+    model.eval()
+    outs = {}
+    for graph in ("off", "on"):
+        tr = Translator(model, dict(model.opt, decode_graph=graph), device=dev)
+        with torch.no_grad():
+            hyp, _ = tr.translate_batch(model.encode(feats=feats), cat, None, None)
+        outs[graph] = hyp
+    assert torch.equal(outs["on"], outs["off"])
+    hyp = outs["on"]
+    assert hyp.shape[0] == B and 4 <= hyp.shape[1] <= 29
+    assert int(hyp.min()) >= 0 and int(hyp.max()) < 10547 and not bool((hyp == 4).any())     # no <mask> left
