@@ -45,6 +45,19 @@
 #include "common.hpp"
 #include <type_traits>
 
+// Tuning aid, compiled in only with -DNACF_GEMM_TRACE (tools/gemm_trace.py): wave 0 of every workgroup records the
+// shader clock at kernel entry / after the prologue / after the k-loop / at the end, plus where it ran.
+#ifdef NACF_GEMM_TRACE
+__device__ unsigned long long* g_gemm_trace = nullptr;
+#define NACF_TRACE_MARK(slot)                                                                               \
+  do {                                                                                                      \
+    if (g_gemm_trace && threadIdx.x == 0)                                                                   \
+      g_gemm_trace[((size_t)blockIdx.z * gridDim.x + blockIdx.x) * 8 + (slot)] = __builtin_readcyclecounter(); \
+  } while (0)
+#else
+#define NACF_TRACE_MARK(slot) do { } while (0)
+#endif
+
 struct GemmShape {
   const float* Q;
   const float* P;
@@ -402,6 +415,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmShape g, Epi epi) {
   constexpr int SMEM = (2 * BUF > RED) ? 2 * BUF : RED;
   __shared__ __attribute__((aligned(16))) float smem[SMEM];
 
+  NACF_TRACE_MARK(0);
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WN, wn = wave % WN;
@@ -619,6 +633,18 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmShape g, Epi epi) {
   }
   __syncthreads();
 
+  NACF_TRACE_MARK(1);
+#ifdef NACF_GEMM_TRACE
+  if (g_gemm_trace && threadIdx.x == 0) {
+    unsigned hw;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+    unsigned xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    g_gemm_trace[((size_t)blockIdx.z * gridDim.x + blockIdx.x) * 8 + 4] = ((unsigned long long)xcc << 32) | hw;
+    g_gemm_trace[((size_t)blockIdx.z * gridDim.x + blockIdx.x) * 8 + 5] = (unsigned long long)nk;
+    g_gemm_trace[((size_t)blockIdx.z * gridDim.x + blockIdx.x) * 8 + 6] = wall_clock64();
+  }
+#endif
   // STEADY iterations are straight-line code (no guards: tile kt+3 exists and is an interior tile of fully
   // populated row tiles), so the scheduler is free to interleave the LDS / global traffic with the MFMAs.
   // The loop body holds both parities (the staging set index must be a compile-time constant); every load is
@@ -714,6 +740,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmShape g, Epi epi) {
     if (kt < nk) iteration(std::false_type{}, S0{}, kt);
   }
 
+  NACF_TRACE_MARK(2);
   if constexpr (ROWS_ARE_K) {
     if (do_colsum) {
       // thread (kk = q / (BM/4), r4 = q % (BM/4)) holds the sums of rows 4*r4 .. 4*r4+3 over its k rows: fold the
@@ -758,6 +785,8 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmShape g, Epi epi) {
     for (int a = 0; a < TM; ++a) mphys[a] = (g.rows && !ROWS_ARE_K && mlog[a] < Meff) ? g.rows[mlog[a]] : mlog[a];
     if (epi.fast_ok() && m0 + BM <= Meff && n0 + BN <= g.N) epi.template tile_fast<TM, TN, PKC>(acc, mphys, ncol, g.N, z);
     else epilogue_all<0, TM, TN, PKC, Epi>(epi, acc, mlog, mphys, ncol, Meff, g.N, z);
+    __builtin_amdgcn_s_waitcnt(0);
+    NACF_TRACE_MARK(3);
   } else {
     // per-row (max, argmax, sum-exp) over this tile's BN columns
     float* redv = smem;                  // [WN][BM]

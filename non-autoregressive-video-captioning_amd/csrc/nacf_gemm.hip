@@ -398,6 +398,12 @@ int nacf_linear_bwd_weight(const float* dZ, int64_t lddz, const float* X, int64_
   return NACF_OK;
 }
 
+#ifdef NACF_GEMM_TRACE
+int nacf_debug_gemm_trace(void* buf) {     // tuning builds only (make trace); not part of the shipped ABI
+  return hipMemcpyToSymbol(HIP_SYMBOL(g_gemm_trace), &buf, sizeof(buf)) == hipSuccess ? NACF_OK : NACF_ELAUNCH;
+}
+#endif
+
 int nacf_gemm_config(int kind, int M, int N, int K, int* tile, int* splits) {
   NACF_CHECK(tile && splits && M > 0 && N > 0 && K > 0, NACF_EINVAL, "nacf_gemm_config: bad argument");
   int t = 0, s = 1;

@@ -10,7 +10,7 @@ import os
 from ctypes import POINTER, c_char_p, c_float, c_int, c_int32, c_int64, c_size_t, c_uint32, c_void_p
 
 _PKG_DIR = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-LIB_PATH = os.path.join(_PKG_DIR, "libnacf_hip.so")
+LIB_PATH = os.environ.get("NACF_HIP_LIB") or os.path.join(_PKG_DIR, "libnacf_hip.so")   # env: tuning builds only
 
 # activations (nacf_hip.h)
 ACT_NONE, ACT_RELU, ACT_GELU_NEW, ACT_TANH, ACT_SIGMOID, ACT_TANH_SIGMOID, ACT_GELU_ERF = range(7)
