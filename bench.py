@@ -136,6 +136,7 @@ def bench_loader(args, nacf_amd, opt, dev, B, L, V, F_, engine):
                         b["category"] = b["category"].view(-1, 1)
                         assert _signature(b) == engine.sig, "loader batch does not match the captured step"
                         engine(b)
+                        ld.bind_outputs(engine.static)     # as misc/run.py:run_train does: build the next batch in place
                         steps += 1
                 return steps
             run(1)

@@ -41,6 +41,7 @@ class ShardLoader:
         so that all ranks run the same number of steps."""
         self.rank, self.world = int(rank), int(world)
         assert 0 <= self.rank < self.world
+        self._into = None
         self.shards, self.table, self.opt = list(shards), table, opt
         self.B, self.dev, self.mode = int(batch_size), torch.device(device), mode
         self.train = mode == "train"
@@ -172,15 +173,29 @@ class ShardLoader:
         self._slot_event[slot] = ev
         return ev
 
+    def bind_outputs(self, buffers):
+        """Build every following batch straight INTO these tensors (a dict shaped like a batch, e.g. the step engine's
+        static graph inputs) whenever their shapes fit: the hand-over to a captured training step then costs no copy.
+        The tensors of a yielded batch are overwritten by the next one."""
+        self._into = buffers
+
+    def _slot(self, name, shape, dtype, index=None):
+        t = (self._into or {}).get(name)
+        if index is not None and isinstance(t, (list, tuple)):
+            t = t[index] if index < len(t) else None
+        if torch.is_tensor(t) and tuple(t.shape) == tuple(shape) and t.dtype == dtype and t.is_contiguous() and t.device == self.dev:
+            return t
+        return torch.empty(shape, dtype=dtype, device=self.dev)
+
     def _build(self, idx_dev, vids_dev, feats_src, idx_host=None):
         opt, n = self.opt, idx_dev.numel()
         batch = {"feats": []}
         for m, s in enumerate(self.shards):
             src, video, src_len = feats_src(m, vids_dev)
+            out = self._slot("feats", (n, self.n_frames[m], s.D), torch.float32, m)
             if video is None and src_len is None:          # host placement: already sampled by the prefetch kernel
-                batch["feats"].append(src.clone())         # (the staging slot is overwritten two batches later)
+                batch["feats"].append(out.copy_(src))      # (the staging slot is overwritten two batches later)
                 continue
-            out = torch.empty(n, self.n_frames[m], s.D, dtype=torch.float32, device=self.dev)
             ops.sample_frames(src, video, src_len, self.n_frames[m], self.frame_mode, out, salt=0x5EED0000 + m, rng=self.rng)
             batch["feats"].append(out)
         caps, lens = self.d_caps.index_select(0, idx_dev), self.d_len.index_select(0, idx_dev)
@@ -188,9 +203,12 @@ class ShardLoader:
         narformer = opt["decoding_type"] == "NARFormer"
         batch.update(ops.build_targets(caps, lens, tags, self.d_dem, self.d_be, opt["max_len"], narformer,
                                        opt.get("visual_word_generation", False), self.train, opt.get("beta", [0, 1]),
-                                       salt=0x7A26E7, rng=self.rng))
-        batch["length_target"] = self.d_lt.index_select(0, vids_dev)
-        batch["category"] = self.d_cat.index_select(0, vids_dev).unsqueeze(1)
+                                       salt=0x7A26E7, rng=self.rng, into=self._into))
+        lt = self._slot("length_target", (n, self.d_lt.shape[1]), torch.float32)
+        batch["length_target"] = torch.index_select(self.d_lt, 0, vids_dev, out=lt)
+        cat = self._slot("category", (n, 1), torch.int64)
+        torch.index_select(self.d_cat, 0, vids_dev, out=cat.view(n))
+        batch["category"] = cat
         batch["sample_index"] = idx_dev
         batch["sample_index_host"] = idx_host       # numpy: lets the caller name the videos without a device sync
         self.rng.advance()

@@ -303,8 +303,13 @@ def run_train(opt, model, crit, optimizer, loader, device, logger=None, epoch=-1
     vocab = loader.dataset.get_vocab()
     if engine is None:
         engine = make_engine(opt, model, crit, optimizer, device, vocab=vocab, **kwargs)
+    inner = getattr(loader, 'inner', loader)
     for data in loader:
         engine(data)
+        if engine.captured and hasattr(inner, 'bind_outputs'):
+            inner.bind_outputs(engine.static)      # from now on the loader builds batches inside the graph's inputs
+    if hasattr(inner, 'bind_outputs'):
+        inner.bind_outputs(None)
     name, loss_info = crit.get_loss_info()
     if logger is not None:
         logger.write_text('\t'.join('%10s: %05.3f' % item for item in zip(name, loss_info)))

@@ -562,15 +562,21 @@ def gather_clips_h2d(dst: Tensor, src_host: Tensor, rows_host) -> None:
 
 def build_targets(caps: Tensor, cap_len: Tensor, pos_tags: Optional[Tensor], tag_demanded: Optional[Tensor],
                   word_is_be: Optional[Tensor], max_len: int, narformer: bool, visual_word: bool, train: bool,
-                  beta=(0.0, 1.0), salt: int = 0, rng: Optional[RngState] = None):
-    """decoder inputs / labels of a batch of captions (dataloader.py:317-425) -> dict of int64 [B, max_len]"""
+                  beta=(0.0, 1.0), salt: int = 0, rng: Optional[RngState] = None, into=None):
+    """decoder inputs / labels of a batch of captions (dataloader.py:317-425) -> dict of int64 [B, max_len];
+    `into`: optional dict of preallocated output tensors of that shape (used when they fit)"""
     assert caps.dtype == torch.int32 and caps.dim() == 2 and caps.stride(1) == 1 and cap_len.dtype == torch.int32
     B = caps.shape[0]
-    mk = lambda: torch.empty(B, max_len, dtype=torch.int64, device=caps.device)
-    out = {"tokens": mk(), "labels": mk()}
+
+    def mk(name):
+        t = into.get(name) if into is not None else None
+        if torch.is_tensor(t) and t.shape == (B, max_len) and t.dtype == torch.int64 and t.is_contiguous() and t.device == caps.device:
+            return t
+        return torch.empty(B, max_len, dtype=torch.int64, device=caps.device)
+    out = {"tokens": mk("tokens"), "labels": mk("labels")}
     vw = bool(visual_word and train)
     if vw:
-        out["tokens_1"], out["labels_1"] = mk(), mk()
+        out["tokens_1"], out["labels_1"] = mk("tokens_1"), mk("labels_1")
     L.check(L.load().nacf_build_targets(_ptr(caps), caps.stride(0), _ptr(cap_len), _ptr(pos_tags), _ptr(tag_demanded),
                                         _ptr(word_is_be), B, max_len, int(narformer), int(vw), int(train),
                                         float(beta[0]), float(beta[1]), int(salt) & 0xFFFFFFFF,
