@@ -11,7 +11,7 @@ opt = nacf_amd.opts.make_opt("NACF", "MSRVTT", with_category=True, max_len=20, v
 m = nacf_amd.get_model(opt); m.load_state_dict(S.init_state_dict(opt, 0)); m.to(dev).eval()
 b = S.synth_batch(opt, 128, 60, seed=1)
 feats = [f.to(dev) for f in b["feats"]]; cat = b["category"].to(dev)
-dopt = dict(m.opt); dopt.update(paradigm="mp", use_ct=True, iterations=5, length_beam_size=6, beam_alpha=1.35)
+dopt = dict(m.opt); dopt.update(paradigm="mp", use_ct=True, iterations=5, length_beam_size=6, beam_alpha=1.35, decode_graph="off")
 tr = Translator(m, dopt, device=dev)
 def once():
     with torch.no_grad():
