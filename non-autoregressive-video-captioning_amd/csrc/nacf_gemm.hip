@@ -316,14 +316,14 @@ int nacf_linear_bwd_data(const float* dZ, int64_t lddz, const float* W, int64_t 
 static int bwd_weight_splits(int M, int N, int K, bool has_rows, int* tile_out) {
   // dW = dZ^T X: small output (N x K), long reduce dimension (M rows, ~55 % of them live under a row list).
   // The reduce-dimension split supplies the parallelism.  tools/sweep_dw_splits.sh: the 128x128 tile wins
-  // only with >= 32 of them AND a long reduce walk (7680+ rows); otherwise 64x64 with ~1024 workgroups.
+  // only with >= 32 of them AND a long reduce walk (7680+ rows); otherwise 64x64 with ~768 workgroups.
   const int m_eff = has_rows ? M * 11 / 20 : M;
   int tile = ((long)cdiv(N, 128) * cdiv(K, 128) >= 32 && m_eff >= 4096) ? 0 : 1;
   const int forced = forced_tile();
   if (forced >= 0) tile = forced;
   const int t = tile == 0 ? 128 : 64;
   const long tiles = (long)cdiv(N, t) * cdiv(K, t);
-  const long want = tile == 0 ? 512 : 1024;
+  const long want = tile == 0 ? 512 : 768;   // tools/dw_rows_bench.py: 192 tiles x 4, 64 x 12, 256 x 3 beat x 6 / x 16 / x 4
   int s = (int)((want + tiles - 1) / tiles);
   // just over one round of workgroups (1280 resident 64-tiles) with a long reduce walk: the few tiles of the second round
   // would run alone for a full walk -- halve the walks instead (vocabulary dW, 1320 tiles x 2311 live rows: 0.351 -> 0.315 ms)
