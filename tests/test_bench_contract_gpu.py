@@ -1,0 +1,32 @@
+"""GPU: bench.py keeps the driver's contract -- ONE JSON line, last on stdout, with the agreed keys."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_bench_prints_one_contract_line(dev):
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "4", "--warmup", "2", "--no-compare",
+                          "--no-loader", "--decode-batches", "2"], capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.strip().splitlines() if l.strip()]
+    d = json.loads(lines[-1])                       # the JSON object is the LAST line
+    assert sum(1 for l in lines if l.lstrip().startswith("{")) == 1
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 4 and d["warmup"] == 2 and d["higher_is_better"] is True
+    assert d["scaling"] == "weak" and d["vs_baseline"] is None and d["dtype"] == "f32" and d["data"] == "synthetic"
+    assert d["unit"] == "videos/s" and d["value"] > 1000 and abs(d["value"] - 128 / d["ms_per_step"] * 1e3) < 0.01 * d["value"]
+    assert "workload" in d["config"] and "model" not in d["config"]
+    r = d["roofline"]
+    assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
+    assert 0.1 < r["frac"] < 1.0 and (r["traffic"] is None or r["traffic"] > 0)
+    c = d["cpu_baseline"]
+    assert c["kind"] == "port" and c["unit"] == "videos/s" and c["value"] > 0 and c["cores"] >= 1 and c["sample"]
+    assert d["decode"]["captions_per_s"] > 100
