@@ -4,7 +4,7 @@ torch.distributed (backend "nccl" IS RCCL on ROCm; "gloo" for the CPU tests).
 The reference has no distributed code at all; semantics here
 are "same as one process with the global batch": every rank holds a full
 replica, takes a contiguous shard of the global batch, and after backward the
-flat fp32 gradient buffer (ONE bucket, 73.8 MB for NACF/MSRVTT-shape) is
+flat fp32 gradient buffer (73.8 MB for NACF/MSRVTT-shape; two buckets, see "Overlap" below) is
 all-reduced (sum); the 1/world scale is folded into the fused Adam launch, so
 clip(+-5) follows the reduce exactly as misc/run.py:258-261 orders them.
 Per-rank losses are normalised by the LOCAL batch (misc/crit.py:40), so the
