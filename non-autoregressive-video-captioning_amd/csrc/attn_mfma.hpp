@@ -601,4 +601,81 @@ __global__ __launch_bounds__(256, KB_WGS) void bwd_kb_kernel(const float* __rest
   }
 }
 
+// ---- LDS-staged forward (cross-attention: no key mask, not causal, dk = 64, up to 128 keys) ---------------------------
+// fwd_kernel streams K and V straight from L2 into MFMA fragments, once per wave: every (sequence, head, block of 32
+// queries) re-reads the same 61 KB, and with two waves per SIMD nothing covers the load latency (80 us for the decode
+// cross-attention whose MFMA time is ~16 us).  Here ONE workgroup owns a (memory row set, head): it copies K and V into
+// LDS once with wide coalesced loads (row pitch 68 floats), and its four waves then walk the (sequence, query block)
+// items of that row set -- the 6 length-beam candidates of a video as 4 blocks of 32 queries, or the two NACF passes
+// of a video -- taking every MFMA operand from LDS.  Same contractions, same softmax, same accumulation order per
+// query row as fwd_kernel: the results are bit-identical.
+constexpr int FL_PITCH = 68;
+template <int DK16>
+__global__ __launch_bounds__(256, 2) void fwd_lds_kernel(const float* __restrict__ Q, int64_t ldq, const float* __restrict__ K,
+                                                          int64_t ldk, const float* __restrict__ V, int64_t ldv,
+                                                          float* __restrict__ O, int64_t ldo, int R, int n_kv, int H, int Lq,
+                                                          int Lk, int kv_div, int kv_mod, int rounds) {
+  constexpr int DK = 16 * DK16;
+  constexpr int NKT = 8;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* Ks = smem;                               // [128][FL_PITCH], rows >= Lk are never read as live keys
+  float* Vs = smem + 128 * FL_PITCH;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int item = blockIdx.x;
+  const int kvr = item / H, h = item % H;
+  const int i = lane & 15, g = lane >> 4;
+  {
+    const float* Kg = K + (int64_t)kvr * Lk * ldk + h * DK;
+    const float* Vg = V + (int64_t)kvr * Lk * ldv + h * DK;
+    constexpr int VPR = DK / 4;                   // f32x4 per row
+    constexpr int NLD = 128 * VPR / 256;          // loads per thread and operand: ALL issued before the first LDS store,
+    f32x4 kr[NLD], vr[NLD];                       // so the copy costs one trip to L2, not NLD of them
+#pragma unroll
+    for (int u = 0; u < NLD; ++u) {
+      const int q = threadIdx.x + 256 * u;
+      const int row = min(q / VPR, Lk - 1), c = (q % VPR) * 4;
+      kr[u] = *reinterpret_cast<const f32x4*>(Kg + (int64_t)row * ldk + c);
+      vr[u] = *reinterpret_cast<const f32x4*>(Vg + (int64_t)row * ldv + c);
+    }
+#pragma unroll
+    for (int u = 0; u < NLD; ++u) {
+      const int q = threadIdx.x + 256 * u;
+      const int row = q / VPR, c = (q % VPR) * 4;
+      if (row < Lk) {
+        *reinterpret_cast<f32x4*>(&Ks[row * FL_PITCH + c]) = kr[u];
+        *reinterpret_cast<f32x4*>(&Vs[row * FL_PITCH + c]) = vr[u];
+      }
+    }
+  }
+  __syncthreads();
+  const int nqb = (Lq + 31) / 32;
+  const int n_items = rounds * nqb;               // (k-th sequence of the row set, block of 32 queries)
+  const float sq = sqrtf((float)DK);
+  for (int it = wave; it < n_items; it += 4) {
+    const int k = it / nqb, qb = it % nqb;
+    const int r = ((k / kv_div) * kv_mod + kvr) * kv_div + k % kv_div;
+    if (!(r < R && (k / kv_div) * kv_mod + kvr < (R + kv_div - 1) / kv_div)) continue;
+    const int q0 = qb * 32;
+    const int nq = min(32, Lq - q0);
+    const float* Qb = Q + ((int64_t)r * Lq + q0) * ldq + h * DK;
+    f32x4 qf[2][DK16];
+#pragma unroll
+    for (int tm = 0; tm < 2; ++tm) load_row_frag<DK16>(qf[tm], Qb, ldq, tm * 16 + i, nq, g);
+    f32x4 sc[2][NKT];
+#pragma unroll
+    for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+      for (int tn = 0; tn < NKT; ++tn) sc[tm][tn] = f32x4{0.f, 0.f, 0.f, 0.f};
+    contract_d<NKT, DK16>(sc, Ks, FL_PITCH, Lk, qf, i, g);
+    softmax_rows<NKT>(sc, sq, nullptr, 0, Lk, i, g);
+    f32x4 o[2][DK16];
+#pragma unroll
+    for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+      for (int td = 0; td < DK16; ++td) o[tm][td] = f32x4{0.f, 0.f, 0.f, 0.f};
+    contract_key<NKT, DK16>(o, sc, Vs, FL_PITCH, Lk, i, g);
+    store_rows<DK16>(o, O + ((int64_t)r * Lq + q0) * ldo + h * DK, ldo, nq, i, g);
+  }
+}
+
 }  // namespace attn

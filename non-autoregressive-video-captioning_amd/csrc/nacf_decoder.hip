@@ -826,6 +826,29 @@ int nacf_attention_fwd(const float* Q, int64_t ldq, const float* K, int64_t ldk,
   // more than 32 queries per sequence run as blocks of 32 (one wave each) when no causal mask ties a query to its index
   if (attn_mfma_ok(causal ? Lq : min(Lq, 32), Lk, dk) && attn_aligned(Q, ldq) && attn_aligned(K, ldk) &&
       attn_aligned(V, ldv) && attn_aligned(O, ldo)) {
+    {
+      // cross-attention over a long memory: one workgroup per (memory row set, head) stages K / V in LDS once and its
+      // waves serve every sequence that attends to it (attn_mfma.hpp:fwd_lds_kernel); NACF_ATTN_LDS=0 keeps fwd_kernel
+      const char* e = getenv("NACF_ATTN_LDS");
+      const int groups = cdiv(R, kv_div);
+      const int n_kv = kv_mod < groups ? kv_mod : groups;
+      const int nseq_max = kv_div * cdiv(groups, kv_mod);
+      // (worth it when the row set feeds all four waves: decode, 4 query blocks per video -- 80 -> 63 us; with the two
+      //  sequences per video of a training step half the waves idle and fwd_kernel's 39 us becomes 52 us)
+      if (Lk > 32 && !key_tokens && !causal && !probs && dk == 64 && nseq_max * cdiv(Lq, 32) >= 4 && !(e && atoi(e) == 0)) {
+        const size_t lds = (size_t)2 * 128 * attn::FL_PITCH * sizeof(float);
+        static bool set_fl = false;
+        if (!set_fl) {
+          (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn::fwd_lds_kernel<4>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+          set_fl = true;
+        }
+        hipLaunchKernelGGL((attn::fwd_lds_kernel<4>), dim3(n_kv * H), dim3(256), lds, as_hip(stream), Q, ldq, K, ldk, V, ldv,
+                           O, ldo, R, n_kv, H, Lq, Lk, kv_div, kv_mod, nseq_max);
+        NACF_LAUNCH_CHECK("nacf_attention_fwd(mfma, lds)");
+        return NACF_OK;
+      }
+    }
     // matrix-core path: one wave per (sequence, head, 32 queries), operands straight from HBM/L2 into MFMA fragments
     const int nqb = cdiv(Lq, 32);
     const dim3 grid(cdiv(R * H * nqb, 4));
