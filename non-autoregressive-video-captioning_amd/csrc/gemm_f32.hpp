@@ -785,7 +785,11 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmShape g, Epi epi) {
     for (int a = 0; a < TM; ++a) mphys[a] = (g.rows && !ROWS_ARE_K && mlog[a] < Meff) ? g.rows[mlog[a]] : mlog[a];
     if (epi.fast_ok() && m0 + BM <= Meff && n0 + BN <= g.N) epi.template tile_fast<TM, TN, PKC>(acc, mphys, ncol, g.N, z);
     else epilogue_all<0, TM, TN, PKC, Epi>(epi, acc, mlog, mphys, ncol, Meff, g.N, z);
+#ifdef NACF_GEMM_TRACE
     __builtin_amdgcn_s_waitcnt(0);
+    if (g_gemm_trace && threadIdx.x == 0)
+      g_gemm_trace[((size_t)blockIdx.z * gridDim.x + blockIdx.x) * 8 + 7] = wall_clock64();
+#endif
     NACF_TRACE_MARK(3);
   } else {
     // per-row (max, argmax, sum-exp) over this tile's BN columns

@@ -41,7 +41,7 @@ assert raw.nacf_debug_gemm_trace(ctypes.c_void_p(0)) == 0
 t = buf.cpu().numpy().reshape(-1, 8)
 t = t[t[:, 0] != 0]
 n = len(t)
-t0, t1, t2, t3, hw, nk, wall = (t[:, i].astype(np.int64) for i in range(7))
+t0, t1, t2, t3, hw, nk, wall, wall_end = (t[:, i].astype(np.int64) for i in range(8))
 ok = t3 > 0
 print("kernel %.1f us, %d workgroups traced (%d reached the epilogue stamp), k-tiles/workgroup %d" % (a.elapsed_time(b) * 1e3, n, int(ok.sum()), int(nk.max())))
 base = t0.min()
@@ -54,6 +54,11 @@ print("k-loop    cycles:", q(loop), "  per k-tile p50 %.0f" % (np.percentile(loo
 print("epilogue  cycles:", q(epi))
 print("total/wg  cycles:", q((t3 - t0)[ok]))
 frac = lambda v: 100.0 * v.sum() / (pro.sum() + loop.sum() + epi.sum())
+dw_ = (wall_end - wall)[ok].astype(np.float64)
+good = dw_ > 0
+if good.any():   # s_memtime ticks per 100 MHz wall tick between the post-fill and the final stamp = the shader clock there
+    mhz = ((t3 - t1)[ok][good] / dw_[good]) * 100.0
+    print("shader clock while the workgroups ran (s_memtime / wall_clock64): p10 %.0f  p50 %.0f  p90 %.0f MHz" % tuple(np.percentile(mhz, [10, 50, 90])))
 print("share of workgroup time: prologue %.1f%%  k-loop %.1f%%  epilogue %.1f%%" % (frac(pro), frac(loop), frac(epi)))
 # placement: HW_ID bits (gfx9): wave_id[3:0] simd_id[5:4] pipe[7:6] cu_id[11:8] sh_id[12] se_id[15:13]
 cu = ((hw >> 8) & 0xF) | (((hw >> 12) & 0x1) << 4) | (((hw >> 13) & 0x7) << 5) | ((hw >> 32) << 8)
