@@ -348,6 +348,18 @@ int nacf_nll_reduce(const float* label_logp, const int64_t* argmax, const int64_
 int nacf_xent_bwd(const float* logp, int64_t ld, float* dlogits, int64_t ldd, int rows, int V,
                   const int64_t* labels, const float* gscale, float scale, int skip_pad_rows,
                   nacf_stream_t stream);
+/* Training vocabulary projection with the soft-max statistics fused into the GEMM epilogue (replaces nacf_linear_fwd +
+ * nacf_vocab_logsoftmax_fwd for models/__init__.py:83 + F.log_softmax + nn.NLLLoss, misc/crit.py:62-114):
+ *   logits[r, :] = hidden[r, :] W^T + bias     (stored raw, row pitch ldl % 4 == 0, live rows of `rs` only)
+ *   lse[r] = log sum_n exp(logits[r, n]);  argmax[r];  label_logp[r] = logits[r, labels[r]] - lse[r]
+ * `ws`: nacf_vocab_argmax_workspace(rows, V) bytes.  Backward: nacf_xent_bwd_lse on the raw logits. */
+int nacf_vocab_lse_fwd(const float* hidden, int64_t ldh, const float* W, int64_t ldw, const float* bias, int rows,
+                       int V, int K, float* logits, int64_t ldl, const int64_t* labels, float* lse, int64_t* argmax,
+                       float* label_logp, void* ws, size_t ws_bytes, const nacf_rowset* rs, nacf_stream_t stream);
+/* dlogits = (exp(logits - lse[row]) - onehot(label)) * gscale[0]*scale for rows with label != PAD, else 0. */
+int nacf_xent_bwd_lse(const float* logits, int64_t ld, const float* lse, float* dlogits, int64_t ldd, int rows, int V,
+                      const int64_t* labels, const float* gscale, float scale, int skip_pad_rows,
+                      nacf_stream_t stream);
 /* Generic log_softmax backward for wide rows (when the caller consumes the
  * log-probs with its own criterion): dlogits = dlogp - exp(logp)*rowsum(dlogp) */
 int nacf_vocab_logsoftmax_bwd(const float* dlogp, int64_t ldg, const float* logp, int64_t ld,

@@ -385,6 +385,10 @@ struct EpiArgmax {
   float* pmax;   // [tiles_n][M]
   float* psum;   // [tiles_n][M]
   int* pidx;     // [tiles_n][M]
+  // training form (nacf_vocab_lse_fwd): the logits are ALSO stored (C[phys row][n], ldc % 4 == 0, 16-byte aligned) and
+  // the sum-exp uses expf; decode (C == nullptr) never materialises them and uses the fast exp
+  float* C = nullptr;
+  int64_t ldc = 0;
   static constexpr bool kArgmax = true;
   __device__ __forceinline__ void operator()(int, int, int, f32x4, int, int, int) const {}
   __device__ __forceinline__ void zero4(int, int, int) const {}
@@ -801,8 +805,11 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmShape g, Epi epi) {
     for (int a = 0; a < TM; ++a) {
       float best = NEG;
       int bidx = 0x7fffffff;
+      const int mrow = m0 + wm * WTM + a * 16 + li;                      // logical row of this lane's accumulators
+      float* crow = nullptr;
+      if (epi.C && mrow < Meff) crow = epi.C + (int64_t)(g.rows ? g.rows[mrow] : mrow) * epi.ldc;
 #pragma unroll
-      for (int b = 0; b < TN; ++b)
+      for (int b = 0; b < TN; ++b) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           const int n = n0 + wn * WTN + b * 16 + lg * 4 + e;
@@ -815,6 +822,16 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmShape g, Epi epi) {
           }
           if (v > best) { best = v; bidx = n; }
         }
+        if (crow) {
+          const int nb = n0 + wn * WTN + b * 16 + lg * 4;
+          if (nb + 3 < g.N) *reinterpret_cast<f32x4*>(crow + nb) = acc[a][b];
+          else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+              if (nb + e < g.N) crow[nb + e] = acc[a][b][e];
+          }
+        }
+      }
 #pragma unroll
       for (int o = 16; o <= 32; o <<= 1) {
         float ov = __shfl_xor(best, o, 64);
@@ -837,7 +854,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmShape g, Epi epi) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           float v = acc[a][b][e];
-          s += (v > -1.0e38f) ? __expf(v - tmax) : 0.f;
+          s += (v > -1.0e38f) ? (epi.C ? expf(v - tmax) : __expf(v - tmax)) : 0.f;
         }
       s += __shfl_xor(s, 16, 64);
       s += __shfl_xor(s, 32, 64);

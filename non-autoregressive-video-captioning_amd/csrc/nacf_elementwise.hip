@@ -710,6 +710,36 @@ __global__ __launch_bounds__(256) void xent_bwd_kernel(const float* __restrict__
   }
 }
 
+// the same from RAW logits and the row's log-sum-exp (nacf_vocab_lse_fwd): softmax = exp(z - lse)
+__global__ __launch_bounds__(256) void xent_bwd_lse_kernel(const float* __restrict__ z, int64_t ld,
+                                                            const float* __restrict__ lse, float* __restrict__ dlogits,
+                                                            int64_t ldd, int V, const int64_t* __restrict__ labels,
+                                                            const float* __restrict__ gscale, float scale,
+                                                            int skip_pad_rows) {
+  const int row = blockIdx.x;
+  const int64_t lab = labels[row];
+  if (skip_pad_rows && lab == NACF_PAD) return;
+  const float g = (gscale ? gscale[0] : 1.f) * scale;
+  const float* p = z + (int64_t)row * ld;
+  float* d = dlogits + (int64_t)row * ldd;
+  const bool vec = ((ld | ldd) & 3) == 0 && ((reinterpret_cast<uintptr_t>(z) | reinterpret_cast<uintptr_t>(dlogits)) & 15) == 0;
+  const int V4 = vec ? (V >> 2) : 0;
+  if (lab == NACF_PAD) {
+    for (int i = threadIdx.x; i < V4; i += 256) reinterpret_cast<f32x4*>(d)[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int i = 4 * V4 + threadIdx.x; i < V; i += 256) d[i] = 0.f;
+  } else {
+    const float l = lse[row];
+    for (int i = threadIdx.x; i < V4; i += 256) {
+      const f32x4 zz = reinterpret_cast<const f32x4*>(p)[i];
+      f32x4 o;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[e] = (expf(zz[e] - l) - ((4 * i + e) == lab ? 1.f : 0.f)) * g;
+      reinterpret_cast<f32x4*>(d)[i] = o;
+    }
+    for (int i = 4 * V4 + threadIdx.x; i < V; i += 256) d[i] = (expf(p[i] - l) - (i == lab ? 1.f : 0.f)) * g;
+  }
+}
+
 __global__ __launch_bounds__(256) void vocab_logsoftmax_bwd_kernel(const float* __restrict__ dlogp, int64_t ldg,
                                                                     const float* __restrict__ logp, int64_t ld,
                                                                     float* __restrict__ dlogits, int64_t ldd, int V) {
@@ -983,6 +1013,15 @@ int nacf_xent_bwd(const float* logp, int64_t ld, float* dlogits, int64_t ldd, in
   hipLaunchKernelGGL(xent_bwd_kernel, dim3(rows), dim3(256), 0, as_hip(stream), logp, ld, dlogits, ldd, V, labels, gscale,
                      scale, skip_pad_rows);
   NACF_LAUNCH_CHECK("nacf_xent_bwd");
+  return NACF_OK;
+}
+
+int nacf_xent_bwd_lse(const float* logits, int64_t ld, const float* lse, float* dlogits, int64_t ldd, int rows, int V,
+                      const int64_t* labels, const float* gscale, float scale, int skip_pad_rows, nacf_stream_t stream) {
+  NACF_CHECK(logits && lse && dlogits && labels && rows > 0 && V > 0, NACF_EINVAL, "nacf_xent_bwd_lse: bad argument");
+  hipLaunchKernelGGL(xent_bwd_lse_kernel, dim3(rows), dim3(256), 0, as_hip(stream), logits, ld, lse, dlogits, ldd, V, labels,
+                     gscale, scale, skip_pad_rows);
+  NACF_LAUNCH_CHECK("nacf_xent_bwd_lse");
   return NACF_OK;
 }
 

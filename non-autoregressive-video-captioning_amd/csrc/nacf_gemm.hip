@@ -149,6 +149,45 @@ __global__ void argmax_merge_kernel(const float* __restrict__ pmax, const float*
   }
 }
 
+// training form of the merge: lse = log sum_n exp(z[n]) per live row from the per-tile (max, sum-exp) pairs, the arg-max
+// (accuracy meter) and log p(label) = z[label] - lse read straight from the stored logits
+__global__ void lse_merge_kernel(const float* __restrict__ pmax, const float* __restrict__ psum,
+                                 const int* __restrict__ pidx, int tiles_n, int rows, const int* __restrict__ live,
+                                 const int* __restrict__ count, const float* __restrict__ logits, int64_t ldl,
+                                 const int64_t* __restrict__ labels, float* __restrict__ lse,
+                                 int64_t* __restrict__ argmax, float* __restrict__ label_logp) {
+  const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);   // logical row
+  const int lane = threadIdx.x & 63;
+  if (row >= rows) return;
+  if (count && row >= *count) return;
+  float best = -3.0e38f;
+  int bidx = 0x7fffffff;
+  for (int t = lane; t < tiles_n; t += 64) {
+    float v = pmax[(int64_t)t * rows + row];
+    int i = pidx[(int64_t)t * rows + row];
+    if (v > best || (v == best && i < bidx)) { best = v; bidx = i; }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    float ov = __shfl_xor(best, o, 64);
+    int oi = __shfl_xor(bidx, o, 64);
+    if (ov > best || (ov == best && oi < bidx)) { best = ov; bidx = oi; }
+  }
+  float s = 0.f;
+  for (int t = lane; t < tiles_n; t += 64) s += psum[(int64_t)t * rows + row] * expf(pmax[(int64_t)t * rows + row] - best);
+  s = wave_sum(s);
+  if (lane == 0) {
+    const int prow = live ? live[row] : row;     // physical slot
+    const float l = best + logf(s);
+    if (lse) lse[prow] = l;
+    if (argmax) argmax[prow] = bidx;
+    if (label_logp && labels) {
+      const int64_t lab = labels[prow];
+      label_logp[prow] = (lab >= 0) ? logits[(int64_t)prow * ldl + lab] - l : 0.f;
+    }
+  }
+}
+
 // partition: rows[0..count) = ascending i with (tokens ? tokens[i] != PAD) && (flags ? flags[i] != 0); the other
 // slots fill rows[count..n) from the END (so they come out descending -- their order is irrelevant, the GEMMs only
 // zero-fill them).  One workgroup, ONE sweep, 4 consecutive slots per thread, wave scans by shuffle.
@@ -460,6 +499,43 @@ int nacf_vocab_argmax(const float* hidden, int64_t ldh, const float* W, int64_t 
                      rs ? rs->rows : nullptr, rs ? rs->count : nullptr, pad_tokens, zero_mask_prob, update_mask, tokens,
                      probs);
   NACF_LAUNCH_CHECK("nacf_vocab_argmax(merge)");
+  return NACF_OK;
+}
+
+// logits = hidden W^T + bias for the live rows, stored, AND their log-sum-exp / arg-max / log p(label) without a
+// second pass over the [rows, V] matrix: the GEMM epilogue emits (max, arg-max, sum-exp) per column tile while the
+// accumulators are still in registers, a small merge kernel finishes the rows.  Replaces nacf_linear_fwd +
+// nacf_vocab_logsoftmax_fwd for models/__init__.py:83 + F.log_softmax + NLLLoss (misc/crit.py:62-114); the
+// backward pass is nacf_xent_bwd_lse on the raw logits.
+int nacf_vocab_lse_fwd(const float* hidden, int64_t ldh, const float* W, int64_t ldw, const float* bias, int rows, int V,
+                       int K, float* logits, int64_t ldl, const int64_t* labels, float* lse, int64_t* argmax,
+                       float* label_logp, void* ws, size_t ws_bytes, const nacf_rowset* rs, nacf_stream_t stream) {
+  NACF_CHECK(hidden && W && logits && lse, NACF_EINVAL, "nacf_vocab_lse_fwd: null pointer");
+  NACF_CHECK(rows > 0 && V > 0 && K > 0 && ldl >= V, NACF_EINVAL, "nacf_vocab_lse_fwd: bad shape");
+  NACF_CHECK(ldl % 4 == 0 && aligned16(logits), NACF_EINVAL, "nacf_vocab_lse_fwd: logits need 16-byte aligned rows (nacf vocab_ld)");
+  NACF_CHECK(ws && ws_bytes >= nacf_vocab_argmax_workspace(rows, V), NACF_EWORKSPACE, "nacf_vocab_lse_fwd: workspace too small");
+  NACF_CHECK(!rs || (rs->rows && rs->count), NACF_EINVAL, "nacf_vocab_lse_fwd: incomplete row set");
+  const int tile = pick_tile(rows, V, 1, rs != nullptr);
+  const int tn = cdiv(V, tile == 0 ? 128 : 64);
+  EpiArgmax epi;
+  epi.bias = bias;
+  epi.pmax = reinterpret_cast<float*>(ws);
+  epi.psum = epi.pmax + (size_t)tn * rows;
+  epi.pidx = reinterpret_cast<int*>(epi.psum + (size_t)tn * rows);
+  epi.C = logits;
+  epi.ldc = ldl;
+  GemmShape g = {};
+  g.Q = hidden; g.P = W; g.ldq = ldh; g.ldp = ldw; g.M = rows; g.N = V; g.K = K;
+  g.k_per_split = cdiv(K, 16) * 16;
+  set_rows(g, rs);
+  g.zero_dead = 0;                       // rows without a label are never read downstream
+  const bool vec = (ldh % 4 == 0) && (ldw % 4 == 0) && aligned16(hidden) && aligned16(W);
+  hipStream_t s = as_hip(stream);
+  launch_gemm<true, true, EpiArgmax>(g, epi, 1, tile, vec, s);
+  NACF_LAUNCH_CHECK("nacf_vocab_lse_fwd(gemm)");
+  hipLaunchKernelGGL(lse_merge_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, s, epi.pmax, epi.psum, epi.pidx, tn, rows,
+                     rs ? rs->rows : nullptr, rs ? rs->count : nullptr, logits, ldl, labels, lse, argmax, label_logp);
+  NACF_LAUNCH_CHECK("nacf_vocab_lse_fwd(merge)");
   return NACF_OK;
 }
 

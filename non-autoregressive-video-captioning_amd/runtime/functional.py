@@ -469,15 +469,17 @@ class FusedVocabXentFn(Function):
         live = ops.rowset_build(tokens=labels)
         buf = _new((rows, ops.vocab_ld(V)), h)
         logits = buf[:, :V]
-        ops.linear_fwd(h, pk.w, logits, ops.Epi(bias=pk.b), live)
         label_logp = _new((rows,), h)
+        lse = _new((rows,), h)
         argmax = _new((rows,), h, torch.int64)
-        ops.vocab_logsoftmax_fwd(logits, V, labels, None, argmax, label_logp, skip_pad_rows=True)
+        # projection with the soft-max statistics out of the GEMM epilogue: the [rows, V] logits are written once and
+        # not read again until the backward pass turns them into the gradient in place
+        ops.vocab_lse_fwd(h, pk.w, pk.b, logits, labels, lse, argmax, label_logp, live)
         stats = cfg.get("out")          # optional slot of the criterion's term slab (LossCombineFn)
         if stats is None:
             stats = _new((5,), h)
         ops.nll_reduce(label_logp, argmax, labels, exclude_mask, stats)
-        ctx.cfg, ctx.h, ctx.logp, ctx.labels, ctx.live = cfg, h, logits, labels, live
+        ctx.cfg, ctx.h, ctx.logp, ctx.labels, ctx.live, ctx.lse = cfg, h, logits, labels, live, lse
         return stats
 
     @staticmethod
@@ -485,11 +487,11 @@ class FusedVocabXentFn(Function):
         pk: Pack = ctx.cfg["pack"]
         rows, V = ctx.logp.shape
         dstats = dstats.contiguous()
-        ops.xent_bwd(ctx.logp, ctx.logp, V, ctx.labels, dstats, 1.0, skip_pad_rows=True)  # in place: logp -> dlogits
+        ops.xent_bwd_lse(ctx.logp, ctx.lse, ctx.logp, V, ctx.labels, dstats, 1.0, skip_pad_rows=True)  # in place: logits -> dlogits
         dh = torch.empty_like(ctx.h)
         ops.linear_bwd_data(ctx.logp, pk.w, dh, rows=ctx.live, zero_dead=True)
         ops.linear_bwd_weight(ctx.logp, ctx.h, pk.gw, pk.gb, beta=1.0, rows=ctx.live)
-        ctx.h = ctx.logp = ctx.live = None
+        ctx.h = ctx.logp = ctx.live = ctx.lse = None
         return (dh, None, None, None) + (None,) * (len(ctx.needs_input_grad) - 4)
 
 
@@ -520,10 +522,10 @@ class FusedVocabXentMultiFn(Function):
         live = ops.rowset_build(tokens=labels)
         buf = _new((rows, ops.vocab_ld(V)), h)
         logits = buf[:, :V]
-        ops.linear_fwd(h, pk.w, logits, ops.Epi(bias=pk.b), live)
         label_logp = _new((rows,), h)
+        lse = _new((rows,), h)
         argmax = _new((rows,), h, torch.int64)
-        ops.vocab_logsoftmax_fwd(logits, V, labels, None, argmax, label_logp, skip_pad_rows=True)
+        ops.vocab_lse_fwd(h, pk.w, pk.b, logits, labels, lse, argmax, label_logp, live)
         outs = cfg.get("outs")
         stats = []
         for i in range(S):
@@ -531,7 +533,7 @@ class FusedVocabXentMultiFn(Function):
             sl = slice(i * rp, (i + 1) * rp)
             ops.nll_reduce(label_logp[sl], argmax[sl], labels[sl], excludes[i], st)
             stats.append(st)
-        ctx.cfg, ctx.h, ctx.logp, ctx.labels, ctx.live, ctx.S = cfg, h, logits, labels, live, S
+        ctx.cfg, ctx.h, ctx.logp, ctx.labels, ctx.live, ctx.S, ctx.lse = cfg, h, logits, labels, live, S, lse
         return tuple(stats)
 
     @staticmethod
@@ -543,11 +545,12 @@ class FusedVocabXentMultiFn(Function):
             sl = slice(i * rp, (i + 1) * rp)
             if g is None:
                 g = torch.zeros(5, dtype=ctx.logp.dtype, device=ctx.logp.device)
-            ops.xent_bwd(ctx.logp[sl], ctx.logp[sl], V, ctx.labels[sl], g.contiguous(), 1.0, skip_pad_rows=True)
+            ops.xent_bwd_lse(ctx.logp[sl], ctx.lse[sl], ctx.logp[sl], V, ctx.labels[sl], g.contiguous(), 1.0,
+                             skip_pad_rows=True)
         dh = torch.empty_like(ctx.h)
         ops.linear_bwd_data(ctx.logp, pk.w, dh, rows=ctx.live, zero_dead=True)
         ops.linear_bwd_weight(ctx.logp, ctx.h, pk.gw, pk.gb, beta=1.0, rows=ctx.live)
-        ctx.h = ctx.logp = ctx.live = None
+        ctx.h = ctx.logp = ctx.live = ctx.lse = None
         return (dh, None, None, None) + (None,) * (len(ctx.needs_input_grad) - 4)
 
 

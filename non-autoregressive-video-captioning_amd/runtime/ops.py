@@ -415,6 +415,29 @@ def vocab_logsoftmax_fwd(logits2d, V, labels, lse, argmax, label_logp, skip_pad_
             "nacf_vocab_logsoftmax_fwd")
 
 
+def vocab_lse_fwd(hidden2d, w, bias, logits2d, labels, lse, argmax, label_logp, rows=None):
+    """logits = hidden @ w^T + bias (stored raw) AND lse / argmax / log p(label) per live row, the soft-max statistics
+    coming out of the GEMM epilogue (no second pass over [rows, V])"""
+    _chk_f32(hidden2d, w, bias, logits2d, lse, label_logp)
+    n_rows, K, ldh = _rows2d(hidden2d)
+    V = w.shape[0]
+    assert logits2d.shape == (n_rows, V) and logits2d.stride(1) == 1
+    lib = L.load()
+    ws = WORKSPACE.get(lib.nacf_vocab_argmax_workspace(n_rows, V), hidden2d.device)
+    tok = PROFILER.begin(0, n_rows, V, K, "EpiArgmax", rows)
+    L.check(lib.nacf_vocab_lse_fwd(_ptr(hidden2d), ldh, _ptr(w), w.stride(0), _ptr(bias), n_rows, V, K, _ptr(logits2d),
+                                   logits2d.stride(0), _ptr(labels), _ptr(lse), _ptr(argmax), _ptr(label_logp), _ptr(ws),
+                                   ws.numel(), _rs(rows), _stream()), "nacf_vocab_lse_fwd")
+    PROFILER.end(tok)
+
+
+def xent_bwd_lse(logits2d, lse, dlogits2d, V, labels, gscale, scale, skip_pad_rows=False):
+    rows = logits2d.shape[0]
+    L.check(L.load().nacf_xent_bwd_lse(_ptr(logits2d), logits2d.stride(0), _ptr(lse), _ptr(dlogits2d),
+                                       dlogits2d.stride(0), rows, V, _ptr(labels), _ptr(gscale), float(scale),
+                                       int(skip_pad_rows), _stream()), "nacf_xent_bwd_lse")
+
+
 def nll_reduce(label_logp, argmax, labels, exclude_mask, out5):
     rows = label_logp.numel()
     L.check(L.load().nacf_nll_reduce(_ptr(label_logp), _ptr(argmax), _ptr(labels), rows, int(exclude_mask),

@@ -809,3 +809,31 @@ def test_cross_attention_backward_model_width(dev, mode, Lk, kb, monkeypatch):
     ops.attention_bwd(qx, kvx[:, :D], kvx[:, D:], do.to(dev), again_q, again_kv[:, :D], again_kv[:, D:], None, 0, R, Bv, H,
                       Lq, Lk, dk, kv_div, kv_mod)
     assert torch.equal(dq, again_q) and torch.equal(dkv, again_kv)        # fixed combination order: run to run identical
+
+
+@pytest.mark.parametrize("rows,V,K", [(70, 101, 64), (300, 10547, 512)])
+def test_vocab_projection_with_fused_softmax_statistics(dev, rows, V, K):
+    """nacf_vocab_lse_fwd: raw logits stored by the GEMM epilogue + lse / argmax / log p(label) from its per-tile
+    partials, live rows only; nacf_xent_bwd_lse turns the logits into the cross-entropy gradient in place"""
+    ops, _ = _ops()
+    h, w, b = rnd(rows, K, seed=1), rnd(V, K, seed=2, scale=0.5), rnd(V, seed=3)
+    labels = torch.randint(0, min(V, 50), (rows,), generator=torch.Generator().manual_seed(4))
+    labels[::5] = PAD
+    z_ref = h.double() @ w.double().t() + b.double()
+    lse_ref = torch.logsumexp(z_ref, dim=1)
+    live = ops.rowset_build(tokens=labels.to(dev))
+    buf = torch.full((rows, ops.vocab_ld(V)), float("nan"), device=dev)
+    logits = buf[:, :V]
+    lse, llp = torch.zeros(rows, device=dev), torch.zeros(rows, device=dev)
+    am = torch.zeros(rows, dtype=torch.int64, device=dev)
+    ops.vocab_lse_fwd(h.to(dev), w.to(dev), b.to(dev), logits, labels.to(dev), lse, am, llp, live)
+    keep = labels != PAD
+    assert err(logits[keep.to(dev)], z_ref[keep]) < 2e-4
+    assert err(lse[keep.to(dev)], lse_ref[keep]) < 1e-4
+    assert torch.equal(am.cpu()[keep], z_ref.argmax(1)[keep])
+    assert err(llp[keep.to(dev)], (z_ref.gather(1, labels.view(-1, 1)).squeeze(1) - lse_ref)[keep]) < 2e-4
+    assert bool(torch.isnan(logits[(~keep).to(dev)]).all())              # rows without a label are not touched
+    g = torch.tensor([0.37], device=dev)
+    ops.xent_bwd_lse(logits, lse, logits, V, labels.to(dev), g, 1.0, skip_pad_rows=True)
+    want = (torch.softmax(z_ref, 1) - torch.nn.functional.one_hot(labels, V).double()) * 0.37
+    assert err(logits[keep.to(dev)], want[keep]) < 5e-6
