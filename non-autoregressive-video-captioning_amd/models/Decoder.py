@@ -133,7 +133,7 @@ class BertDecoder(nn.Module):
                 all_attentions = all_attentions + (att,)
         hidden = x2.view(R, Lq, D)
         embs = None
-        if out_rows is None:
+        if out_rows is None and kwargs.get('want_embs', True):     # Seq2Seq drops `embs` (seq2seq.py:94,124): it asks not to
             with torch.no_grad():
                 embs = ops.masked_mean_fwd(hidden.detach(), tgt_seq, torch.empty(R, D, device=hidden.device))
         outputs = ([hidden], embs,)
@@ -183,5 +183,5 @@ class BertDecoderDisentangled(nn.Module):
             kwargs = dict(kwargs, row_map=('mod', enc_output.shape[0]))
             hidden, embs = self.forward_(both, enc_output, category, **kwargs)[:2]
             h0, h1 = HalvesFn.apply(hidden)
-            return (BatchedPasses([h0, h1], hidden), embs[B:],)
+            return (BatchedPasses([h0, h1], hidden), None if embs is None else embs[B:],)
         return self.forward_(tgt_seq, enc_output, category, **kwargs)

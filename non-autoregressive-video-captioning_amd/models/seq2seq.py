@@ -134,7 +134,7 @@ class Seq2Seq(nn.Module):
             eo = results['enc_output']
             self._cut = [t for t in (eo if isinstance(eo, (list, tuple)) else [eo]) if t.requires_grad]
         inputs_for_decoder = self.prepare_inputs_for_decoder(results, category)
-        hidden_states, embs, *_ = self.decoder(tgt_tokens, decoding_type=decoding_type,
+        hidden_states, embs, *_ = self.decoder(tgt_tokens, decoding_type=decoding_type, want_embs=False,
                                                pooled_memory=results['_pooled_memory'], **inputs_for_decoder)
         if not isinstance(hidden_states, list):
             hidden_states = [hidden_states]
