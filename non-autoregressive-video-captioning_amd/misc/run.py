@@ -331,6 +331,10 @@ def train_network_all(opt, model, device, summarywriter=None, **kwargs):
         model = load_satisfied_weights(model=model, checkpoint_path=opt['teacher_path'],
                                        str_mapping={'decoder.bert.': 'decoder.'})
     model.to(device)
+    # this loop owns the criterion, so the vocabulary projection + log-softmax + NLL run as ONE fused function
+    # (runtime/functional.py:FusedVocabXentMultiFn) unless the caller asked for materialised log-probs
+    opt.setdefault('fused_loss', True)
+    getattr(model, 'opt', {}).setdefault('fused_loss', opt['fused_loss'])
     rank0 = not dist.is_initialized() or dist.get_rank() == 0
     optimizer = get_optimizer(opt, model, summarywriter=summarywriter)
     crit = get_criterion(opt, summarywriter=summarywriter)

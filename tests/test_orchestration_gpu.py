@@ -147,7 +147,7 @@ def _run_opt(tmp, paths, V, **over):
     import nacf_amd
     return nacf_amd.opts.make_opt(
         "NACF", "MSRVTT", with_category=True, dim_hidden=64, num_attention_heads=4, intermediate_size=128, dim_i=32,
-        dim_m=32, max_len=10, hidden_dropout_prob=0.1, encoder_dropout=0.1, vocab_size=V, fused_loss=True, n_frames=8,
+        dim_m=32, max_len=10, hidden_dropout_prob=0.1, encoder_dropout=0.1, vocab_size=V, n_frames=8,
         beta=[0.35, 0.9], use_ct=True, iterations=3, length_beam_size=3, beam_alpha=1.0, paradigm="mp",
         info_corpus=os.path.join(tmp, "info_corpus.pkl"), reference=os.path.join(tmp, "refs.pkl"),
         feats_m=[paths["m"]], feats_i=[paths["i"]], checkpoint_path=os.path.join(tmp, "ckpt"), batch_size=8,
@@ -165,6 +165,7 @@ def test_train_network_all_end_to_end(dev, tmp_path):
     torch.manual_seed(0)
     model = nacf_amd.get_model(opt)
     best, final = train_network_all(model.opt, model, dev)
+    assert model.opt['fused_loss'] is True          # the run loop turns the fused vocabulary loss on by default
     ck = os.path.join(tmp, "ckpt")
     rows = list(csv.DictReader(open(os.path.join(ck, "trainning_record.csv"))))
     assert 2 <= len(rows) <= 8 and [int(r["epoch"]) for r in rows] == list(range(len(rows)))
