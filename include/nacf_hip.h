@@ -462,6 +462,13 @@ int nacf_adam_step(float* param, const float* grad, float* exp_avg, float* exp_a
                    int64_t n, const float* lr, int64_t* step_count,
                    float beta1, float beta2, float eps, float weight_decay,
                    float grad_clip, float grad_scale, nacf_stream_t stream);
+/* The same update over a PART of the flat buffers (data-parallel training updates the parameters whose gradient
+ * bucket has been reduced while the other bucket is still in flight): bump != 0 increments step_count first -- exactly
+ * one part of a step does. */
+int nacf_adam_step_part(float* param, const float* grad, float* exp_avg, float* exp_avg_sq,
+                        int64_t n, const float* lr, int64_t* step_count,
+                        float beta1, float beta2, float eps, float weight_decay,
+                        float grad_clip, float grad_scale, int bump, nacf_stream_t stream);
 
 #ifdef __cplusplus
 }

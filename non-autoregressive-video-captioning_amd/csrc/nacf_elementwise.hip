@@ -1034,17 +1034,24 @@ int nacf_vocab_logsoftmax_bwd(const float* dlogp, int64_t ldg, const float* logp
   return NACF_OK;
 }
 
-int nacf_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, const float* lr,
-                   int64_t* step_count, float beta1, float beta2, float eps, float weight_decay, float grad_clip,
-                   float grad_scale, nacf_stream_t stream) {
+int nacf_adam_step_part(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, const float* lr,
+                        int64_t* step_count, float beta1, float beta2, float eps, float weight_decay, float grad_clip,
+                        float grad_scale, int bump, nacf_stream_t stream) {
   NACF_CHECK(param && grad && exp_avg && exp_avg_sq && lr && step_count && n > 0, NACF_EINVAL,
              "nacf_adam_step: bad argument");
   hipStream_t s = as_hip(stream);
-  hipLaunchKernelGGL(adam_bump_kernel, dim3(1), dim3(1), 0, s, step_count);
+  if (bump) hipLaunchKernelGGL(adam_bump_kernel, dim3(1), dim3(1), 0, s, step_count);
   hipLaunchKernelGGL(adam_step_kernel, dim3(grid_for(n, 256, 4096)), dim3(256), 0, s, param, grad, exp_avg, exp_avg_sq, n,
                      lr, step_count, beta1, beta2, eps, weight_decay, grad_clip, grad_scale);
   NACF_LAUNCH_CHECK("nacf_adam_step");
   return NACF_OK;
+}
+
+int nacf_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, const float* lr,
+                   int64_t* step_count, float beta1, float beta2, float eps, float weight_decay, float grad_clip,
+                   float grad_scale, nacf_stream_t stream) {
+  return nacf_adam_step_part(param, grad, exp_avg, exp_avg_sq, n, lr, step_count, beta1, beta2, eps, weight_decay, grad_clip,
+                             grad_scale, 1, stream);
 }
 
 }  // extern "C"

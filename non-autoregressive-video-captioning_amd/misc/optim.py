@@ -34,13 +34,16 @@ class FusedAdam(object):
     def zero_grad(self):
         self.model.zero_grad()
 
-    def step(self, grad_scale=1.0):
+    def step(self, grad_scale=1.0, lo=None, hi=None, bump=True):
+        """lo / hi: update only flat[lo:hi] (one gradient bucket of the data-parallel step); exactly one part of a
+        step passes bump=True, and it must come first"""
         if self._flat is not self.model.flat:   # model moved (.to/.cuda) after the optimiser was built
             self._alloc()
             self.lr_dev.fill_(self.param_groups[0]['lr'])
         f = self._flat
-        ops.adam_step(f.data, f.grad, self.exp_avg, self.exp_avg_sq, self.lr_dev, self.step_dev, self.betas[0],
-                      self.betas[1], self.eps, self.wd, self.grad_clip, grad_scale)
+        sl = slice(lo, hi)
+        ops.adam_step(f.data[sl], f.grad[sl], self.exp_avg[sl], self.exp_avg_sq[sl], self.lr_dev, self.step_dev,
+                      self.betas[0], self.betas[1], self.eps, self.wd, self.grad_clip, grad_scale, bump=bump)
 
 
 class ScheduledOptim(object):

@@ -13,7 +13,8 @@ dropout and masking seeds (Philox {seed, step} advanced by a kernel), Adam's ste
 
 N > 1 ranks (runtime/ddp.py): the backward pass is split at the encoder outputs into two graphs; the decoder-side
 gradient bucket is all-reduced (RCCL, torch.distributed's own stream -- never captured) while the encoder-side graph
-replays, the rest after it, then the Adam graph.
+replays, the rest after it; the decoder-side parameters are updated (their own Adam graph) while the second bucket is
+still in flight, the encoder-side ones after it.
 
 A batch whose shapes differ from the captured ones (the ragged tail of an epoch) runs launch by launch.
 """
@@ -57,7 +58,8 @@ class TrainStep(object):
         self.adam = optimizer._optimizer if self.sched is not None else optimizer
         self.graph_mode, self.eager_steps = graph, int(eager_steps)
         self.multi = ddp is not None and (ddp.world > 1 or ddp.force)
-        self.staged = self.multi and ddp.bucket_split() is not None
+        self.split = ddp.bucket_split() if self.multi else None
+        self.staged = self.split is not None
         self.grad_scale = ddp.grad_scale if self.multi else 1.0
         self.static = self.sig = None
         self.loss = None                    # device scalar: the last step's loss
@@ -79,23 +81,35 @@ class TrainStep(object):
     def _back(self):
         self.ddp.backward_from_cut(self._hold['cut'], self._hold['grads'])
 
-    def _update(self):
-        self.adam.step(grad_scale=self.grad_scale)
+    def _update(self, part=None):
+        """part None: every parameter; 0: the late bucket flat[split:] (starts the step), 1: the rest flat[:split]"""
+        if part is None:
+            self.adam.step(grad_scale=self.grad_scale)
+        elif part == 0:
+            self.adam.step(grad_scale=self.grad_scale, lo=self.split, hi=None, bump=True)
+        else:
+            self.adam.step(grad_scale=self.grad_scale, lo=0, hi=self.split, bump=False)
 
-    def _reduce_around(self, second_stage):
+    def _reduce_around(self, second_stage, update_late, update_early):
+        """bucket 0 (decoder side) travels while the encoder's backward runs; its parameters are then updated while
+        bucket 1 (encoder side) travels"""
         w1 = self.ddp.all_reduce_bucket(0)
         second_stage()
         w2 = self.ddp.all_reduce_bucket(1)
-        for w in (w1, w2):
-            if w is not None:
-                w.wait()
+        if w1 is not None:
+            w1.wait()
+        update_late()
+        if w2 is not None:
+            w2.wait()
+        update_early()
 
     def _eager(self, b):
         self._front(b)
         if self.staged:
-            self._reduce_around(self._back)
+            self._reduce_around(self._back, lambda: self._update(0), lambda: self._update(1))
             self._hold.clear()
-        elif self.multi:
+            return
+        if self.multi:
             self.ddp.all_reduce_gradients()
         self._update()
 
@@ -120,7 +134,14 @@ class TrainStep(object):
                 with torch.cuda.graph(back, stream=side, pool=front.pool(), **mode):
                     self._back()
                 self._hold.clear()
-            if self.multi:
+            if self.staged:                 # one Adam graph per gradient bucket
+                upd = []
+                for part in (0, 1):
+                    g_ = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(g_, stream=side, pool=front.pool(), **mode):
+                        self._update(part)
+                    upd.append(g_)
+            elif self.multi:
                 upd = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(upd, stream=side, pool=front.pool(), **mode):
                     self._update()
@@ -135,11 +156,12 @@ class TrainStep(object):
         front, back, upd = self.graphs
         front.replay()
         if self.staged:
-            self._reduce_around(back.replay)
-        elif self.multi:
-            self.ddp.all_reduce_gradients()
-        if upd is not None:
-            upd.replay()
+            self._reduce_around(back.replay, upd[0].replay, upd[1].replay)
+        else:
+            if self.multi:
+                self.ddp.all_reduce_gradients()
+            if upd is not None:
+                upd.replay()
         self.crit._loss_cnt = [c + d for c, d in zip(self.crit._loss_cnt, self.count_delta)]
 
     def _graph_ready(self):

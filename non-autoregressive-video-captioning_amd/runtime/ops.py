@@ -532,11 +532,14 @@ def best_candidate(tokens, probs, teacher, beam, alpha, B, lbs, Lp, out_tokens, 
 
 
 # ---------------------------------------------------------------- optimiser
-def adam_step(param, grad, m, v, lr_dev, step_dev, beta1, beta2, eps, weight_decay, grad_clip, grad_scale):
+def adam_step(param, grad, m, v, lr_dev, step_dev, beta1, beta2, eps, weight_decay, grad_clip, grad_scale, bump=True):
+    """param / grad / m / v may be equal-length slices of the flat buffers; bump: this call starts a new step"""
     _chk_f32(param, grad, m, v, lr_dev)
-    L.check(L.load().nacf_adam_step(_ptr(param), _ptr(grad), _ptr(m), _ptr(v), param.numel(), _ptr(lr_dev),
-                                    _ptr(step_dev), float(beta1), float(beta2), float(eps), float(weight_decay),
-                                    float(grad_clip), float(grad_scale), _stream()), "nacf_adam_step")
+    assert param.numel() == grad.numel() == m.numel() == v.numel() and param.is_contiguous()
+    L.check(L.load().nacf_adam_step_part(_ptr(param), _ptr(grad), _ptr(m), _ptr(v), param.numel(), _ptr(lr_dev),
+                                         _ptr(step_dev), float(beta1), float(beta2), float(eps), float(weight_decay),
+                                         float(grad_clip), float(grad_scale), int(bool(bump)), _stream()),
+            "nacf_adam_step")
 
 
 # ---------------------------------------------------------------- AR beam search

@@ -415,3 +415,34 @@ def test_reference_default_shapes_train_and_decode(dev, B):
     hyp = outs["on"]
     assert hyp.shape[0] == B and 4 <= hyp.shape[1] <= 29
     assert int(hyp.min()) >= 0 and int(hyp.max()) < 10547 and not bool((hyp == 4).any())     # no <mask> left
+
+
+def test_adam_in_two_parts_equals_one_launch(dev):
+    """data-parallel steps update the decoder-side parameters while the encoder-side gradient bucket is still being
+    reduced: Adam over flat[split:] (bumping the step) then flat[:split] must equal one launch over everything"""
+    import nacf_amd
+    from nacf_amd import synthetic as S
+    from nacf_amd.misc.optim import get_optimizer
+    from nacf_amd.runtime.ddp import DataParallel
+    opt = nacf_amd.opts.make_opt("NACF", "MSRVTT", with_category=True, dim_hidden=64, num_attention_heads=4,
+                                 intermediate_size=128, dim_i=32, dim_m=32, max_len=10, vocab_size=101, n_frames=6)
+    outs = []
+    for parts in (False, True):
+        model = nacf_amd.get_model(opt)
+        model.load_state_dict(S.init_state_dict(opt, seed=0))
+        model.to(dev)
+        optim = get_optimizer(model.opt, model)
+        split = DataParallel(model).bucket_split()
+        assert 0 < split < model.flat.data.numel()
+        g = torch.Generator().manual_seed(1)
+        for step in range(3):
+            model.flat.grad.copy_((torch.rand(model.flat.grad.numel(), generator=g) * 12 - 6).to(dev))   # some beyond the clip
+            optim.step_update_learning_rate()
+            if parts:
+                optim._optimizer.step(grad_scale=0.5, lo=split, hi=None, bump=True)
+                optim._optimizer.step(grad_scale=0.5, lo=0, hi=split, bump=False)
+            else:
+                optim._optimizer.step(grad_scale=0.5)
+        outs.append((model.flat.data.clone(), int(optim._optimizer.step_dev)))
+    assert outs[0][1] == outs[1][1] == 3
+    assert torch.equal(outs[0][0], outs[1][0])
