@@ -399,7 +399,8 @@ def main():
                                       "feats, seq_len %d, V=%d, dropout 0.5, Adam" % (B, L, V),
                           "global_batch": B * world, "seq_len": L, "vocab": V, "params": n_params,
                           "parallelism": "dp%d" % world, "hipgraph": bool(use_graph), "live_row_gemms": True,
-                          "overlapped_allreduce": bool(staged)},
+                          "overlapped_allreduce": bool(staged),
+                          "gradient_buckets": (3 if engine.three else 2) if staged else 1},
                "roofline": roofline, "cpu_baseline": cpu, "decode": decode, "config5_ar_vs_na": compare,
                "loader_fed": loader_leg, "config1_nab": nab,
                "final_loss": round(final_loss, 4),

@@ -67,6 +67,46 @@ class DataParallel(object):
                 return None
         return lo
 
+    def head_split(self):
+        """Offset `h` (> bucket_split()) such that flat.grad[h:] holds exactly the gradients of model.head_parameters()
+        (the vocabulary projection: complete as soon as backward has passed the decoder's output); None if there is no
+        such tail."""
+        head_fn = getattr(self.model, 'head_parameters', None)
+        s = self.bucket_split()
+        if head_fn is None or s is None:
+            return None
+        head = {id(p) for p in head_fn()}
+        if not head:
+            return None
+        flat = self.model.flat
+        lo = min(flat.offset[i] for i in head)
+        for p in flat.params:
+            if (flat.offset[id(p)] >= lo) != (id(p) in head):
+                return None
+        return lo if lo > s else None
+
+    def backward_head(self, loss):
+        """Stage 0 of the three-stage backward: from the loss to the decoder's output / the length head's output
+        (model._cut_head); writes the vocabulary-projection gradients."""
+        cut = list(self.model._cut_head)
+        head = [p for p in self.model.head_parameters() if p.requires_grad]
+        grads = torch.autograd.grad(loss, cut + head, allow_unused=True)
+        return cut, list(grads[:len(cut)])
+
+    def backward_mid(self, head_cut, head_grads):
+        """Stage 1 of three: from the decoder's output down to the encoder outputs (decoder + length head)."""
+        cut = list(self.model._cut)
+        head_ids = {id(p) for p in self.model.head_parameters()}
+        late = [p for p in self.model.late_parameters() if p.requires_grad and id(p) not in head_ids]
+        pairs = [(t, g) for t, g in zip(head_cut, head_grads) if g is not None]
+        grads = torch.autograd.grad([t for t, _ in pairs], cut + late, grad_outputs=[g for _, g in pairs], allow_unused=True)
+        return cut, list(grads[:len(cut)])
+
+    def all_reduce_range(self, lo, hi, async_op=True):
+        if self.world == 1 and not self.force:
+            return None
+        return dist.all_reduce(self.model.flat.grad[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=async_op)
+
     def backward_to_cut(self, loss):
         """Stage 1: backward from the loss down to the encoder outputs (model._cut).  The decoder-side parameters are
         listed as inputs too so that every Function that only leads to parameters (e.g. an embedding lookup) still

@@ -11,9 +11,9 @@ Everything data dependent stays on the device inside the captured sequence: live
 dropout and masking seeds (Philox {seed, step} advanced by a kernel), Adam's step counter and learning rate
 (`FusedAdam.step_dev / lr_dev`), the criterion's meters (`Criterion._meters`).
 
-N > 1 ranks (runtime/ddp.py): the backward pass is split at the encoder outputs into two graphs; the decoder-side
-gradient bucket is all-reduced (RCCL, torch.distributed's own stream -- never captured) while the encoder-side graph
-replays, the rest after it; the decoder-side parameters are updated (their own Adam graph) while the second bucket is
+N > 1 ranks (runtime/ddp.py): the backward pass is split at the decoder's output and at the encoder outputs into
+three graphs; each gradient bucket (vocabulary projection | decoder side | encoder side) is all-reduced (RCCL,
+torch.distributed's own stream -- never captured) while the next backward graph replays, the last one after it; the decoder-side parameters are updated (their own Adam graph) while the second bucket is
 still in flight, the encoder-side ones after it.
 
 A batch whose shapes differ from the captured ones (the ragged tail of an epoch) runs launch by launch.
@@ -60,11 +60,13 @@ class TrainStep(object):
         self.multi = ddp is not None and (ddp.world > 1 or ddp.force)
         self.split = ddp.bucket_split() if self.multi else None
         self.staged = self.split is not None
+        self.hsplit = ddp.head_split() if self.staged else None      # three buckets when the vocabulary projection is a tail
+        self.three = None                   # decided at the first step (needs model._cut_head of a fused-loss forward)
         self.grad_scale = ddp.grad_scale if self.multi else 1.0
         self.static = self.sig = None
         self.loss = None                    # device scalar: the last step's loss
         self.n_steps = 0
-        self.graphs = None                  # (front, encoder-side backward | None, adam | None)
+        self.graphs = None                  # (front, decoder-side backward | None, encoder-side backward | None, adam)
         self.count_delta = None
         self._hold = {}
 
@@ -72,11 +74,18 @@ class TrainStep(object):
     def _front(self, b):
         self.adam.zero_grad()
         loss = self.crit.get_loss(self.forward(b))
-        if self.staged:
+        if self.staged and self.three is None:
+            self.three = self.hsplit is not None and bool(getattr(self.model, '_cut_head', None))
+        if self.staged and self.three:
+            self._hold['hcut'], self._hold['hgrads'] = self.ddp.backward_head(loss)
+        elif self.staged:
             self._hold['cut'], self._hold['grads'] = self.ddp.backward_to_cut(loss)
         else:
             loss.backward()
         self.loss.copy_(loss.detach())
+
+    def _mid(self):
+        self._hold['cut'], self._hold['grads'] = self.ddp.backward_mid(self._hold['hcut'], self._hold['hgrads'])
 
     def _back(self):
         self.ddp.backward_from_cut(self._hold['cut'], self._hold['grads'])
@@ -90,23 +99,32 @@ class TrainStep(object):
         else:
             self.adam.step(grad_scale=self.grad_scale, lo=0, hi=self.split, bump=False)
 
-    def _reduce_around(self, second_stage, update_late, update_early):
-        """bucket 0 (decoder side) travels while the encoder's backward runs; its parameters are then updated while
-        bucket 1 (encoder side) travels"""
-        w1 = self.ddp.all_reduce_bucket(0)
-        second_stage()
-        w2 = self.ddp.all_reduce_bucket(1)
-        if w1 is not None:
-            w1.wait()
+    def _reduce_around(self, mid_stage, last_stage, update_late, update_early):
+        """Gradient buckets leave as soon as they are complete and travel (RCCL's own stream, in this order) under the
+        backward stages that follow: [vocabulary projection | under the decoder's backward,] decoder side | under the
+        encoder's backward, encoder side | under the Adam update of everything that has already landed."""
+        n = self.model.flat.grad.numel()
+        works = []
+        if self.three:
+            works.append(self.ddp.all_reduce_range(self.hsplit, n))
+            mid_stage()
+            works.append(self.ddp.all_reduce_range(self.split, self.hsplit))
+        else:
+            works.append(self.ddp.all_reduce_range(self.split, n))
+        last_stage()
+        w_last = self.ddp.all_reduce_range(0, self.split)
+        for w in works:
+            if w is not None:
+                w.wait()
         update_late()
-        if w2 is not None:
-            w2.wait()
+        if w_last is not None:
+            w_last.wait()
         update_early()
 
     def _eager(self, b):
         self._front(b)
         if self.staged:
-            self._reduce_around(self._back, lambda: self._update(0), lambda: self._update(1))
+            self._reduce_around(self._mid, self._back, lambda: self._update(0), lambda: self._update(1))
             self._hold.clear()
             return
         if self.multi:
@@ -128,8 +146,12 @@ class TrainStep(object):
                 self._front(self.static)
                 if not self.multi:
                     self._update()
-            back = upd = None
+            back = upd = mid = None
             if self.staged:                 # same memory pool: the autograd graph of `front` is still alive
+                if self.three:
+                    mid = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(mid, stream=side, pool=front.pool(), **mode):
+                        self._mid()
                 back = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(back, stream=side, pool=front.pool(), **mode):
                     self._back()
@@ -150,13 +172,13 @@ class TrainStep(object):
         # as the per-replay delta and undo them
         self.count_delta = [a - b for a, b in zip(self.crit._loss_cnt, before)]
         self.crit._loss_cnt = before
-        self.graphs = (front, back, upd)
+        self.graphs = (front, mid, back, upd)
 
     def _replay(self):
-        front, back, upd = self.graphs
+        front, mid, back, upd = self.graphs
         front.replay()
         if self.staged:
-            self._reduce_around(back.replay, upd[0].replay, upd[1].replay)
+            self._reduce_around(mid.replay if mid is not None else None, back.replay, upd[0].replay, upd[1].replay)
         else:
             if self.multi:
                 self.ddp.all_reduce_gradients()

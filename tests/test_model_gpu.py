@@ -446,3 +446,56 @@ def test_adam_in_two_parts_equals_one_launch(dev):
         outs.append((model.flat.data.clone(), int(optim._optimizer.step_dev)))
     assert outs[0][1] == outs[1][1] == 3
     assert torch.equal(outs[0][0], outs[1][0])
+
+
+@pytest.mark.parametrize("name", ["tiny_nacf_train", "tiny_nab_train"])
+def test_three_stage_backward_matches_single_pass(dev, name):
+    """runtime/ddp.py: backward in three stages (loss -> decoder output -> encoder outputs -> inputs), the boundaries of
+    the three gradient buckets: each stage completes exactly its own bucket and the total equals loss.backward()"""
+    import nacf_amd
+    from nacf_amd.misc.crit import get_criterion
+    from nacf_amd.runtime.ddp import DataParallel
+    from nacf_amd import synthetic as S
+    g = load_gold(name)
+    opt = dict(gold_opt(g), fused_loss=True)
+    b = gold_batch(g, dev)
+    tokens, labels = _tok_labels(opt, b)
+    grads = []
+    for staged in (False, True):
+        model = nacf_amd.get_model(opt)
+        model.load_state_dict(S.init_state_dict(opt, seed=0))
+        model.to(dev).train()
+        crit = get_criterion(model.opt)
+        ddp = DataParallel(model)
+        model.zero_grad()
+        res = model(feats=b["feats"], tgt_tokens=tokens, category=b["category"])
+        res["tgt_word_labels"] = labels
+        res["tgt_length"] = b["tgt_length"]
+        loss = crit.get_loss(res)
+        if staged:
+            s1, s2 = ddp.bucket_split(), ddp.head_split()
+            assert s1 is not None and s2 is not None and 0 < s1 < s2 < model.flat.total
+            assert model.flat.total - s2 == sum(p.numel() for p in model.tgt_word_prj.parameters())
+            G = model.flat.grad
+            hc, hg = ddp.backward_head(loss)
+            assert float(G[:s2].abs().max()) == 0.0 and float(G[s2:].abs().max()) > 0       # only the vocabulary projection
+            head = G[s2:].clone()
+            cut, gr = ddp.backward_mid(hc, hg)
+            assert float(G[:s1].abs().max()) == 0.0 and float(G[s1:s2].abs().max()) > 0 and torch.equal(head, G[s2:])
+            mid = G[s1:s2].clone()
+            ddp.backward_from_cut(cut, gr)
+            assert torch.equal(head, G[s2:]) and torch.equal(mid, G[s1:s2]) and float(G[:s1].abs().max()) > 0
+        else:
+            loss.backward()
+        grads.append(model.flat.grad.clone())
+    assert float((grads[0] - grads[1]).abs().max()) <= 1e-6 * float(grads[0].abs().max())
+
+
+def test_tied_weights_fall_back_to_two_buckets(dev):
+    import nacf_amd
+    from nacf_amd.runtime.ddp import DataParallel
+    g = load_gold("tiny_nab_variants_train")
+    opt = dict(gold_opt(g), fused_loss=True)
+    assert opt["tie_weights"]
+    model = nacf_amd.get_model(opt).to(dev)
+    assert DataParallel(model).head_split() is None
