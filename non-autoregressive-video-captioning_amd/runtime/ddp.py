@@ -4,7 +4,7 @@ torch.distributed (backend "nccl" IS RCCL on ROCm; "gloo" for the CPU tests).
 The reference has no distributed code at all; semantics here
 are "same as one process with the global batch": every rank holds a full
 replica, takes a contiguous shard of the global batch, and after backward the
-flat fp32 gradient buffer (73.8 MB for NACF/MSRVTT-shape; two buckets, see "Overlap" below) is
+flat fp32 gradient buffer (73.8 MB for NACF/MSRVTT-shape; two or three buckets, see "Overlap" below) is
 all-reduced (sum); the 1/world scale is folded into the fused Adam launch, so
 clip(+-5) follows the reduce exactly as misc/run.py:258-261 orders them.
 Per-rank losses are normalised by the LOCAL batch (misc/crit.py:40), so the
@@ -16,6 +16,9 @@ finishes the decoder side first.  `backward_to_cut` / `backward_from_cut` split 
 outputs; the all-reduce of the decoder-side bucket (61 of 74 MB) is launched between the two and runs on
 torch.distributed's own stream while the encoder's backward (~1 ms of GEMMs) executes.  xGMI is point-to-point, so
 at 2 GPUs a 74 MB ring step crosses ONE link: hiding it matters most at small N.
+With the fused vocabulary loss there is a third bucket: `backward_head` stops at the decoder's output
+(model._cut_head), at which point the vocabulary projection's gradients (the tail of the flat buffer, 21.6 MB) are
+complete and leave under the decoder's backward (`backward_mid`); runtime/engine.py drives the sequence.
 """
 import torch
 import torch.distributed as dist
