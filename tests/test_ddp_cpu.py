@@ -71,6 +71,18 @@ def _worker(rank, world, port, out):
     for w in works:
         w.wait()
     buckets_ok = bool(torch.equal(model.flat.grad, one_bucket)) and layout_ok
+    # three buckets: vocabulary projection (tail) | decoder side | encoder side, reduced as ranges
+    model.zero_grad()
+    for k, p in model.named_parameters():
+        p.grad.copy_(g[k])
+    hs = ddp.head_split()
+    head = {id(p) for p in model.head_parameters()}
+    head_ok = (hs is not None and split < hs < model.flat.total and
+               all((model.flat.offset[id(p)] >= hs) == (id(p) in head) for p in model.flat.params))
+    works = [ddp.all_reduce_range(hs, model.flat.total), ddp.all_reduce_range(split, hs), ddp.all_reduce_range(0, split)]
+    for w in works:
+        w.wait()
+    buckets_ok = buckets_ok and head_ok and bool(torch.equal(model.flat.grad, one_bucket))
     if rank == 0:
         full = _grads(sd, opt, batch, 0, G)
         err = max(float((reduced[k] - full[k]).abs().max()) for k in full)
@@ -92,7 +104,7 @@ def test_two_rank_gloo_allreduce_equals_global_batch_gradient():
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    assert all(r[0] for r in res), "replicas differ after broadcast, or the two-bucket all-reduce != the single bucket"
+    assert all(r[0] for r in res), "replicas differ after broadcast, or the two- / three-bucket all-reduce != the single bucket"
     assert sorted(r[1] for r in res) == [(0, 4), (4, 8)]
     assert max(r[2] for r in res) < 2e-6
 
