@@ -30,3 +30,21 @@ def test_bench_prints_one_contract_line(dev):
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["unit"] == "videos/s" and c["value"] > 0 and c["cores"] >= 1 and c["sample"]
     assert d["decode"]["captions_per_s"] > 100
+
+
+def test_multi_rank_launch_sequence_with_one_rank_group(dev):
+    """NACF_BENCH_FORCE_DIST=1 runs the N > 1 step (three backward graphs, bucketed RCCL all-reduces on their own stream,
+    Adam per bucket) with a 1-rank process group: it must capture, and train exactly like the single-graph step"""
+    def run(env_extra):
+        env = dict(os.environ, **env_extra)
+        out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "6", "--warmup", "2", "--no-compare",
+                              "--no-loader", "--no-decode", "--no-cpu-baseline"], capture_output=True, text=True,
+                             timeout=600, cwd=ROOT, env=env)
+        assert out.returncode == 0, out.stderr[-2000:]
+        return json.loads([l for l in out.stdout.strip().splitlines() if l.strip()][-1])
+    single = run({})
+    multi = run({"NACF_BENCH_FORCE_DIST": "1", "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": "29577"})
+    assert multi["config"]["hipgraph"] is True and multi["config"]["overlapped_allreduce"] is True
+    assert multi["config"]["gradient_buckets"] == 3 and single["config"]["gradient_buckets"] == 1
+    assert multi["final_loss"] == single["final_loss"]
+    assert multi["value"] > 0.8 * single["value"]
