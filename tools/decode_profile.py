@@ -8,7 +8,8 @@ from nacf_amd import synthetic as S
 dev = torch.device("cuda:0")
 opt = nacf_amd.opts.make_opt("NACF", "MSRVTT", with_category=True, max_len=20, vocab_size=10547, fused_loss=True)
 m = nacf_amd.get_model(opt); m.load_state_dict(S.init_state_dict(opt, 0)); m.to(dev).eval()
-b = S.synth_batch(opt, 128, 60, seed=1)
+B = int(os.environ.get('DECODE_BATCH', '128'))
+b = S.synth_batch(opt, B, 60, seed=1)
 feats = [f.to(dev) for f in b["feats"]]; cat = b["category"].to(dev)
 dopt = dict(m.opt); dopt.update(paradigm="mp", use_ct=True, iterations=5, length_beam_size=6, beam_alpha=1.35)
 tr = Translator(m, dopt, device=dev)
@@ -21,4 +22,5 @@ torch.cuda.synchronize(); t = time.perf_counter()
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 5
 for _ in range(n): once()
 torch.cuda.synchronize()
-print("ms per batch", (time.perf_counter() - t) / n * 1e3)
+dt = (time.perf_counter() - t) / n
+print("ms per batch", dt * 1e3, "captions/s", B / dt)
