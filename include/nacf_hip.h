@@ -173,6 +173,7 @@ int nacf_linear_bwd_weight(const float* dZ, int64_t lddz, const float* X, int64_
  * kind 0 = linear_fwd (also vocab_argmax), 1 = linear_bwd_data, 2 = linear_bwd_weight,
  * with the SAME (M, N, K) the entry point takes.  tile[0] = 128 or 64 (square
  * workgroup tile), splits[0] = number of reduce-dimension splits. */
+/* kind: 0 fwd, 1 dX, 2 dW; | 0x100: called with a live-row list; | 0x200: fwd with a transcendental activation */
 int nacf_gemm_config(int kind, int M, int N, int K, int* tile, int* splits);
 
 /* Backward of the fused epilogue: from dY produce dZ (grad of the pre-bias

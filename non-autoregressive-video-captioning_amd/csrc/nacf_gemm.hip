@@ -446,15 +446,17 @@ int nacf_debug_gemm_trace(void* buf) {     // tuning builds only (make trace); n
 int nacf_gemm_config(int kind, int M, int N, int K, int* tile, int* splits) {
   NACF_CHECK(tile && splits && M > 0 && N > 0 && K > 0, NACF_EINVAL, "nacf_gemm_config: bad argument");
   int t = 0, s = 1;
-  if (kind == 0) t = pick_tile(M, N, 1);
+  const bool with_rows = (kind & 0x100) != 0, heavy = (kind & 0x200) != 0;   // as the launch itself will see them
+  kind &= 0xff;
+  if (kind == 0) t = pick_tile(M, N, 1, with_rows, heavy);
   else if (kind == 1) {
-    s = bwd_data_splits(M, N, K, false);
+    s = bwd_data_splits(M, N, K, with_rows);
     const int kps = cdiv(cdiv(N, s), 16) * 16;
     s = cdiv(N, kps);
-    t = pick_tile(M, K, s);
+    t = pick_tile(M, K, s, with_rows);
   }
   else if (kind == 2) {
-    s = bwd_weight_splits(M, N, K, false, &t);
+    s = bwd_weight_splits(M, N, K, with_rows, &t);
     const int kps = cdiv(cdiv(M, s), 16) * 16;
     s = cdiv(M, kps);
   } else {
@@ -480,7 +482,7 @@ int nacf_vocab_argmax(const float* hidden, int64_t ldh, const float* W, int64_t 
   NACF_CHECK(ws && ws_bytes >= nacf_vocab_argmax_workspace(rows, V), NACF_EWORKSPACE,
              "nacf_vocab_argmax: workspace too small");
   NACF_CHECK(!rs || (rs->rows && rs->count), NACF_EINVAL, "nacf_vocab_argmax: incomplete row set");
-  const int tile = pick_tile(rows, V, 1);
+  const int tile = pick_tile(rows, V, 1, rs != nullptr);
   const int tn = cdiv(V, tile == 0 ? 128 : 64);
   EpiArgmax epi;
   epi.bias = bias;

@@ -72,21 +72,22 @@ class GemmProfiler:
         self.enabled = False
         self.records = []
 
-    def kernel_name(self, kind, M, N, K, epi):
+    def kernel_name(self, kind, M, N, K, epi, flags=0):
         tile, splits = ctypes.c_int(0), ctypes.c_int(0)
-        L.check(L.load().nacf_gemm_config(kind, M, N, K, ctypes.byref(tile), ctypes.byref(splits)), "nacf_gemm_config")
+        L.check(L.load().nacf_gemm_config(kind | flags, M, N, K, ctypes.byref(tile), ctypes.byref(splits)),
+                "nacf_gemm_config")
         q, p_ = self._LAYOUT[kind]
         self._last_splits = splits.value
         return "gemm_f32_kernel<%d, %d, 2, 2, %s, %s, true, %s>" % (tile.value, tile.value, q, p_, epi)
 
-    def begin(self, kind, M, N, K, epi, rows=None):
+    def begin(self, kind, M, N, K, epi, rows=None, heavy=False):
         if not self.enabled:
             return None
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         a.record()
         # kind 2 (dW: GEMM + split-K combine + bias column-sum) and EpiArgmax (GEMM + merge) spans hold
         # more than one kernel; only single-kernel spans are comparable with rocprof's per-kernel average
-        name = self.kernel_name(kind, M, N, K, epi)
+        name = self.kernel_name(kind, M, N, K, epi, (0x100 if rows is not None else 0) | (0x200 if heavy else 0))
         single = kind != 2 and epi != "EpiArgmax" and self._last_splits == 1
         return (name, (M, N, K), a, b, single, rows)
 
@@ -187,7 +188,9 @@ def linear_fwd(x: Tensor, w: Tensor, out: Tensor, epi: Optional[Epi] = None, row
     N, K2, ldw = _rows2d(w)
     assert K == K2 and out.shape == (M, N), (x.shape, w.shape, out.shape)
     ep = epi.cstruct() if epi is not None else L.Epilogue()
-    tok = PROFILER.begin(0, M, N, K, "EpiLinear", rows)
+    tok = PROFILER.begin(0, M, N, K, "EpiLinear", rows,
+                         heavy=epi is not None and epi.act in (L.ACT_GELU_NEW, L.ACT_GELU_ERF, L.ACT_TANH, L.ACT_SIGMOID,
+                                                               L.ACT_TANH_SIGMOID))
     L.check(L.load().nacf_linear_fwd(_ptr(x), ldx, _ptr(w), ldw, _ptr(out), out.stride(0), M, N, K,
                                      ctypes.byref(ep), _rs(rows, zero_dead), _stream()), "nacf_linear_fwd")
     PROFILER.end(tok)
