@@ -60,7 +60,11 @@ typedef struct ihipStream_t* nacf_stream_t; /* == hipStream_t */
 
 const char* nacf_last_error(void);
 int nacf_version(void);
-/* number of exported compute entry points (used by the loader self-check) */
+/* number of entry points this header declares (every `nacf_*` function below and above, the three bookkeeping ones
+ * included).  nacf_abi_count() returns the value the LIBRARY was built with; the ctypes loader
+ * (runtime/lib.py:load) refuses a library whose count differs from its own signature table, so a stale
+ * libnacf_hip.so next to a newer Python package fails at import time, not at the first missing symbol. */
+#define NACF_ABI_COUNT 60
 int nacf_abi_count(void);
 
 /* ---- batch construction (reference: dataloader.py) ----------------------------------------

@@ -130,6 +130,10 @@ def load() -> ctypes.CDLL:
             raise NacfLibraryError(f"{LIB_PATH} does not export {name}; rebuild the extension")
         fn.restype = res
         fn.argtypes = args
+    built = lib.nacf_abi_count()
+    if built != len(SIGNATURES):
+        raise NacfLibraryError(f"{LIB_PATH} was built with {built} entry points, this package binds {len(SIGNATURES)}: "
+                               "stale build, run `make -C non-autoregressive-video-captioning_amd/csrc`")
     _lib = lib
     return lib
 

@@ -18,3 +18,18 @@ def dev():
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
     return torch.device("cuda:0")
+
+
+# tuning / test knobs the library reads with getenv() on every call: a test may set them ONLY through monkeypatch
+# (restored afterwards).  A leaked value would silently change which kernels every later test exercises -- e.g. the
+# golden train / decode parity of test_model_gpu.py running on forced 128x128 tiles and not on the production
+# heuristic -- so every test starts by asserting that none of them is set.
+TUNING_ENV = ("NACF_GEMM_TILE", "NACF_GEMM_SPLITS", "NACF_GEMM_MODE", "NACF_ATTN_VALU", "NACF_ATTN_LDS", "NACF_ATTN_KB",
+              "NACF_ATTN_WPI", "NACF_HIP_LIB")
+
+
+@pytest.fixture(autouse=True)
+def _no_leaked_tuning_env():
+    leaked = [k for k in TUNING_ENV if k in os.environ]
+    assert not leaked, "tuning environment leaked into this test: %s" % leaked
+    yield

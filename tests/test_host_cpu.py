@@ -25,6 +25,9 @@ def test_library_exports_every_header_symbol():
     assert declared == set(lib.SIGNATURES), declared ^ set(lib.SIGNATURES)
     assert handle.nacf_version() >= 1
     assert handle.nacf_last_error() is not None
+    # the loader self-check: header macro == library's answer == number of declarations == ctypes table
+    macro = int(re.search(r"#define\s+NACF_ABI_COUNT\s+(\d+)", hdr).group(1))
+    assert macro == len(declared) == handle.nacf_abi_count() == len(lib.SIGNATURES)
 
 
 def test_no_cpu_fallback():

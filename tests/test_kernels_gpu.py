@@ -35,8 +35,7 @@ def err(a, b):
 def test_linear_fwd_plain(dev, M, N, K, tile, monkeypatch):
     ops, _ = _ops()
     x, w, b = rnd(M, K, seed=1), rnd(N, K, seed=2), rnd(N, seed=3)
-    import os
-    os.environ["NACF_GEMM_TILE"] = tile  # read once per process: exercised by running pytest twice (see README); harmless here
+    monkeypatch.setenv("NACF_GEMM_TILE", tile)   # read per call by the library; restored after the test
     y = torch.empty(M, N, device=dev)
     ops.linear_fwd(x.to(dev), w.to(dev), y, ops.Epi(bias=b.to(dev)))
     ref = x.double() @ w.double().t() + b.double()
@@ -837,3 +836,70 @@ def test_vocab_projection_with_fused_softmax_statistics(dev, rows, V, K):
     ops.xent_bwd_lse(logits, lse, logits, V, labels.to(dev), g, 1.0, skip_pad_rows=True)
     want = (torch.softmax(z_ref, 1) - torch.nn.functional.one_hot(labels, V).double()) * 0.37
     assert err(logits[keep.to(dev)], want[keep]) < 5e-6
+
+
+# ------------------------------------------------------------------ the exact GEMM shapes of the bench step (B=128)
+def _close64(got, ref, K, what):
+    """fp32 accumulation over K terms of O(1) data vs fp64"""
+    tol = 2e-6 * math.sqrt(K) * max(1.0, float(ref.abs().max()))
+    e = err(got, ref)
+    assert e < tol, (what, e, tol)
+
+
+def test_bench_shape_vocab_gemms_vs_fp64(dev):
+    """vocabulary projection at the bench shape (models/__init__.py:83; 2B*L = 5120 slots, V = 10547, D = 512, about
+    45 % of them labelled): forward logits + soft-max statistics, dX (reduce over V, split-K) and dW (reduce over the
+    live rows, split-K) against fp64 on the host, with the production tile / split heuristics"""
+    ops, _ = _ops()
+    M, V, K = 5120, 10547, 512
+    g = torch.Generator().manual_seed(0)
+    h, w = rnd(M, K, seed=1, scale=0.5), rnd(V, K, seed=2, scale=0.1)
+    labels = torch.randint(6, V, (M,), generator=g)
+    labels[torch.rand(M, generator=g) < 0.55] = PAD
+    live_idx = labels.ne(PAD).nonzero().squeeze(1)
+    hd, wd, ld = h.to(dev), w.to(dev), labels.to(dev)
+    live = ops.rowset_build(tokens=ld)
+    buf = torch.empty(M, ops.vocab_ld(V), device=dev)
+    logits = buf[:, :V]
+    lse, llp = torch.empty(M, device=dev), torch.empty(M, device=dev)
+    am = torch.empty(M, dtype=torch.int64, device=dev)
+    ops.vocab_lse_fwd(hd, wd, None, logits, ld, lse, am, llp, live)
+    ref = h[live_idx].double() @ w.double().t()
+    _close64(logits[live_idx.to(dev)], ref, K, "vocab fwd")
+    assert err(lse[live_idx.to(dev)], torch.logsumexp(ref, 1)) < 2e-5
+    # backward operands: a dense-looking dlogits on the live rows, garbage (NaN) on the dead ones -- never read
+    dz = torch.full((M, ops.vocab_ld(V)), float("nan"))
+    dzl = rnd(live_idx.numel(), V, seed=3, scale=0.01)
+    dz[live_idx, :V] = dzl
+    dzd = dz.to(dev)[:, :V]
+    dx = torch.empty(M, K, device=dev)
+    ops.linear_bwd_data(dzd, wd, dx, rows=live, zero_dead=True)
+    _close64(dx[live_idx.to(dev)], dzl.double() @ w.double(), V, "vocab dX")
+    dead = labels.eq(PAD).to(dev)
+    assert float(dx[dead].abs().max()) == 0.0
+    dw = torch.zeros(V, K, device=dev)
+    ops.linear_bwd_weight(dzd, hd, dw, None, beta=0.0, rows=live)
+    _close64(dw, dzl.double().t() @ h[live_idx].double(), live_idx.numel(), "vocab dW")
+
+
+@pytest.mark.parametrize("M,N,K,what", [(7680, 512, 2048, "encoder Linear (models/Encoder.py:62)"),
+                                        (15360, 1024, 512, "cross K|V of the memory (models/bert.py:146-148)"),
+                                        (7680, 1024, 512, "HighWay w1|w2 (models/Encoder.py:19-25)"),
+                                        (5120, 2048, 512, "FFN up (models/bert.py:227-230)"),
+                                        (5120, 512, 2048, "FFN down (models/bert.py:240-247)")])
+def test_bench_shape_linear_fwd_dx_dw_vs_fp64(dev, M, N, K, what):
+    """every dense Linear of the B=128 step at its real size: forward, dX and dW (+ bias gradient) vs fp64"""
+    ops, _ = _ops()
+    x, w, b = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=0.1), rnd(N, seed=3)
+    dz = rnd(M, N, seed=4, scale=0.05)
+    xd, wd, dzd = x.to(dev), w.to(dev), dz.to(dev)
+    y = torch.empty(M, N, device=dev)
+    ops.linear_fwd(xd, wd, y, ops.Epi(bias=b.to(dev)))
+    _close64(y, x.double() @ w.double().t() + b.double(), K, what + " fwd")
+    dx = torch.empty(M, K, device=dev)
+    ops.linear_bwd_data(dzd, wd, dx)
+    _close64(dx, dz.double() @ w.double(), N, what + " dX")
+    dw, db = torch.zeros(N, K, device=dev), torch.zeros(N, device=dev)
+    ops.linear_bwd_weight(dzd, xd, dw, db, beta=0.0)
+    _close64(dw, dz.double().t() @ x.double(), M, what + " dW")
+    _close64(db, dz.double().sum(0), M, what + " db")
