@@ -64,7 +64,7 @@ int nacf_version(void);
  * included).  nacf_abi_count() returns the value the LIBRARY was built with; the ctypes loader
  * (runtime/lib.py:load) refuses a library whose count differs from its own signature table, so a stale
  * libnacf_hip.so next to a newer Python package fails at import time, not at the first missing symbol. */
-#define NACF_ABI_COUNT 60
+#define NACF_ABI_COUNT 67
 int nacf_abi_count(void);
 
 /* ---- batch construction (reference: dataloader.py) ----------------------------------------
@@ -179,6 +179,55 @@ int nacf_linear_bwd_weight(const float* dZ, int64_t lddz, const float* X, int64_
  * workgroup tile), splits[0] = number of reduce-dimension splits. */
 /* kind: 0 fwd, 1 dX, 2 dW; | 0x100: called with a live-row list; | 0x200: fwd with a transcendental activation */
 int nacf_gemm_config(int kind, int M, int N, int K, int* tile, int* splits);
+
+/* ------------------------------------------------------------------------
+ * GEMM arithmetic mode and pre-split weight images (round 2)
+ * Every GEMM entry point above (and nacf_vocab_argmax / nacf_vocab_lse_fwd below) runs on one of:
+ *   NACF_GEMM_F32     v_mfma_f32_16x16x4_f32: exact fp32 products, 157 TFLOP/s peak
+ *   NACF_GEMM_BF16X3  v_mfma_f32_16x16x32_bf16 on an EXACT three-term bf16 split of every fp32 operand, six MFMAs
+ *                     per product block (dropped terms <= 2^-24 relative): fp32-accurate results -- same parity
+ *                     bars, bit-exact greedy tokens -- at up to 2.5 PFLOP/s / 6 = 417 TFLOP/s
+ *   NACF_GEMM_BF16    the same MFMA on operands rounded to bf16 (fp32 accumulate, fp32 master weights): the
+ *                     throughput mode of BASELINE.json configs[1]; logits within ~1e-2, tokens NOT bit-exact
+ * The mode is process-wide; the environment variable NACF_GEMM_MODE (f32 | bf16 | bf16x3) overrides it per call.
+ * Operands that are not 16-byte addressable fall back to the fp32 kernels.
+ * ---------------------------------------------------------------------- */
+#define NACF_GEMM_F32 0
+#define NACF_GEMM_BF16 1
+#define NACF_GEMM_BF16X3 3
+#define NACF_GEMM_DEFAULT_MODE NACF_GEMM_F32
+int nacf_gemm_set_mode(int mode);
+int nacf_gemm_get_mode(void);
+/* template name of the GEMM kernel the calling thread launched last (matches rocprofv3's kernel names) */
+const char* nacf_gemm_last_kernel(void);
+
+/* Weight images.  A weight matrix is the P operand of its forward GEMM (y = x W^T) and, transposed, of its dX GEMM
+ * (dX = dZ W), for every row tile of both: in the bf16 modes it is converted / split ONCE per optimiser step into
+ * bf16 image planes (ns = 1 or 3 planes, `plane_elems` elements apart) and the GEMMs copy those:
+ *   nacf_wimage_register   : [w_base, w_base + n_elems) (a model's flat fp32 parameter buffer) has row-major image
+ *                            planes at img_base with IDENTICAL element offsets: any W inside the range with
+ *                            ldw % 8 == 0 and an offset % 8 == 0 is found by address;
+ *   nacf_wimage_register_t : the matrix W [N, K] (row pitch ldw) has the transposed image imgT [K, ldt], ldt % 8 == 0,
+ *                            pad columns n >= N zero (found by exact address / shape);
+ *   nacf_wimage_unregister : forget every image whose fp32 source starts inside [w_base, w_base + n_elems);
+ *   nacf_wimage_refresh    : rebuild the images listed in a DEVICE table of descriptors from the current fp32 values
+ *                            (one launch, n_tiles = sum of ceil(N/32)*ceil(K/32) workgroups; capturable).
+ * Registration is host-side bookkeeping only; the caller owns all buffers and must refresh after changing weights
+ * (models/seq2seq.py does so at every forward entry). */
+typedef struct nacf_wimage_desc {
+  const float* w;        /* [N, ld] fp32 source */
+  uint16_t* img;         /* [ns][N, ldi] or NULL */
+  uint16_t* imgT;        /* [ns][K, ldt] or NULL */
+  int64_t ld, ldi, ldt, plane, planeT;
+  int32_t N, K;
+  int32_t tile0;         /* index of this matrix' first 32x32 tile in the launch */
+  int32_t tiles_k;       /* ceil(K / 32) */
+} nacf_wimage_desc;
+int nacf_wimage_register(const float* w_base, int64_t n_elems, const uint16_t* img_base, int64_t plane_elems, int ns);
+int nacf_wimage_register_t(const float* w, int N, int K, int64_t ldw, const uint16_t* imgT, int64_t ldt,
+                           int64_t plane_elems, int ns);
+int nacf_wimage_unregister(const float* w_base, int64_t n_elems);
+int nacf_wimage_refresh(const nacf_wimage_desc* table, int n_desc, int n_tiles, int ns, nacf_stream_t stream);
 
 /* Backward of the fused epilogue: from dY produce dZ (grad of the pre-bias
  * GEMM output) and, when ep->residual != NULL, dR (+= when accumulate_dR).

@@ -1,0 +1,548 @@
+// GEMMs on the CDNA4 bf16 matrix cores (v_mfma_f32_16x16x32_bf16, fp32 accumulate) with the SAME operand
+// conventions, row-set handling, split-K and fused epilogues as gemm_f32.hpp:
+//
+//   C[m][n] = sum_k Qop[m][k] * Pop[n][k]
+//
+// The fp32 MFMA of gemm_f32.hpp runs at the fp32 VECTOR rate (157 TFLOP/s); the bf16 MFMA is 16x faster per
+// instruction.  Two ways of using it, selected per launch (template parameter NS = number of bf16 terms an fp32
+// operand is split into):
+//
+//   NS = 1  "throughput": operands rounded to bf16 (RNE), fp32 accumulate.  One MFMA per 16x16x32 block.
+//   NS = 3  "exact":      every fp32 operand x is split EXACTLY into three bf16 terms x = h + m + l
+//                         (h = bf16(x), m = bf16(x - h), l = bf16(x - h - m); 3 x 8 significand bits = the 24 of fp32)
+//                         and the product block is formed from the six largest cross terms
+//                             Pl*Qh + Ph*Ql + Pm*Qm + Pm*Qh + Ph*Qm + Ph*Qh          (small terms first)
+//                         accumulated in fp32.  The three dropped terms are <= 2^-24 of the product, i.e. at fp32
+//                         round-off: measured error against fp64 is at or below the fp32-MFMA kernel's (tests), and
+//                         greedy NA-decode tokens stay bit-exact against the reference.  6 MFMAs per block:
+//                         2.5 PFLOP/s / 6 = 417 TFLOP/s of fp32-accurate product rate vs 157 on the fp32 MFMA.
+//
+// Operand sources (compile time, per operand):
+//   SRC_F32_KC   fp32, reduce-dim contiguous  (activations x, dZ)          -> converted / split while staging
+//   SRC_F32_MC   fp32, row-dim contiguous     (both operands of dW)        -> 4x4 register transpose + convert
+//   SRC_BF16_KC  bf16 image(s) of a weight matrix, reduce-dim contiguous   -> copied (no VALU work).  The images
+//                (W for the forward GEMM, W^T for dX) are rebuilt from the fp32 master weights once per step
+//                (nacf_wimage_refresh): weights are reused by every row tile and by forward AND backward, so
+//                they are split once, not once per tile.
+//
+// LDS always holds bf16, K-contiguous: a plane is [rows][32 k] = 64-byte rows, 16-byte chunks XOR-swizzled with
+// lds_sw(row) exactly as the KC tiles of gemm_f32.hpp (same geometry: conflict-free ds_read_b128 fragments,
+// conflict-free ds_write_b128 staging).  A fragment (row = lane & 15, k-chunk = lane >> 4) is ONE ds_read_b128
+// per split plane and feeds one K = 32 MFMA.  The MFMA is issued swapped (a = P fragment, b = Q fragment) so the
+// accumulator map equals the KC/KC map of gemm_f32.hpp and its epilogues (EpiLinear / EpiStore / EpiArgmax) are
+// reused unchanged.
+//
+// Pipeline: global -> registers one k-tile ahead, registers -> LDS (convert / split here, once per element),
+// LDS -> fragments -> MFMA.  STAGES = 2 LDS images (one barrier per k-tile) where they fit; the exact mode's
+// 128x128 tile (48 KB per image) uses one image and two barriers -- a k-tile there is 96 MFMAs per wave, and two
+// to three workgroups per CU cover each other's barriers.
+#pragma once
+#include "gemm_f32.hpp"
+
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+
+enum : int { SRC_F32_KC = 0, SRC_F32_MC = 1, SRC_BF16_KC = 2 };
+
+// two fp32 -> packed bf16 pair (a in the low half), round-to-nearest-even: v_cvt_pk_bf16_f32
+__device__ __forceinline__ uint32_t bf16_pack_rne(float a, float b) {
+  bf16x2_t r = __builtin_convertvector(f32x2_t{a, b}, bf16x2_t);
+  return __builtin_bit_cast(uint32_t, r);
+}
+__device__ __forceinline__ float bf16_lo_f32(uint32_t p) { return __uint_as_float(p << 16); }
+__device__ __forceinline__ float bf16_hi_f32(uint32_t p) { return __uint_as_float(p & 0xffff0000u); }
+
+// (a, b) -> NS packed bf16 pairs whose sum is (a, b): exactly for NS = 3, to 2^-9 / 2^-17 relative for NS = 1 / 2.
+// The residuals a - bf16(a) are exact in fp32 (Sterbenz), so the terms are the successive bf16 roundings.
+template <int NS>
+__device__ __forceinline__ void bf16_split2(float a, float b, uint32_t (&w)[NS]) {
+  w[0] = bf16_pack_rne(a, b);
+  if constexpr (NS > 1) {
+    a -= bf16_lo_f32(w[0]);
+    b -= bf16_hi_f32(w[0]);
+    w[1] = bf16_pack_rne(a, b);
+  }
+  if constexpr (NS > 2) {
+    a -= bf16_lo_f32(w[1]);
+    b -= bf16_hi_f32(w[1]);
+    w[2] = bf16_pack_rne(a, b);
+  }
+}
+
+// ---------------------------------------------------------------- staging: global -> registers -> LDS planes
+// An LDS plane of R rows is R*4 16-byte chunks: chunk (row, c) at plane[row * 4 + (c ^ lds_sw(row))].
+
+// fp32, k-contiguous rows: thread unit = (row, 8-k chunk), two float4 loads, one ds_write_b128 per plane
+template <int R, int NS>
+struct StageF32KC {
+  static constexpr int U = R / 64;
+  f32x4 v[U][2];
+  const float* ptr[U];   // (clamped) physical row base + 8 * chunk
+  bool ok[U];            // row inside the matrix
+  __device__ __forceinline__ void init(const float* base, int64_t ld, int r0, int rmax, const int* rowlist, int tid) {
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int q = tid + 256 * u;
+      const int gr = r0 + (q >> 2);
+      const int gc = min(gr, rmax - 1);
+      const int ph = rowlist ? rowlist[gc] : gc;
+      ok[u] = gr < rmax;
+      ptr[u] = base + (int64_t)ph * ld + (q & 3) * 8;
+    }
+  }
+  __device__ __forceinline__ void load_fast(int k0) {
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      v[u][0] = *reinterpret_cast<const f32x4*>(ptr[u] + k0);
+      v[u][1] = *reinterpret_cast<const f32x4*>(ptr[u] + k0 + 4);
+    }
+  }
+  __device__ __forceinline__ void load_checked(int k0, int kend, int tid) {
+    const int c = tid & 3;
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int nv = kend - (k0 + 8 * c + 4 * h);
+        f32x4 t = {0.f, 0.f, 0.f, 0.f};
+        if (ok[u] && nv > 0) {
+          const float* p = ptr[u] + k0 + 4 * h;
+          if (nv >= 4) t = *reinterpret_cast<const f32x4*>(p);
+          else {
+            t[0] = p[0];
+            if (nv > 1) t[1] = p[1];
+            if (nv > 2) t[2] = p[2];
+          }
+        }
+        v[u][h] = t;
+      }
+  }
+  __device__ __forceinline__ void write(uint4* plane0, int tid) const {
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int q = tid + 256 * u;
+      const int row = q >> 2, c = q & 3;
+      uint32_t w0[NS], w1[NS], w2[NS], w3[NS];
+      bf16_split2<NS>(v[u][0][0], v[u][0][1], w0);
+      bf16_split2<NS>(v[u][0][2], v[u][0][3], w1);
+      bf16_split2<NS>(v[u][1][0], v[u][1][1], w2);
+      bf16_split2<NS>(v[u][1][2], v[u][1][3], w3);
+#pragma unroll
+      for (int p = 0; p < NS; ++p) plane0[p * (R * 4) + row * 4 + (c ^ lds_sw(row))] = uint4{w0[p], w1[p], w2[p], w3[p]};
+    }
+  }
+};
+
+// fp32, row-contiguous (the reduce index walks the matrix ROWS, optionally through `kmap`): thread unit = 4 rows x
+// 4 k, four float4 loads (one per k), a 4x4 transpose in registers, one ds_write_b64 per row per plane.
+// unit = (rq = row quad, mq = k quad) with mq fastest: a wave's 64 lanes read 8 k-rows x 128 contiguous bytes.
+// ROT rotates the thread -> unit map by 128 threads (R = 64 has 128 units: the second operand goes to waves 2-3).
+template <int R, int NS, int ROT>
+struct StageF32MC {
+  static constexpr int UNITS = R * 2;
+  f32x4 v[4];
+  int kidx[4];           // physical k rows of the NEXT tile to load (prefetched when a kmap is given)
+  const float* ptr;      // base + r0 + 4 * rq
+  int rq, mq, nvalid;
+  bool active;
+  __device__ __forceinline__ void init(const float* base, int r0, int rmax, int tid) {
+    const int unit = (tid + ROT) & 255;
+    active = unit < UNITS;
+    mq = unit & 7;
+    rq = unit >> 3;
+    ptr = base + r0 + 4 * rq;
+    nvalid = min(4, max(0, rmax - (r0 + 4 * rq)));
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { v[j] = f32x4{0.f, 0.f, 0.f, 0.f}; kidx[j] = 0; }
+  }
+  __device__ __forceinline__ void load_kidx(int k0, int kmax, const int* __restrict__ kmap) {
+    if (kmap && active) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) kidx[j] = kmap[min(k0 + 4 * mq + j, kmax - 1)];
+    }
+  }
+  // interior k-tile of a fully populated row tile; idx_ready: kidx holds this tile's rows
+  __device__ __forceinline__ void load_fast(int k0, int64_t ld, const int* __restrict__ kmap, bool idx_ready) {
+    if (active) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int gk = k0 + 4 * mq + j;
+        const int pk = kmap ? (idx_ready ? kidx[j] : kmap[gk]) : gk;
+        v[j] = *reinterpret_cast<const f32x4*>(ptr + (int64_t)pk * ld);
+      }
+    }
+  }
+  __device__ __forceinline__ void load_checked(int k0, int kend, int64_t ld, const int* __restrict__ kmap) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int gk = k0 + 4 * mq + j;
+      f32x4 t = {0.f, 0.f, 0.f, 0.f};
+      if (active && gk < kend && nvalid > 0) {
+        const int pk = kmap ? kmap[gk] : gk;
+        const float* p = ptr + (int64_t)pk * ld;
+        if (nvalid == 4) t = *reinterpret_cast<const f32x4*>(p);
+        else {
+          t[0] = p[0];
+          if (nvalid > 1) t[1] = p[1];
+          if (nvalid > 2) t[2] = p[2];
+        }
+      }
+      v[j] = t;
+    }
+  }
+  __device__ __forceinline__ void write(uint4* plane0) const {
+    if (active) {
+      uint2* p8 = reinterpret_cast<uint2*>(plane0);
+      const int c = mq >> 1, half = mq & 1;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int row = 4 * rq + e;
+        uint32_t wa[NS], wb[NS];
+        bf16_split2<NS>(v[0][e], v[1][e], wa);
+        bf16_split2<NS>(v[2][e], v[3][e], wb);
+#pragma unroll
+        for (int p = 0; p < NS; ++p) p8[(p * (R * 4) + row * 4 + (c ^ lds_sw(row))) * 2 + half] = uint2{wa[p], wb[p]};
+      }
+    }
+  }
+};
+
+// bf16 image planes, k-contiguous rows: copied
+template <int R, int NS>
+struct StageBF16KC {
+  static constexpr int U = R / 64;
+  uint4 v[U][NS];
+  const unsigned short* ptr[U];
+  bool ok[U];
+  __device__ __forceinline__ void init(const unsigned short* img, int64_t ld, int r0, int rmax, int tid) {
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int q = tid + 256 * u;
+      const int gr = r0 + (q >> 2);
+      ok[u] = gr < rmax;
+      ptr[u] = img + (int64_t)min(gr, rmax - 1) * ld + (q & 3) * 8;
+    }
+  }
+  __device__ __forceinline__ void load_fast(int k0, int64_t plane) {
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+#pragma unroll
+      for (int p = 0; p < NS; ++p) v[u][p] = *reinterpret_cast<const uint4*>(ptr[u] + p * plane + k0);
+  }
+  // images are padded so that a chunk is either wholly inside the reduce range or wholly outside (K % 8 == 0)
+  __device__ __forceinline__ void load_checked(int k0, int kend, int64_t plane, int tid) {
+    const bool in = k0 + 8 * (tid & 3) < kend;
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+#pragma unroll
+      for (int p = 0; p < NS; ++p)
+        v[u][p] = (ok[u] && in) ? *reinterpret_cast<const uint4*>(ptr[u] + p * plane + k0) : uint4{0u, 0u, 0u, 0u};
+  }
+  __device__ __forceinline__ void write(uint4* plane0, int tid) const {
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int q = tid + 256 * u;
+      const int row = q >> 2, c = q & 3;
+#pragma unroll
+      for (int p = 0; p < NS; ++p) plane0[p * (R * 4) + row * 4 + (c ^ lds_sw(row))] = v[u][p];
+    }
+  }
+};
+
+template <int SRC, int R, int NS, int ROT> struct StagerOf;
+template <int R, int NS, int ROT> struct StagerOf<SRC_F32_KC, R, NS, ROT> { using type = StageF32KC<R, NS>; };
+template <int R, int NS, int ROT> struct StagerOf<SRC_F32_MC, R, NS, ROT> { using type = StageF32MC<R, NS, ROT>; };
+template <int R, int NS, int ROT> struct StagerOf<SRC_BF16_KC, R, NS, ROT> { using type = StageBF16KC<R, NS>; };
+
+__device__ __forceinline__ bf16x8_t lds_frag(const uint4* plane, int row, int g) {
+  return __builtin_bit_cast(bf16x8_t, plane[row * 4 + (g ^ lds_sw(row))]);
+}
+
+// ---------------------------------------------------------------- kernel
+template <int BM, int BN, int QSRC, int PSRC, int NS, int STAGES, class Epi>
+__global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmShape g, Epi epi) {
+  constexpr int BK = 32;
+  constexpr int WM = 2, WN = 2;
+  constexpr int WTM = BM / WM, WTN = BN / WN;
+  constexpr int TM = WTM / 16, TN = WTN / 16;
+  constexpr bool QKC = QSRC != SRC_F32_MC, PKC = PSRC != SRC_F32_MC;
+  constexpr bool ROWS_ARE_K = !QKC && !PKC;
+  static_assert(QSRC != SRC_BF16_KC, "the Q operand is an activation (fp32)");
+  static_assert(QKC || !PKC, "layouts: NT (KC, KC), NN via a transposed image (KC, KC), NN (KC, MC), TN (MC, MC)");
+  static_assert(NS == 1 || NS == 3, "1 = bf16 throughput, 3 = exact fp32 split");
+  static_assert(BM % 64 == 0 && BN % 64 == 0, "stager granularity");
+  constexpr int QPL = BM * 4, PPL = BN * 4;            // 16-byte chunks per plane
+  constexpr int STAGE = NS * (QPL + PPL);
+  constexpr int RED = Epi::kArgmax ? (3 * WN * BM + 3) / 4 : (BM + 3) / 4;   // epilogue scratch (floats -> chunks)
+  constexpr int SMEM = (STAGES * STAGE > RED) ? STAGES * STAGE : RED;
+  __shared__ uint4 smem[SMEM];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+  const int li = lane & 15, lg = lane >> 4;
+
+  // live-row list: NT / NN bound the row walk, TN bounds the reduce walk (see gemm_f32.hpp)
+  int Meff = g.M, Keff = g.K;
+  if (g.count) {
+    const int c = *g.count;
+    if (ROWS_ARE_K) Keff = min(Keff, c);
+    else Meff = min(Meff, c);
+  }
+  const int tiles_m_live = (Meff + BM - 1) / BM;
+  const int nwg = tiles_m_live * g.tiles_n;
+  const int bid = blockIdx.x;
+  if (bid >= nwg) {
+    // workgroups past the live tiles zero-fill the dead rows of the output (nacf_rowset.zero_dead)
+    if constexpr (!ROWS_ARE_K) {
+      if (g.zero_dead && g.rows && blockIdx.z == 0) {
+        const int dt = bid - nwg;
+        const int j0 = (dt / g.tiles_n) * BM, c0 = (dt % g.tiles_n) * BN;
+        const int n_dead = g.M - Meff;
+        for (int q = tid; q < BM * (BN / 4); q += 256) {
+          const int j = j0 + q / (BN / 4), n = c0 + (q % (BN / 4)) * 4;
+          if (j < n_dead && n < g.N) epi.zero4(g.rows[Meff + j], n, g.N);
+        }
+      }
+    }
+    return;
+  }
+  // XCD-aware bijective tile order over the LIVE tiles (n fastest inside an XCD's contiguous run)
+  const int xq = nwg >> 3, xr = nwg & 7;
+  const int xcd = bid & 7, slot = bid >> 3;
+  const int logical = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + slot;
+  const int tile_m = logical / g.tiles_n, tile_n = logical % g.tiles_n;
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+
+  const int z = blockIdx.z;
+  int kps = g.k_per_split;
+  if (ROWS_ARE_K && g.count && gridDim.z > 1) {
+    kps = (((Keff + (int)gridDim.z - 1) / (int)gridDim.z) + BK - 1) / BK * BK;   // re-balance over the LIVE rows
+    if (kps < BK) kps = BK;
+  }
+  const int kbeg = z * kps;
+  const int kend = min(Keff, kbeg + kps);
+  const int nk = kend > kbeg ? (kend - kbeg + BK - 1) / BK : 0;
+  const int* kmap = ROWS_ARE_K ? g.rows : nullptr;
+
+  typename StagerOf<QSRC, BM, NS, 0>::type qs;
+  typename StagerOf<PSRC, BN, NS, (BN == 64 ? 128 : 0)>::type ps;
+  if constexpr (QSRC == SRC_F32_KC) qs.init(g.Q, g.ldq, m0, Meff, g.rows, tid);
+  else qs.init(g.Q, m0, g.M, tid);
+  if constexpr (PSRC == SRC_F32_KC) ps.init(g.P, g.ldp, n0, g.N, nullptr, tid);
+  else if constexpr (PSRC == SRC_F32_MC) ps.init(g.P, n0, g.N, tid);
+  else ps.init(g.Pimg, g.ldpi, n0, g.N, tid);
+  // row-contiguous operands take the unchecked loader only when the whole row tile is inside the matrix
+  const bool q_full = QKC || (m0 + BM <= g.M);
+  const bool p_full = PKC || (n0 + BN <= g.N);
+  const bool rows_full = q_full && p_full;
+
+  auto load_tile = [&](int kt, bool idx_ready) {
+    const int k0 = kbeg + kt * BK;
+    const bool fast = rows_full && (k0 + BK <= kend);
+    if constexpr (QSRC == SRC_F32_KC) { if (fast) qs.load_fast(k0); else qs.load_checked(k0, kend, tid); }
+    else { if (fast) qs.load_fast(k0, g.ldq, kmap, idx_ready); else qs.load_checked(k0, kend, g.ldq, kmap); }
+    if constexpr (PSRC == SRC_F32_KC) { if (fast) ps.load_fast(k0); else ps.load_checked(k0, kend, tid); }
+    else if constexpr (PSRC == SRC_F32_MC) { if (fast) ps.load_fast(k0, g.ldp, kmap, idx_ready); else ps.load_checked(k0, kend, g.ldp, kmap); }
+    else { if (fast) ps.load_fast(k0, g.pimg_plane); else ps.load_checked(k0, kend, g.pimg_plane, tid); }
+  };
+  auto prefetch_kidx = [&](int kt) {      // reduce-row indices of tile kt (row-list dW), one tile ahead of its loads
+    if constexpr (ROWS_ARE_K) {
+      if (kmap && kt < nk) {
+        qs.load_kidx(kbeg + kt * BK, Keff, kmap);
+        ps.load_kidx(kbeg + kt * BK, Keff, kmap);
+      }
+    }
+  };
+  const bool do_colsum = ROWS_ARE_K && (g.colsum_part || g.colsum_out) && tile_n == 0;
+  f32x4 qsum = {0.f, 0.f, 0.f, 0.f};
+  auto write_tile = [&](int stage) {
+    uint4* base = smem + stage * STAGE;
+    if constexpr (QSRC == SRC_F32_KC) qs.write(base, tid);
+    else {
+      qs.write(base);
+      if (do_colsum) qsum += (qs.v[0] + qs.v[1]) + (qs.v[2] + qs.v[3]);   // every k-tile is written exactly once
+    }
+    if constexpr (PSRC == SRC_F32_MC) ps.write(base + NS * QPL);
+    else ps.write(base + NS * QPL, tid);
+  };
+
+  f32x4 acc[TM][TN];
+#pragma unroll
+  for (int a = 0; a < TM; ++a)
+#pragma unroll
+    for (int b = 0; b < TN; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  auto compute = [&](int stage) {
+    const uint4* qpl = smem + stage * STAGE;
+    const uint4* ppl = qpl + NS * QPL;
+    bf16x8_t pf[TN][NS];
+#pragma unroll
+    for (int b = 0; b < TN; ++b)
+#pragma unroll
+      for (int p = 0; p < NS; ++p) pf[b][p] = lds_frag(ppl + p * PPL, wn * WTN + b * 16 + li, lg);
+#pragma unroll
+    for (int a = 0; a < TM; ++a) {
+      bf16x8_t qf[NS];
+#pragma unroll
+      for (int p = 0; p < NS; ++p) qf[p] = lds_frag(qpl + p * QPL, wm * WTM + a * 16 + li, lg);
+      if constexpr (NS == 1) {
+#pragma unroll
+        for (int b = 0; b < TN; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pf[b][0], qf[0], acc[a][b], 0, 0, 0);
+      } else {
+        // six cross terms, smallest first; the same accumulator comes back after TN MFMAs
+#pragma unroll
+        for (int b = 0; b < TN; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pf[b][2], qf[0], acc[a][b], 0, 0, 0);
+#pragma unroll
+        for (int b = 0; b < TN; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pf[b][0], qf[2], acc[a][b], 0, 0, 0);
+#pragma unroll
+        for (int b = 0; b < TN; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pf[b][1], qf[1], acc[a][b], 0, 0, 0);
+#pragma unroll
+        for (int b = 0; b < TN; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pf[b][1], qf[0], acc[a][b], 0, 0, 0);
+#pragma unroll
+        for (int b = 0; b < TN; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pf[b][0], qf[1], acc[a][b], 0, 0, 0);
+#pragma unroll
+        for (int b = 0; b < TN; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pf[b][0], qf[0], acc[a][b], 0, 0, 0);
+      }
+    }
+  };
+
+  // ---- pipeline: G(t) global -> registers, W(t) registers -> LDS image (convert / split), C(t) fragments + MFMAs
+  if (nk > 0) {
+    load_tile(0, false);
+    prefetch_kidx(1);
+    write_tile(0);
+    if (nk > 1) { load_tile(1, true); prefetch_kidx(2); }
+  }
+  __syncthreads();
+#pragma nounroll
+  for (int kt = 0; kt < nk; ++kt) {
+    if constexpr (STAGES == 2) {
+      // W(kt+1) goes into the image C(kt-1) read (a barrier ago); G(kt+2) has all of C(kt) to land
+      if (kt + 1 < nk) write_tile((kt + 1) & 1);
+      if (kt + 2 < nk) { load_tile(kt + 2, true); prefetch_kidx(kt + 3); }
+      compute(kt & 1);
+      __syncthreads();
+    } else {
+      compute(0);
+      __syncthreads();
+      if (kt + 1 < nk) {
+        write_tile(0);
+        if (kt + 2 < nk) { load_tile(kt + 2, true); prefetch_kidx(kt + 3); }
+      }
+      __syncthreads();
+    }
+  }
+
+  if constexpr (ROWS_ARE_K) {
+    if (do_colsum) {
+      // db[n] = sum_m dZ[m][n]: the thread of unit (rq, mq) holds the sums of rows 4rq..4rq+3 over its k quads;
+      // the 8 lanes of a row quad sit in one wave, so a 3-step butterfly finishes it (fixed order: deterministic)
+#pragma unroll
+      for (int o = 1; o < 8; o <<= 1) {
+        qsum[0] += __shfl_xor(qsum[0], o, 64); qsum[1] += __shfl_xor(qsum[1], o, 64);
+        qsum[2] += __shfl_xor(qsum[2], o, 64); qsum[3] += __shfl_xor(qsum[3], o, 64);
+      }
+      float* red = reinterpret_cast<float*>(smem);   // [BM]; the tile images are dead after the loop's last barrier
+      if (qs.active && qs.mq == 0) *reinterpret_cast<f32x4*>(&red[4 * qs.rq]) = qsum;
+      __syncthreads();
+      if (tid < BM) {
+        const int m = m0 + tid;
+        if (m < g.M) {
+          const float t = red[tid];
+          if (g.colsum_out) g.colsum_out[m] = (g.colsum_beta != 0.f) ? t + g.colsum_beta * g.colsum_out[m] : t;
+          else g.colsum_part[(int64_t)z * g.M + m] = t;
+        }
+      }
+    }
+  }
+
+  // ---- accumulator map (= the KC / KC map of gemm_f32.hpp): acc[a][b][e] is row a*16 + li, column b*16 + lg*4 + e
+  int mlog[TM], ncol[TN];
+#pragma unroll
+  for (int a = 0; a < TM; ++a) mlog[a] = m0 + wm * WTM + a * 16 + li;
+#pragma unroll
+  for (int j = 0; j < TN; ++j) ncol[j] = n0 + wn * WTN + j * 16 + lg * 4;
+  if constexpr (!Epi::kArgmax) {
+    int mphys[TM];
+#pragma unroll
+    for (int a = 0; a < TM; ++a) mphys[a] = (g.rows && !ROWS_ARE_K && mlog[a] < Meff) ? g.rows[mlog[a]] : mlog[a];
+    if (epi.fast_ok() && m0 + BM <= Meff && n0 + BN <= g.N) epi.template tile_fast<TM, TN, true>(acc, mphys, ncol, g.N, z);
+    else epilogue_all<0, TM, TN, true, Epi>(epi, acc, mlog, mphys, ncol, Meff, g.N, z);
+  } else {
+    argmax_epilogue<BM, BN, WM, WN, TM, TN>(reinterpret_cast<float*>(smem), g, epi, acc, m0, n0, Meff, tile_n, wm, wn, li, lg, tid);
+  }
+}
+
+// ---------------------------------------------------------------- weight images
+// One launch rebuilds every registered image from the fp32 master weights: for matrix i (N x K, row pitch ld),
+//   img [s][n * ldi + k]  = bf16 term s of W[n][k]        (forward:  P = W,   reduce over k)
+//   imgT[s][k * ldt + n]  = bf16 term s of W[n][k]        (dX:       P = W^T, reduce over n; pad columns n >= N are 0)
+// A workgroup converts one 32 x 32 tile; the transposed copy goes through LDS so both stores are row-contiguous.
+typedef nacf_wimage_desc WImageDesc;   // include/nacf_hip.h
+
+template <int NS>
+__global__ __launch_bounds__(256) void wimage_refresh_kernel(const WImageDesc* __restrict__ descs, int n_desc) {
+  __shared__ unsigned short tile[NS][32][36];     // 72-byte rows: 8-byte aligned quads, 18-dword stride spreads banks
+  // binary search of the descriptor that owns this workgroup
+  int lo = 0, hi = n_desc - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (descs[mid].tile0 <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
+  }
+  const WImageDesc d = descs[lo];
+  const int t = blockIdx.x - d.tile0;
+  const int n0 = (t / d.tiles_k) * 32, k0 = (t % d.tiles_k) * 32;
+  const int r = threadIdx.x >> 3, c4 = (threadIdx.x & 7) * 4;     // 32 rows x 8 column quads
+  const int n = n0 + r, k = k0 + c4;
+  float x[4] = {0.f, 0.f, 0.f, 0.f};
+  if (n < d.N) {
+    const float* src = d.w + (int64_t)n * d.ld + k;
+    if (k + 4 <= d.K && (d.ld & 3) == 0 && (reinterpret_cast<uintptr_t>(d.w) & 15) == 0) {
+      const f32x4 v = *reinterpret_cast<const f32x4*>(src);
+      x[0] = v[0]; x[1] = v[1]; x[2] = v[2]; x[3] = v[3];
+    } else {
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        if (k + e < d.K) x[e] = src[e];
+    }
+  }
+  uint32_t w0[NS], w1[NS];
+  bf16_split2<NS>(x[0], x[1], w0);
+  bf16_split2<NS>(x[2], x[3], w1);
+#pragma unroll
+  for (int p = 0; p < NS; ++p) {
+    if (d.img && n < d.N) {
+      unsigned short* dst = d.img + p * d.plane + (int64_t)n * d.ldi + k;
+      if (k + 4 <= d.ldi && (d.ldi & 3) == 0 && (reinterpret_cast<uintptr_t>(d.img) & 7) == 0 && (d.plane & 3) == 0)
+        *reinterpret_cast<uint2*>(dst) = uint2{w0[p], w1[p]};
+      else {
+        const unsigned short h[4] = {(unsigned short)(w0[p] & 0xffffu), (unsigned short)(w0[p] >> 16),
+                                     (unsigned short)(w1[p] & 0xffffu), (unsigned short)(w1[p] >> 16)};
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if (k + e < d.ldi) dst[e] = h[e];          // pad columns (k >= K) receive zeros
+      }
+    }
+    *reinterpret_cast<uint2*>(&tile[p][r][c4]) = uint2{w0[p], w1[p]};
+  }
+  if (d.imgT) {
+    __syncthreads();
+    const int kk = k0 + r, nn = n0 + c4;    // transposed: thread (r, c4) writes imgT[k0 + r][n0 + c4 .. + 3]
+    if (kk < d.K) {
+#pragma unroll
+      for (int p = 0; p < NS; ++p) {
+        const unsigned short h[4] = {tile[p][c4][r], tile[p][c4 + 1][r], tile[p][c4 + 2][r], tile[p][c4 + 3][r]};
+        unsigned short* dst = d.imgT + p * d.planeT + (int64_t)kk * d.ldt + nn;
+        if (nn + 4 <= d.ldt && (d.ldt & 3) == 0 && (reinterpret_cast<uintptr_t>(d.imgT) & 7) == 0 && (d.planeT & 3) == 0)
+          *reinterpret_cast<uint2*>(dst) = uint2{(uint32_t)h[0] | ((uint32_t)h[1] << 16), (uint32_t)h[2] | ((uint32_t)h[3] << 16)};
+        else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if (nn + e < d.ldt) dst[e] = h[e];       // pad columns (n >= N) receive zeros (tile rows n >= N hold zeros)
+        }
+      }
+    }
+  }
+}

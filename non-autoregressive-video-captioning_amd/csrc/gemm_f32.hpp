@@ -74,6 +74,11 @@ struct GemmShape {
   float* colsum_part;
   float* colsum_out;
   float colsum_beta;
+  // bf16 matrix-core kernels only (gemm_bf16.hpp): the P operand as pre-converted bf16 image(s), K-contiguous rows
+  // (element (row, k) of split plane s at Pimg[s * pimg_plane + row * ldpi + k]); nullptr = convert P in the kernel
+  const unsigned short* Pimg;
+  int64_t ldpi;
+  int64_t pimg_plane;
 };
 
 __device__ __forceinline__ int lds_sw(int row) { return (-(row >> 2)) & 3; }
@@ -401,6 +406,101 @@ __device__ __forceinline__ void epilogue_all(const Epi& epi, f32x4 (&acc)[TM][TN
     constexpr int a = IDX / TN, b = IDX % TN;
     epi(mlog[a], mphys[a], ncol[b], out_vec<PKC>(acc, a, b), M, N, z);
     epilogue_all<IDX + 1, TM, TN, PKC, Epi>(epi, acc, mlog, mphys, ncol, M, N, z);
+  }
+}
+
+// ---------------------------------------------------------------- fused soft-max statistics (EpiArgmax)
+// per-row (max, argmax, sum-exp) over this workgroup tile's BN columns; accumulator map: acc[a][b][e] is row
+// wm*WTM + a*16 + li, column wn*WTN + b*16 + lg*4 + e of the tile (KC / KC operands).  `smem` is scratch of at least
+// 3*WN*BM floats that no wave still reads as a tile image (the callers end their main loop with a barrier).
+template <int BM, int BN, int WM, int WN, int TM, int TN>
+__device__ __forceinline__ void argmax_epilogue(float* smem, const GemmShape& g, const EpiArgmax& epi, f32x4 (&acc)[TM][TN],
+                                                int m0, int n0, int Meff, int tile_n, int wm, int wn, int li, int lg, int tid) {
+  constexpr int WTM = BM / WM, WTN = BN / WN;
+  {
+    // per-row (max, argmax, sum-exp) over this tile's BN columns
+    float* redv = smem;                  // [WN][BM]
+    float* reds = smem + WN * BM;        // [WN][BM]
+    int* redi = reinterpret_cast<int*>(smem + 2 * WN * BM);
+    const float NEG = -3.0e38f;
+#pragma unroll
+    for (int a = 0; a < TM; ++a) {
+      float best = NEG;
+      int bidx = 0x7fffffff;
+      const int mrow = m0 + wm * WTM + a * 16 + li;                      // logical row of this lane's accumulators
+      float* crow = nullptr;
+      if (epi.C && mrow < Meff) crow = epi.C + (int64_t)(g.rows ? g.rows[mrow] : mrow) * epi.ldc;
+#pragma unroll
+      for (int b = 0; b < TN; ++b) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int n = n0 + wn * WTN + b * 16 + lg * 4 + e;
+          float v = NEG;
+          if (n < g.N) {
+            v = acc[a][b][e] + (epi.bias ? epi.bias[n] : 0.f);
+            acc[a][b][e] = v;
+          } else {
+            acc[a][b][e] = NEG;
+          }
+          if (v > best) { best = v; bidx = n; }
+        }
+        if (crow) {
+          const int nb = n0 + wn * WTN + b * 16 + lg * 4;
+          if (nb + 3 < g.N) *reinterpret_cast<f32x4*>(crow + nb) = acc[a][b];
+          else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+              if (nb + e < g.N) crow[nb + e] = acc[a][b][e];
+          }
+        }
+      }
+#pragma unroll
+      for (int o = 16; o <= 32; o <<= 1) {
+        float ov = __shfl_xor(best, o, 64);
+        int oi = __shfl_xor(bidx, o, 64);
+        if (ov > best || (ov == best && oi < bidx)) { best = ov; bidx = oi; }
+      }
+      const int row = wm * WTM + a * 16 + li;
+      if (lg == 0) { redv[wn * BM + row] = best; redi[wn * BM + row] = bidx; }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int a = 0; a < TM; ++a) {
+      const int row = wm * WTM + a * 16 + li;
+      float tmax = redv[row];
+#pragma unroll
+      for (int w = 1; w < WN; ++w) tmax = fmaxf(tmax, redv[w * BM + row]);
+      float s = 0.f;
+#pragma unroll
+      for (int b = 0; b < TN; ++b)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float v = acc[a][b][e];
+          s += (v > -1.0e38f) ? (epi.C ? expf(v - tmax) : __expf(v - tmax)) : 0.f;
+        }
+      s += __shfl_xor(s, 16, 64);
+      s += __shfl_xor(s, 32, 64);
+      if (lg == 0) reds[wn * BM + row] = s;
+    }
+    __syncthreads();
+    for (int row = tid; row < BM; row += 256) {
+      const int m = m0 + row;
+      if (m >= Meff) continue;
+      float best = redv[row];
+      int bidx = redi[row];
+      float s = reds[row];
+#pragma unroll
+      for (int w = 1; w < WN; ++w) {
+        float ov = redv[w * BM + row];
+        int oi = redi[w * BM + row];
+        if (ov > best || (ov == best && oi < bidx)) { best = ov; bidx = oi; }
+        s += reds[w * BM + row];
+      }
+      const int64_t o = (int64_t)tile_n * g.M + m;
+      epi.pmax[o] = best;
+      epi.psum[o] = s;
+      epi.pidx[o] = bidx;
+    }
   }
 }
 
@@ -796,88 +896,6 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmShape g, Epi epi) {
 #endif
     NACF_TRACE_MARK(3);
   } else {
-    // per-row (max, argmax, sum-exp) over this tile's BN columns
-    float* redv = smem;                  // [WN][BM]
-    float* reds = smem + WN * BM;        // [WN][BM]
-    int* redi = reinterpret_cast<int*>(smem + 2 * WN * BM);
-    const float NEG = -3.0e38f;
-#pragma unroll
-    for (int a = 0; a < TM; ++a) {
-      float best = NEG;
-      int bidx = 0x7fffffff;
-      const int mrow = m0 + wm * WTM + a * 16 + li;                      // logical row of this lane's accumulators
-      float* crow = nullptr;
-      if (epi.C && mrow < Meff) crow = epi.C + (int64_t)(g.rows ? g.rows[mrow] : mrow) * epi.ldc;
-#pragma unroll
-      for (int b = 0; b < TN; ++b) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const int n = n0 + wn * WTN + b * 16 + lg * 4 + e;
-          float v = NEG;
-          if (n < g.N) {
-            v = acc[a][b][e] + (epi.bias ? epi.bias[n] : 0.f);
-            acc[a][b][e] = v;
-          } else {
-            acc[a][b][e] = NEG;
-          }
-          if (v > best) { best = v; bidx = n; }
-        }
-        if (crow) {
-          const int nb = n0 + wn * WTN + b * 16 + lg * 4;
-          if (nb + 3 < g.N) *reinterpret_cast<f32x4*>(crow + nb) = acc[a][b];
-          else {
-#pragma unroll
-            for (int e = 0; e < 4; ++e)
-              if (nb + e < g.N) crow[nb + e] = acc[a][b][e];
-          }
-        }
-      }
-#pragma unroll
-      for (int o = 16; o <= 32; o <<= 1) {
-        float ov = __shfl_xor(best, o, 64);
-        int oi = __shfl_xor(bidx, o, 64);
-        if (ov > best || (ov == best && oi < bidx)) { best = ov; bidx = oi; }
-      }
-      const int row = wm * WTM + a * 16 + li;
-      if (lg == 0) { redv[wn * BM + row] = best; redi[wn * BM + row] = bidx; }
-    }
-    __syncthreads();
-#pragma unroll
-    for (int a = 0; a < TM; ++a) {
-      const int row = wm * WTM + a * 16 + li;
-      float tmax = redv[row];
-#pragma unroll
-      for (int w = 1; w < WN; ++w) tmax = fmaxf(tmax, redv[w * BM + row]);
-      float s = 0.f;
-#pragma unroll
-      for (int b = 0; b < TN; ++b)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          float v = acc[a][b][e];
-          s += (v > -1.0e38f) ? (epi.C ? expf(v - tmax) : __expf(v - tmax)) : 0.f;
-        }
-      s += __shfl_xor(s, 16, 64);
-      s += __shfl_xor(s, 32, 64);
-      if (lg == 0) reds[wn * BM + row] = s;
-    }
-    __syncthreads();
-    for (int row = tid; row < BM; row += 256) {
-      const int m = m0 + row;
-      if (m >= Meff) continue;
-      float best = redv[row];
-      int bidx = redi[row];
-      float s = reds[row];
-#pragma unroll
-      for (int w = 1; w < WN; ++w) {
-        float ov = redv[w * BM + row];
-        int oi = redi[w * BM + row];
-        if (ov > best || (ov == best && oi < bidx)) { best = ov; bidx = oi; }
-        s += reds[w * BM + row];
-      }
-      const int64_t o = (int64_t)tile_n * g.M + m;
-      epi.pmax[o] = best;
-      epi.psum[o] = s;
-      epi.pidx[o] = bidx;
-    }
+    argmax_epilogue<BM, BN, WM, WN, TM, TN>(smem, g, epi, acc, m0, n0, Meff, tile_n, wm, wn, li, lg, tid);
   }
 }

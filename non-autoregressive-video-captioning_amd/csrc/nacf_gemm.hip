@@ -1,12 +1,59 @@
 // C entry points built on the fp32 MFMA GEMM: nn.Linear forward/backward and
 // the fused vocabulary projection + softmax-max used by NA decoding.
 #include "gemm_f32.hpp"
+#include "gemm_bf16_launch.hpp"
 #include <stdlib.h>
 #include <string.h>
+#include <vector>
 
 namespace {
 
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+// ---- arithmetic mode of every GEMM entry point (process-wide; include/nacf_hip.h NACF_GEMM_*)
+int g_mode = NACF_GEMM_DEFAULT_MODE;
+int gemm_mode() {
+  const char* e = getenv("NACF_GEMM_MODE");   // tuning / test knob, read per call: 0 | 1 | 3 (or f32 | bf16 | bf16x3)
+  if (e && *e) {
+    if (!strcmp(e, "f32") || !strcmp(e, "0")) return NACF_GEMM_F32;
+    if (!strcmp(e, "bf16") || !strcmp(e, "1")) return NACF_GEMM_BF16;
+    if (!strcmp(e, "bf16x3") || !strcmp(e, "3")) return NACF_GEMM_BF16X3;
+  }
+  return g_mode;
+}
+inline int kalign() { return gemm_mode() == NACF_GEMM_F32 ? 16 : 32; }   // k-tile depth of the kernel family in use
+
+thread_local char g_last_f32_kernel[160] = "";
+thread_local bool g_last_was_bf16 = false;
+
+// ---- registry of pre-split bf16 weight images (nacf_wimage_register*)
+struct ImgRange { const float* w; int64_t n; const unsigned short* img; int64_t plane; int ns; };
+struct ImgT { const float* w; int N, K; int64_t ld; const unsigned short* imgT; int64_t ldt, plane; int ns; };
+std::vector<ImgRange> g_img_ranges;
+std::vector<ImgT> g_img_t;
+
+// row-major image of W [N, K] (row pitch ldw) when W lies inside a registered fp32 range: same offsets, bf16 elements
+bool find_image(const float* W, int64_t ldw, int N, int K, int ns, GemmShape& g) {
+  if (K % 8 != 0 || ldw % 8 != 0) return false;
+  for (const ImgRange& r : g_img_ranges) {
+    if (r.ns != ns || W < r.w || W >= r.w + r.n) continue;
+    const int64_t off = W - r.w;
+    if (off % 8 != 0 || off + (int64_t)(N - 1) * ldw + K > r.n) return false;
+    g.Pimg = r.img + off; g.ldpi = ldw; g.pimg_plane = r.plane;
+    return true;
+  }
+  return false;
+}
+// transposed image of exactly this matrix (dX = dZ W: P = W^T, rows = the K output columns, reduce over N)
+bool find_image_t(const float* W, int64_t ldw, int N, int K, int ns, GemmShape& g) {
+  for (const ImgT& t : g_img_t) {
+    if (t.w == W && t.N == N && t.K == K && t.ld == ldw && t.ns == ns) {
+      g.Pimg = t.imgT; g.ldpi = t.ldt; g.pimg_plane = t.plane;
+      return true;
+    }
+  }
+  return false;
+}
 
 // tile selection: 0 = 128x128, 1 = 64x64.  Override with NACF_GEMM_TILE=128|64.
 int forced_tile() {
@@ -28,9 +75,17 @@ int pick_tile(int M, int N, int splits, bool has_rows = false, bool heavy_epilog
   return big >= (has_rows ? 1536 : 768) ? 0 : 1;
 }
 
+template <class Epi> const char* epi_name();
+template <> const char* epi_name<EpiLinear>() { return "EpiLinear"; }
+template <> const char* epi_name<EpiStore>() { return "EpiStore"; }
+template <> const char* epi_name<EpiArgmax>() { return "EpiArgmax"; }
+
 template <bool QKC, bool PKC, class Epi>
 void launch_gemm(const GemmShape& g0, const Epi& epi, int splits, int tile, bool vec, hipStream_t s) {
   GemmShape g = g0;
+  snprintf(g_last_f32_kernel, sizeof(g_last_f32_kernel), "gemm_f32_kernel<%d, %d, 2, 2, %s, %s, %s, %s>", tile == 0 ? 128 : 64,
+           tile == 0 ? 128 : 64, QKC ? "true" : "false", PKC ? "true" : "false", vec ? "true" : "false", epi_name<Epi>());
+  g_last_was_bf16 = false;
   if (tile == 0) {
     g.tiles_m = cdiv(g.M, 128);
     g.tiles_n = cdiv(g.N, 128);
@@ -277,12 +332,20 @@ int nacf_linear_fwd(const float* X, int64_t ldx, const float* W, int64_t ldw, fl
   epi.vec_bias = ((!epi.ep.bias || aligned16(epi.ep.bias)) && (no_drop || N % 4 == 0)) ? 1 : 0;
   GemmShape g = {};
   g.Q = X; g.P = W; g.ldq = ldx; g.ldp = ldw; g.M = M; g.N = N; g.K = K;
-  g.k_per_split = cdiv(K, 16) * 16;
+  g.k_per_split = cdiv(K, 32) * 32;
   set_rows(g, rs);
   const bool vec = (ldx % 4 == 0) && (ldw % 4 == 0) && aligned16(X) && aligned16(W);
   const bool heavy = epi.ep.act == NACF_ACT_GELU_NEW || epi.ep.act == NACF_ACT_GELU_ERF || epi.ep.act == NACF_ACT_TANH ||
                      epi.ep.act == NACF_ACT_SIGMOID || epi.ep.act == NACF_ACT_TANH_SIGMOID;
-  launch_gemm<true, true, EpiLinear>(g, epi, 1, pick_tile(M, N, 1, rs != nullptr, heavy), vec, as_hip(stream));
+  const int mode = gemm_mode();
+  const int tile = pick_tile(M, N, 1, rs != nullptr, heavy);
+  if (mode != NACF_GEMM_F32 && vec) {          // bf16 matrix cores (16-byte addressable operands only)
+    find_image(W, ldw, N, K, mode, g);
+    launch_bf16_linear(g, epi, tile, mode, as_hip(stream));
+    g_last_was_bf16 = true;
+  } else {
+    launch_gemm<true, true, EpiLinear>(g, epi, 1, tile, vec, as_hip(stream));
+  }
   NACF_LAUNCH_CHECK("nacf_linear_fwd");
   return NACF_OK;
 }
@@ -327,10 +390,13 @@ int nacf_linear_bwd_data(const float* dZ, int64_t lddz, const float* W, int64_t 
   hipStream_t s = as_hip(stream);
   GemmShape g = {};
   g.Q = dZ; g.P = W; g.ldq = lddz; g.ldp = ldw; g.M = M; g.N = K; g.K = N;
-  g.k_per_split = cdiv(cdiv(N, splits), 16) * 16;
+  const bool vec = (lddz % 4 == 0) && (ldw % 4 == 0) && aligned16(dZ) && aligned16(W);
+  const int mode = gemm_mode();
+  const bool bf16 = mode != NACF_GEMM_F32 && vec;
+  const int ka = bf16 ? 32 : 16;
+  g.k_per_split = cdiv(cdiv(N, splits), ka) * ka;
   set_rows(g, rs);
   const int real_splits = cdiv(N, g.k_per_split);
-  const bool vec = (lddz % 4 == 0) && (ldw % 4 == 0) && aligned16(dZ) && aligned16(W);
   EpiStore epi;
   if (real_splits > 1) {
     epi.C = reinterpret_cast<float*>(ws); epi.ldc = K; epi.beta = 0.f; epi.slab_stride = (int64_t)M * K;
@@ -340,7 +406,13 @@ int nacf_linear_bwd_data(const float* dZ, int64_t lddz, const float* W, int64_t 
     epi.C = dX; epi.ldc = lddx; epi.beta = beta; epi.slab_stride = 0;
     epi.vec_out = ((lddx % 4 == 0) && aligned16(dX)) ? 1 : 0;
   }
-  launch_gemm<true, false, EpiStore>(g, epi, real_splits, pick_tile(M, K, real_splits, rs != nullptr), vec, s);
+  if (bf16) {
+    find_image_t(W, ldw, N, K, mode, g);       // P = W^T image [K, N] when registered, else the fp32 W read transposed
+    launch_bf16_dx(g, epi, real_splits, pick_tile(M, K, real_splits, rs != nullptr), mode, s);
+    g_last_was_bf16 = true;
+  } else {
+    launch_gemm<true, false, EpiStore>(g, epi, real_splits, pick_tile(M, K, real_splits, rs != nullptr), vec, s);
+  }
   NACF_LAUNCH_CHECK("nacf_linear_bwd_data");
   if (real_splits > 1) {
     const int64_t total = (int64_t)M * K;
@@ -403,10 +475,13 @@ int nacf_linear_bwd_weight(const float* dZ, int64_t lddz, const float* X, int64_
   // output cols = k (P = X, MC: element (k, m) at X[m*ldx + k]), reduce = m (through the live-row list if given)
   GemmShape g = {};
   g.Q = dZ; g.P = X; g.ldq = lddz; g.ldp = ldx; g.M = N; g.N = K; g.K = M;
-  g.k_per_split = cdiv(cdiv(M, splits), 16) * 16;
+  const bool vec = (lddz % 4 == 0) && (ldx % 4 == 0) && aligned16(dZ) && aligned16(X);
+  const int mode = gemm_mode();
+  const bool bf16 = mode != NACF_GEMM_F32 && vec;
+  const int ka = bf16 ? 32 : 16;
+  g.k_per_split = cdiv(cdiv(M, splits), ka) * ka;
   set_rows(g, rs);
   const int real_splits = cdiv(M, g.k_per_split);
-  const bool vec = (lddz % 4 == 0) && (ldx % 4 == 0) && aligned16(dZ) && aligned16(X);
   float* slabs = reinterpret_cast<float*>(ws);
   EpiStore epi;
   if (real_splits > 1) {
@@ -420,7 +495,12 @@ int nacf_linear_bwd_weight(const float* dZ, int64_t lddz, const float* X, int64_
     if (real_splits > 1) g.colsum_part = part;
     else { g.colsum_out = db; g.colsum_beta = beta; }
   }
-  launch_gemm<false, false, EpiStore>(g, epi, real_splits, tile, vec, s);
+  if (bf16) {
+    launch_bf16_dw(g, epi, real_splits, tile, mode, s);
+    g_last_was_bf16 = true;
+  } else {
+    launch_gemm<false, false, EpiStore>(g, epi, real_splits, tile, vec, s);
+  }
   NACF_LAUNCH_CHECK("nacf_linear_bwd_weight(gemm)");
   if (real_splits > 1) {
     const bool v4 = (K % 4 == 0) && (lddw % 4 == 0) && aligned16(dW) && aligned16(slabs);
@@ -443,6 +523,51 @@ int nacf_debug_gemm_trace(void* buf) {     // tuning builds only (make trace); n
 }
 #endif
 
+int nacf_gemm_set_mode(int mode) {
+  NACF_CHECK(mode == NACF_GEMM_F32 || mode == NACF_GEMM_BF16 || mode == NACF_GEMM_BF16X3, NACF_EINVAL,
+             "nacf_gemm_set_mode: mode must be 0 (f32), 1 (bf16) or 3 (bf16x3), got %d", mode);
+  g_mode = mode;
+  return NACF_OK;
+}
+int nacf_gemm_get_mode(void) { return gemm_mode(); }
+const char* nacf_gemm_last_kernel(void) { return g_last_was_bf16 ? bf16_last_kernel_name() : g_last_f32_kernel; }
+
+int nacf_wimage_register(const float* w_base, int64_t n_elems, const uint16_t* img_base, int64_t plane_elems, int ns) {
+  NACF_CHECK(w_base && img_base && n_elems > 0 && (ns == 1 || ns == 3) && plane_elems >= n_elems, NACF_EINVAL,
+             "nacf_wimage_register: bad argument");
+  NACF_CHECK(aligned16(w_base) && aligned16(img_base) && plane_elems % 8 == 0, NACF_EINVAL,
+             "nacf_wimage_register: buffers must be 16-byte aligned, planes a multiple of 8 elements apart");
+  for (ImgRange& r : g_img_ranges)
+    if (r.w == w_base && r.ns == ns) { r = ImgRange{w_base, n_elems, img_base, plane_elems, ns}; return NACF_OK; }
+  g_img_ranges.push_back(ImgRange{w_base, n_elems, img_base, plane_elems, ns});
+  return NACF_OK;
+}
+int nacf_wimage_register_t(const float* w, int N, int K, int64_t ldw, const uint16_t* imgT, int64_t ldt, int64_t plane_elems,
+                           int ns) {
+  NACF_CHECK(w && imgT && N > 0 && K > 0 && ldw >= K && ldt >= N && (ns == 1 || ns == 3), NACF_EINVAL,
+             "nacf_wimage_register_t: bad argument");
+  NACF_CHECK(aligned16(imgT) && ldt % 8 == 0 && plane_elems % 8 == 0 && plane_elems >= (int64_t)K * ldt, NACF_EINVAL,
+             "nacf_wimage_register_t: image rows must be 16-byte aligned (ldt %% 8 == 0)");
+  for (ImgT& t : g_img_t)
+    if (t.w == w && t.ns == ns) { t = ImgT{w, N, K, ldw, imgT, ldt, plane_elems, ns}; return NACF_OK; }
+  g_img_t.push_back(ImgT{w, N, K, ldw, imgT, ldt, plane_elems, ns});
+  return NACF_OK;
+}
+int nacf_wimage_unregister(const float* w_base, int64_t n_elems) {
+  NACF_CHECK(w_base && n_elems > 0, NACF_EINVAL, "nacf_wimage_unregister: bad argument");
+  for (size_t i = g_img_ranges.size(); i-- > 0;)
+    if (g_img_ranges[i].w >= w_base && g_img_ranges[i].w < w_base + n_elems) g_img_ranges.erase(g_img_ranges.begin() + i);
+  for (size_t i = g_img_t.size(); i-- > 0;)
+    if (g_img_t[i].w >= w_base && g_img_t[i].w < w_base + n_elems) g_img_t.erase(g_img_t.begin() + i);
+  return NACF_OK;
+}
+int nacf_wimage_refresh(const nacf_wimage_desc* table, int n_desc, int n_tiles, int ns, nacf_stream_t stream) {
+  NACF_CHECK(table && n_desc > 0 && n_tiles > 0 && (ns == 1 || ns == 3), NACF_EINVAL, "nacf_wimage_refresh: bad argument");
+  launch_wimage_refresh(table, n_desc, n_tiles, ns, as_hip(stream));
+  NACF_LAUNCH_CHECK("nacf_wimage_refresh");
+  return NACF_OK;
+}
+
 int nacf_gemm_config(int kind, int M, int N, int K, int* tile, int* splits) {
   NACF_CHECK(tile && splits && M > 0 && N > 0 && K > 0, NACF_EINVAL, "nacf_gemm_config: bad argument");
   int t = 0, s = 1;
@@ -451,13 +576,13 @@ int nacf_gemm_config(int kind, int M, int N, int K, int* tile, int* splits) {
   if (kind == 0) t = pick_tile(M, N, 1, with_rows, heavy);
   else if (kind == 1) {
     s = bwd_data_splits(M, N, K, with_rows);
-    const int kps = cdiv(cdiv(N, s), 16) * 16;
+    const int kps = cdiv(cdiv(N, s), kalign()) * kalign();
     s = cdiv(N, kps);
     t = pick_tile(M, K, s, with_rows);
   }
   else if (kind == 2) {
     s = bwd_weight_splits(M, N, K, with_rows, &t);
-    const int kps = cdiv(cdiv(M, s), 16) * 16;
+    const int kps = cdiv(cdiv(M, s), kalign()) * kalign();
     s = cdiv(M, kps);
   } else {
     nacf_set_error("nacf_gemm_config: bad kind %d", kind);
@@ -491,11 +616,18 @@ int nacf_vocab_argmax(const float* hidden, int64_t ldh, const float* W, int64_t 
   epi.pidx = reinterpret_cast<int*>(epi.psum + (size_t)tn * rows);
   GemmShape g = {};
   g.Q = hidden; g.P = W; g.ldq = ldh; g.ldp = ldw; g.M = rows; g.N = V; g.K = K;
-  g.k_per_split = cdiv(K, 16) * 16;
+  g.k_per_split = cdiv(K, 32) * 32;
   set_rows(g, rs);
   const bool vec = (ldh % 4 == 0) && (ldw % 4 == 0) && aligned16(hidden) && aligned16(W);
   hipStream_t s = as_hip(stream);
-  launch_gemm<true, true, EpiArgmax>(g, epi, 1, tile, vec, s);
+  const int mode = gemm_mode();
+  if (mode != NACF_GEMM_F32 && vec) {
+    find_image(W, ldw, V, K, mode, g);
+    launch_bf16_argmax(g, epi, tile, mode, s);
+    g_last_was_bf16 = true;
+  } else {
+    launch_gemm<true, true, EpiArgmax>(g, epi, 1, tile, vec, s);
+  }
   NACF_LAUNCH_CHECK("nacf_vocab_argmax(gemm)");
   hipLaunchKernelGGL(argmax_merge_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, s, epi.pmax, epi.psum, epi.pidx, tn, rows,
                      rs ? rs->rows : nullptr, rs ? rs->count : nullptr, pad_tokens, zero_mask_prob, update_mask, tokens,
@@ -528,12 +660,19 @@ int nacf_vocab_lse_fwd(const float* hidden, int64_t ldh, const float* W, int64_t
   epi.ldc = ldl;
   GemmShape g = {};
   g.Q = hidden; g.P = W; g.ldq = ldh; g.ldp = ldw; g.M = rows; g.N = V; g.K = K;
-  g.k_per_split = cdiv(K, 16) * 16;
+  g.k_per_split = cdiv(K, 32) * 32;
   set_rows(g, rs);
   g.zero_dead = 0;                       // rows without a label are never read downstream
   const bool vec = (ldh % 4 == 0) && (ldw % 4 == 0) && aligned16(hidden) && aligned16(W);
   hipStream_t s = as_hip(stream);
-  launch_gemm<true, true, EpiArgmax>(g, epi, 1, tile, vec, s);
+  const int mode = gemm_mode();
+  if (mode != NACF_GEMM_F32 && vec) {
+    find_image(W, ldw, V, K, mode, g);
+    launch_bf16_argmax(g, epi, tile, mode, s);
+    g_last_was_bf16 = true;
+  } else {
+    launch_gemm<true, true, EpiArgmax>(g, epi, 1, tile, vec, s);
+  }
   NACF_LAUNCH_CHECK("nacf_vocab_lse_fwd(gemm)");
   hipLaunchKernelGGL(lse_merge_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, s, epi.pmax, epi.psum, epi.pidx, tn, rows,
                      rs ? rs->rows : nullptr, rs ? rs->count : nullptr, logits, ldl, labels, lse, argmax, label_logp);

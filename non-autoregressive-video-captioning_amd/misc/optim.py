@@ -38,7 +38,14 @@ class FusedAdam(object):
         """lo / hi: update only flat[lo:hi] (one gradient bucket of the data-parallel step); exactly one part of a
         step passes bump=True, and it must come first"""
         if self._flat is not self.model.flat:   # model moved (.to/.cuda) after the optimiser was built
+            if torch.cuda.is_current_stream_capturing():
+                raise RuntimeError('nacf_amd: the model was re-homed during a hipGraph capture')
+            old = (self.exp_avg, self.exp_avg_sq, self.step_dev)
             self._alloc()
+            if old[0].numel() == self.exp_avg.numel():      # same layout on a new device: the Adam state moves along
+                self.exp_avg.copy_(old[0])
+                self.exp_avg_sq.copy_(old[1])
+                self.step_dev.copy_(old[2])
             self.lr_dev.fill_(self.param_groups[0]['lr'])
         f = self._flat
         sl = slice(lo, hi)

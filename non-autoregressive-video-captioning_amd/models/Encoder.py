@@ -54,8 +54,8 @@ class Encoder_HighWay(nn.Module):
         self._rt = rt
         self._cfg = []
         for s in self.streams:
-            self._cfg.append(dict(lin=flat.pack([s[0].weight], [s[0].bias]),
-                                  hw=flat.pack([s[1].w1.weight, s[1].w2.weight], [s[1].w1.bias, s[1].w2.bias]),
+            self._cfg.append(dict(lin=flat.pack([s[0].weight], [s[0].bias], image='fwd'),    # no dX: the features need no gradient
+                                  hw=flat.pack([s[1].w1.weight, s[1].w2.weight], [s[1].w1.bias, s[1].w2.bias], image='both'),
                                   p=self.dropout, salt=rt.next_salt(),
                                   params=[s[0].weight, s[0].bias, s[1].w1.weight, s[1].w1.bias, s[1].w2.weight,
                                           s[1].w2.bias]))

@@ -21,8 +21,8 @@ class Predictor_length(nn.Module):
 
     def nacf_bind(self, flat, rt):
         self._rt = rt
-        self._cfg = dict(l1=flat.pack([self.net[0].weight], [self.net[0].bias]),
-                         l2=flat.pack([self.net[3].weight], [self.net[3].bias]), p=self.p, salt=rt.next_salt())
+        self._cfg = dict(l1=flat.pack([self.net[0].weight], [self.net[0].bias], image='both'),
+                         l2=flat.pack([self.net[3].weight], [self.net[3].bias], image='both'), p=self.p, salt=rt.next_salt())
 
     def forward(self, enc_output, pooled=None, **kwargs):
         if isinstance(enc_output, list):

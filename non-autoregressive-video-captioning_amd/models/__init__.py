@@ -45,6 +45,10 @@ def get_model(opt):
     assert 'vocab_size' in opt, "opt['vocab_size'] must be set (train.py:73 does it from the corpus)"
     assert not opt.get('use_preEncoder', False)
     opt = complete_opt(opt)
+    if opt.get('gemm_mode') is not None:
+        # arithmetic of every GEMM (process-wide, see nacf_hip.h NACF_GEMM_*): 'f32' | 'bf16x3' (exact) | 'bf16'
+        from ..runtime import ops
+        ops.set_gemm_mode(opt['gemm_mode'])
     sizes = {'i': opt['dim_i'], 'm': opt['dim_m'], 'a': opt['dim_a'], 'o': opt['dim_o']}
     input_size = [sizes[c] for c in opt['modality'].lower()]
     encoder = get_encoder(opt, input_size)

@@ -156,22 +156,23 @@ class BertLayer(nn.Module):
         a, c = self.attention, self.attend_to_enc_output
         self._pk = dict(
             qkv=flat.pack([a.self.query.weight, a.self.key.weight, a.self.value.weight],
-                          [a.self.query.bias, a.self.key.bias, a.self.value.bias]),
-            so=flat.pack([a.output.dense.weight], [a.output.dense.bias]),
-            cq=flat.pack([c.self.query.weight], [c.self.query.bias]),
-            ckv=flat.pack([c.self.key.weight, c.self.value.weight], [c.self.key.bias, c.self.value.bias]),
-            co=flat.pack([c.output.dense.weight], [c.output.dense.bias]),
-            f1=flat.pack([self.intermediate.dense.weight], [self.intermediate.dense.bias]),
-            f2=flat.pack([self.output.dense.weight], [self.output.dense.bias]))
+                          [a.self.query.bias, a.self.key.bias, a.self.value.bias], image='both'),
+            so=flat.pack([a.output.dense.weight], [a.output.dense.bias], image='both'),
+            cq=flat.pack([c.self.query.weight], [c.self.query.bias], image='both'),
+            ckv=flat.pack([c.self.key.weight, c.self.value.weight], [c.self.key.bias, c.self.value.bias], image='both'),
+            co=flat.pack([c.output.dense.weight], [c.output.dense.bias], image='both'),
+            f1=flat.pack([self.intermediate.dense.weight], [self.intermediate.dense.bias], image='both'),
+            f2=flat.pack([self.output.dense.weight], [self.output.dense.bias], image='both'))
         if self.with_layernorm:
             for key, m in (('ln_so', a.output), ('ln_co', c.output), ('ln_f2', self.output)):
                 self._pk[key] = flat.pack([m.LayerNorm.weight], [m.LayerNorm.bias])
         self._salts = [rt.next_salt() for _ in range(4)]
         pa = self.pos_attention
         if pa is not None:
-            self._pk['pqk'] = flat.pack([pa.self.query.weight, pa.self.key.weight], [pa.self.query.bias, pa.self.key.bias])
-            self._pk['pv'] = flat.pack([pa.self.value.weight], [pa.self.value.bias])
-            self._pk['po'] = flat.pack([pa.output.dense.weight], [pa.output.dense.bias])
+            self._pk['pqk'] = flat.pack([pa.self.query.weight, pa.self.key.weight], [pa.self.query.bias, pa.self.key.bias],
+                                        image='both')
+            self._pk['pv'] = flat.pack([pa.self.value.weight], [pa.self.value.bias], image='both')
+            self._pk['po'] = flat.pack([pa.output.dense.weight], [pa.output.dense.bias], image='both')
             self._salt_pos = rt.next_salt()
         self._params = [p for p in self.parameters()]
 

@@ -48,6 +48,8 @@ class Seq2Seq(nn.Module):
                             self.decoder) if m is not None]
 
     def _flatten(self):
+        if self.flat is not None and self.flat.images is not None:
+            self.flat.images.close()
         groups = [g for m in self._parts() for g in m.nacf_groups()]
         groups.append([self.tgt_word_prj.weight])
         if self.tgt_word_prj.bias is not None:
@@ -59,12 +61,24 @@ class Seq2Seq(nn.Module):
         for m in self._parts():
             m.nacf_bind(self.flat, self.rt)
         self._vocab_pack = self.flat.pack([self.tgt_word_prj.weight],
-                                          [self.tgt_word_prj.bias] if self.tgt_word_prj.bias is not None else None)
+                                          [self.tgt_word_prj.bias] if self.tgt_word_prj.bias is not None else None,
+                                          image='both')
 
     def _apply(self, fn, *args, **kwargs):
+        before = (self.flat.data.device, self.flat.data.dtype, self.flat.data.data_ptr())
         out = super()._apply(fn, *args, **kwargs)
-        self._flatten()  # .to()/.cuda() re-homes the tensors: rebuild the flat views on the new device
+        p0 = self.flat.params[0]
+        moved = (p0.device, p0.dtype) != before[:2] or not self._views_intact()
+        if moved:
+            # .to(device) / .cuda() re-homed the tensors: rebuild the flat views there.  A no-op call (.to(same device),
+            # .float()) must NOT re-flatten: captured step graphs and the optimiser's moments are tied to the buffers.
+            self._flatten()
         return out
+
+    def _views_intact(self):
+        base = self.flat.data
+        lo, hi = base.data_ptr(), base.data_ptr() + base.numel() * base.element_size()
+        return all(lo <= p.data_ptr() < hi for p in self.flat.params)
 
     def head_parameters(self):
         """parameters between the decoder's output and the loss (the vocabulary projection) -- unless it is tied to the
@@ -93,6 +107,9 @@ class Seq2Seq(nn.Module):
         results = {}
         if self.opt.get('automatic_mask', False):
             raise NotImplementedError('nacf_amd: automatic_mask is not built')
+        # bf16 GEMM modes: the weight images follow the fp32 master weights at every forward entry (one launch; the
+        # forward's and the backward's GEMMs then read images of exactly the weights an fp32 kernel would read)
+        self.flat.sync_images()
         enc_streams, _ = self.encoder([f.contiguous() for f in feats])
         with torch.no_grad():  # mean-over-time hidden: only LSTM decoders consume it (seq2seq.py:66-68)
             hid = [MeanTimeFn.apply(s.detach()) for s in enc_streams]

@@ -34,6 +34,18 @@ class RowSet(ctypes.Structure):
     _fields_ = [("rows", c_void_p), ("count", c_void_p), ("zero_dead", ctypes.c_int32)]
 
 
+class WImageDesc(ctypes.Structure):
+    """struct nacf_wimage_desc: one weight matrix of the bf16 image table (nacf_wimage_refresh)."""
+    _fields_ = [("w", c_void_p), ("img", c_void_p), ("imgT", c_void_p),
+                ("ld", c_int64), ("ldi", c_int64), ("ldt", c_int64), ("plane", c_int64), ("planeT", c_int64),
+                ("N", c_int32), ("K", c_int32), ("tile0", c_int32), ("tiles_k", c_int32)]
+
+
+# GEMM arithmetic modes (nacf_hip.h NACF_GEMM_*)
+GEMM_F32, GEMM_BF16, GEMM_BF16X3 = 0, 1, 3
+GEMM_MODE_BY_NAME = {"f32": GEMM_F32, "bf16": GEMM_BF16, "bf16x3": GEMM_BF16X3}
+GEMM_MODE_NAME = {v: k for k, v in GEMM_MODE_BY_NAME.items()}
+
 _P, _I, _L, _F, _U, _S = c_void_p, c_int, c_int64, c_float, c_uint32, c_size_t
 _EP = POINTER(Epilogue)
 _RS = POINTER(RowSet)
@@ -50,6 +62,13 @@ SIGNATURES = {
     "nacf_linear_bwd_data": (c_int, [_P, _L, _P, _L, _P, _L, _I, _I, _I, _F, _P, _S, _RS, _P]),
     "nacf_linear_bwd_weight_workspace": (_S, [_I, _I, _I]),
     "nacf_gemm_config": (c_int, [_I, _I, _I, _I, _P, _P]),
+    "nacf_gemm_set_mode": (c_int, [_I]),
+    "nacf_gemm_get_mode": (c_int, []),
+    "nacf_gemm_last_kernel": (c_char_p, []),
+    "nacf_wimage_register": (c_int, [_P, _L, _P, _L, _I]),
+    "nacf_wimage_register_t": (c_int, [_P, _I, _I, _L, _P, _L, _L, _I]),
+    "nacf_wimage_unregister": (c_int, [_P, _L]),
+    "nacf_wimage_refresh": (c_int, [_P, _I, _I, _I, _P]),
     "nacf_linear_bwd_weight": (c_int, [_P, _L, _P, _L, _P, _L, _P, _I, _I, _I, _F, _P, _S, _RS, _P]),
     "nacf_epilogue_bwd": (c_int, [_P, _L, _P, _L, _P, _L, _I, _I, _I, _EP, _P]),
     "nacf_sample_frames": (c_int, [_P, _P, _P, _I, _I, _I, _I, _I, _U, _P, _P, _P, _P]),

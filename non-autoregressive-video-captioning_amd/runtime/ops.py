@@ -72,13 +72,11 @@ class GemmProfiler:
         self.enabled = False
         self.records = []
 
-    def kernel_name(self, kind, M, N, K, epi, flags=0):
+    def _splits(self, kind, M, N, K, flags=0):
         tile, splits = ctypes.c_int(0), ctypes.c_int(0)
         L.check(L.load().nacf_gemm_config(kind | flags, M, N, K, ctypes.byref(tile), ctypes.byref(splits)),
                 "nacf_gemm_config")
-        q, p_ = self._LAYOUT[kind]
-        self._last_splits = splits.value
-        return "gemm_f32_kernel<%d, %d, 2, 2, %s, %s, true, %s>" % (tile.value, tile.value, q, p_, epi)
+        return splits.value
 
     def begin(self, kind, M, N, K, epi, rows=None, heavy=False):
         if not self.enabled:
@@ -87,30 +85,116 @@ class GemmProfiler:
         a.record()
         # kind 2 (dW: GEMM + split-K combine + bias column-sum) and EpiArgmax (GEMM + merge) spans hold
         # more than one kernel; only single-kernel spans are comparable with rocprof's per-kernel average
-        name = self.kernel_name(kind, M, N, K, epi, (0x100 if rows is not None else 0) | (0x200 if heavy else 0))
-        single = kind != 2 and epi != "EpiArgmax" and self._last_splits == 1
-        return (name, (M, N, K), a, b, single, rows)
+        splits = self._splits(kind, M, N, K, (0x100 if rows is not None else 0) | (0x200 if heavy else 0))
+        single = kind != 2 and epi != "EpiArgmax" and splits == 1
+        return [None, (M, N, K), a, b, single, rows, kind]
 
     def end(self, tok):
         if tok is not None:
             tok[3].record()
+            # the template name of the kernel the entry point just launched (= rocprofv3's kernel name)
+            tok[0] = (L.load().nacf_gemm_last_kernel() or b"?").decode()
             self.records.append(tok)
 
     def summary(self):
         out = {}
-        for name, shape, a, b, single, rows in self.records:
-            r = out.setdefault(name, dict(calls=0, flops=0.0, dense_flops=0.0, ms=0.0, shapes=set(), single=single))
+        for name, shape, a, b, single, rows, kind in self.records:
+            r = out.setdefault(name, dict(calls=0, flops=0.0, dense_flops=0.0, ms=0.0, shapes=set(), single=single,
+                                          by_shape={}))
             M, N, K = shape
             m_live = min(M, int(rows.count)) if rows is not None else M   # flops actually executed (live rows only)
             r["calls"] += 1
             r["flops"] += 2.0 * m_live * N * K
             r["dense_flops"] += 2.0 * M * N * K
-            r["ms"] += a.elapsed_time(b)
+            ms = a.elapsed_time(b)
+            r["ms"] += ms
+            r["single"] = r["single"] and single
             r["shapes"].add(shape)
+            q = r["by_shape"].setdefault((kind,) + tuple(shape), dict(calls=0, flops=0.0, ms=0.0))
+            q["calls"] += 1
+            q["flops"] += 2.0 * m_live * N * K
+            q["ms"] += ms
         return out
 
 
 PROFILER = GemmProfiler()
+
+
+# ---------------------------------------------------------------- GEMM arithmetic mode / weight images
+def gemm_mode() -> int:
+    """effective mode of the GEMM entry points: L.GEMM_F32 | L.GEMM_BF16 | L.GEMM_BF16X3 (env NACF_GEMM_MODE overrides)"""
+    return int(L.load().nacf_gemm_get_mode())
+
+
+def set_gemm_mode(mode) -> None:
+    """process-wide: 'f32' (exact fp32 MFMA), 'bf16x3' (exact three-term split on the bf16 matrix cores), 'bf16'"""
+    if isinstance(mode, str):
+        if mode not in L.GEMM_MODE_BY_NAME:
+            raise ValueError("gemm_mode must be one of %s (got %r)" % (sorted(L.GEMM_MODE_BY_NAME), mode))
+        mode = L.GEMM_MODE_BY_NAME[mode]
+    L.check(L.load().nacf_gemm_set_mode(int(mode)), "nacf_gemm_set_mode")
+
+
+class WeightImages:
+    """bf16 image planes of the GEMM weight matrices that live in ONE flat fp32 buffer (see nacf_wimage_* in
+    nacf_hip.h).  mats: [(offset, N, K, want_transposed)], each matrix contiguous ([N, K], row pitch K) at
+    flat[offset:].  The row-major planes mirror the flat buffer's offsets (any row slice of a registered matrix is
+    found by address); transposed images [K, round_up(N, 8)] serve the dX GEMMs.  `refresh()` is one launch."""
+
+    def __init__(self, flat: Tensor, mats, ns: int):
+        assert flat.is_cuda and flat.dtype == torch.float32 and flat.is_contiguous() and flat.data_ptr() % 16 == 0
+        assert ns in (1, 3)
+        self.flat, self.ns, self.mats = flat, int(ns), list(mats)
+        total = (flat.numel() + 7) // 8 * 8
+        self.img = torch.zeros(ns, total, dtype=torch.int16, device=flat.device)
+        t_off, t_total = [], 0
+        for off, N, K, want_t in self.mats:
+            assert off % 8 == 0 and off + N * K <= flat.numel(), "GEMM weights must start on 32-byte boundaries of the flat buffer"
+            t_off.append(t_total if want_t else None)
+            if want_t:
+                t_total += K * ((N + 7) // 8 * 8)
+        self.imgT = torch.zeros(ns, max(t_total, 8), dtype=torch.int16, device=flat.device)
+        descs = (L.WImageDesc * len(self.mats))()
+        tile0 = 0
+        self._t = []
+        for d, (off, N, K, want_t), to in zip(descs, self.mats, t_off):
+            ldt = (N + 7) // 8 * 8
+            d.w = flat.data_ptr() + 4 * off
+            d.img = self.img.data_ptr() + 2 * off if K % 8 == 0 else None
+            d.imgT = self.imgT.data_ptr() + 2 * to if want_t else None
+            d.ld, d.ldi, d.ldt, d.plane, d.planeT = K, K, ldt, self.img.stride(0), self.imgT.stride(0)
+            d.N, d.K, d.tile0, d.tiles_k = N, K, tile0, (K + 31) // 32
+            tile0 += ((N + 31) // 32) * ((K + 31) // 32)
+            if want_t:
+                self._t.append((d.w, N, K, d.imgT, ldt))
+        self.n_tiles = tile0
+        raw = bytes(descs)
+        self.table = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(flat.device)
+        self.n_desc = len(self.mats)
+        lib = L.load()
+        L.check(lib.nacf_wimage_register(_ptr(flat), flat.numel(), _ptr(self.img), self.img.stride(0), self.ns),
+                "nacf_wimage_register")
+        for w, N, K, it, ldt in self._t:
+            L.check(lib.nacf_wimage_register_t(ctypes.c_void_p(w), N, K, K, ctypes.c_void_p(it), ldt, self.imgT.stride(0),
+                                               self.ns), "nacf_wimage_register_t")
+        self._registered = True
+
+    def refresh(self) -> None:
+        """rebuild every image from the current fp32 values (asynchronous on the current stream; capturable)"""
+        if self.n_desc:
+            L.check(L.load().nacf_wimage_refresh(_ptr(self.table), self.n_desc, self.n_tiles, self.ns, _stream()),
+                    "nacf_wimage_refresh")
+
+    def close(self) -> None:
+        if getattr(self, "_registered", False):
+            self._registered = False
+            try:
+                L.load().nacf_wimage_unregister(_ptr(self.flat), self.flat.numel())
+            except Exception:  # noqa: BLE001  (interpreter shutdown)
+                pass
+
+    def __del__(self):
+        self.close()
 
 
 class RngState:

@@ -36,7 +36,7 @@ class FlatParams:
     gradient into a second one).  ``groups`` lists parameters that must be
     adjacent, in order, so packed views (w1|w2, q|k|v, k|v) are plain slices."""
 
-    ALIGN = 4  # floats (16 B)
+    ALIGN = 8  # floats (32 B): the bf16 image planes of the weights mirror these offsets and need 16-byte rows
 
     def __init__(self, groups: Sequence[Sequence[nn.Parameter]]):
         seen = set()
@@ -60,6 +60,8 @@ class FlatParams:
         self.data = torch.zeros(self.total, dtype=torch.float32, device=device)
         self.grad = torch.zeros(self.total, dtype=torch.float32, device=device)
         self.params: List[nn.Parameter] = [p for g in layout for p in g]
+        self.image_specs: List[tuple] = []      # (offset, N, K, want_transposed) of every GEMM weight (pack(..., image=))
+        self.images = None                      # ops.WeightImages of the bf16 GEMM modes
         with torch.no_grad():
             for p in self.params:
                 o, n = self.offset[id(p)], p.numel()
@@ -83,8 +85,33 @@ class FlatParams:
                 return p.grad is not None and p.grad.data_ptr() == self.grad[o:].data_ptr()
         return True
 
-    def pack(self, ws: Sequence[nn.Parameter], bs: Optional[Sequence[nn.Parameter]] = None) -> Pack:
-        """Packed (row-concatenated) view of adjacent weights [+ biases]."""
+    def sync_images(self) -> None:
+        """bf16 GEMM modes: (re)build the weight images from the current fp32 values.  Called at every forward entry
+        (models/seq2seq.py), so the GEMMs of that forward AND of its backward read images of exactly the weights the
+        fp32 kernels would read; one ~40 us launch (captured with the step).  Nothing to do in the fp32 mode."""
+        from . import ops
+        mode = ops.gemm_mode()
+        if mode == 0 or not self.data.is_cuda:
+            if self.images is not None:
+                self.images.close()
+                self.images = None
+            return
+        if self.images is None or self.images.ns != mode or self.images.flat.data_ptr() != self.data.data_ptr():
+            if torch.cuda.is_current_stream_capturing():
+                raise RuntimeError("nacf_amd: weight images must exist before a hipGraph capture (run a warm-up step)")
+            if self.images is not None:
+                self.images.close()
+            self.images = ops.WeightImages(self.data, self.image_specs, mode)
+        self.images.refresh()
+
+    def pack(self, ws: Sequence[nn.Parameter], bs: Optional[Sequence[nn.Parameter]] = None,
+             image: Optional[str] = None) -> Pack:
+        """Packed (row-concatenated) view of adjacent weights [+ biases].  image: 'fwd' (the matrix is the P operand
+        of a forward GEMM) or 'both' (also of a dX GEMM): listed for the bf16 weight images."""
+        if image is not None and ws and ws[0] is not None and ws[0].dim() == 2:
+            spec = (self.offset[id(ws[0])], sum(p.shape[0] for p in ws), ws[0].shape[1], image == 'both')
+            if spec[:3] not in [s_[:3] for s_ in self.image_specs]:
+                self.image_specs.append(spec)
         def cat(ps):
             if ps is None or len(ps) == 0 or ps[0] is None:
                 return None, None

@@ -425,8 +425,11 @@ def test_full_shape_train_step_vs_oracle(dev, B, L):
     new = model.state_dict()
     for k, ref in o_grads.items():
         d = (new[k].detach().cpu() - sd_o[k]).abs()
+        # what Adam normalises is clip(g) + weight_decay * w (misc/optim.py:61-62): that sum must be well determined
         g64 = d_grads[k]
-        solid = (g64.abs() > 2e-6) & (g64.abs() > 20 * (grads[k].double() - g64).abs())
+        eff = g64.clamp(-clip, clip) + opt["weight_decay"] * sd[k].double()
+        noise = torch.maximum((grads[k].double() - g64).abs(), (ref.double() - g64).abs())
+        solid = (eff.abs() > 2e-6) & (eff.abs() > 20 * noise)
         assert float(d[solid].max() if solid.any() else 0.0) < 1.5e-4, k
         assert float(d.max()) <= 2.05 * opt["learning_rate"], k
         if ref.dim() == 2 and ref.numel() >= 512 * 512 and "embeddings" not in k and "tgt_word_prj" not in k:
