@@ -167,6 +167,8 @@ def main():
     ap.add_argument("--no-compare", action="store_true", help="skip the ARB2 beam-5 vs NACF decode comparison (config 5)")
     ap.add_argument("--no-loader", action="store_true", help="skip the shard-loader leg (SURVEY 8f row 1)")
     ap.add_argument("--loader-videos", type=int, default=1024, help="videos in the synthetic feature shards")
+    ap.add_argument("--gemm-mode", choices=["f32", "bf16x3", "bf16"], default=None,
+                    help="GEMM arithmetic of the headline leg (default: the library default)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -192,6 +194,8 @@ def main():
     from nacf_amd import synthetic as O   # seeded synthetic weights / batches (input generators only)
 
     B, L, V, F_ = args.batch, args.seq_len, args.vocab, 60
+    if args.gemm_mode is not None:
+        ops.set_gemm_mode(args.gemm_mode)
     opt = make_opt(nacf_amd, L, V)
     sd = O.init_state_dict(opt, seed=0)
     model = nacf_amd.get_model(opt)

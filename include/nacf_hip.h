@@ -64,7 +64,7 @@ int nacf_version(void);
  * included).  nacf_abi_count() returns the value the LIBRARY was built with; the ctypes loader
  * (runtime/lib.py:load) refuses a library whose count differs from its own signature table, so a stale
  * libnacf_hip.so next to a newer Python package fails at import time, not at the first missing symbol. */
-#define NACF_ABI_COUNT 67
+#define NACF_ABI_COUNT 66
 int nacf_abi_count(void);
 
 /* ---- batch construction (reference: dataloader.py) ----------------------------------------
@@ -195,7 +195,7 @@ int nacf_gemm_config(int kind, int M, int N, int K, int* tile, int* splits);
 #define NACF_GEMM_F32 0
 #define NACF_GEMM_BF16 1
 #define NACF_GEMM_BF16X3 3
-#define NACF_GEMM_DEFAULT_MODE NACF_GEMM_F32
+#define NACF_GEMM_DEFAULT_MODE NACF_GEMM_BF16X3
 int nacf_gemm_set_mode(int mode);
 int nacf_gemm_get_mode(void);
 /* template name of the GEMM kernel the calling thread launched last (matches rocprofv3's kernel names) */
@@ -203,12 +203,14 @@ const char* nacf_gemm_last_kernel(void);
 
 /* Weight images.  A weight matrix is the P operand of its forward GEMM (y = x W^T) and, transposed, of its dX GEMM
  * (dX = dZ W), for every row tile of both: in the bf16 modes it is converted / split ONCE per optimiser step into
- * bf16 image planes (ns = 1 or 3 planes, `plane_elems` elements apart) and the GEMMs copy those:
- *   nacf_wimage_register   : [w_base, w_base + n_elems) (a model's flat fp32 parameter buffer) has row-major image
- *                            planes at img_base with IDENTICAL element offsets: any W inside the range with
- *                            ldw % 8 == 0 and an offset % 8 == 0 is found by address;
- *   nacf_wimage_register_t : the matrix W [N, K] (row pitch ldw) has the transposed image imgT [K, ldt], ldt % 8 == 0,
- *                            pad columns n >= N zero (found by exact address / shape);
+ * bf16 image planes (ns = 1 or 3 planes, `plane_elems` elements apart) and the GEMMs copy those.  The images are
+ * k-TILE-MAJOR, zero-padded to whole 32-wide k-tiles (a layout private to this library: the 64 bytes a row
+ * contributes to one k-tile sit next to its neighbours', so a wave's load is 1 KB of whole cache lines):
+ *   img  [s][(k / 32) * N + n][k % 32] = term s of W[n][k]     ceil(K/32) * 32 * N elements per plane
+ *   imgT [s][(n / 32) * K + k][n % 32] = term s of W[n][k]     ceil(N/32) * 32 * K elements per plane
+ *   nacf_wimage_register   : the matrix W [N, K] (row pitch ldw) has these images (either may be NULL).  The forward
+ *                            image also serves any run of whole rows of W (packed q|k|v used slice-wise); the
+ *                            transposed one is found by exact address / shape;
  *   nacf_wimage_unregister : forget every image whose fp32 source starts inside [w_base, w_base + n_elems);
  *   nacf_wimage_refresh    : rebuild the images listed in a DEVICE table of descriptors from the current fp32 values
  *                            (one launch, n_tiles = sum of ceil(N/32)*ceil(K/32) workgroups; capturable).
@@ -216,16 +218,15 @@ const char* nacf_gemm_last_kernel(void);
  * (models/seq2seq.py does so at every forward entry). */
 typedef struct nacf_wimage_desc {
   const float* w;        /* [N, ld] fp32 source */
-  uint16_t* img;         /* [ns][N, ldi] or NULL */
-  uint16_t* imgT;        /* [ns][K, ldt] or NULL */
-  int64_t ld, ldi, ldt, plane, planeT;
+  uint16_t* img;         /* forward image planes or NULL */
+  uint16_t* imgT;        /* transposed image planes or NULL */
+  int64_t ld, plane, planeT;
   int32_t N, K;
   int32_t tile0;         /* index of this matrix' first 32x32 tile in the launch */
   int32_t tiles_k;       /* ceil(K / 32) */
 } nacf_wimage_desc;
-int nacf_wimage_register(const float* w_base, int64_t n_elems, const uint16_t* img_base, int64_t plane_elems, int ns);
-int nacf_wimage_register_t(const float* w, int N, int K, int64_t ldw, const uint16_t* imgT, int64_t ldt,
-                           int64_t plane_elems, int ns);
+int nacf_wimage_register(const float* w, int N, int K, int64_t ldw, const uint16_t* img, int64_t plane_elems,
+                         const uint16_t* imgT, int64_t planeT_elems, int ns);
 int nacf_wimage_unregister(const float* w_base, int64_t n_elems);
 int nacf_wimage_refresh(const nacf_wimage_desc* table, int n_desc, int n_tiles, int ns, nacf_stream_t stream);
 

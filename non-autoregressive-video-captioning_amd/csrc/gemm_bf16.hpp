@@ -20,10 +20,13 @@
 // Operand sources (compile time, per operand):
 //   SRC_F32_KC   fp32, reduce-dim contiguous  (activations x, dZ)          -> converted / split while staging
 //   SRC_F32_MC   fp32, row-dim contiguous     (both operands of dW)        -> 4x4 register transpose + convert
-//   SRC_BF16_KC  bf16 image(s) of a weight matrix, reduce-dim contiguous   -> copied (no VALU work).  The images
-//                (W for the forward GEMM, W^T for dX) are rebuilt from the fp32 master weights once per step
-//                (nacf_wimage_refresh): weights are reused by every row tile and by forward AND backward, so
-//                they are split once, not once per tile.
+//   SRC_BF16_KC  bf16 image(s) of a weight matrix, k-TILE-MAJOR: [k / 32][row][32]   -> copied (no VALU work).
+//                The images (W for the forward GEMM, W^T for dX) are rebuilt from the fp32 master weights once
+//                per step (nacf_wimage_refresh): weights are reused by every row tile and by forward AND backward,
+//                so they are split once, not once per tile -- and in OUR layout, so that the 64 bytes a row
+//                contributes to a k-tile sit next to its neighbours' (a wave's load covers 8 full 128-byte lines;
+//                with a row-major image it touched 16 half-used ones and the k-loop was bound by the texture
+//                addresser: 34 cycles per wave load).
 //
 // LDS always holds bf16, K-contiguous: a plane is [rows][32 k] = 64-byte rows, 16-byte chunks XOR-swizzled with
 // lds_sw(row) exactly as the KC tiles of gemm_f32.hpp (same geometry: conflict-free ds_read_b128 fragments,
@@ -40,10 +43,26 @@
 #include "gemm_f32.hpp"
 
 typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+// native vectors (HIP's u32x4 / u32x2 are class types: arrays of them inside the staging structs ended up in scratch)
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
 typedef float f32x2_t __attribute__((ext_vector_type(2)));
 
 enum : int { SRC_F32_KC = 0, SRC_F32_MC = 1, SRC_BF16_KC = 2 };
+
+// Tuning aid, compiled in only with -DNACF_BF16_TRACE (make trace; tools/bf16_trace.py): wave 0 of every workgroup
+// adds up the shader-clock cycles it spends in each phase of the k-loop and stores them at the end:
+//   [0] compute (fragment reads + MFMA issue)  [1] barrier after compute  [2] wait for the staged global loads
+//   [3] convert / split + LDS stores + issue of the next loads  [4] barrier after the stores  [5] whole kernel  [6] k-tiles
+#ifdef NACF_BF16_TRACE
+__device__ unsigned long long* g_bf16_trace = nullptr;
+#define BF16_T(var) const unsigned long long var = __builtin_readcyclecounter()
+#define BF16_TACC(slot, a, b) tacc[slot] += (b) - (a)
+#else
+#define BF16_T(var) do { } while (0)
+#define BF16_TACC(slot, a, b) do { } while (0)
+#endif
 
 // two fp32 -> packed bf16 pair (a in the low half), round-to-nearest-even: v_cvt_pk_bf16_f32
 __device__ __forceinline__ uint32_t bf16_pack_rne(float a, float b) {
@@ -53,83 +72,85 @@ __device__ __forceinline__ uint32_t bf16_pack_rne(float a, float b) {
 __device__ __forceinline__ float bf16_lo_f32(uint32_t p) { return __uint_as_float(p << 16); }
 __device__ __forceinline__ float bf16_hi_f32(uint32_t p) { return __uint_as_float(p & 0xffff0000u); }
 
-// (a, b) -> NS packed bf16 pairs whose sum is (a, b): exactly for NS = 3, to 2^-9 / 2^-17 relative for NS = 1 / 2.
-// The residuals a - bf16(a) are exact in fp32 (Sterbenz), so the terms are the successive bf16 roundings.
+// (a, b) -> NS packed bf16 pairs (a in the low halves).
+//   NS = 1: round to nearest even (v_cvt_pk_bf16_f32).
+//   NS = 3: EXACT split by truncation, x = h + m + l: h = the top 16 bits of x (8 significant bits), m = the top 16 bits
+//           of x - h, l = x - h - m.  Each residual is exact in fp32 and loses >= 8 leading significant bits, so after
+//           two steps at most 8 remain and l is a bf16 value: the three terms add up to x bit for bit.  Only full-rate
+//           integer / add ops (v_and, v_sub, v_perm): 11 per pair.
+__device__ __forceinline__ uint32_t bf16_pack_top(float a, float b) {      // {top16(b), top16(a)}
+  return __builtin_amdgcn_perm(__float_as_uint(b), __float_as_uint(a), 0x07060302u);
+}
+__device__ __forceinline__ float f32_top16(float x) { return __uint_as_float(__float_as_uint(x) & 0xffff0000u); }
 template <int NS>
 __device__ __forceinline__ void bf16_split2(float a, float b, uint32_t (&w)[NS]) {
-  w[0] = bf16_pack_rne(a, b);
-  if constexpr (NS > 1) {
-    a -= bf16_lo_f32(w[0]);
-    b -= bf16_hi_f32(w[0]);
-    w[1] = bf16_pack_rne(a, b);
-  }
-  if constexpr (NS > 2) {
-    a -= bf16_lo_f32(w[1]);
-    b -= bf16_hi_f32(w[1]);
-    w[2] = bf16_pack_rne(a, b);
+  if constexpr (NS == 1) {
+    w[0] = bf16_pack_rne(a, b);
+  } else {
+    static_assert(NS == 3, "1 or 3 terms");
+    w[0] = bf16_pack_top(a, b);
+    a -= f32_top16(a);
+    b -= f32_top16(b);
+    w[1] = bf16_pack_top(a, b);
+    a -= f32_top16(a);
+    b -= f32_top16(b);
+    w[2] = bf16_pack_top(a, b);
   }
 }
 
 // ---------------------------------------------------------------- staging: global -> registers -> LDS planes
 // An LDS plane of R rows is R*4 16-byte chunks: chunk (row, c) at plane[row * 4 + (c ^ lds_sw(row))].
 
-// fp32, k-contiguous rows: thread unit = (row, 8-k chunk), two float4 loads, one ds_write_b128 per plane
+// fp32, k-contiguous rows: thread unit = (row, 16-byte chunk j of the row's 128-byte k-tile segment), 8 lanes per row,
+// so every wave load covers 8 whole 128-byte lines; one float4 load and one ds_write_b64 per plane per unit
 template <int R, int NS>
 struct StageF32KC {
-  static constexpr int U = R / 64;
-  f32x4 v[U][2];
-  const float* ptr[U];   // (clamped) physical row base + 8 * chunk
+  static constexpr int U = R / 32;
+  f32x4 v[U];
+  const float* ptr[U];   // (clamped) physical row base + 4 * j
   bool ok[U];            // row inside the matrix
   __device__ __forceinline__ void init(const float* base, int64_t ld, int r0, int rmax, const int* rowlist, int tid) {
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      const int q = tid + 256 * u;
-      const int gr = r0 + (q >> 2);
+      const int gr = r0 + (tid >> 3) + 32 * u;
       const int gc = min(gr, rmax - 1);
       const int ph = rowlist ? rowlist[gc] : gc;
       ok[u] = gr < rmax;
-      ptr[u] = base + (int64_t)ph * ld + (q & 3) * 8;
+      ptr[u] = base + (int64_t)ph * ld + (tid & 7) * 4;
     }
   }
   __device__ __forceinline__ void load_fast(int k0) {
 #pragma unroll
-    for (int u = 0; u < U; ++u) {
-      v[u][0] = *reinterpret_cast<const f32x4*>(ptr[u] + k0);
-      v[u][1] = *reinterpret_cast<const f32x4*>(ptr[u] + k0 + 4);
-    }
+    for (int u = 0; u < U; ++u) v[u] = *reinterpret_cast<const f32x4*>(ptr[u] + k0);
   }
   __device__ __forceinline__ void load_checked(int k0, int kend, int tid) {
-    const int c = tid & 3;
-#pragma unroll
-    for (int u = 0; u < U; ++u)
-#pragma unroll
-      for (int h = 0; h < 2; ++h) {
-        const int nv = kend - (k0 + 8 * c + 4 * h);
-        f32x4 t = {0.f, 0.f, 0.f, 0.f};
-        if (ok[u] && nv > 0) {
-          const float* p = ptr[u] + k0 + 4 * h;
-          if (nv >= 4) t = *reinterpret_cast<const f32x4*>(p);
-          else {
-            t[0] = p[0];
-            if (nv > 1) t[1] = p[1];
-            if (nv > 2) t[2] = p[2];
-          }
-        }
-        v[u][h] = t;
-      }
-  }
-  __device__ __forceinline__ void write(uint4* plane0, int tid) const {
+    const int nv = kend - (k0 + 4 * (tid & 7));
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      const int q = tid + 256 * u;
-      const int row = q >> 2, c = q & 3;
-      uint32_t w0[NS], w1[NS], w2[NS], w3[NS];
-      bf16_split2<NS>(v[u][0][0], v[u][0][1], w0);
-      bf16_split2<NS>(v[u][0][2], v[u][0][3], w1);
-      bf16_split2<NS>(v[u][1][0], v[u][1][1], w2);
-      bf16_split2<NS>(v[u][1][2], v[u][1][3], w3);
+      f32x4 t = {0.f, 0.f, 0.f, 0.f};
+      if (ok[u] && nv > 0) {
+        const float* p = ptr[u] + k0;
+        if (nv >= 4) t = *reinterpret_cast<const f32x4*>(p);
+        else {
+          t[0] = p[0];
+          if (nv > 1) t[1] = p[1];
+          if (nv > 2) t[2] = p[2];
+        }
+      }
+      v[u] = t;
+    }
+  }
+  __device__ __forceinline__ void write(u32x4* plane0, int tid) const {
+    u32x2* p8 = reinterpret_cast<u32x2*>(plane0);
+    const int j = tid & 7;
 #pragma unroll
-      for (int p = 0; p < NS; ++p) plane0[p * (R * 4) + row * 4 + (c ^ lds_sw(row))] = uint4{w0[p], w1[p], w2[p], w3[p]};
+    for (int u = 0; u < U; ++u) {
+      const int row = (tid >> 3) + 32 * u;
+      uint32_t wa[NS], wb[NS];
+      bf16_split2<NS>(v[u][0], v[u][1], wa);
+      bf16_split2<NS>(v[u][2], v[u][3], wb);
+#pragma unroll
+      for (int p = 0; p < NS; ++p) p8[(p * (R * 4) + row * 4 + ((j >> 1) ^ lds_sw(row))) * 2 + (j & 1)] = u32x2{wa[p], wb[p]};
     }
   }
 };
@@ -191,9 +212,9 @@ struct StageF32MC {
       v[j] = t;
     }
   }
-  __device__ __forceinline__ void write(uint4* plane0) const {
+  __device__ __forceinline__ void write(u32x4* plane0) const {
     if (active) {
-      uint2* p8 = reinterpret_cast<uint2*>(plane0);
+      u32x2* p8 = reinterpret_cast<u32x2*>(plane0);
       const int c = mq >> 1, half = mq & 1;
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
@@ -202,44 +223,35 @@ struct StageF32MC {
         bf16_split2<NS>(v[0][e], v[1][e], wa);
         bf16_split2<NS>(v[2][e], v[3][e], wb);
 #pragma unroll
-        for (int p = 0; p < NS; ++p) p8[(p * (R * 4) + row * 4 + (c ^ lds_sw(row))) * 2 + half] = uint2{wa[p], wb[p]};
+        for (int p = 0; p < NS; ++p) p8[(p * (R * 4) + row * 4 + (c ^ lds_sw(row))) * 2 + half] = u32x2{wa[p], wb[p]};
       }
     }
   }
 };
 
-// bf16 image planes, k-contiguous rows: copied
+// bf16 image planes, k-tile-major ([k / 32][row][32], zero-padded to whole k-tiles): a row tile of one k-tile is
+// R * 64 contiguous bytes; copied
 template <int R, int NS>
 struct StageBF16KC {
   static constexpr int U = R / 64;
-  uint4 v[U][NS];
-  const unsigned short* ptr[U];
-  bool ok[U];
-  __device__ __forceinline__ void init(const unsigned short* img, int64_t ld, int r0, int rmax, int tid) {
+  u32x4 v[U][NS];
+  const unsigned short* ptr[U];   // k-tile 0: (clamped) row * 32 + 8 * chunk
+  __device__ __forceinline__ void init(const unsigned short* img, int r0, int rmax, int tid) {
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const int q = tid + 256 * u;
-      const int gr = r0 + (q >> 2);
-      ok[u] = gr < rmax;
-      ptr[u] = img + (int64_t)min(gr, rmax - 1) * ld + (q & 3) * 8;
+      ptr[u] = img + (int64_t)min(r0 + (q >> 2), rmax - 1) * 32 + (q & 3) * 8;
     }
   }
-  __device__ __forceinline__ void load_fast(int k0, int64_t plane) {
+  // kt_stride: elements between consecutive k-tiles (= rows of the registered matrix * 32)
+  __device__ __forceinline__ void load(int k0, int64_t kt_stride, int64_t plane) {
+    const int64_t off = (int64_t)(k0 >> 5) * kt_stride;
 #pragma unroll
     for (int u = 0; u < U; ++u)
 #pragma unroll
-      for (int p = 0; p < NS; ++p) v[u][p] = *reinterpret_cast<const uint4*>(ptr[u] + p * plane + k0);
+      for (int p = 0; p < NS; ++p) v[u][p] = *reinterpret_cast<const u32x4*>(ptr[u] + p * plane + off);
   }
-  // images are padded so that a chunk is either wholly inside the reduce range or wholly outside (K % 8 == 0)
-  __device__ __forceinline__ void load_checked(int k0, int kend, int64_t plane, int tid) {
-    const bool in = k0 + 8 * (tid & 3) < kend;
-#pragma unroll
-    for (int u = 0; u < U; ++u)
-#pragma unroll
-      for (int p = 0; p < NS; ++p)
-        v[u][p] = (ok[u] && in) ? *reinterpret_cast<const uint4*>(ptr[u] + p * plane + k0) : uint4{0u, 0u, 0u, 0u};
-  }
-  __device__ __forceinline__ void write(uint4* plane0, int tid) const {
+  __device__ __forceinline__ void write(u32x4* plane0, int tid) const {
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const int q = tid + 256 * u;
@@ -255,13 +267,13 @@ template <int R, int NS, int ROT> struct StagerOf<SRC_F32_KC, R, NS, ROT> { usin
 template <int R, int NS, int ROT> struct StagerOf<SRC_F32_MC, R, NS, ROT> { using type = StageF32MC<R, NS, ROT>; };
 template <int R, int NS, int ROT> struct StagerOf<SRC_BF16_KC, R, NS, ROT> { using type = StageBF16KC<R, NS>; };
 
-__device__ __forceinline__ bf16x8_t lds_frag(const uint4* plane, int row, int g) {
+__device__ __forceinline__ bf16x8_t lds_frag(const u32x4* plane, int row, int g) {
   return __builtin_bit_cast(bf16x8_t, plane[row * 4 + (g ^ lds_sw(row))]);
 }
 
 // ---------------------------------------------------------------- kernel
 template <int BM, int BN, int QSRC, int PSRC, int NS, int STAGES, class Epi>
-__global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmShape g, Epi epi) {
+__global__ __launch_bounds__(256, (BM == 64 ? 3 : 2)) void gemm_bf16_kernel(GemmShape g, Epi epi) {
   constexpr int BK = 32;
   constexpr int WM = 2, WN = 2;
   constexpr int WTM = BM / WM, WTN = BN / WN;
@@ -276,7 +288,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmShape g, Epi epi)
   constexpr int STAGE = NS * (QPL + PPL);
   constexpr int RED = Epi::kArgmax ? (3 * WN * BM + 3) / 4 : (BM + 3) / 4;   // epilogue scratch (floats -> chunks)
   constexpr int SMEM = (STAGES * STAGE > RED) ? STAGES * STAGE : RED;
-  __shared__ uint4 smem[SMEM];
+  __shared__ u32x4 smem[SMEM];
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
@@ -332,20 +344,23 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmShape g, Epi epi)
   else qs.init(g.Q, m0, g.M, tid);
   if constexpr (PSRC == SRC_F32_KC) ps.init(g.P, g.ldp, n0, g.N, nullptr, tid);
   else if constexpr (PSRC == SRC_F32_MC) ps.init(g.P, n0, g.N, tid);
-  else ps.init(g.Pimg, g.ldpi, n0, g.N, tid);
+  else ps.init(g.Pimg, n0, g.N, tid);
   // row-contiguous operands take the unchecked loader only when the whole row tile is inside the matrix
   const bool q_full = QKC || (m0 + BM <= g.M);
   const bool p_full = PKC || (n0 + BN <= g.N);
   const bool rows_full = q_full && p_full;
 
   auto load_tile = [&](int kt, bool idx_ready) {
+#ifdef BF16_EXP_NOLOAD    // timing experiment only: the k-loop re-uses the first tiles' registers
+    if (kt >= 2) return;
+#endif
     const int k0 = kbeg + kt * BK;
     const bool fast = rows_full && (k0 + BK <= kend);
     if constexpr (QSRC == SRC_F32_KC) { if (fast) qs.load_fast(k0); else qs.load_checked(k0, kend, tid); }
     else { if (fast) qs.load_fast(k0, g.ldq, kmap, idx_ready); else qs.load_checked(k0, kend, g.ldq, kmap); }
     if constexpr (PSRC == SRC_F32_KC) { if (fast) ps.load_fast(k0); else ps.load_checked(k0, kend, tid); }
     else if constexpr (PSRC == SRC_F32_MC) { if (fast) ps.load_fast(k0, g.ldp, kmap, idx_ready); else ps.load_checked(k0, kend, g.ldp, kmap); }
-    else { if (fast) ps.load_fast(k0, g.pimg_plane); else ps.load_checked(k0, kend, g.pimg_plane, tid); }
+    else ps.load(k0, g.ldpi, g.pimg_plane);      // zero-padded to whole k-tiles, rows clamped: never out of bounds
   };
   auto prefetch_kidx = [&](int kt) {      // reduce-row indices of tile kt (row-list dW), one tile ahead of its loads
     if constexpr (ROWS_ARE_K) {
@@ -358,7 +373,11 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmShape g, Epi epi)
   const bool do_colsum = ROWS_ARE_K && (g.colsum_part || g.colsum_out) && tile_n == 0;
   f32x4 qsum = {0.f, 0.f, 0.f, 0.f};
   auto write_tile = [&](int stage) {
-    uint4* base = smem + stage * STAGE;
+#ifdef BF16_EXP_NOSTORE   // timing experiment only
+    if (stage >= 0 && nk > 1000000) return;
+    { asm volatile("" :: "v"(qs.v[0]), "v"(ps.v[0])); if (kbeg >= 0) return; }
+#endif
+    u32x4* base = smem + stage * STAGE;
     if constexpr (QSRC == SRC_F32_KC) qs.write(base, tid);
     else {
       qs.write(base);
@@ -375,8 +394,8 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmShape g, Epi epi)
     for (int b = 0; b < TN; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   auto compute = [&](int stage) {
-    const uint4* qpl = smem + stage * STAGE;
-    const uint4* ppl = qpl + NS * QPL;
+    const u32x4* qpl = smem + stage * STAGE;
+    const u32x4* ppl = qpl + NS * QPL;
     bf16x8_t pf[TN][NS];
 #pragma unroll
     for (int b = 0; b < TN; ++b)
@@ -408,6 +427,10 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmShape g, Epi epi)
     }
   };
 
+#ifdef NACF_BF16_TRACE
+  unsigned long long tacc[5] = {0, 0, 0, 0, 0};
+  const unsigned long long t_begin = __builtin_readcyclecounter();
+#endif
   // ---- pipeline: G(t) global -> registers, W(t) registers -> LDS image (convert / split), C(t) fragments + MFMAs
   if (nk > 0) {
     load_tile(0, false);
@@ -420,20 +443,48 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmShape g, Epi epi)
   for (int kt = 0; kt < nk; ++kt) {
     if constexpr (STAGES == 2) {
       // W(kt+1) goes into the image C(kt-1) read (a barrier ago); G(kt+2) has all of C(kt) to land
+      BF16_T(t0);
+#ifdef NACF_BF16_TRACE
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+      BF16_T(t1);
       if (kt + 1 < nk) write_tile((kt + 1) & 1);
       if (kt + 2 < nk) { load_tile(kt + 2, true); prefetch_kidx(kt + 3); }
+      BF16_T(t2);
       compute(kt & 1);
+      BF16_T(t3);
       __syncthreads();
+      BF16_T(t4);
+      BF16_TACC(2, t0, t1); BF16_TACC(3, t1, t2); BF16_TACC(0, t2, t3); BF16_TACC(1, t3, t4);
     } else {
+      BF16_T(t0);
       compute(0);
+      BF16_T(t1);
       __syncthreads();
+      BF16_T(t2);
+#ifdef NACF_BF16_TRACE
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+      BF16_T(t3);
       if (kt + 1 < nk) {
         write_tile(0);
         if (kt + 2 < nk) { load_tile(kt + 2, true); prefetch_kidx(kt + 3); }
       }
+      BF16_T(t4);
       __syncthreads();
+      BF16_T(t5);
+      BF16_TACC(0, t0, t1); BF16_TACC(1, t1, t2); BF16_TACC(2, t2, t3); BF16_TACC(3, t3, t4); BF16_TACC(4, t4, t5);
     }
   }
+#ifdef NACF_BF16_TRACE
+  if (g_bf16_trace && tid == 0) {
+    unsigned long long* o = g_bf16_trace + ((size_t)blockIdx.z * gridDim.x + blockIdx.x) * 8;
+    for (int i = 0; i < 5; ++i) o[i] = tacc[i];
+    o[5] = __builtin_readcyclecounter() - t_begin;
+    o[6] = (unsigned long long)nk;
+    o[7] = wall_clock64();
+  }
+#endif
 
   if constexpr (ROWS_ARE_K) {
     if (do_colsum) {
@@ -477,9 +528,9 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmShape g, Epi epi)
 
 // ---------------------------------------------------------------- weight images
 // One launch rebuilds every registered image from the fp32 master weights: for matrix i (N x K, row pitch ld),
-//   img [s][n * ldi + k]  = bf16 term s of W[n][k]        (forward:  P = W,   reduce over k)
-//   imgT[s][k * ldt + n]  = bf16 term s of W[n][k]        (dX:       P = W^T, reduce over n; pad columns n >= N are 0)
-// A workgroup converts one 32 x 32 tile; the transposed copy goes through LDS so both stores are row-contiguous.
+//   img [s][(k / 32) * N + n][k % 32] = bf16 term s of W[n][k]     (forward: P = W,   reduce over k, zero-padded to 32)
+//   imgT[s][(n / 32) * K + k][n % 32] = bf16 term s of W[n][k]     (dX:      P = W^T, reduce over n, zero-padded to 32)
+// A workgroup converts one 32 x 32 tile; the transposed copy goes through LDS so both stores are 64-byte rows.
 typedef nacf_wimage_desc WImageDesc;   // include/nacf_hip.h
 
 template <int NS>
@@ -513,35 +564,20 @@ __global__ __launch_bounds__(256) void wimage_refresh_kernel(const WImageDesc* _
   bf16_split2<NS>(x[2], x[3], w1);
 #pragma unroll
   for (int p = 0; p < NS; ++p) {
-    if (d.img && n < d.N) {
-      unsigned short* dst = d.img + p * d.plane + (int64_t)n * d.ldi + k;
-      if (k + 4 <= d.ldi && (d.ldi & 3) == 0 && (reinterpret_cast<uintptr_t>(d.img) & 7) == 0 && (d.plane & 3) == 0)
-        *reinterpret_cast<uint2*>(dst) = uint2{w0[p], w1[p]};
-      else {
-        const unsigned short h[4] = {(unsigned short)(w0[p] & 0xffffu), (unsigned short)(w0[p] >> 16),
-                                     (unsigned short)(w1[p] & 0xffffu), (unsigned short)(w1[p] >> 16)};
-#pragma unroll
-        for (int e = 0; e < 4; ++e)
-          if (k + e < d.ldi) dst[e] = h[e];          // pad columns (k >= K) receive zeros
-      }
-    }
-    *reinterpret_cast<uint2*>(&tile[p][r][c4]) = uint2{w0[p], w1[p]};
+    // img[k / 32][n][k % 32]: the 64 bytes of row n in k-tile k0 / 32; columns k >= K receive zeros (x = 0 there)
+    if (d.img && n < d.N)
+      *reinterpret_cast<u32x2*>(d.img + p * d.plane + ((int64_t)(k0 >> 5) * d.N + n) * 32 + c4) = u32x2{w0[p], w1[p]};
+    *reinterpret_cast<u32x2*>(&tile[p][r][c4]) = u32x2{w0[p], w1[p]};
   }
   if (d.imgT) {
     __syncthreads();
-    const int kk = k0 + r, nn = n0 + c4;    // transposed: thread (r, c4) writes imgT[k0 + r][n0 + c4 .. + 3]
+    const int kk = k0 + r;    // imgT[n / 32][k][n % 32]: thread (r, c4) writes row k0 + r, columns n0 + c4 .. + 3 (zeros for n >= N)
     if (kk < d.K) {
 #pragma unroll
       for (int p = 0; p < NS; ++p) {
-        const unsigned short h[4] = {tile[p][c4][r], tile[p][c4 + 1][r], tile[p][c4 + 2][r], tile[p][c4 + 3][r]};
-        unsigned short* dst = d.imgT + p * d.planeT + (int64_t)kk * d.ldt + nn;
-        if (nn + 4 <= d.ldt && (d.ldt & 3) == 0 && (reinterpret_cast<uintptr_t>(d.imgT) & 7) == 0 && (d.planeT & 3) == 0)
-          *reinterpret_cast<uint2*>(dst) = uint2{(uint32_t)h[0] | ((uint32_t)h[1] << 16), (uint32_t)h[2] | ((uint32_t)h[3] << 16)};
-        else {
-#pragma unroll
-          for (int e = 0; e < 4; ++e)
-            if (nn + e < d.ldt) dst[e] = h[e];       // pad columns (n >= N) receive zeros (tile rows n >= N hold zeros)
-        }
+        const uint32_t lo = (uint32_t)tile[p][c4][r] | ((uint32_t)tile[p][c4 + 1][r] << 16);
+        const uint32_t hi = (uint32_t)tile[p][c4 + 2][r] | ((uint32_t)tile[p][c4 + 3][r] << 16);
+        *reinterpret_cast<u32x2*>(d.imgT + p * d.planeT + ((int64_t)(n0 >> 5) * d.K + kk) * 32 + c4) = u32x2{lo, hi};
       }
     }
   }

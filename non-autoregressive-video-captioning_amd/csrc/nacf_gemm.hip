@@ -26,29 +26,30 @@ inline int kalign() { return gemm_mode() == NACF_GEMM_F32 ? 16 : 32; }   // k-ti
 thread_local char g_last_f32_kernel[160] = "";
 thread_local bool g_last_was_bf16 = false;
 
-// ---- registry of pre-split bf16 weight images (nacf_wimage_register*)
-struct ImgRange { const float* w; int64_t n; const unsigned short* img; int64_t plane; int ns; };
-struct ImgT { const float* w; int N, K; int64_t ld; const unsigned short* imgT; int64_t ldt, plane; int ns; };
-std::vector<ImgRange> g_img_ranges;
-std::vector<ImgT> g_img_t;
+// ---- registry of pre-split bf16 weight images (nacf_wimage_register): one entry per weight matrix
+struct ImgMat { const float* w; int N, K; int64_t ld; const unsigned short* img; int64_t plane;
+                const unsigned short* imgT; int64_t planeT; int ns; };
+std::vector<ImgMat> g_imgs;
 
-// row-major image of W [N, K] (row pitch ldw) when W lies inside a registered fp32 range: same offsets, bf16 elements
+// forward image of W [N, K] (row pitch ldw): W is a registered matrix or a run of whole rows of one (packed q|k|v
+// weights used slice-wise).  k-tile-major: row n of k-tile t at img[(t * N_registered + n) * 32]
 bool find_image(const float* W, int64_t ldw, int N, int K, int ns, GemmShape& g) {
-  if (K % 8 != 0 || ldw % 8 != 0) return false;
-  for (const ImgRange& r : g_img_ranges) {
-    if (r.ns != ns || W < r.w || W >= r.w + r.n) continue;
-    const int64_t off = W - r.w;
-    if (off % 8 != 0 || off + (int64_t)(N - 1) * ldw + K > r.n) return false;
-    g.Pimg = r.img + off; g.ldpi = ldw; g.pimg_plane = r.plane;
+  for (const ImgMat& m : g_imgs) {
+    if (m.ns != ns || !m.img || m.ld != ldw || m.K != K || W < m.w) continue;
+    const int64_t off = W - m.w;
+    if (off % m.ld != 0) continue;
+    const int64_t n0 = off / m.ld;
+    if (n0 + N > m.N) continue;
+    g.Pimg = m.img + n0 * 32; g.ldpi = (int64_t)m.N * 32; g.pimg_plane = m.plane;
     return true;
   }
   return false;
 }
 // transposed image of exactly this matrix (dX = dZ W: P = W^T, rows = the K output columns, reduce over N)
 bool find_image_t(const float* W, int64_t ldw, int N, int K, int ns, GemmShape& g) {
-  for (const ImgT& t : g_img_t) {
-    if (t.w == W && t.N == N && t.K == K && t.ld == ldw && t.ns == ns) {
-      g.Pimg = t.imgT; g.ldpi = t.ldt; g.pimg_plane = t.plane;
+  for (const ImgMat& m : g_imgs) {
+    if (m.w == W && m.N == N && m.K == K && m.ld == ldw && m.ns == ns && m.imgT) {
+      g.Pimg = m.imgT; g.ldpi = (int64_t)m.K * 32; g.pimg_plane = m.planeT;
       return true;
     }
   }
@@ -73,6 +74,29 @@ int pick_tile(int M, int N, int splits, bool has_rows = false, bool heavy_epilog
   // 640 big tiles, 128x128 wins from 960).  With a live-row list the host does not know how many row tiles
   // survive (typically 40-60 %), so ask for twice the tiles.
   return big >= (has_rows ? 1536 : 768) ? 0 : 1;
+}
+
+// The bf16 matrix-core kernels (gemm_bf16.hpp) want other tiles than the fp32 ones: the 128x128 kernel amortises the
+// staging work (convert / split + LDS stores + load issue, the longer phase of a k-tile) over 4x the MFMAs but runs
+// only two workgroups per CU.  Measured (tools/gemm_bench.py --modes, tools/dw_rows_bench.py; profiles/r02_*):
+// with >= ~200 big tiles the big tile wins (forward: 136 vs 112 TF exact at 240 tiles, K = 2048), a live-row
+// forward needs ~400 (the row list costs the big tile more edge work), dX in the throughput mode from ~90.
+// kind: 0 forward, 1 dX.  ns: 1 throughput, 3 exact.
+int pick_tile_bf16(int kind, int M, int N, int splits, bool has_rows, int ns, bool heavy_epilogue = false) {
+  const int forced = forced_tile();
+  if (forced >= 0) return forced;
+  const int m_eff = has_rows ? (int)((long)M * 29 / 50) : M;       // ~58 % of the slots are live (not known to the host)
+  const long big = (long)cdiv(m_eff > 0 ? m_eff : 1, 128) * cdiv(N, 128) * splits;
+  long thr;
+  if (kind == 0) {
+    // throughput mode: the small-tile kernel runs 7-8 workgroups per CU and hides a row list's edge work and a
+    // transcendental epilogue (tanh|sigmoid, gelu) far better: 64x64 unless the launch is huge (the vocabulary)
+    thr = has_rows ? (ns == 1 ? 1500 : 400) : 200;
+    if (heavy_epilogue && ns == 1) thr = 1L << 40;
+  } else {
+    thr = (ns == 1) ? 90 : (has_rows ? 300 : 200);
+  }
+  return big >= thr ? 0 : 1;
 }
 
 template <class Epi> const char* epi_name();
@@ -338,13 +362,12 @@ int nacf_linear_fwd(const float* X, int64_t ldx, const float* W, int64_t ldw, fl
   const bool heavy = epi.ep.act == NACF_ACT_GELU_NEW || epi.ep.act == NACF_ACT_GELU_ERF || epi.ep.act == NACF_ACT_TANH ||
                      epi.ep.act == NACF_ACT_SIGMOID || epi.ep.act == NACF_ACT_TANH_SIGMOID;
   const int mode = gemm_mode();
-  const int tile = pick_tile(M, N, 1, rs != nullptr, heavy);
   if (mode != NACF_GEMM_F32 && vec) {          // bf16 matrix cores (16-byte addressable operands only)
     find_image(W, ldw, N, K, mode, g);
-    launch_bf16_linear(g, epi, tile, mode, as_hip(stream));
+    launch_bf16_linear(g, epi, pick_tile_bf16(0, M, N, 1, rs != nullptr, mode, heavy), mode, as_hip(stream));
     g_last_was_bf16 = true;
   } else {
-    launch_gemm<true, true, EpiLinear>(g, epi, 1, tile, vec, as_hip(stream));
+    launch_gemm<true, true, EpiLinear>(g, epi, 1, pick_tile(M, N, 1, rs != nullptr, heavy), vec, as_hip(stream));
   }
   NACF_LAUNCH_CHECK("nacf_linear_fwd");
   return NACF_OK;
@@ -408,7 +431,7 @@ int nacf_linear_bwd_data(const float* dZ, int64_t lddz, const float* W, int64_t 
   }
   if (bf16) {
     find_image_t(W, ldw, N, K, mode, g);       // P = W^T image [K, N] when registered, else the fp32 W read transposed
-    launch_bf16_dx(g, epi, real_splits, pick_tile(M, K, real_splits, rs != nullptr), mode, s);
+    launch_bf16_dx(g, epi, real_splits, pick_tile_bf16(1, M, K, real_splits, rs != nullptr, mode), mode, s);
     g_last_was_bf16 = true;
   } else {
     launch_gemm<true, false, EpiStore>(g, epi, real_splits, pick_tile(M, K, real_splits, rs != nullptr), vec, s);
@@ -422,6 +445,30 @@ int nacf_linear_bwd_data(const float* dZ, int64_t lddz, const float* W, int64_t 
     NACF_LAUNCH_CHECK("nacf_linear_bwd_data(reduce)");
   }
   return NACF_OK;
+}
+
+// dW on the bf16 matrix cores: the 128x128 tile from 16 output tiles on (132 vs 90 TF exact, 134 vs 91 bf16 on the
+// FFN weights with 2980 live rows); splits: the fewest that give >= 480 workgroups with a well-filled last round
+// (512 resident workgroups per round), each split walking >= 160 reduce rows (5 k-tiles).
+static int bwd_weight_splits_bf16(int M, int N, int K, bool has_rows, int* tile_out) {
+  const int m_eff = has_rows ? M * 11 / 20 : M;
+  int tile = ((long)cdiv(N, 128) * cdiv(K, 128) >= 16 && m_eff >= 1024) ? 0 : 1;
+  const int forced = forced_tile();
+  if (forced >= 0) tile = forced;
+  const int t = tile == 0 ? 128 : 64;
+  const long tiles = (long)cdiv(N, t) * cdiv(K, t);
+  const long slots = tile == 0 ? 512 : 768;
+  int max_s = m_eff / 160 > 0 ? m_eff / 160 : 1;
+  if (max_s > 64) max_s = 64;
+  int s = 1;
+  for (; s < max_s; ++s) {
+    const long wgs = tiles * s;
+    const long rounds = (wgs + slots - 1) / slots;
+    if (wgs >= slots * 15 / 16 && wgs * 100 >= rounds * slots * 85) break;
+  }
+  { const char* e = getenv("NACF_GEMM_SPLITS"); if (e && atoi(e) > 0) s = atoi(e); }
+  *tile_out = tile;
+  return s;
 }
 
 static int bwd_weight_splits(int M, int N, int K, bool has_rows, int* tile_out) {
@@ -451,7 +498,10 @@ static int bwd_weight_splits(int M, int N, int K, bool has_rows, int* tile_out) 
 size_t nacf_linear_bwd_weight_workspace(int M, int N, int K) {
   int tile;
   const int a = bwd_weight_splits(M, N, K, false, &tile), b = bwd_weight_splits(M, N, K, true, &tile);
-  const int s = a > b ? a : b;
+  const int c = bwd_weight_splits_bf16(M, N, K, false, &tile), d = bwd_weight_splits_bf16(M, N, K, true, &tile);
+  int s = a > b ? a : b;      // whichever kernel family the call ends up on (mode, alignment)
+  if (c > s) s = c;
+  if (d > s) s = d;
   const size_t slabs = s > 1 ? (size_t)s * N * K * sizeof(float) : 0;
   const size_t col = (size_t)64 * N * sizeof(float);
   return slabs + col + 256;
@@ -469,15 +519,15 @@ int nacf_linear_bwd_weight(const float* dZ, int64_t lddz, const float* X, int64_
   NACF_CHECK(aligned16(ws), NACF_EINVAL, "nacf_linear_bwd_weight: workspace must be 16-byte aligned");
   NACF_CHECK(!rs || (rs->rows && rs->count), NACF_EINVAL, "nacf_linear_bwd_weight: incomplete row set");
   int tile;
-  const int splits = bwd_weight_splits(M, N, K, rs != nullptr, &tile);
+  const bool vec = (lddz % 4 == 0) && (ldx % 4 == 0) && aligned16(dZ) && aligned16(X);
+  const int mode = gemm_mode();
+  const bool bf16 = mode != NACF_GEMM_F32 && vec;
+  const int splits = bf16 ? bwd_weight_splits_bf16(M, N, K, rs != nullptr, &tile) : bwd_weight_splits(M, N, K, rs != nullptr, &tile);
   hipStream_t s = as_hip(stream);
   // dW[n][k] = sum_m dZ[m][n] X[m][k]: output rows = n (Q = dZ, MC: element (n, m) at dZ[m*lddz + n]),
   // output cols = k (P = X, MC: element (k, m) at X[m*ldx + k]), reduce = m (through the live-row list if given)
   GemmShape g = {};
   g.Q = dZ; g.P = X; g.ldq = lddz; g.ldp = ldx; g.M = N; g.N = K; g.K = M;
-  const bool vec = (lddz % 4 == 0) && (ldx % 4 == 0) && aligned16(dZ) && aligned16(X);
-  const int mode = gemm_mode();
-  const bool bf16 = mode != NACF_GEMM_F32 && vec;
   const int ka = bf16 ? 32 : 16;
   g.k_per_split = cdiv(cdiv(M, splits), ka) * ka;
   set_rows(g, rs);
@@ -532,33 +582,23 @@ int nacf_gemm_set_mode(int mode) {
 int nacf_gemm_get_mode(void) { return gemm_mode(); }
 const char* nacf_gemm_last_kernel(void) { return g_last_was_bf16 ? bf16_last_kernel_name() : g_last_f32_kernel; }
 
-int nacf_wimage_register(const float* w_base, int64_t n_elems, const uint16_t* img_base, int64_t plane_elems, int ns) {
-  NACF_CHECK(w_base && img_base && n_elems > 0 && (ns == 1 || ns == 3) && plane_elems >= n_elems, NACF_EINVAL,
+int nacf_wimage_register(const float* w, int N, int K, int64_t ldw, const uint16_t* img, int64_t plane_elems,
+                         const uint16_t* imgT, int64_t planeT_elems, int ns) {
+  NACF_CHECK(w && N > 0 && K > 0 && ldw >= K && (img || imgT) && (ns == 1 || ns == 3), NACF_EINVAL,
              "nacf_wimage_register: bad argument");
-  NACF_CHECK(aligned16(w_base) && aligned16(img_base) && plane_elems % 8 == 0, NACF_EINVAL,
-             "nacf_wimage_register: buffers must be 16-byte aligned, planes a multiple of 8 elements apart");
-  for (ImgRange& r : g_img_ranges)
-    if (r.w == w_base && r.ns == ns) { r = ImgRange{w_base, n_elems, img_base, plane_elems, ns}; return NACF_OK; }
-  g_img_ranges.push_back(ImgRange{w_base, n_elems, img_base, plane_elems, ns});
-  return NACF_OK;
-}
-int nacf_wimage_register_t(const float* w, int N, int K, int64_t ldw, const uint16_t* imgT, int64_t ldt, int64_t plane_elems,
-                           int ns) {
-  NACF_CHECK(w && imgT && N > 0 && K > 0 && ldw >= K && ldt >= N && (ns == 1 || ns == 3), NACF_EINVAL,
-             "nacf_wimage_register_t: bad argument");
-  NACF_CHECK(aligned16(imgT) && ldt % 8 == 0 && plane_elems % 8 == 0 && plane_elems >= (int64_t)K * ldt, NACF_EINVAL,
-             "nacf_wimage_register_t: image rows must be 16-byte aligned (ldt %% 8 == 0)");
-  for (ImgT& t : g_img_t)
-    if (t.w == w && t.ns == ns) { t = ImgT{w, N, K, ldw, imgT, ldt, plane_elems, ns}; return NACF_OK; }
-  g_img_t.push_back(ImgT{w, N, K, ldw, imgT, ldt, plane_elems, ns});
+  NACF_CHECK((!img || (aligned16(img) && plane_elems % 8 == 0 && plane_elems >= (int64_t)cdiv(K, 32) * 32 * N)) &&
+             (!imgT || (aligned16(imgT) && planeT_elems % 8 == 0 && planeT_elems >= (int64_t)cdiv(N, 32) * 32 * K)),
+             NACF_EINVAL, "nacf_wimage_register: images must be 16-byte aligned and hold whole 32-wide k-tiles");
+  const ImgMat e{w, N, K, ldw, img, plane_elems, imgT, planeT_elems, ns};
+  for (ImgMat& m : g_imgs)
+    if (m.w == w && m.ns == ns) { m = e; return NACF_OK; }
+  g_imgs.push_back(e);
   return NACF_OK;
 }
 int nacf_wimage_unregister(const float* w_base, int64_t n_elems) {
   NACF_CHECK(w_base && n_elems > 0, NACF_EINVAL, "nacf_wimage_unregister: bad argument");
-  for (size_t i = g_img_ranges.size(); i-- > 0;)
-    if (g_img_ranges[i].w >= w_base && g_img_ranges[i].w < w_base + n_elems) g_img_ranges.erase(g_img_ranges.begin() + i);
-  for (size_t i = g_img_t.size(); i-- > 0;)
-    if (g_img_t[i].w >= w_base && g_img_t[i].w < w_base + n_elems) g_img_t.erase(g_img_t.begin() + i);
+  for (size_t i = g_imgs.size(); i-- > 0;)
+    if (g_imgs[i].w >= w_base && g_imgs[i].w < w_base + n_elems) g_imgs.erase(g_imgs.begin() + i);
   return NACF_OK;
 }
 int nacf_wimage_refresh(const nacf_wimage_desc* table, int n_desc, int n_tiles, int ns, nacf_stream_t stream) {
@@ -573,15 +613,17 @@ int nacf_gemm_config(int kind, int M, int N, int K, int* tile, int* splits) {
   int t = 0, s = 1;
   const bool with_rows = (kind & 0x100) != 0, heavy = (kind & 0x200) != 0;   // as the launch itself will see them
   kind &= 0xff;
-  if (kind == 0) t = pick_tile(M, N, 1, with_rows, heavy);
+  const int mode = gemm_mode();
+  const bool bf16 = mode != NACF_GEMM_F32;     // (assumes 16-byte addressable operands)
+  if (kind == 0) t = bf16 ? pick_tile_bf16(0, M, N, 1, with_rows, mode, heavy) : pick_tile(M, N, 1, with_rows, heavy);
   else if (kind == 1) {
     s = bwd_data_splits(M, N, K, with_rows);
     const int kps = cdiv(cdiv(N, s), kalign()) * kalign();
     s = cdiv(N, kps);
-    t = pick_tile(M, K, s, with_rows);
+    t = bf16 ? pick_tile_bf16(1, M, K, s, with_rows, mode) : pick_tile(M, K, s, with_rows);
   }
   else if (kind == 2) {
-    s = bwd_weight_splits(M, N, K, with_rows, &t);
+    s = bf16 ? bwd_weight_splits_bf16(M, N, K, with_rows, &t) : bwd_weight_splits(M, N, K, with_rows, &t);
     const int kps = cdiv(cdiv(M, s), kalign()) * kalign();
     s = cdiv(M, kps);
   } else {
@@ -607,7 +649,8 @@ int nacf_vocab_argmax(const float* hidden, int64_t ldh, const float* W, int64_t 
   NACF_CHECK(ws && ws_bytes >= nacf_vocab_argmax_workspace(rows, V), NACF_EWORKSPACE,
              "nacf_vocab_argmax: workspace too small");
   NACF_CHECK(!rs || (rs->rows && rs->count), NACF_EINVAL, "nacf_vocab_argmax: incomplete row set");
-  const int tile = pick_tile(rows, V, 1, rs != nullptr);
+  const bool bf16_fam = gemm_mode() != NACF_GEMM_F32 && (ldh % 4 == 0) && (ldw % 4 == 0) && aligned16(hidden) && aligned16(W);
+  const int tile = bf16_fam ? pick_tile_bf16(0, rows, V, 1, rs != nullptr, gemm_mode()) : pick_tile(rows, V, 1, rs != nullptr);
   const int tn = cdiv(V, tile == 0 ? 128 : 64);
   EpiArgmax epi;
   epi.bias = bias;
@@ -649,7 +692,8 @@ int nacf_vocab_lse_fwd(const float* hidden, int64_t ldh, const float* W, int64_t
   NACF_CHECK(ldl % 4 == 0 && aligned16(logits), NACF_EINVAL, "nacf_vocab_lse_fwd: logits need 16-byte aligned rows (nacf vocab_ld)");
   NACF_CHECK(ws && ws_bytes >= nacf_vocab_argmax_workspace(rows, V), NACF_EWORKSPACE, "nacf_vocab_lse_fwd: workspace too small");
   NACF_CHECK(!rs || (rs->rows && rs->count), NACF_EINVAL, "nacf_vocab_lse_fwd: incomplete row set");
-  const int tile = pick_tile(rows, V, 1, rs != nullptr);
+  const bool bf16_fam = gemm_mode() != NACF_GEMM_F32 && (ldh % 4 == 0) && (ldw % 4 == 0) && aligned16(hidden) && aligned16(W);
+  const int tile = bf16_fam ? pick_tile_bf16(0, rows, V, 1, rs != nullptr, gemm_mode()) : pick_tile(rows, V, 1, rs != nullptr);
   const int tn = cdiv(V, tile == 0 ? 128 : 64);
   EpiArgmax epi;
   epi.bias = bias;

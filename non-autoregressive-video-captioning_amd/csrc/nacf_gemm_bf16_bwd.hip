@@ -1,5 +1,6 @@
 // bf16 matrix-core instantiations: the two backward GEMMs of nn.Linear (EpiStore: accumulate / split-K slabs)
 #undef NACF_GEMM_TRACE
+#undef NACF_BF16_TRACE   // the phase stamps are compiled into the forward instantiations only
 #include "gemm_bf16_launch.hpp"
 
 void launch_bf16_dx(GemmShape g, const EpiStore& epi, int splits, int tile, int ns, hipStream_t s) {

@@ -18,3 +18,9 @@ void launch_wimage_refresh(const WImageDesc* descs, int n_desc, int n_tiles, int
   if (ns == 1) hipLaunchKernelGGL(wimage_refresh_kernel<1>, dim3(n_tiles), dim3(256), 0, s, descs, n_desc);
   else hipLaunchKernelGGL(wimage_refresh_kernel<3>, dim3(n_tiles), dim3(256), 0, s, descs, n_desc);
 }
+
+#ifdef NACF_BF16_TRACE
+extern "C" int nacf_debug_bf16_trace(void* buf) {     // tuning builds only (make trace); not part of the shipped ABI
+  return hipMemcpyToSymbol(HIP_SYMBOL(g_bf16_trace), &buf, sizeof(buf)) == hipSuccess ? 0 : -3;
+}
+#endif

@@ -37,7 +37,7 @@ class RowSet(ctypes.Structure):
 class WImageDesc(ctypes.Structure):
     """struct nacf_wimage_desc: one weight matrix of the bf16 image table (nacf_wimage_refresh)."""
     _fields_ = [("w", c_void_p), ("img", c_void_p), ("imgT", c_void_p),
-                ("ld", c_int64), ("ldi", c_int64), ("ldt", c_int64), ("plane", c_int64), ("planeT", c_int64),
+                ("ld", c_int64), ("plane", c_int64), ("planeT", c_int64),
                 ("N", c_int32), ("K", c_int32), ("tile0", c_int32), ("tiles_k", c_int32)]
 
 
@@ -65,8 +65,7 @@ SIGNATURES = {
     "nacf_gemm_set_mode": (c_int, [_I]),
     "nacf_gemm_get_mode": (c_int, []),
     "nacf_gemm_last_kernel": (c_char_p, []),
-    "nacf_wimage_register": (c_int, [_P, _L, _P, _L, _I]),
-    "nacf_wimage_register_t": (c_int, [_P, _I, _I, _L, _P, _L, _L, _I]),
+    "nacf_wimage_register": (c_int, [_P, _I, _I, _L, _P, _L, _P, _L, _I]),
     "nacf_wimage_unregister": (c_int, [_P, _L]),
     "nacf_wimage_refresh": (c_int, [_P, _I, _I, _I, _P]),
     "nacf_linear_bwd_weight": (c_int, [_P, _L, _P, _L, _P, _L, _P, _I, _I, _I, _F, _P, _S, _RS, _P]),

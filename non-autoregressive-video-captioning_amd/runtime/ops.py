@@ -138,45 +138,40 @@ def set_gemm_mode(mode) -> None:
 class WeightImages:
     """bf16 image planes of the GEMM weight matrices that live in ONE flat fp32 buffer (see nacf_wimage_* in
     nacf_hip.h).  mats: [(offset, N, K, want_transposed)], each matrix contiguous ([N, K], row pitch K) at
-    flat[offset:].  The row-major planes mirror the flat buffer's offsets (any row slice of a registered matrix is
-    found by address); transposed images [K, round_up(N, 8)] serve the dX GEMMs.  `refresh()` is one launch."""
+    flat[offset:].  Forward images (k-tile-major, zero-padded to whole k-tiles) serve y = x W^T -- also for a run of
+    whole rows of a registered matrix -- transposed ones the dX GEMMs.  `refresh()` is one launch."""
 
     def __init__(self, flat: Tensor, mats, ns: int):
         assert flat.is_cuda and flat.dtype == torch.float32 and flat.is_contiguous() and flat.data_ptr() % 16 == 0
         assert ns in (1, 3)
         self.flat, self.ns, self.mats = flat, int(ns), list(mats)
-        total = (flat.numel() + 7) // 8 * 8
-        self.img = torch.zeros(ns, total, dtype=torch.int16, device=flat.device)
-        t_off, t_total = [], 0
+        up32 = lambda v: (v + 31) // 32 * 32
+        f_off, t_off, f_total, t_total = [], [], 0, 0
         for off, N, K, want_t in self.mats:
-            assert off % 8 == 0 and off + N * K <= flat.numel(), "GEMM weights must start on 32-byte boundaries of the flat buffer"
+            assert off + N * K <= flat.numel()
+            f_off.append(f_total)
+            f_total += up32(K) * N
             t_off.append(t_total if want_t else None)
             if want_t:
-                t_total += K * ((N + 7) // 8 * 8)
+                t_total += up32(N) * K
+        self.img = torch.zeros(ns, max(f_total, 8), dtype=torch.int16, device=flat.device)
         self.imgT = torch.zeros(ns, max(t_total, 8), dtype=torch.int16, device=flat.device)
-        descs = (L.WImageDesc * len(self.mats))()
+        descs = (L.WImageDesc * max(len(self.mats), 1))()
         tile0 = 0
-        self._t = []
-        for d, (off, N, K, want_t), to in zip(descs, self.mats, t_off):
-            ldt = (N + 7) // 8 * 8
+        lib = L.load()
+        for d, (off, N, K, want_t), fo, to in zip(descs, self.mats, f_off, t_off):
             d.w = flat.data_ptr() + 4 * off
-            d.img = self.img.data_ptr() + 2 * off if K % 8 == 0 else None
+            d.img = self.img.data_ptr() + 2 * fo
             d.imgT = self.imgT.data_ptr() + 2 * to if want_t else None
-            d.ld, d.ldi, d.ldt, d.plane, d.planeT = K, K, ldt, self.img.stride(0), self.imgT.stride(0)
+            d.ld, d.plane, d.planeT = K, self.img.stride(0), self.imgT.stride(0)
             d.N, d.K, d.tile0, d.tiles_k = N, K, tile0, (K + 31) // 32
             tile0 += ((N + 31) // 32) * ((K + 31) // 32)
-            if want_t:
-                self._t.append((d.w, N, K, d.imgT, ldt))
+            L.check(lib.nacf_wimage_register(ctypes.c_void_p(d.w), N, K, K, ctypes.c_void_p(d.img), d.plane,
+                                             ctypes.c_void_p(d.imgT) if want_t else None, d.planeT, self.ns),
+                    "nacf_wimage_register")
         self.n_tiles = tile0
-        raw = bytes(descs)
-        self.table = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(flat.device)
         self.n_desc = len(self.mats)
-        lib = L.load()
-        L.check(lib.nacf_wimage_register(_ptr(flat), flat.numel(), _ptr(self.img), self.img.stride(0), self.ns),
-                "nacf_wimage_register")
-        for w, N, K, it, ldt in self._t:
-            L.check(lib.nacf_wimage_register_t(ctypes.c_void_p(w), N, K, K, ctypes.c_void_p(it), ldt, self.imgT.stride(0),
-                                               self.ns), "nacf_wimage_register_t")
+        self.table = torch.frombuffer(bytearray(bytes(descs)), dtype=torch.uint8).to(flat.device)
         self._registered = True
 
     def refresh(self) -> None:

@@ -36,7 +36,7 @@ class FlatParams:
     gradient into a second one).  ``groups`` lists parameters that must be
     adjacent, in order, so packed views (w1|w2, q|k|v, k|v) are plain slices."""
 
-    ALIGN = 8  # floats (32 B): the bf16 image planes of the weights mirror these offsets and need 16-byte rows
+    ALIGN = 8  # floats (32 B)
 
     def __init__(self, groups: Sequence[Sequence[nn.Parameter]]):
         seen = set()

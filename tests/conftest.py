@@ -8,8 +8,24 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 
+def pytest_addoption(parser):
+    parser.addoption("--gemm-mode", default=None, choices=["f32", "bf16x3", "bf16"],
+                     help="run the whole suite with this GEMM arithmetic mode (library-wide nacf_gemm_set_mode); "
+                          "default: the library's own default")
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session", autouse=True)
+def _gemm_mode(request):
+    mode = request.config.getoption("--gemm-mode")
+    if mode is not None:
+        import nacf_amd  # noqa: F401
+        from nacf_amd.runtime import ops
+        ops.set_gemm_mode(mode)
+    yield
 
 
 @pytest.fixture(scope="session")

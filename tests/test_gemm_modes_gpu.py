@@ -210,7 +210,7 @@ def test_weight_images_equal_in_kernel_conversion_bit_for_bit(dev, mode, tile, m
     offs, off = [], 0
     for N, K in mats:
         offs.append(off)
-        off += (N * K + 7) // 8 * 8
+        off += (N * K + 3) // 4 * 4
     flat = rnd(off, seed=11, scale=0.5).to(dev)
     ws = [flat[o:o + N * K].view(N, K) for o, (N, K) in zip(offs, mats)]
 
@@ -218,7 +218,9 @@ def test_weight_images_equal_in_kernel_conversion_bit_for_bit(dev, mode, tile, m
         outs = []
         for w in ws:
             N, K = w.shape
-            x, dz = rnd(300, K, seed=N).to(dev), rnd(300, N, seed=K + N).to(dev)
+            x = rnd(300, K, seed=N).to(dev)
+            dzb = rnd(300, (N + 3) // 4 * 4, seed=K + N).to(dev)      # 16-byte row pitch, as the model's padded logits
+            dz = dzb[:, :N]
             y, dx = torch.empty(300, N, device=dev), torch.empty(300, K, device=dev)
             ops.linear_fwd(x, w, y, None)
             k1 = L.load().nacf_gemm_last_kernel().decode()

@@ -1,0 +1,54 @@
+"""Where does a workgroup of the bf16 matrix-core GEMM spend its cycles?  (tuning aid; needs `make -C .../csrc trace`)
+Wave 0 of every workgroup accumulates shader-clock cycles per k-loop phase (csrc/gemm_bf16.hpp, NACF_BF16_TRACE):
+compute | barrier | wait for the staged global loads | convert + LDS stores + next loads | barrier.
+usage: NACF_GEMM_MODE=bf16x3 python tools/bf16_trace.py M:N:K [tile] [--images]     (forward GEMM only)"""
+import ctypes, os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+os.environ.setdefault("NACF_HIP_LIB", os.path.join(ROOT, "non-autoregressive-video-captioning_amd", "libnacf_hip_trace.so"))
+import numpy as np
+import torch
+import nacf_amd  # noqa: F401
+from nacf_amd.runtime import lib as L, ops
+
+dev = torch.device("cuda:0")
+M, N, K = (int(v) for v in sys.argv[1].split(":"))
+args = sys.argv[2:]
+images = "--images" in args
+args = [a for a in args if not a.startswith("--")]
+if args:
+    os.environ["NACF_GEMM_TILE"] = args[0]
+g = torch.Generator().manual_seed(0)
+r = lambda *s: (torch.rand(*s, generator=g) * 2 - 1).to(dev)
+x, w, y = r(M, K), r(N, K), torch.empty(M, ops.vocab_ld(N), device=dev)[:, :N]
+imgs = None
+if images:
+    imgs = ops.WeightImages(w.reshape(-1), [(0, N, K, False)], ops.gemm_mode())
+    imgs.refresh()
+f = lambda: ops.linear_fwd(x, w, y, None)
+L.load()
+raw = ctypes.CDLL(L.LIB_PATH)
+raw.nacf_debug_bf16_trace.argtypes = [ctypes.c_void_p]
+for _ in range(5):
+    f()
+torch.cuda.synchronize()
+buf = torch.zeros(1 << 20, dtype=torch.int64, device=dev)
+assert raw.nacf_debug_bf16_trace(ctypes.c_void_p(buf.data_ptr())) == 0
+a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+a.record(); f(); b.record()
+torch.cuda.synchronize()
+assert raw.nacf_debug_bf16_trace(ctypes.c_void_p(0)) == 0
+print(L.load().nacf_gemm_last_kernel().decode())
+t = buf.cpu().numpy().reshape(-1, 8)
+t = t[t[:, 5] != 0].astype(np.float64)
+nk = t[:, 6].max()
+print("kernel %.1f us (with stamps), %d workgroups, %d k-tiles each" % (a.elapsed_time(b) * 1e3, len(t), nk))
+names = ["compute", "barrier after compute", "wait global loads", "convert + LDS stores + next loads", "barrier after stores"]
+tot = t[:, 5]
+print("whole workgroup: p50 %.0f cycles (p10 %.0f, p90 %.0f); per k-tile %.0f" % (np.percentile(tot, 50), np.percentile(tot, 10), np.percentile(tot, 90), np.percentile(tot, 50) / nk))
+for i, n in enumerate(names):
+    v = t[:, i] / nk
+    print("  %-34s per k-tile: p50 %6.0f  p10 %6.0f  p90 %6.0f   (%4.1f %% of the workgroup's life)" % (n, np.percentile(v, 50), np.percentile(v, 10), np.percentile(v, 90), 100 * t[:, i].sum() / tot.sum()))
+print("  outside the k-loop (prologue + epilogue): %4.1f %%" % (100 * (1 - t[:, :5].sum() / tot.sum())))
+if imgs is not None:
+    imgs.close()

@@ -25,14 +25,22 @@ SHAPES = [
 PAD = 0
 
 
-def run(kind, M, N, K, iters, dev):
+def run(kind, M, N, K, iters, dev, images=False):
     g = torch.Generator(device="cpu").manual_seed(0)
     r = lambda *s: (torch.rand(*s, generator=g) * 2 - 1).to(dev)
+    imgs = None
+    mode = ops.gemm_mode()
     if kind == 0:
         x, w, y = r(M, K + PAD)[:, :K], r(N, K + PAD)[:, :K], torch.empty(M, ops.vocab_ld(N), device=dev)[:, :N]
+        if images and mode != 0 and PAD == 0:
+            imgs = ops.WeightImages(w.reshape(-1), [(0, N, K, False)], mode)
+            imgs.refresh()
         f = lambda: ops.linear_fwd(x, w, y, None)
     elif kind == 1:
         dz, w, dx = r(M, ops.vocab_ld(N))[:, :N], r(N, K), torch.empty(M, K, device=dev)
+        if images and mode != 0:
+            imgs = ops.WeightImages(w.reshape(-1), [(0, N, K, True)], mode)
+            imgs.refresh()
         f = lambda: ops.linear_bwd_data(dz, w, dx)
     else:
         dz, x, dw = r(M, ops.vocab_ld(N))[:, :N], r(M, K), torch.empty(N, K, device=dev)
@@ -47,6 +55,8 @@ def run(kind, M, N, K, iters, dev):
     b.record()
     torch.cuda.synchronize()
     ms = a.elapsed_time(b) / iters
+    if imgs is not None:
+        imgs.close()
     return ms, 2.0 * M * N * K / (ms * 1e-3) / 1e12
 
 
@@ -57,12 +67,14 @@ def main():
     ap.add_argument("--tiles", type=str, default="64,128", help="NACF_GEMM_TILE values to compare")
     ap.add_argument("--shapes", type=str, default="", help="extra shapes 'kind:M:N:K,...' (kind 0 fwd, 1 dX, 2 dW)")
     ap.add_argument("--pad", type=int, default=0, help="extra floats of row pitch on the K-contiguous fwd operands")
+    ap.add_argument("--modes", type=str, default="f32", help="NACF_GEMM_MODE values to compare: f32,bf16x3,bf16")
+    ap.add_argument("--images", action="store_true", help="bf16 modes: weights come from pre-split images (as in the model)")
     args = ap.parse_args()
     global PAD
     PAD = args.pad
     dev = torch.device("cuda:0")
-    tiles = args.tiles.split(",")
-    print("%-12s %-26s " % ("gemm", "M,N,K") + " ".join("%10s %10s" % ("ms@" + t, "TF@" + t) for t in tiles))
+    tiles = [m + "/" + t for m in args.modes.split(",") for t in args.tiles.split(",")]
+    print("%-12s %-22s " % ("gemm", "M,N,K") + " ".join("%13s %7s" % ("ms@" + t, "TF") for t in tiles))
     shapes = SHAPES
     if args.shapes:
         shapes = [("custom k%s" % t.split(":")[0],) + tuple(int(v) for v in t.split(":")) for t in args.shapes.split(",")]
@@ -70,10 +82,10 @@ def main():
         if args.only and args.only not in label:
             continue
         res = []
-        for tile in tiles:
-            os.environ["NACF_GEMM_TILE"] = tile
-            res.append(run(kind, M, N, K, args.iters, dev))
-        print("%-12s %-26s " % (label, "%d,%d,%d" % (M, N, K)) + " ".join("%10.3f %10.1f" % r for r in res))
+        for mt in tiles:
+            os.environ["NACF_GEMM_MODE"], os.environ["NACF_GEMM_TILE"] = mt.split("/")
+            res.append(run(kind, M, N, K, args.iters, dev, args.images))
+        print("%-12s %-22s " % (label, "%d,%d,%d" % (M, N, K)) + " ".join("%13.3f %7.1f" % r for r in res))
 
 
 if __name__ == "__main__":

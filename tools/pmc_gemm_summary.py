@@ -18,14 +18,18 @@ def main():
         for r in csv.DictReader(open(os.path.join(base, "trace_%s.csv" % i))):
             dur[r["Dispatch_Id"]] = int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
         for r in csv.DictReader(open(path)):
-            if "gemm_f32_kernel" not in r["Kernel_Name"]:
+            if "gemm_f32_kernel" not in r["Kernel_Name"] and "gemm_bf16_kernel" not in r["Kernel_Name"]:
                 continue
             d = per[(i, r["Dispatch_Id"])]
             d["kernel"] = r["Kernel_Name"].split("(")[0][5:60]
             d["grid"] = r["Grid_Size"]
             d["us"] = dur.get(r["Dispatch_Id"], 0) / 1e3
             d[r["Counter_Name"]] = float(r["Counter_Value"])
+    seen = collections.Counter()
     for (i, disp), d in sorted(per.items(), key=lambda kv: (kv[0][0], int(kv[0][1]))):
+        seen[(i, d["kernel"])] += 1
+        if seen[(i, d["kernel"])] > 2 and "--all" not in sys.argv:      # two dispatches per kernel and pass are enough
+            continue
         extra = ""
         if "GRBM_GUI_ACTIVE" in d and d["us"] > 0:
             act = d["GRBM_GUI_ACTIVE"] / 8.0
