@@ -199,8 +199,9 @@ class Criterion(object):
         return total
 
     def get_fieldsnames(self):
-        n_acc = 2 if self.vw else 1
-        return ['Word Acc%d' % i for i in range(n_acc)] + ['Perplexity'] + [n for n, c in zip(self.names, self.crit) if c != 'lang']
+        """CSV columns this criterion adds to trainning_record.csv: the loss names of every term that is NOT the
+        language-generation one, as the reference (misc/crit.py:199-209) -- e.g. ['Length Loss']"""
+        return [n for n, c in zip(self.names, self.crit) if c != 'lang']
 
     def get_loss_info(self):
         names = list(self.names)

@@ -20,6 +20,7 @@ TensorBoard writers are accepted and used only if the caller passes one (tensorb
 """
 import json
 import os
+import sys
 import pickle
 import shutil
 import time
@@ -31,6 +32,7 @@ import torch.distributed as dist
 
 from ..config import Constants
 from ..models.Translator import Translator
+from ..opts import persistable
 from ..runtime.ddp import DataParallel
 from ..runtime.engine import TrainStep
 from .cocoeval import COCOScorer
@@ -333,8 +335,9 @@ def train_network_all(opt, model, device, summarywriter=None, **kwargs):
     model.to(device)
     # this loop owns the criterion, so the vocabulary projection + log-softmax + NLL run as ONE fused function
     # (runtime/functional.py:FusedVocabXentMultiFn) unless the caller asked for materialised log-probs
-    opt.setdefault('fused_loss', True)
-    getattr(model, 'opt', {}).setdefault('fused_loss', opt['fused_loss'])
+    # (a runtime switch of the MODEL OBJECT: neither the caller's opt nor the checkpoint's `settings` carry it, so a
+    # reloaded checkpoint returns the reference's `tgt_word_logprobs` again)
+    model.opt['fused_loss'] = bool(opt.get('fused_loss', True))
     rank0 = not dist.is_initialized() or dist.get_rank() == 0
     optimizer = get_optimizer(opt, model, summarywriter=summarywriter)
     crit = get_criterion(opt, summarywriter=summarywriter)
@@ -349,6 +352,10 @@ def train_network_all(opt, model, device, summarywriter=None, **kwargs):
     vocab = vali_loader.dataset.get_vocab()
     scorer = kwargs.get('scorer') or COCOScorer()
     standard = [k for k in opt.get('standard', ['METEOR', 'CIDEr']) if k in getattr(scorer, 'available', [k])]
+    dropped = [k for k in opt.get('standard', ['METEOR', 'CIDEr']) if k not in standard]
+    if dropped and rank0:
+        print('[nacf_amd] WARNING: %s not available from this scorer (no METEOR jar / JVM here): best-model selection uses '
+              '%s only -- the reference selects on METEOR + CIDEr' % (dropped, standard), file=sys.stderr)
     folder_path = os.path.join(opt['checkpoint_path'], 'tmp_models')
     best_model = k_PriorityQueue(k_best_model=opt.get('k_best_model', 1), folder_path=folder_path, standard=standard)
     logger = CsvLogger(filepath=opt['checkpoint_path'], filename='trainning_record.csv',
@@ -365,6 +372,14 @@ def train_network_all(opt, model, device, summarywriter=None, **kwargs):
 
         if (epoch + 1) > opt['start_eval_epoch'] and (epoch + 1) % opt['save_checkpoint_every'] == 0:
             stop = torch.zeros(1, device=device)
+            if dist.is_initialized() and dist.get_world_size() > 1 and not model.opt.get('sync_bn', False):
+                # per-rank BatchNorm: every rank saw 1/world of the data.  Average the running statistics so that the
+                # evaluated / saved model reflects all of it (with sync_bn they are identical already)
+                for m in model.modules():
+                    if isinstance(m, torch.nn.BatchNorm1d):
+                        for buf in (m.running_mean, m.running_var):
+                            dist.all_reduce(buf, op=dist.ReduceOp.SUM)
+                            buf.div_(dist.get_world_size())
             if rank0:                        # replicas are identical: rank 0 evaluates, the others wait for its verdict
                 res = run_eval(opt, model, crit_eval, vali_loader, vocab, device, teacher_model=teacher_model,
                                analyze=True, scorer=scorer, summarywriter=summarywriter, global_step=epoch)
@@ -373,7 +388,8 @@ def train_network_all(opt, model, device, summarywriter=None, **kwargs):
                     res.setdefault(k, float('nan'))
                 logger.write(res)
                 save_checkpoint({'epoch': epoch + 1, 'state_dict': model.state_dict(), 'validate_result': res,
-                                 'settings': opt}, False, filepath=opt['checkpoint_path'], filename='checkpoint.pth.tar')
+                                 'settings': persistable(opt)}, False, filepath=opt['checkpoint_path'],
+                                filename='checkpoint.pth.tar')
                 model_name = 'model_%04d.pth.tar' % res['epoch']
                 go_on, info = best_model.check(res, opt, os.path.join(folder_path, model_name), model_name)
                 if go_on:

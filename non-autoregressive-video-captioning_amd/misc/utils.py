@@ -25,7 +25,8 @@ def _read(checkpoint_path):
 def load_model_and_opt(checkpoint_path, device, return_other_info=False):
     from ..models import get_model
     checkpoint = _read(checkpoint_path)
-    opt = checkpoint['settings']
+    from ..opts import persistable
+    opt = persistable(checkpoint['settings'])     # runtime-only keys never configure a reloaded model
     model = get_model(opt)
     model.load_state_dict(checkpoint['state_dict'])
     model.to(device)

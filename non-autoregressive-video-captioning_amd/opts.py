@@ -23,7 +23,18 @@ DEFAULTS = dict(
     beam_size=1, beam_alpha=1.0, topk=1, paradigm='mp', length_beam_size=6, iterations=5, q=1, q_iterations=1,
     use_ct=False, length_bias=0, crit=['lang'], crit_name=['Cap Loss'], crit_scale=[1.0],
     n_frames=8, dim_a=1, dim_m=2048, dim_i=2048, dim_o=1,
+    # evaluation / checkpointing defaults of the training driver (opts.py:75-85; read by misc/run.py and misc/logger.py)
+    start_eval_epoch=0, save_checkpoint_every=1, tolerence=1000, k_best_model=1, standard=['METEOR', 'CIDEr'],
 )
+
+# keys that configure THIS runtime, not the model: never written into a checkpoint's `settings` (the reference's
+# loaders would carry them along, and a reloaded model must return the reference's forward contract by default)
+RUNTIME_KEYS = ('fused_loss', 'hipgraph', 'decode_graph', 'gemm_mode', 'sync_bn')
+
+
+def persistable(opt):
+    """a copy of `opt` without the runtime-only keys (what goes into checkpoint['settings'])"""
+    return {k: v for k, v in opt.items() if k not in RUNTIME_KEYS}
 
 
 def load_methods():

@@ -41,22 +41,38 @@ def _rows2d(t: Tensor):
 
 # ---------------------------------------------------------------- workspace
 class _Workspace:
-    """One grow-only scratch buffer per device; kernels on one stream run in
-    order, so consecutive ops can share it.  Must be warmed up (grown to its
-    final size) before a hipGraph capture."""
+    """One grow-only scratch buffer per device; kernels on one stream run in order, so consecutive ops can share it.
+
+    hipGraph safety: a captured graph (the training step, a decode batch) bakes this buffer's address into its
+    split-K / BatchNorm / soft-max-statistics launches.  Growing the buffer later (a bigger decode batch, a teacher
+    model, a wider vocabulary) must therefore never free the old one: once any capture has seen a buffer it is
+    RETIRED instead of released when a larger one replaces it -- replays keep writing into memory that still
+    belongs to them, new launches use the new buffer.  Growth during a capture itself is an error (warm up first)."""
 
     def __init__(self):
         self.buf = {}
+        self.in_graph = set()      # device keys whose current buffer has been handed out during a capture
+        self.retired = []          # buffers captured graphs may still reference: kept alive for the process lifetime
 
     def get(self, nbytes: int, device) -> Tensor:
         key = device.index if device.index is not None else torch.cuda.current_device()
         b = self.buf.get(key)
+        capturing = torch.cuda.is_current_stream_capturing()
         if b is None or b.numel() < nbytes:
-            if torch.cuda.is_current_stream_capturing():
+            if capturing:
                 raise L.NacfLibraryError("workspace growth during graph capture: run a warm-up step first")
+            if b is not None and key in self.in_graph:
+                self.retired.append(b)
+                self.in_graph.discard(key)
             b = torch.empty(max(int(nbytes * 1.25), 1 << 20), dtype=torch.uint8, device=device)
             self.buf[key] = b
+        if capturing:
+            self.in_graph.add(key)
         return b
+
+    def reserve(self, nbytes: int, device) -> None:
+        """grow to at least nbytes now (before a capture), e.g. to the larger of the training and decoding needs"""
+        self.get(int(nbytes), torch.device(device))
 
 
 WORKSPACE = _Workspace()
