@@ -4,25 +4,31 @@
   python bench.py --gpus N --steps K --warmup W          (N=1)
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 
-Workload (BASELINE.json configs[2]/[3]): NACF, MSRVTT-shape
-synthetic batch -- 128 videos per GPU, motion+image features 60x2048 fp32 each
-(U[0,1)), seq_len 20, V = 10547, category embeddings, dropout 0.5 as in the
-reference defaults, random-init weights.  One "step" = zero_grad + forward (two
-decoder passes) + fused loss + backward + [RCCL all-reduce of the flat gradient
-bucket] + clip(+-5) + Adam, inputs resident in HBM.  value = global videos/s.
-Also reported (same JSON line): NA-decode captions/s (mask-predict + coarse
-templates, T=5, lbs=6), the live roofline of the dominant GEMM kernel (HIP
-events around every launch of it) and the CPU baseline (the oracle timed on the
-host cores, bounded sample).  Arithmetic is fp32 on the MFMA f32 path (exact
-parity mode).  Nothing is cached across steps; the only work not executed is
-work whose result is identically zero in the reference too: decoder rows whose
-token is <pad> and vocabulary rows without a label (live-row GEMMs, DESIGN.md
-section 4) -- gradients, loss and decoded tokens are unchanged (parity tests run this
-same path).  The roofline counts only the FLOPs actually executed.
+Headline workload (BASELINE.json configs[2]/[3]): NACF, MSRVTT-shape synthetic batch -- 128 videos per
+GPU, motion+image features 60x2048 fp32 each (U[0,1)), seq_len 20, V = 10547, category embeddings, dropout 0.5 as in
+the reference defaults, random-init weights.  One "step" = zero_grad + forward (two decoder passes) + fused loss +
+backward + [RCCL all-reduce of the flat gradient buckets] + clip(+-5) + Adam, inputs resident in HBM, the whole step
+one hipGraph.  value = global videos/s over EXACTLY --steps steps (barrier + synchronize on both sides, max over ranks).
+
+Arithmetic: every GEMM runs in the library's default mode `bf16x3` -- fp32 operands split exactly into three bf16
+terms, six v_mfma_f32_16x16x32_bf16 per product block, fp32 accumulate: fp32-accurate (the parity tests run this mode:
+logits <= 1e-3, greedy NA tokens bit-exact), hence "dtype": "f32".  --gemm-mode f32 | bf16 selects the fp32 MFMA or the
+bf16 throughput mode for the headline leg; the bf16 mode is always reported as its own leg (configs[1]).
+
+Nothing is cached across steps; the only work not executed is work whose result is identically zero in the reference
+too: decoder rows whose token is <pad> and vocabulary rows without a label (live-row GEMMs).
+The rooflines count only FLOPs actually executed, as 2*M_live*N*K (never the 6x MFMA work of the split).
+
+Same JSON line (rank 0, N = 1): `roofline` (dominant GEMM kernel, live HIP-event timing), `cpu_baseline` (the oracle
+on the host cores, bounded sample: all cores and one thread), `decode` (NA mask-predict + coarse templates, with its
+own roofline and CPU baseline), `train_L30` (the reference's MSRVTT default length), `config1_nab_bf16`,
+`nacf_bf16`, `config5_ar_vs_na`, `loader_fed`.
 """
 import argparse
+import glob
 import json
 import os
+import statistics
 import sys
 import time
 
@@ -34,69 +40,246 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 METRIC = "training videos/sec (whole node) + NA-decode captions/sec, NACF MSRVTT-shape"
-PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_*_f32 dense peak
+# MI355X_MICROARCH.md: dense MFMA peaks at 2.4 GHz
+PEAK_F32_MFMA_TFLOPS = 157.3          # v_mfma_f32_16x16x4_f32
+PEAK_BF16_MFMA_TFLOPS = 2500.0        # v_mfma_f32_16x16x32_bf16 / 32x32x16
+MODE_PEAK = {"f32": PEAK_F32_MFMA_TFLOPS, "bf16": PEAK_BF16_MFMA_TFLOPS, "bf16x3": PEAK_BF16_MFMA_TFLOPS / 6.0}
+MODE_NOTE = {
+    "f32": "fp32 MFMA (v_mfma_f32_16x16x4_f32), 157.3 TFLOP/s dense",
+    "bf16": "bf16 MFMA on operands rounded to bf16, fp32 accumulate, 2500 TFLOP/s dense",
+    "bf16x3": "bf16 MFMA on an exact 3-term bf16 split of the fp32 operands, 6 MFMAs per product block: peak = 2500 / 6 "
+              "TFLOP/s of fp32-accurate products (executed MFMA rate = 6 x achieved)",
+}
 
 
-def make_opt(nacf_amd, L, V):
-    return nacf_amd.opts.make_opt("NACF", "MSRVTT", with_category=True, max_len=L, vocab_size=V, n_frames=60,
-                                  fused_loss=True, beta=[0.35, 0.9], use_ct=True, iterations=5, length_beam_size=6,
-                                  beam_alpha=1.35, paradigm="mp")
+def make_opt(nacf_amd, method, L, V, **kw):
+    base = dict(with_category=True, max_len=L, vocab_size=V, n_frames=60, fused_loss=True, beta=[0.35, 0.9], iterations=5,
+                length_beam_size=6, beam_alpha=1.35, paradigm="mp")
+    if method == "NACF":
+        base["use_ct"] = True
+    base.update(kw)
+    return nacf_amd.opts.make_opt(method, "MSRVTT", **base)
 
 
-def bench_nab(nacf_amd, dev, B, L, V, F_):
-    """train-step and decode throughput of NAB (BASELINE.json configs[1]) with the step captured in a hipGraph"""
+def build_model(nacf_amd, opt, dev, seed=0):
+    from nacf_amd import synthetic as O
+    model = nacf_amd.get_model(opt)
+    model.load_state_dict({k: v.clone() for k, v in O.init_state_dict(opt, seed=seed).items()})
+    return model.to(dev)
+
+
+def to_batch(b, dev, vw):
+    out = {"feats": [f.to(dev) for f in b["feats"]], "tokens": b["tokens"].to(dev), "labels": b["labels"].to(dev),
+           "category": b["category"].to(dev), "length_target": b["tgt_length"].to(dev)}
+    if vw:
+        out["tokens_1"], out["labels_1"] = b["tokens_1"].to(dev), b["labels_1"].to(dev)
+    return out
+
+
+def make_engine(model, dev, batch, ddp=None, graph="auto", eager_steps=2):
+    """the step engine misc/run.py:run_train drives: launch-by-launch warm-up steps, then hipGraph replay"""
     from nacf_amd.misc.crit import get_criterion
     from nacf_amd.misc.optim import get_optimizer
-    from nacf_amd.models.Translator import Translator
-    from nacf_amd import synthetic as O
-    opt = nacf_amd.opts.make_opt("NAB", "MSRVTT", with_category=True, max_len=L, vocab_size=V, n_frames=60, fused_loss=True,
-                                 beta=[0.35, 0.9], iterations=5, length_beam_size=6, beam_alpha=1.35, paradigm="mp")
-    model = nacf_amd.get_model(opt)
-    model.load_state_dict({k: v.clone() for k, v in O.init_state_dict(opt, seed=0).items()})
-    model.to(dev).train()
-    crit, optim = get_criterion(model.opt), get_optimizer(model.opt, model)
-    b = O.synth_batch(opt, B, F_, seed=3)
-    feats = [f.to(dev) for f in b["feats"]]
-    tokens, labels = b["tokens"].to(dev), b["labels"].to(dev)
-    category, tgt_length = b["category"].to(dev), b["tgt_length"].to(dev)
-
     from nacf_amd.misc.run import get_forword_results
     from nacf_amd.runtime.engine import TrainStep
-    engine = TrainStep(model, crit, optim, lambda bb: get_forword_results(model.opt, model, bb, dev), graph="on")
-    engine({"feats": feats, "tokens": tokens, "labels": labels, "category": category, "length_target": tgt_length})
-    for _ in range(5):          # two more launch-by-launch steps, capture, replays
+    crit, optim = get_criterion(model.opt), get_optimizer(model.opt, model)
+    engine = TrainStep(model, crit, optim, lambda bb: get_forword_results(model.opt, model, bb, dev), ddp=ddp, graph=graph,
+                       eager_steps=eager_steps)
+    engine(batch)
+    for _ in range(eager_steps - 1):
         engine()
-    assert engine.captured
     torch.cuda.synchronize()
+    for _ in range(3):                            # capture + first replays
+        engine()
+    torch.cuda.synchronize()
+    return engine, crit, optim
+
+
+def timed_steps(engine, n, barrier=None):
+    (barrier or torch.cuda.synchronize)()
     t0 = time.perf_counter()
-    n = 30
     for _ in range(n):
         engine()
+    (barrier or torch.cuda.synchronize)()
+    return time.perf_counter() - t0
+
+
+def median_step_ms(engine, min_seconds=1.0, max_steps=400):
+    """per-step wall times from HIP events around single replays, repeated until >= min_seconds of timed work"""
+    evs = []
+    t0 = time.perf_counter()
+    while len(evs) < max_steps and (len(evs) < 50 or time.perf_counter() - t0 < min_seconds):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        engine()
+        b.record()
+        evs.append((a, b))
     torch.cuda.synchronize()
-    dt = (time.perf_counter() - t0) / n
+    ms = sorted(a.elapsed_time(b) for a, b in evs)
+    return {"median_ms": round(statistics.median(ms), 4), "p10_ms": round(ms[len(ms) // 10], 4),
+            "p90_ms": round(ms[len(ms) * 9 // 10], 4), "steps": len(ms)}
+
+
+def gemm_profile(run_once, n_prof=3):
+    """HIP events around every GEMM launch of n_prof launch-by-launch passes -> per-kernel-class table"""
+    from nacf_amd.runtime import ops
+    ops.PROFILER.records = []
+    ops.PROFILER.enabled = True
+    for _ in range(n_prof):
+        run_once()
+    torch.cuda.synchronize()
+    ops.PROFILER.enabled = False
+    summ = ops.PROFILER.summary()
+    ops.PROFILER.records = []
+    return summ
+
+
+def newest_traffic_table():
+    """profiles/r*_pmc_traffic.json with the newest mtime (PMC counters cannot be collected inside this process; the
+    table comes from separate rocprofv3 --pmc passes of this same command, tools/pmc_traffic.py)"""
+    files = glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json"))
+    if not files:
+        return None
+    path = max(files, key=os.path.getmtime)
+    try:
+        return path, (time.time() - os.path.getmtime(path)) / 3600.0, json.load(open(path))
+    except (OSError, ValueError):
+        return None
+
+
+def roofline_from(summ, n_prof, mode, prefer_single=True):
+    """dominant kernel = the GEMM kernel class with the largest total time whose spans are ONE kernel each (spans of
+    dW entry points also contain the split-K combine: listed in the table, not chosen)"""
+    cands = [(k, v) for k, v in summ.items() if v["single"]] if prefer_single else list(summ.items())
+    if not cands:
+        cands = list(summ.items())
+    name, r = max(cands, key=lambda kv: kv[1]["ms"])
+    family = "bf16" if name.startswith("gemm_bf16") else "f32"
+    ns = 3 if (family == "bf16" and ", 3, " in name) else 1
+    kmode = "f32" if family == "f32" else ("bf16x3" if ns == 3 else "bf16")
+    peak = MODE_PEAK[kmode]
+    achieved = r["flops"] / (r["ms"] * 1e-3) / 1e12
+    gemm_ms = sum(v["ms"] for v in summ.values()) / n_prof
+    all_tf = sum(v["flops"] for v in summ.values()) / n_prof / (gemm_ms * 1e-3) / 1e12
+    rl = {"bound": "mfma", "kernel": name, "achieved": round(achieved, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
+          "frac": round(achieved / peak, 4), "traffic": None, "peak_basis": MODE_NOTE[kmode],
+          "launches_per_pass": r["calls"] // n_prof, "avg_launch_ms": round(r["ms"] / r["calls"], 4),
+          "flops_per_pass": r["flops"] / n_prof, "all_gemm_ms_per_pass": round(gemm_ms, 3),
+          "all_gemm_tflops": round(all_tf, 2), "all_gemm_frac_of_mode_peak": round(all_tf / MODE_PEAK[mode], 4),
+          # rocprofv3 --pmc on this kernel family (profiles/r02_gemm_pmc_counters.txt) and the per-phase cycle stamps of
+          # tools/bf16_trace.py (profiles/r02_bf16_phase_trace.txt): the matrix pipe is NOT what limits K = 512 launches
+          "limiter": "per k-tile the staging phase (global-load issue ~32 B/clk/CU, operand split, LDS stores) is longer "
+                     "than the MFMA phase and two 128x128 workgroups fit a CU: SQ_VALU_MFMA_BUSY ~45 % of active cycles; "
+                     "`bound` names the roof the kernel is priced against, not a saturated unit"}
+    tab = newest_traffic_table()
+    if tab is not None:
+        path, age_h, data = tab
+        hits = [e for e in data.get("kernels", []) if name in e["kernel"]]
+        if hits:
+            n_l = sum(e["launches_sampled"] for e in hits)
+            rl["traffic"] = int(sum(e["hbm_bytes"] * e["launches_sampled"] for e in hits) / n_l)
+            rl["traffic_source"] = "%s (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, bytes/launch; file age %.1f h)" % (
+                os.path.relpath(path, ROOT), age_h)
+    table = {k: {"calls_per_pass": v["calls"] // n_prof, "ms_per_pass": round(v["ms"] / n_prof, 3),
+                 "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2), "span_is_one_kernel": v["single"]}
+             for k, v in summ.items()}
+    return rl, table
+
+
+def bench_decode(model, dev, feats, category, n_batches, with_roofline=True, mode="bf16x3"):
+    from nacf_amd.models.Translator import Translator
     model.eval()
+    B = feats[0].shape[0]
     tr = Translator(model, dict(model.opt), device=dev)
 
-    def dec():
+    def dec_once():
         with torch.no_grad():
-            return tr.translate_batch(model.encode(feats=feats), category, None, None)
-    for _ in range(4):
-        dec()
+            hyp, _ = tr.translate_batch(model.encode(feats=feats), category, None, None)
+        return hyp
+    for _ in range(4):       # launch by launch, hipGraph capture (decoding/na_generate.py), first replays
+        hyp = dec_once()
     torch.cuda.synchronize()
     t1 = time.perf_counter()
-    for _ in range(10):
-        dec()
+    for _ in range(n_batches):
+        hyp = dec_once()
     torch.cuda.synchronize()
-    ddt = (time.perf_counter() - t1) / 10
-    return {"batch": B, "train_videos_per_s": round(B / dt, 1), "train_ms_per_step": round(dt * 1e3, 3),
-            "decode_captions_per_s": round(B / ddt, 1), "decode_ms_per_batch": round(ddt * 1e3, 2), "dtype": "f32"}
+    ddt = (time.perf_counter() - t1) / n_batches
+    out = {"captions_per_s": round(B / ddt, 1), "ms_per_batch": round(ddt * 1e3, 2), "batch": B,
+           "paradigm": "mp+ct" if model.opt.get("use_ct") else "mp", "iterations": 5, "length_beam_size": 6,
+           "width": int(hyp.shape[1]), "hipgraph": any(k[0] != "seen" for k in getattr(model, "_nacf_decode_graphs", {}))}
+    if with_roofline:
+        # executed FLOPs / kernel times of launch-by-launch decodes (graph off) through the GEMM profiler
+        tr_e = Translator(model, dict(model.opt, decode_graph="off"), device=dev)
+
+        def eager():
+            with torch.no_grad():
+                tr_e.translate_batch(model.encode(feats=feats), category, None, None)
+        eager()
+        summ = gemm_profile(eager, n_prof=2)
+        rl, table = roofline_from(summ, 2, mode, prefer_single=False)
+        tot_f = sum(v["flops"] for v in summ.values()) / 2
+        rl["executed_gflop_per_caption"] = round(tot_f / B / 1e9, 3)
+        rl["as_written_gflop_per_caption"] = 17.51 if model.opt.get("use_ct") else 14.66     # SURVEY.md 8(d)
+        rl["whole_decode_executed_tflops"] = round(tot_f / ddt / 1e12, 2)
+        out["roofline"] = rl
+        out["gemm_kernels"] = table
+    model.train()
+    return out
+
+
+def bench_nab_bf16(nacf_amd, dev, B, L, V, F_):
+    """BASELINE.json configs[1]: NAB, bf16 compute / fp32 master weights, batch 64, seq_len 20: train step + decode
+    throughput in the bf16 mode, and against its fp32-accurate twin (same weights, same batch, mode bf16x3): logits
+    error and greedy NA-token agreement (reported, not asserted -- bf16 flips argmaxes)."""
+    from nacf_amd import synthetic as O
+    from nacf_amd.runtime import ops
+    from nacf_amd.models.Translator import Translator
+    opt = make_opt(nacf_amd, "NAB", L, V)
+    b = O.synth_batch(opt, B, F_, seed=3)
+    res = {}
+    twins = {}
+    for mode in ("bf16x3", "bf16"):
+        ops.set_gemm_mode(mode)
+        model = build_model(nacf_amd, opt, dev)
+        model.eval()
+        feats, cat = [f.to(dev) for f in b["feats"]], b["category"].to(dev)
+        with torch.no_grad():
+            enc = model.encode(feats=feats)
+            hid, *_ = model.decoder(b["tokens"].to(dev), enc_output=enc["enc_output"], category=cat)
+            hid = hid[-1] if isinstance(hid, list) else hid
+            logp = model.vocab_logprobs(hid)
+            hyp, _ = Translator(model, dict(model.opt, decode_graph="off"), device=dev).translate_batch(enc, cat, None, None)
+        twins[mode] = (logp.float().cpu(), hyp.cpu(), b["tokens"].ne(0))
+        if mode == "bf16":
+            model.train()
+            engine, crit, optim = make_engine(model, dev, to_batch(b, dev, False), graph="on")
+            dt = timed_steps(engine, 40) / 40
+            summ = gemm_profile(lambda: (optim.zero_grad(), crit.get_loss(engine.forward(engine.static)).backward(),
+                                         optim._optimizer.step(grad_scale=1.0)))
+            rl, _ = roofline_from(summ, 3, "bf16")
+            dec = bench_decode(model, dev, feats, cat, 10, with_roofline=False)
+            res.update({"batch": B, "dtype": "bf16", "train_videos_per_s": round(B / dt, 1), "train_ms_per_step": round(dt * 1e3, 3),
+                        "decode_captions_per_s": dec["captions_per_s"], "decode_ms_per_batch": dec["ms_per_batch"], "roofline": rl})
+            del engine
+        del model
+    (lp3, hyp3, live), (lp1, hyp1, _) = twins["bf16x3"], twins["bf16"]
+    w = min(hyp3.shape[1], hyp1.shape[1])
+    d = (lp3 - lp1).abs()[live]
+    res["vs_fp32_twin"] = {"logprob_max_abs_err": round(float(d.max()), 5), "logprob_mean_abs_err": round(float(d.mean()), 6),
+                           "share_of_logprobs_within_1e-3": round(float((d <= 1e-3).float().mean()), 4),
+                           "teacher_forced_argmax_agreement": round(float((lp3.argmax(-1) == lp1.argmax(-1))[live].float().mean()), 4),
+                           "na_decode_token_agreement": round(float((hyp3[:, :w] == hyp1[:, :w]).float().mean()), 4),
+                           "note": "random-init weights: logit margins are tiny (median 0.12, SURVEY.md section 7), so "
+                                   "free-running mask-predict decodes diverge after the first flipped argmax"}
+    return res
 
 
 def bench_loader(args, nacf_amd, opt, dev, B, L, V, F_, engine):
     """Train-step throughput when every batch comes from nacf_amd.data.ShardLoader (synthetic shards written to a
     temp dir): per step the engine copies the loader's tensors into the graph's static input buffers and replays the
-    captured step (runtime/engine.py -- the same object misc/run.py:run_train drives).  Reports the three placements of the shards: HBM-resident (no PCIe per step), pinned host memory (one
-    DMA per clip, PCIe-inclusive) and memory-mapped file (host-thread gather into pinned staging + upload)."""
+    captured step (runtime/engine.py -- the same object misc/run.py:run_train drives).  Reports the three placements of
+    the shards: HBM-resident (no PCIe per step), pinned host memory (one DMA per clip, PCIe-inclusive) and memory-mapped
+    file (host-thread gather into pinned staging + upload)."""
     import shutil
     import tempfile
     import numpy as np
@@ -152,23 +335,88 @@ def bench_loader(args, nacf_amd, opt, dev, B, L, V, F_, engine):
         shutil.rmtree(tmp, ignore_errors=True)
 
 
+def cpu_model_name():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def bench_cpu(opt, sd, O, B, F_, budget_s=18.0):
+    """The oracle (plain eager PyTorch fp32 restatement of the reference) on this box's host cores: the NACF train step
+    on the SAME batch shape as the GPU leg with all cores, then with one thread on a smaller batch, and the NA decode.
+    Bounded samples (the default run must finish in minutes); 1 warm-up each, median of the timed steps.  SURVEY.md 8(d)."""
+    from oracle import nacf_oracle as ORACLE   # the CPU checker: imported for THIS leg only, never measured as product
+
+    def train_leg(cb, threads, budget, min_steps):
+        torch.set_num_threads(threads)
+        cbatch = O.synth_batch(opt, cb, F_, seed=1)
+        sd_c = {k: v.clone() for k, v in sd.items()}
+        st = {}
+
+        def step():
+            return ORACLE.train_step(sd_c, dict(opt), cbatch["feats"], [cbatch["tokens_1"], cbatch["tokens"]], cbatch["category"],
+                                     [cbatch["labels_1"], cbatch["labels"]], cbatch["tgt_length"], st,
+                                     lr=opt["learning_rate"], training=True)
+        step()                                           # warm-up
+        ts = []
+        t_all = time.perf_counter()
+        while len(ts) < min_steps or (time.perf_counter() - t_all < budget and len(ts) < 10):
+            t0 = time.perf_counter()
+            step()
+            ts.append(time.perf_counter() - t0)
+        return cb / statistics.median(ts), len(ts)
+    ncpu = os.cpu_count()
+    all_threads = torch.get_num_threads()
+    v_all, n_all = train_leg(B, all_threads, budget_s, 2)
+    v_one, n_one = train_leg(8, 1, budget_s * 0.6, 2)
+    torch.set_num_threads(all_threads)
+    # NA decode (mask-predict + coarse templates, T = 5, lbs = 6), batch 32
+    db = O.synth_batch(opt, 32, F_, seed=2)
+    dec = dict(paradigm="mp", use_ct=True, iterations=5, length_beam_size=6, beam_alpha=1.35)
+
+    def dstep():
+        with torch.no_grad():
+            enc = ORACLE.encode(sd, opt, db["feats"], training=False)
+            return ORACLE.generate(sd, opt, dec, enc, db["category"])
+    dstep()
+    ts = []
+    t_all = time.perf_counter()
+    while len(ts) < 2 or (time.perf_counter() - t_all < budget_s * 0.5 and len(ts) < 10):
+        t0 = time.perf_counter()
+        dstep()
+        ts.append(time.perf_counter() - t0)
+    return {"value": round(v_all, 2), "unit": "videos/s", "cores": all_threads, "kind": "port",
+            "sample": "NACF train step (fwd+loss+bwd+clip+Adam, dropout 0.5) of %d videos, same shapes as the GPU leg: 1 warm-up + "
+                      "%d timed steps, median; oracle = plain eager PyTorch fp32" % (B, n_all),
+            "cpu_model": cpu_model_name(), "logical_cpus": ncpu,
+            "one_thread": {"value": round(v_one, 3), "unit": "videos/s", "cores": 1,
+                           "sample": "same step, 8 videos, 1 warm-up + %d timed steps, median" % n_one},
+            "decode": {"value": round(32 / statistics.median(ts), 2), "unit": "captions/s", "cores": all_threads,
+                       "sample": "oracle encode + generate (mp + coarse templates, T=5, lbs=6) of 32 videos: 1 warm-up + %d timed, "
+                                 "median" % len(ts)}}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=128, help="videos per GPU")
     ap.add_argument("--seq-len", type=int, default=20)
     ap.add_argument("--vocab", type=int, default=10547)
     ap.add_argument("--graph", choices=["auto", "on", "off"], default="auto")
+    ap.add_argument("--gemm-mode", choices=["f32", "bf16x3", "bf16"], default="bf16x3",
+                    help="GEMM arithmetic of the headline leg (bf16x3 = fp32-accurate split on the bf16 MFMA: the parity mode)")
     ap.add_argument("--no-decode", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--decode-batches", type=int, default=20)
-    ap.add_argument("--no-compare", action="store_true", help="skip the ARB2 beam-5 vs NACF decode comparison (config 5)")
+    ap.add_argument("--no-compare", action="store_true", help="skip the extra legs (config 1 bf16, NACF bf16, L=30, config 5)")
     ap.add_argument("--no-loader", action="store_true", help="skip the shard-loader leg (SURVEY 8f row 1)")
     ap.add_argument("--loader-videos", type=int, default=1024, help="videos in the synthetic feature shards")
-    ap.add_argument("--gemm-mode", choices=["f32", "bf16x3", "bf16"], default=None,
-                    help="GEMM arithmetic of the headline leg (default: the library default)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -178,7 +426,7 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     # NACF_BENCH_FORCE_DIST=1: run the N>1 code path (staged backward, bucketed RCCL all-reduce on its own stream,
-    # separate Adam graph) with a 1-rank process group -- the mechanics can be exercised on a 1-GPU box
+    # separate Adam graphs) with a 1-rank process group -- the mechanics can be exercised on a 1-GPU box
     force_dist = os.environ.get("NACF_BENCH_FORCE_DIST") == "1"
     if world > 1 or force_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -186,229 +434,158 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     import nacf_amd
-    from nacf_amd.misc.crit import get_criterion
-    from nacf_amd.misc.optim import get_optimizer
-    from nacf_amd.models.Translator import Translator
     from nacf_amd.runtime import ops
     from nacf_amd.runtime.ddp import DataParallel
     from nacf_amd import synthetic as O   # seeded synthetic weights / batches (input generators only)
 
     B, L, V, F_ = args.batch, args.seq_len, args.vocab, 60
-    if args.gemm_mode is not None:
-        ops.set_gemm_mode(args.gemm_mode)
-    opt = make_opt(nacf_amd, L, V)
+    mode = args.gemm_mode
+    ops.set_gemm_mode(mode)
+    opt = make_opt(nacf_amd, "NACF", L, V)
     sd = O.init_state_dict(opt, seed=0)
-    model = nacf_amd.get_model(opt)
-    model.load_state_dict({k: v.clone() for k, v in sd.items()})
-    model.to(dev).train()
+    model = build_model(nacf_amd, opt, dev)
+    model.train()
     ddp = DataParallel(model, force_collectives=force_dist)
     ddp.broadcast_parameters()
     multi = world > 1 or force_dist
-    crit = get_criterion(model.opt)
-    optim = get_optimizer(model.opt, model)
     n_params = sum(p.numel() for p in model.parameters())
 
     # each rank owns its shard of the global batch (seeded per rank), resident in HBM
-    batch = O.synth_batch(opt, B, F_, seed=1 + rank)
-    feats = [f.to(dev) for f in batch["feats"]]
-    tokens = [batch["tokens_1"].to(dev), batch["tokens"].to(dev)]
-    labels = [batch["labels_1"].to(dev), batch["labels"].to(dev)]
-    category = batch["category"].to(dev)
-    tgt_length = batch["tgt_length"].to(dev)
-    from nacf_amd.misc.run import get_forword_results
-    from nacf_amd.runtime.engine import TrainStep
-
-    # the step engine misc/run.py:run_train drives: launch-by-launch warm-up steps, then ONE hipGraph per step
-    # (N > 1: backward in two graphs so the decoder-side gradient bucket (61 of 74 MB) is all-reduced while the
-    # encoder's backward still runs, then the Adam graph -- runtime/engine.py, runtime/ddp.py)
-    n_eager = max(args.warmup, 2)
-    engine = TrainStep(model, crit, optim, lambda bb: get_forword_results(model.opt, model, bb, dev),
-                       ddp=ddp if multi else None, graph=args.graph, eager_steps=n_eager)
-    staged = engine.staged
-    engine({"feats": feats, "tokens_1": tokens[0], "tokens": tokens[1], "labels_1": labels[0], "labels": labels[1],
-            "category": category, "length_target": tgt_length})
-    for _ in range(n_eager - 1):                  # untimed warm-up (also grows workspaces before capture)
-        engine()
-    torch.cuda.synchronize()
-    for _ in range(3):                            # capture + first replays
-        engine()
+    batch = to_batch(O.synth_batch(opt, B, F_, seed=1 + rank), dev, True)
+    engine, crit, optim = make_engine(model, dev, batch, ddp=ddp if multi else None, graph=args.graph,
+                                      eager_steps=max(args.warmup, 2))
     use_graph = engine.captured
-    step = engine
-    loss_buf = engine.loss
+    staged = engine.staged
 
     def barrier():
         if multi:
             dist.barrier()
         torch.cuda.synchronize()
 
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    barrier()
-    dt = time.perf_counter() - t0
+    dt = timed_steps(engine, args.steps, barrier)
     if multi:
         tt = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt)
     ms_per_step = dt / args.steps * 1e3
     videos_per_s = B * world * args.steps / dt
-    final_loss = float(loss_buf)
+    final_loss = float(engine.loss)
+    rank_losses = None
+    if multi:                                   # every rank's loss (different shards: all must be finite and close)
+        ls = [torch.zeros(1, device=dev) for _ in range(world)]
+        dist.all_gather(ls, engine.loss.detach().reshape(1).float())
+        rank_losses = [round(float(x), 4) for x in ls]
 
     out = None
     if rank == 0:
-        # ---- live roofline: HIP events around every GEMM launch of a few eager steps
-        ops.PROFILER.enabled = True
-        n_prof = 3
-        for _ in range(n_prof):                  # rank-local launch-by-launch steps (no collective: only rank 0 is here)
-            optim.zero_grad()
-            crit.get_loss(get_forword_results(model.opt, model, engine.static, dev)).backward()
-            optim._optimizer.step(grad_scale=1.0)
-        torch.cuda.synchronize()
-        ops.PROFILER.enabled = False
-        summ = ops.PROFILER.summary()
-        ops.PROFILER.records = []
-        # dominant kernel = the single-launch GEMM class with the largest total time (spans of the dW
-        # entry point also contain the split-K combine and bias column-sum kernels: listed, not chosen)
-        dom = max(((k, v) for k, v in summ.items() if v["single"]), key=lambda kv: kv[1]["ms"])
-        name, r = dom
-        achieved = r["flops"] / (r["ms"] * 1e-3) / 1e12
-        gemm_ms = sum(v["ms"] for v in summ.values()) / n_prof
-        roofline = {"bound": "mfma", "kernel": name, "achieved": round(achieved, 2), "peak": PEAK_F32_MFMA_TFLOPS,
-                    "unit": "TFLOP/s", "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
-                    "launches_per_step": r["calls"] // n_prof,
-                    "avg_launch_ms": round(r["ms"] / r["calls"], 4),
-                    "flops_per_step": r["flops"] / n_prof,
-                    "all_gemm_ms_per_step": round(gemm_ms, 3),
-                    "all_gemm_tflops": round(sum(v["flops"] for v in summ.values()) / n_prof / (gemm_ms * 1e-3) / 1e12, 2),
-                    # not measured in this run: tools/gemm_trace.py (s_memtime vs wall_clock64 inside the workgroups)
-                    "note": "peak is the 2.4 GHz paper figure; under this kernel's load the shader clock was measured at "
-                            "2.05-2.13 GHz (134-140 TF at full MFMA issue), see DESIGN.md section 4"}
-        # HBM traffic of that kernel: PMC counters cannot be collected from inside this process, so the
-        # figure comes from the committed rocprofv3 --pmc passes of this same command (tools/pmc_traffic.py),
-        # averaged per launch over all launches of the kernel; null if the table is missing.
-        try:
-            tab = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
-            hits = [e for e in tab["kernels"] if e["kernel"].startswith("void " + name)]
-            if hits:
-                n_l = sum(e["launches_sampled"] for e in hits)
-                roofline["traffic"] = int(sum(e["hbm_bytes"] * e["launches_sampled"] for e in hits) / n_l)
-                roofline["traffic_source"] = "profiles/r01_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, bytes/launch)"
-        except (OSError, ValueError, KeyError):
-            pass
-        gemm_table = {k: {"calls_per_step": v["calls"] // n_prof, "ms_per_step": round(v["ms"] / n_prof, 3),
-                          "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2),
-                          "span_is_one_kernel": v["single"]} for k, v in summ.items()}
+        extra_timing = median_step_ms(engine) if not multi else None
 
-        # ---- NA decode throughput (captions/s incl. encode), same model in eval mode
+        def eager_step():           # rank-local launch-by-launch step (no collective: only rank 0 is here)
+            optim.zero_grad()
+            crit.get_loss(engine.forward(engine.static)).backward()
+            optim._optimizer.step(grad_scale=1.0)
+        summ = gemm_profile(eager_step)
+        roofline, gemm_table = roofline_from(summ, 3, mode)
+
+        feats, category = batch["feats"], batch["category"]
         decode = None
         if not args.no_decode and world == 1:
-            model.eval()
-            tr = Translator(model, dict(model.opt), device=dev)
-            def dec_once():
-                with torch.no_grad():
-                    enc = model.encode(feats=feats)
-                    hyp, _ = tr.translate_batch(enc, category, None, None)
-                return hyp
-            for _ in range(4):       # launch by launch, hipGraph capture (decoding/na_generate.py), first replays
-                dec_once()
-            torch.cuda.synchronize()
-            t1 = time.perf_counter()
-            for _ in range(args.decode_batches):
-                hyp = dec_once()
-            torch.cuda.synchronize()
-            ddt = (time.perf_counter() - t1) / args.decode_batches
-            decode = {"captions_per_s": round(B / ddt, 1), "ms_per_batch": round(ddt * 1e3, 2), "batch": B,
-                      "paradigm": "mp+ct", "iterations": 5, "length_beam_size": 6, "width": int(hyp.shape[1]),
-                      "hipgraph": any(k[0] != "seen" for k in getattr(model, "_nacf_decode_graphs", {}))}
-            model.train()
+            decode = bench_decode(model, dev, feats, category, args.decode_batches, mode=mode)
 
-        # ---- the same step fed by the shard loader (features gathered / frame-sampled / masked on
-        # the device) instead of one resident synthetic batch; "streaming" includes the PCIe upload of every batch
         loader_leg = None
         if not args.no_loader and engine.captured and not multi:
             loader_leg = bench_loader(args, nacf_amd, model.opt, dev, B, L, V, F_, engine)
 
-        # ---- BASELINE.json configs[4]: ARB2 beam-5 autoregressive decode vs NACF parallel decode, batch 256
-        compare = None
-        if not args.no_compare and not args.no_decode and world == 1:
-            CB = 256
-            cb = O.synth_batch(opt, CB, F_, seed=7)
-            cfeats = [f.to(dev) for f in cb["feats"]]
-            ccat = cb["category"].to(dev)
-            def timed(fn, n=5):
-                for _ in range(4):
-                    fn()
-                torch.cuda.synchronize()
-                t_ = time.perf_counter()
-                for _ in range(n):
-                    fn()
-                torch.cuda.synchronize()
-                return (time.perf_counter() - t_) / n
-            model.eval()
-            tr_na = Translator(model, dict(model.opt), device=dev)
-            def na():
-                with torch.no_grad():
-                    return tr_na.translate_batch(model.encode(feats=cfeats), ccat, None, None)
-            t_na = timed(na)
-            aopt = nacf_amd.opts.make_opt("ARB2", "MSRVTT", with_category=True, max_len=L, vocab_size=V, n_frames=60,
-                                          beam_size=5, beam_alpha=1.0, topk=1)
-            amodel = nacf_amd.get_model(aopt)
-            amodel.load_state_dict({k: v.clone() for k, v in O.init_state_dict(aopt, seed=0).items()})
-            amodel.to(dev).eval()
-            tr_ar = Translator(amodel, dict(amodel.opt), device=dev)
-            def ar():
-                with torch.no_grad():
-                    return tr_ar.translate_batch(amodel.encode(feats=cfeats), ccat, None, None)
-            t_ar = timed(ar)
-            compare = {"batch": CB, "nacf_mp_ct_captions_per_s": round(CB / t_na, 1),
-                       "arb2_beam5_captions_per_s": round(CB / t_ar, 1), "nacf_over_arb2": round(t_ar / t_na, 2),
-                       "note": "random-init weights: AR hypotheses rarely emit <eos>, so beam search runs all max_len-1 steps"}
-            del amodel
-            model.train()
-
-        # ---- BASELINE.json configs[1]: NAB (single-pass masked-LM decoder), MSRVTT-shape, batch 64, seq_len 20 --
-        # the same engine on the other NA model family (fp32 here: see DESIGN.md on bf16 and greedy-token parity)
-        nab = None
+        l30 = nacf_bf16 = nab = compare = None
         if not args.no_compare and world == 1:
-            nab = bench_nab(nacf_amd, dev, 64, L, V, F_)
+            # ---- the reference's MSRVTT default length (opts.py:161-169: max_len 30), same model / batch size
+            opt30 = make_opt(nacf_amd, "NACF", 30, V)
+            m30 = build_model(nacf_amd, opt30, dev)
+            m30.train()
+            e30, _, _ = make_engine(m30, dev, to_batch(O.synth_batch(opt30, B, F_, seed=1), dev, True), graph="on")
+            d30 = timed_steps(e30, 40) / 40
+            l30 = {"seq_len": 30, "batch": B, "videos_per_s": round(B / d30, 1), "ms_per_step": round(d30 * 1e3, 3),
+                   "gemm_mode": mode, "algorithmic_gflop_per_video_as_written": 5.210}
+            del e30, m30
 
-        # ---- CPU baseline: the oracle (plain eager PyTorch fp32 restatement) on this box's host cores
+            # ---- BASELINE.json configs[4]: ARB2 beam-5 autoregressive decode vs NACF parallel decode, batch 256
+            if not args.no_decode:
+                from nacf_amd.models.Translator import Translator
+                CB = 256
+                cb = O.synth_batch(opt, CB, F_, seed=7)
+                cfeats, ccat = [f.to(dev) for f in cb["feats"]], cb["category"].to(dev)
+
+                def timed(fn, n=5):
+                    for _ in range(4):
+                        fn()
+                    torch.cuda.synchronize()
+                    t_ = time.perf_counter()
+                    for _ in range(n):
+                        fn()
+                    torch.cuda.synchronize()
+                    return (time.perf_counter() - t_) / n
+                model.eval()
+                tr_na = Translator(model, dict(model.opt), device=dev)
+
+                def na():
+                    with torch.no_grad():
+                        return tr_na.translate_batch(model.encode(feats=cfeats), ccat, None, None)
+                t_na = timed(na)
+                aopt = nacf_amd.opts.make_opt("ARB2", "MSRVTT", with_category=True, max_len=L, vocab_size=V, n_frames=60,
+                                              beam_size=5, beam_alpha=1.0, topk=1)
+                amodel = build_model(nacf_amd, aopt, dev)
+                amodel.eval()
+                tr_ar = Translator(amodel, dict(amodel.opt), device=dev)
+
+                def ar():
+                    with torch.no_grad():
+                        return tr_ar.translate_batch(amodel.encode(feats=cfeats), ccat, None, None)
+                t_ar = timed(ar)
+                compare = {"batch": CB, "nacf_mp_ct_captions_per_s": round(CB / t_na, 1),
+                           "arb2_beam5_captions_per_s": round(CB / t_ar, 1), "nacf_over_arb2": round(t_ar / t_na, 2),
+                           "gemm_mode": mode,
+                           "note": "random-init weights: AR hypotheses rarely emit <eos>, so beam search runs all max_len-1 steps"}
+                del amodel
+                model.train()
+
+            # ---- bf16 throughput mode: NACF (same workload as the headline) and BASELINE.json configs[1] (NAB, batch 64)
+            ops.set_gemm_mode("bf16")
+            mb = build_model(nacf_amd, opt, dev)
+            mb.train()
+            eb, cb_, ob_ = make_engine(mb, dev, batch, graph="on")
+            db_ = timed_steps(eb, 40) / 40
+            sb = gemm_profile(lambda: (ob_.zero_grad(), cb_.get_loss(eb.forward(eb.static)).backward(),
+                                       ob_._optimizer.step(grad_scale=1.0)))
+            rlb, _ = roofline_from(sb, 3, "bf16")
+            decb = bench_decode(mb, dev, feats, category, 10, with_roofline=False) if not args.no_decode else None
+            nacf_bf16 = {"dtype": "bf16", "batch": B, "videos_per_s": round(B / db_, 1), "ms_per_step": round(db_ * 1e3, 3),
+                         "final_loss": round(float(eb.loss), 4), "roofline": rlb,
+                         "decode_captions_per_s": decb["captions_per_s"] if decb else None,
+                         "note": "fp32 master weights / activations in HBM, every GEMM operand rounded to bf16 (RNE), fp32 accumulate"}
+            del eb, mb
+            nab = bench_nab_bf16(nacf_amd, dev, 64, L, V, F_)
+            ops.set_gemm_mode(mode)
+
         cpu = None
         if not args.no_cpu_baseline and world == 1:      # reported at N=1 only (the other ranks would sit in a barrier)
-            from oracle import nacf_oracle as ORACLE   # the CPU checker: imported for THIS leg only, never measured as product
-            cb = 32
-            cbatch = O.synth_batch(opt, cb, F_, seed=1)
-            sd_c = {k: v.clone() for k, v in sd.items()}
-            st = {}
-            copt = dict(opt)
-            def cpu_step():
-                return ORACLE.train_step(sd_c, copt, cbatch["feats"], [cbatch["tokens_1"], cbatch["tokens"]],
-                                    cbatch["category"], [cbatch["labels_1"], cbatch["labels"]],
-                                    cbatch["tgt_length"], st, lr=opt["learning_rate"], training=True)
-            cpu_step()
-            t2 = time.perf_counter()
-            n_cpu = 0
-            while n_cpu < 2 or (time.perf_counter() - t2 < 10 and n_cpu < 20):
-                cpu_step(); n_cpu += 1
-            cdt = (time.perf_counter() - t2) / n_cpu
-            cpu = {"value": round(cb / cdt, 2), "unit": "videos/s", "cores": torch.get_num_threads(), "kind": "port",
-                   "sample": "%d NACF train steps (fwd+loss+bwd+clip+Adam, dropout 0.5) of %d videos, same shapes; "
-                             "oracle = plain eager PyTorch fp32, host has %d logical CPUs" % (n_cpu, cb, os.cpu_count())}
+            cpu = bench_cpu(opt, sd, O, B, F_)
 
         out = {"metric": METRIC, "value": round(videos_per_s, 1), "unit": "videos/s", "n_gpus": world,
                "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
-               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32" if mode != "bf16" else "bf16",
+               "data": "synthetic",
                "config": {"workload": "NACF train step, MSRVTT-shape (configs[2]/[3]): %d videos/GPU, 2x60x2048 fp32 "
                                       "feats, seq_len %d, V=%d, dropout 0.5, Adam" % (B, L, V),
+                          "gemm_mode": mode, "arithmetic": MODE_NOTE[mode],
                           "global_batch": B * world, "seq_len": L, "vocab": V, "params": n_params,
                           "parallelism": "dp%d" % world, "hipgraph": bool(use_graph), "live_row_gemms": True,
+                          "sync_bn": bool(model.opt.get("sync_bn", False)),
                           "overlapped_allreduce": bool(staged),
                           "gradient_buckets": (3 if engine.three else 2) if staged else 1},
-               "roofline": roofline, "cpu_baseline": cpu, "decode": decode, "config5_ar_vs_na": compare,
-               "loader_fed": loader_leg, "config1_nab": nab,
-               "final_loss": round(final_loss, 4),
-               "gemm_kernels": gemm_table}
+               "timing": extra_timing, "rank_losses": rank_losses,
+               "roofline": roofline, "cpu_baseline": cpu, "decode": decode, "train_L30": l30,
+               "nacf_bf16": nacf_bf16, "config1_nab_bf16": nab, "config5_ar_vs_na": compare,
+               "loader_fed": loader_leg, "final_loss": round(final_loss, 4), "gemm_kernels": gemm_table}
     if multi:
         dist.barrier()
         dist.destroy_process_group()

@@ -64,7 +64,7 @@ int nacf_version(void);
  * included).  nacf_abi_count() returns the value the LIBRARY was built with; the ctypes loader
  * (runtime/lib.py:load) refuses a library whose count differs from its own signature table, so a stale
  * libnacf_hip.so next to a newer Python package fails at import time, not at the first missing symbol. */
-#define NACF_ABI_COUNT 66
+#define NACF_ABI_COUNT 70
 int nacf_abi_count(void);
 
 /* ---- batch construction (reference: dataloader.py) ----------------------------------------
@@ -271,6 +271,30 @@ int nacf_bn_concat_bwd(const float* dOut, const float* x, float* dx, int B, int 
                        const float* save_mean, const float* save_invstd,
                        float* dweight, float* dbias, float beta,
                        void* ws, size_t ws_bytes, nacf_stream_t stream);
+
+/* Data-parallel ("synchronised") BatchNorm: models/joint_representation.py:43-45 computes batch statistics over ALL
+ * B*F rows of the batch; with the batch sharded over ranks the same two-pass statistics are formed over the global batch
+ * by exchanging one [D] vector per pass.  The library knows nothing about processes: the caller
+ * all-reduces (sum) the vectors between the calls.
+ *   nacf_bn_sync_stat(x, .., sum_global = NULL)  -> out[d] = sum_r x[r, d]                      (all-reduce -> S)
+ *   nacf_bn_sync_stat(x, .., sum_global = S)     -> out[d] = sum_r (x[r, d] - S[d] / n_total)^2  (all-reduce -> Q)
+ *   nacf_bn_concat_fwd_sync(.., S, Q, n_total)   normalises with mean = S/n, var = Q/n (running_var: Q/(n-1))
+ *   nacf_bn_sync_bwd_stat  -> sums2 = [sum dy | sum dy*xhat] over the LOCAL rows (all-reduce -> global), and
+ *                             dbias / dweight (+)= the local sums (the gradient all-reduce adds the ranks up)
+ *   nacf_bn_concat_bwd_sync(.., sums2_global, n_total)   dx = w*invstd*(dy - sum_dy/n - xhat*sum_dyx/n)
+ * n_total = rows of ALL ranks.  ws: nacf_bn_workspace(rows, D) bytes. */
+int nacf_bn_sync_stat(const float* x, int rows, int D, const float* sum_global, int64_t n_total, float* out, void* ws,
+                      size_t ws_bytes, nacf_stream_t stream);
+int nacf_bn_concat_fwd_sync(const float* x, float* out, int B, int F, int D, int M_total, int f_off, const float* weight,
+                            const float* bias, float* running_mean, float* running_var, int64_t* num_batches_tracked,
+                            float* save_mean, float* save_invstd, float momentum, float eps, const float* sum_global,
+                            const float* sqdev_global, int64_t n_total, nacf_stream_t stream);
+int nacf_bn_sync_bwd_stat(const float* dOut, const float* x, int B, int F, int D, int M_total, int f_off,
+                          const float* save_mean, const float* save_invstd, float* sums2, float* dweight, float* dbias,
+                          float beta, void* ws, size_t ws_bytes, nacf_stream_t stream);
+int nacf_bn_concat_bwd_sync(const float* dOut, const float* x, float* dx, int B, int F, int D, int M_total, int f_off,
+                            const float* weight, const float* save_mean, const float* save_invstd, const float* sums2_global,
+                            int64_t n_total, nacf_stream_t stream);
 
 /* mean over the time axis: out[b, :] = mean_t x[b, t, :]   (x is [B, T, D]);
  * models/Predictor.py:29, models/Decoder.py:137, models/Encoder.py:51 */

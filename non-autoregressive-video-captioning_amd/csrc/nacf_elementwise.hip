@@ -103,7 +103,7 @@ __global__ void bn_partial_sum_kernel(const float* __restrict__ x, int rows, int
 }
 // stage B: mean from partials, then partial sum of squared deviations
 __global__ void bn_partial_sqdev_kernel(const float* __restrict__ x, int rows, int D, int rows_per, int S,
-                                        const float* __restrict__ part_sum, float* __restrict__ part_sq) {
+                                        const float* __restrict__ part_sum, float* __restrict__ part_sq, float n_stat) {
   __shared__ float red[4][64];
   const int c = blockIdx.x * 64 + (threadIdx.x & 63);
   const int rl = threadIdx.x >> 6;
@@ -111,7 +111,7 @@ __global__ void bn_partial_sqdev_kernel(const float* __restrict__ x, int rows, i
   float mean = 0.f;
   if (c < D) {
     for (int s = 0; s < S; ++s) mean += part_sum[(int64_t)s * D + c];
-    mean /= (float)rows;
+    mean /= n_stat;
   }
   float acc = 0.f;
   if (c < D)
@@ -130,7 +130,8 @@ __global__ void bn_apply_kernel(const float* __restrict__ x, float* __restrict__
                                 float* __restrict__ running_mean, float* __restrict__ running_var,
                                 int64_t* __restrict__ nbt, float* __restrict__ save_mean,
                                 float* __restrict__ save_invstd, int training, float momentum, float eps, int S,
-                                const float* __restrict__ part_sum, const float* __restrict__ part_sq, int rows_per) {
+                                const float* __restrict__ part_sum, const float* __restrict__ part_sq, int rows_per,
+                                float n_stat) {
   const int c = blockIdx.x * 64 + (threadIdx.x & 63);
   const int rl = threadIdx.x >> 6;
   const int rows = B * F;
@@ -140,11 +141,11 @@ __global__ void bn_apply_kernel(const float* __restrict__ x, float* __restrict__
   if (training) {
     float sm = 0.f, sq = 0.f;
     for (int s = 0; s < S; ++s) { sm += part_sum[(int64_t)s * D + c]; sq += part_sq[(int64_t)s * D + c]; }
-    mean = sm / (float)rows;
-    const float var_b = sq / (float)rows;
+    mean = sm / n_stat;
+    const float var_b = sq / n_stat;
     invstd = 1.0f / sqrtf(var_b + eps);
     if (blockIdx.y == 0 && rl == 0) {
-      const float var_u = sq / (float)(rows > 1 ? rows - 1 : 1);
+      const float var_u = sq / (n_stat > 1.f ? n_stat - 1.f : 1.f);
       if (running_mean) running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mean;
       if (running_var) running_var[c] = (1.f - momentum) * running_var[c] + momentum * var_u;
       if (save_mean) save_mean[c] = mean;
@@ -196,7 +197,7 @@ __global__ void bn_bwd_apply_kernel(const float* __restrict__ dOut, const float*
                                     const float* __restrict__ w, const float* __restrict__ save_mean,
                                     const float* __restrict__ save_invstd, float* __restrict__ dweight,
                                     float* __restrict__ dbias, float beta, int S, int rows_per,
-                                    const float* __restrict__ part_dy, const float* __restrict__ part_dyx) {
+                                    const float* __restrict__ part_dy, const float* __restrict__ part_dyx, float n_stat) {
   const int c = blockIdx.x * 64 + (threadIdx.x & 63);
   const int rl = threadIdx.x >> 6;
   const int rows = B * F;
@@ -210,7 +211,7 @@ __global__ void bn_bwd_apply_kernel(const float* __restrict__ dOut, const float*
   }
   const float mean = save_mean[c], invstd = save_invstd[c];
   const float ww = w ? w[c] : 1.f;
-  const float invn = 1.f / (float)rows;
+  const float invn = 1.f / n_stat;
   for (int r = r0 + rl; r < r1; r += 4) {
     const int bi = r / F, f = r % F;
     const float dy = dOut[((int64_t)bi * M_total + f_off + f) * D + c];
@@ -255,13 +256,14 @@ __global__ __launch_bounds__(256) void bn_partial_sum_v4_kernel(const float* __r
   if (rg == 0 && c < D) *reinterpret_cast<f32x4*>(part + (int64_t)blockIdx.y * D + c) = t;
 }
 __global__ __launch_bounds__(256) void bn_partial_sqdev_v4_kernel(const float* __restrict__ x, int rows, int D, int rows_per, int S,
-                                                                  const float* __restrict__ part_sum, float* __restrict__ part_sq) {
+                                                                  const float* __restrict__ part_sum, float* __restrict__ part_sq,
+                                                                  float n_stat) {
   __shared__ f32x4 red[16][16];
   const int c4 = threadIdx.x & 15, rg = threadIdx.x >> 4;
   const int c = blockIdx.x * 64 + c4 * 4;
   const int r0 = blockIdx.y * rows_per, r1 = min(rows, r0 + rows_per);
   f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-  const f32x4 mean = bn_sum_parts(part_sum, S, D, c, c < D, red, rg, c4) / (float)rows;
+  const f32x4 mean = bn_sum_parts(part_sum, S, D, c, c < D, red, rg, c4) / n_stat;
   if (c < D) {
 #pragma unroll 4
     for (int r = r0 + rg; r < r1; r += 16) {
@@ -279,7 +281,7 @@ __global__ __launch_bounds__(256) void bn_apply_v4_kernel(const float* __restric
                                                           float* __restrict__ save_mean, float* __restrict__ save_invstd,
                                                           int training, float momentum, float eps, int S,
                                                           const float* __restrict__ part_sum, const float* __restrict__ part_sq,
-                                                          int rows_per) {
+                                                          int rows_per, float n_stat) {
   const int c4 = threadIdx.x & 15, rg = threadIdx.x >> 4;
   const int c = blockIdx.x * 64 + c4 * 4;
   __shared__ f32x4 red[16][16];
@@ -293,12 +295,12 @@ __global__ __launch_bounds__(256) void bn_apply_v4_kernel(const float* __restric
   if (c >= D) return;
   f32x4 mean, invstd;
   if (training) {
-    mean = sm / (float)rows;
-    const f32x4 var_b = sq / (float)rows;
+    mean = sm / n_stat;
+    const f32x4 var_b = sq / n_stat;
 #pragma unroll
     for (int e = 0; e < 4; ++e) invstd[e] = 1.0f / sqrtf(var_b[e] + eps);
     if (blockIdx.y == 0 && rg == 0) {
-      const f32x4 var_u = sq / (float)(rows > 1 ? rows - 1 : 1);
+      const f32x4 var_u = sq / (n_stat > 1.f ? n_stat - 1.f : 1.f);
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         if (running_mean) running_mean[c + e] = (1.f - momentum) * running_mean[c + e] + momentum * mean[e];
@@ -355,7 +357,8 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_v4_kernel(const float* __res
                                                               const float* __restrict__ w, const float* __restrict__ save_mean,
                                                               const float* __restrict__ save_invstd, float* __restrict__ dweight,
                                                               float* __restrict__ dbias, float beta, int S, int rows_per,
-                                                              const float* __restrict__ part_dy, const float* __restrict__ part_dyx) {
+                                                              const float* __restrict__ part_dy, const float* __restrict__ part_dyx,
+                                                              float n_stat) {
   const int c4 = threadIdx.x & 15, rg = threadIdx.x >> 4;
   const int c = blockIdx.x * 64 + c4 * 4;
   const int rows = B * F;
@@ -374,7 +377,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_v4_kernel(const float* __res
   const f32x4 mean = *reinterpret_cast<const f32x4*>(save_mean + c), invstd = *reinterpret_cast<const f32x4*>(save_invstd + c);
   f32x4 ww = {1.f, 1.f, 1.f, 1.f};
   if (w) ww = *reinterpret_cast<const f32x4*>(w + c);
-  const float invn = 1.f / (float)rows;
+  const float invn = 1.f / n_stat;
 #pragma unroll 4
   for (int r = r0 + rg; r < r1; r += 16) {
     const int bi = r / F, f = r % F;
@@ -382,6 +385,18 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_v4_kernel(const float* __res
     const f32x4 xh = (*reinterpret_cast<const f32x4*>(x + (int64_t)r * D + c) - mean) * invstd;
     *reinterpret_cast<f32x4*>(dx + (int64_t)r * D + c) = ww * invstd * (dy - sdy * invn - xh * sdyx * invn);
   }
+}
+
+// column totals of S slab partials in fixed order: out[d] = sum_s part[s][d]; optionally acc[d] = beta * acc[d] + total
+// (data-parallel BatchNorm: the vectors the ranks exchange, and the LOCAL weight / bias gradients)
+__global__ void bn_fold_parts_kernel(const float* __restrict__ part, int S, int D, float* __restrict__ out,
+                                     float* __restrict__ acc, float beta) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= D) return;
+  float t = 0.f;
+  for (int s = 0; s < S; ++s) t += part[(int64_t)s * D + c];
+  if (out) out[c] = t;
+  if (acc) acc[c] = (beta != 0.f) ? t + beta * acc[c] : t;
 }
 
 // ------------------------------------------------------------------ time mean
@@ -859,19 +874,19 @@ int nacf_bn_concat_fwd(const float* x, float* out, int B, int F, int D, int M_to
   if (v4) {
     if (training) {
       hipLaunchKernelGGL(bn_partial_sum_v4_kernel, grid, dim3(256), 0, s, x, rows, D, rows_per, part_sum);
-      hipLaunchKernelGGL(bn_partial_sqdev_v4_kernel, grid, dim3(256), 0, s, x, rows, D, rows_per, S, part_sum, part_sq);
+      hipLaunchKernelGGL(bn_partial_sqdev_v4_kernel, grid, dim3(256), 0, s, x, rows, D, rows_per, S, part_sum, part_sq, (float)rows);
     }
     hipLaunchKernelGGL(bn_apply_v4_kernel, grid, dim3(256), 0, s, x, out, B, F, D, M_total, f_off, weight, bias, running_mean,
                        running_var, num_batches_tracked, save_mean, save_invstd, training, momentum, eps, S, part_sum,
-                       part_sq, rows_per);
+                       part_sq, rows_per, (float)rows);
   } else {
     if (training) {
       hipLaunchKernelGGL(bn_partial_sum_kernel, grid, dim3(256), 0, s, x, rows, D, rows_per, part_sum);
-      hipLaunchKernelGGL(bn_partial_sqdev_kernel, grid, dim3(256), 0, s, x, rows, D, rows_per, S, part_sum, part_sq);
+      hipLaunchKernelGGL(bn_partial_sqdev_kernel, grid, dim3(256), 0, s, x, rows, D, rows_per, S, part_sum, part_sq, (float)rows);
     }
     hipLaunchKernelGGL(bn_apply_kernel, grid, dim3(256), 0, s, x, out, B, F, D, M_total, f_off, weight, bias, running_mean,
                        running_var, num_batches_tracked, save_mean, save_invstd, training, momentum, eps, S, part_sum,
-                       part_sq, rows_per);
+                       part_sq, rows_per, (float)rows);
   }
   NACF_LAUNCH_CHECK("nacf_bn_concat_fwd");
   return NACF_OK;
@@ -894,14 +909,112 @@ int nacf_bn_concat_bwd(const float* dOut, const float* x, float* dx, int B, int 
     hipLaunchKernelGGL(bn_bwd_partial_v4_kernel, grid, dim3(256), 0, s, dOut, x, B, F, D, M_total, f_off, save_mean,
                        save_invstd, rows_per, part_dy, part_dyx);
     hipLaunchKernelGGL(bn_bwd_apply_v4_kernel, grid, dim3(256), 0, s, dOut, x, dx, B, F, D, M_total, f_off, weight, save_mean,
-                       save_invstd, dweight, dbias, beta, S, rows_per, part_dy, part_dyx);
+                       save_invstd, dweight, dbias, beta, S, rows_per, part_dy, part_dyx, (float)rows);
   } else {
     hipLaunchKernelGGL(bn_bwd_partial_kernel, grid, dim3(256), 0, s, dOut, x, B, F, D, M_total, f_off, save_mean,
                        save_invstd, rows_per, part_dy, part_dyx);
     hipLaunchKernelGGL(bn_bwd_apply_kernel, grid, dim3(256), 0, s, dOut, x, dx, B, F, D, M_total, f_off, weight, save_mean,
-                       save_invstd, dweight, dbias, beta, S, rows_per, part_dy, part_dyx);
+                       save_invstd, dweight, dbias, beta, S, rows_per, part_dy, part_dyx, (float)rows);
   }
   NACF_LAUNCH_CHECK("nacf_bn_concat_bwd");
+  return NACF_OK;
+}
+
+// ---- data-parallel (synchronised) BatchNorm: the same two-pass statistics over the GLOBAL batch, cut where the ranks
+// exchange a [D] vector (the caller all-reduces between the calls; nothing here knows about processes)
+int nacf_bn_sync_stat(const float* x, int rows, int D, const float* sum_global, int64_t n_total, float* out, void* ws,
+                      size_t ws_bytes, nacf_stream_t stream) {
+  NACF_CHECK(x && out && rows > 0 && D > 0 && n_total >= rows, NACF_EINVAL, "nacf_bn_sync_stat: bad argument");
+  NACF_CHECK(ws && ws_bytes >= nacf_bn_workspace(rows, D), NACF_EWORKSPACE, "nacf_bn_sync_stat: workspace too small");
+  int S, rows_per;
+  bn_split(rows, &S, &rows_per);
+  float* part = reinterpret_cast<float*>(ws);
+  hipStream_t s = as_hip(stream);
+  dim3 grid(cdiv(D, 64), S);
+  const bool v4 = (D % 4 == 0) && bn_aligned16(x, sum_global, ws);
+  if (!sum_global) {
+    if (v4) hipLaunchKernelGGL(bn_partial_sum_v4_kernel, grid, dim3(256), 0, s, x, rows, D, rows_per, part);
+    else hipLaunchKernelGGL(bn_partial_sum_kernel, grid, dim3(256), 0, s, x, rows, D, rows_per, part);
+  } else {            // squared deviations from the GLOBAL mean = sum_global / n_total (one "slab" of partial sums)
+    if (v4) hipLaunchKernelGGL(bn_partial_sqdev_v4_kernel, grid, dim3(256), 0, s, x, rows, D, rows_per, 1, sum_global, part, (float)n_total);
+    else hipLaunchKernelGGL(bn_partial_sqdev_kernel, grid, dim3(256), 0, s, x, rows, D, rows_per, 1, sum_global, part, (float)n_total);
+  }
+  hipLaunchKernelGGL(bn_fold_parts_kernel, dim3(cdiv(D, 256)), dim3(256), 0, s, part, S, D, out, (float*)nullptr, 0.f);
+  NACF_LAUNCH_CHECK("nacf_bn_sync_stat");
+  return NACF_OK;
+}
+
+int nacf_bn_concat_fwd_sync(const float* x, float* out, int B, int F, int D, int M_total, int f_off, const float* weight,
+                            const float* bias, float* running_mean, float* running_var, int64_t* num_batches_tracked,
+                            float* save_mean, float* save_invstd, float momentum, float eps, const float* sum_global,
+                            const float* sqdev_global, int64_t n_total, nacf_stream_t stream) {
+  NACF_CHECK(x && out && sum_global && sqdev_global && B > 0 && F > 0 && D > 0 && n_total >= (int64_t)B * F, NACF_EINVAL,
+             "nacf_bn_concat_fwd_sync: bad argument");
+  NACF_CHECK(f_off >= 0 && f_off + F <= M_total, NACF_EINVAL, "nacf_bn_concat_fwd_sync: frame window outside the memory");
+  const int rows = B * F;
+  int S, rows_per;
+  bn_split(rows, &S, &rows_per);
+  hipStream_t s = as_hip(stream);
+  dim3 grid(cdiv(D, 64), S);
+  if ((D % 4 == 0) && bn_aligned16(x, out, weight, bias, save_mean, save_invstd, sum_global, sqdev_global))
+    hipLaunchKernelGGL(bn_apply_v4_kernel, grid, dim3(256), 0, s, x, out, B, F, D, M_total, f_off, weight, bias, running_mean,
+                       running_var, num_batches_tracked, save_mean, save_invstd, 1, momentum, eps, 1, sum_global, sqdev_global,
+                       rows_per, (float)n_total);
+  else
+    hipLaunchKernelGGL(bn_apply_kernel, grid, dim3(256), 0, s, x, out, B, F, D, M_total, f_off, weight, bias, running_mean,
+                       running_var, num_batches_tracked, save_mean, save_invstd, 1, momentum, eps, 1, sum_global, sqdev_global,
+                       rows_per, (float)n_total);
+  NACF_LAUNCH_CHECK("nacf_bn_concat_fwd_sync");
+  return NACF_OK;
+}
+
+int nacf_bn_sync_bwd_stat(const float* dOut, const float* x, int B, int F, int D, int M_total, int f_off,
+                          const float* save_mean, const float* save_invstd, float* sums2, float* dweight, float* dbias,
+                          float beta, void* ws, size_t ws_bytes, nacf_stream_t stream) {
+  NACF_CHECK(dOut && x && save_mean && save_invstd && sums2, NACF_EINVAL, "nacf_bn_sync_bwd_stat: null pointer");
+  NACF_CHECK(B > 0 && F > 0 && D > 0 && f_off >= 0 && f_off + F <= M_total, NACF_EINVAL, "nacf_bn_sync_bwd_stat: bad shape");
+  NACF_CHECK(ws && ws_bytes >= nacf_bn_workspace(B * F, D), NACF_EWORKSPACE, "nacf_bn_sync_bwd_stat: workspace too small");
+  const int rows = B * F;
+  int S, rows_per;
+  bn_split(rows, &S, &rows_per);
+  float* part_dy = reinterpret_cast<float*>(ws);
+  float* part_dyx = part_dy + (size_t)BN_MAX_SLABS * D;
+  hipStream_t s = as_hip(stream);
+  dim3 grid(cdiv(D, 64), S);
+  if ((D % 4 == 0) && bn_aligned16(dOut, x, save_mean, save_invstd, ws))
+    hipLaunchKernelGGL(bn_bwd_partial_v4_kernel, grid, dim3(256), 0, s, dOut, x, B, F, D, M_total, f_off, save_mean,
+                       save_invstd, rows_per, part_dy, part_dyx);
+  else
+    hipLaunchKernelGGL(bn_bwd_partial_kernel, grid, dim3(256), 0, s, dOut, x, B, F, D, M_total, f_off, save_mean,
+                       save_invstd, rows_per, part_dy, part_dyx);
+  // the LOCAL sums are this rank's bias / weight gradient (the gradient all-reduce adds the ranks up); the vectors
+  // in sums2 = [sum dy | sum dy*xhat] are what the ranks exchange for dx
+  hipLaunchKernelGGL(bn_fold_parts_kernel, dim3(cdiv(D, 256)), dim3(256), 0, s, part_dy, S, D, sums2, dbias, beta);
+  hipLaunchKernelGGL(bn_fold_parts_kernel, dim3(cdiv(D, 256)), dim3(256), 0, s, part_dyx, S, D, sums2 + D, dweight, beta);
+  NACF_LAUNCH_CHECK("nacf_bn_sync_bwd_stat");
+  return NACF_OK;
+}
+
+int nacf_bn_concat_bwd_sync(const float* dOut, const float* x, float* dx, int B, int F, int D, int M_total, int f_off,
+                            const float* weight, const float* save_mean, const float* save_invstd, const float* sums2_global,
+                            int64_t n_total, nacf_stream_t stream) {
+  NACF_CHECK(dOut && x && dx && save_mean && save_invstd && sums2_global, NACF_EINVAL, "nacf_bn_concat_bwd_sync: null pointer");
+  NACF_CHECK(B > 0 && F > 0 && D > 0 && f_off >= 0 && f_off + F <= M_total && n_total >= (int64_t)B * F, NACF_EINVAL,
+             "nacf_bn_concat_bwd_sync: bad shape");
+  const int rows = B * F;
+  int S, rows_per;
+  bn_split(rows, &S, &rows_per);
+  hipStream_t s = as_hip(stream);
+  dim3 grid(cdiv(D, 64), S);
+  if ((D % 4 == 0) && bn_aligned16(dOut, x, dx, weight, save_mean, save_invstd, sums2_global))
+    hipLaunchKernelGGL(bn_bwd_apply_v4_kernel, grid, dim3(256), 0, s, dOut, x, dx, B, F, D, M_total, f_off, weight, save_mean,
+                       save_invstd, (float*)nullptr, (float*)nullptr, 0.f, 1, rows_per, sums2_global, sums2_global + D,
+                       (float)n_total);
+  else
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, grid, dim3(256), 0, s, dOut, x, dx, B, F, D, M_total, f_off, weight, save_mean,
+                       save_invstd, (float*)nullptr, (float*)nullptr, 0.f, 1, rows_per, sums2_global, sums2_global + D,
+                       (float)n_total);
+  NACF_LAUNCH_CHECK("nacf_bn_concat_bwd_sync");
   return NACF_OK;
 }
 

@@ -386,6 +386,45 @@ def bn_concat_bwd(dout, x, dx, f_off, weight, save_mean, save_invstd, dweight, d
                                    _ptr(ws), ws.numel(), _stream()), "nacf_bn_concat_bwd")
 
 
+def bn_sync_stat(x, sum_global, n_total, out):
+    """one pass of the global-batch BatchNorm statistics over this rank's rows (see nacf_bn_sync_stat): the column
+    sums (sum_global None) or the squared deviations from the global mean sum_global / n_total"""
+    _chk_f32(x, sum_global, out)
+    B, F, D = x.shape
+    lib = L.load()
+    ws = WORKSPACE.get(lib.nacf_bn_workspace(B * F, D), x.device)
+    L.check(lib.nacf_bn_sync_stat(_ptr(x), B * F, D, _ptr(sum_global), int(n_total), _ptr(out), _ptr(ws), ws.numel(), _stream()),
+            "nacf_bn_sync_stat")
+
+
+def bn_concat_fwd_sync(x, out, f_off, weight, bias, running_mean, running_var, nbt, save_mean, save_invstd, sum_global,
+                       sqdev_global, n_total, momentum=0.1, eps=1e-5):
+    _chk_f32(x, out, weight, bias, running_mean, running_var, save_mean, save_invstd, sum_global, sqdev_global)
+    B, F, D = x.shape
+    L.check(L.load().nacf_bn_concat_fwd_sync(_ptr(x), _ptr(out), B, F, D, out.shape[1], f_off, _ptr(weight), _ptr(bias),
+                                             _ptr(running_mean), _ptr(running_var), _ptr(nbt), _ptr(save_mean),
+                                             _ptr(save_invstd), float(momentum), float(eps), _ptr(sum_global),
+                                             _ptr(sqdev_global), int(n_total), _stream()), "nacf_bn_concat_fwd_sync")
+
+
+def bn_sync_bwd_stat(dout, x, f_off, save_mean, save_invstd, sums2, dweight, dbias, beta=1.0):
+    _chk_f32(dout, x, save_mean, save_invstd, sums2, dweight, dbias)
+    B, F, D = x.shape
+    lib = L.load()
+    ws = WORKSPACE.get(lib.nacf_bn_workspace(B * F, D), x.device)
+    L.check(lib.nacf_bn_sync_bwd_stat(_ptr(dout), _ptr(x), B, F, D, dout.shape[1], f_off, _ptr(save_mean), _ptr(save_invstd),
+                                      _ptr(sums2), _ptr(dweight), _ptr(dbias), float(beta), _ptr(ws), ws.numel(), _stream()),
+            "nacf_bn_sync_bwd_stat")
+
+
+def bn_concat_bwd_sync(dout, x, dx, f_off, weight, save_mean, save_invstd, sums2_global, n_total):
+    _chk_f32(dout, x, dx, weight, save_mean, save_invstd, sums2_global)
+    B, F, D = x.shape
+    L.check(L.load().nacf_bn_concat_bwd_sync(_ptr(dout), _ptr(x), _ptr(dx), B, F, D, dout.shape[1], f_off, _ptr(weight),
+                                             _ptr(save_mean), _ptr(save_invstd), _ptr(sums2_global), int(n_total), _stream()),
+            "nacf_bn_concat_bwd_sync")
+
+
 def mean_time_fwd(x, out):
     _chk_f32(x, out)
     B, T, D = x.shape
