@@ -441,7 +441,9 @@ def main():
     B, L, V, F_ = args.batch, args.seq_len, args.vocab, 60
     mode = args.gemm_mode
     ops.set_gemm_mode(mode)
-    opt = make_opt(nacf_amd, "NACF", L, V)
+    # more than one rank: BatchNorm statistics of the GLOBAL batch (three [2, 512]-class all-reduces per step), so that
+    # N-rank training is one process with the global batch (models/joint_representation.py:43-45)
+    opt = make_opt(nacf_amd, "NACF", L, V, sync_bn=(world > 1 or force_dist) and os.environ.get("NACF_BENCH_SYNC_BN", "1") != "0")
     sd = O.init_state_dict(opt, seed=0)
     model = build_model(nacf_amd, opt, dev)
     model.train()

@@ -23,6 +23,8 @@ class Joint_Representaion_Learner(nn.Module):  # (sic) upstream spelling is part
                 self.norm_list.append(m)
                 self.add_module('%s%d' % ('bn' if self.is_bn else 'ln', i), m)
         self._packs = None
+        self.sync_bn = bool(opt.get('sync_bn', False))
+        self._sync = None            # set by runtime.ddp.DataParallel when opt['sync_bn'] and more than one rank trains
 
     def nacf_groups(self):
         return [[p] for m in self.norm_list for p in (m.weight, m.bias)]
@@ -42,7 +44,8 @@ class Joint_Representaion_Learner(nn.Module):  # (sic) upstream spelling is part
             return LNConcatFn.apply(cfg, len(encoder_outputs), *encoder_outputs, *params), encoder_hiddens
         mods = [dict(pack=pk, running_mean=m.running_mean, running_var=m.running_var, nbt=m.num_batches_tracked)
                 for pk, m in zip(self._packs, self.norm_list)]
-        cfg = dict(mods=mods, training=self.training, momentum=self.norm_list[0].momentum, eps=self.norm_list[0].eps)
+        cfg = dict(mods=mods, training=self.training, momentum=self.norm_list[0].momentum, eps=self.norm_list[0].eps,
+                   sync=self._sync if self.sync_bn else None)
         params = [p for m in self.norm_list for p in (m.weight, m.bias)]
         out = BNConcatFn.apply(cfg, len(encoder_outputs), *encoder_outputs, *params)
         return out, encoder_hiddens

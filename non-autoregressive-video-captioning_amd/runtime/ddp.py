@@ -8,8 +8,10 @@ flat fp32 gradient buffer (73.8 MB for NACF/MSRVTT-shape; two or three buckets, 
 all-reduced (sum); the 1/world scale is folded into the fused Adam launch, so
 clip(+-5) follows the reduce exactly as misc/run.py:258-261 orders them.
 Per-rank losses are normalised by the LOCAL batch (misc/crit.py:40), so the
-mean of rank gradients equals the global-batch gradient.  BatchNorm statistics
-are per-rank (documented deviation; the fusion layer sees 7 680 rows per rank).
+mean of rank gradients equals the global-batch gradient.  BatchNorm (the one place where samples interact,
+models/joint_representation.py:43-45): per-rank statistics by default; with opt['sync_bn'] the statistics are those of
+the global batch -- the ranks exchange one [n_modalities, 512] vector per statistics pass (`sync_point`, three tiny
+all-reduces per step) and N-rank training IS one process with the global batch (tests/test_ddp_cpu.py, world 2 and 4).
 
 Overlap: the flat buffer is laid out encoder | fusion | length head | decoder | vocabulary projection, and backward
 finishes the decoder side first.  `backward_to_cut` / `backward_from_cut` split the backward pass at the encoder
@@ -39,6 +41,21 @@ class DataParallel(object):
         self.rank = dist.get_rank(process_group) if dist.is_initialized() else 0
         # issue the collectives even for a 1-rank group (exercises the N>1 launch sequence on one GPU)
         self.force = bool(force_collectives) and dist.is_initialized()
+        self._capture_break = None      # set by runtime/engine.py while it captures: ends a hipGraph at a collective
+        self.n_sync_points = 0
+        jr = getattr(model, 'joint_representation_learner', None)
+        if jr is not None and getattr(jr, 'sync_bn', False):
+            jr._sync = self if (self.world > 1 or self.force) else None
+
+    # ---- collectives INSIDE forward / backward (SyncBN statistics)
+    def all_reduce(self, t):
+        """sum `t` over the ranks, ordered with the current stream.  While the engine captures a step this ends the
+        running hipGraph, records the collective and opens the next graph (RCCL calls are never captured)."""
+        self.n_sync_points += 1
+        if self._capture_break is not None:
+            self._capture_break(t)
+        else:
+            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
 
     @property
     def grad_scale(self):

@@ -14,7 +14,9 @@ dropout and masking seeds (Philox {seed, step} advanced by a kernel), Adam's ste
 N > 1 ranks (runtime/ddp.py): the backward pass is split at the decoder's output and at the encoder outputs into
 three graphs; each gradient bucket (vocabulary projection | decoder side | encoder side) is all-reduced (RCCL,
 torch.distributed's own stream -- never captured) while the next backward graph replays, the last one after it; the decoder-side parameters are updated (their own Adam graph) while the second bucket is
-still in flight, the encoder-side ones after it.
+still in flight, the encoder-side ones after it.  With opt['sync_bn'] the forward and the encoder-side backward reach
+three more collectives (the BatchNorm statistics of the global batch): every stage is therefore captured as a SEQUENCE
+of hipGraphs cut at those points (`_capture_stage`), and the replay issues the collectives between them.
 
 A batch whose shapes differ from the captured ones (the ragged tail of an epoch) runs launch by launch.
 """
@@ -131,42 +133,82 @@ class TrainStep(object):
             self.ddp.all_reduce_gradients()
         self._update()
 
+    def _capture_stage(self, fn, pool, mode):
+        """Run `fn` under stream capture.  The result is a launch SEQUENCE: hipGraphs cut wherever the code reached a
+        collective inside forward / backward (DataParallel.all_reduce: the SyncBN statistics) -- RCCL calls are never
+        captured, the replay issues them between the graphs.  All graphs share one memory pool (the autograd graph
+        and its saved tensors live across the cuts)."""
+        seq = []
+        cur = [None]
+
+        def begin():
+            g = torch.cuda.CUDAGraph()
+            if pool[0] is None:
+                g.capture_begin(capture_error_mode=mode)
+            else:
+                g.capture_begin(pool=pool[0], capture_error_mode=mode)
+            cur[0] = g
+
+        def end():
+            g = cur[0]
+            g.capture_end()
+            if pool[0] is None:
+                pool[0] = g.pool()
+            seq.append(g)
+            cur[0] = None
+
+        def brk(t):
+            end()
+            seq.append(t)
+            begin()
+        if self.ddp is not None:
+            self.ddp._capture_break = brk
+        begin()
+        try:
+            fn()
+        finally:
+            if cur[0] is not None:
+                end()
+            if self.ddp is not None:
+                self.ddp._capture_break = None
+        return seq
+
+    def _run_seq(self, seq):
+        for item in seq:
+            if isinstance(item, torch.cuda.CUDAGraph):
+                item.replay()
+            else:                           # a tensor: the collective recorded at this point of the step
+                self.ddp.all_reduce(item)
+
     def _capture(self):
         dev = self.loss.device
         before = list(self.crit._loss_cnt)
         # drain first: RCCL's watchdog thread polls the events of unfinished collectives, which is illegal while a
         # capture is open in another thread ("thread_local" below keeps unrelated threads out of it as well)
         torch.cuda.synchronize(dev)
-        mode = dict(capture_error_mode='thread_local')
+        # 'thread_local' keeps unrelated threads out of the capture.  With SyncBN the capture is cut and re-opened INSIDE
+        # the backward pass, i.e. on autograd's device thread, and only a 'relaxed' capture may be ended by another
+        # thread than the one that began it (hipErrorStreamCaptureWrongThread otherwise).
+        jr = getattr(self.model, 'joint_representation_learner', None)
+        mode = 'relaxed' if (self.multi and getattr(jr, '_sync', None) is not None) else 'thread_local'
+        pool = [None]
         side = torch.cuda.Stream(device=dev)
         side.wait_stream(torch.cuda.current_stream(dev))
         with torch.cuda.stream(side):
-            front = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(front, stream=side, **mode):
+            def front_fn():
                 self._front(self.static)
                 if not self.multi:
                     self._update()
+            front = self._capture_stage(front_fn, pool, mode)
             back = upd = mid = None
             if self.staged:                 # same memory pool: the autograd graph of `front` is still alive
                 if self.three:
-                    mid = torch.cuda.CUDAGraph()
-                    with torch.cuda.graph(mid, stream=side, pool=front.pool(), **mode):
-                        self._mid()
-                back = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(back, stream=side, pool=front.pool(), **mode):
-                    self._back()
+                    mid = self._capture_stage(self._mid, pool, mode)
+                back = self._capture_stage(self._back, pool, mode)
                 self._hold.clear()
-            if self.staged:                 # one Adam graph per gradient bucket
-                upd = []
-                for part in (0, 1):
-                    g_ = torch.cuda.CUDAGraph()
-                    with torch.cuda.graph(g_, stream=side, pool=front.pool(), **mode):
-                        self._update(part)
-                    upd.append(g_)
+                upd = [self._capture_stage(lambda part=part: self._update(part), pool, mode) for part in (0, 1)]
             elif self.multi:
-                upd = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(upd, stream=side, pool=front.pool(), **mode):
-                    self._update()
+                upd = self._capture_stage(self._update, pool, mode)
         torch.cuda.current_stream(dev).wait_stream(side)
         # capturing ran the host side of get_loss once without executing anything: take its sample-count increments
         # as the per-replay delta and undo them
@@ -176,14 +218,16 @@ class TrainStep(object):
 
     def _replay(self):
         front, mid, back, upd = self.graphs
-        front.replay()
+        run = self._run_seq
+        run(front)
         if self.staged:
-            self._reduce_around(mid.replay if mid is not None else None, back.replay, upd[0].replay, upd[1].replay)
+            self._reduce_around((lambda: run(mid)) if mid is not None else None, lambda: run(back),
+                                lambda: run(upd[0]), lambda: run(upd[1]))
         else:
             if self.multi:
                 self.ddp.all_reduce_gradients()
             if upd is not None:
-                upd.replay()
+                run(upd)
         self.crit._loss_cnt = [c + d for c, d in zip(self.crit._loss_cnt, self.count_delta)]
 
     def _graph_ready(self):

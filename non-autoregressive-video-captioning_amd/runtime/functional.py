@@ -91,7 +91,12 @@ class EncoderStreamFn(Function):
 
 class BNConcatFn(Function):
     """per-modality BatchNorm1d over B*F rows + temporal concat
-    (models/joint_representation.py:40-51)."""
+    (models/joint_representation.py:40-51).
+
+    cfg['sync'] (data-parallel training with opt['sync_bn']): an object with `.all_reduce(tensor)` (sum over ranks, in
+    stream order) and `.world`.  The statistics are then those of the GLOBAL batch -- the reference is one process
+    with the whole batch -- formed by the same two passes, each rank contributing its rows and the ranks exchanging
+    one [n_modalities, D] vector per pass (two in forward, one [n_modalities, 2, D] in backward)."""
 
     @staticmethod
     def forward(ctx, cfg, n_mod, *args):
@@ -99,17 +104,32 @@ class BNConcatFn(Function):
         B, _, D = xs[0].shape
         M_total = sum(x.shape[1] for x in xs)
         out = _new((B, M_total, D), xs[0])
+        sync = cfg.get("sync") if cfg["training"] else None
         saves = []
         f_off = 0
+        stats = None
+        if sync is not None:
+            stats = _new((2, n_mod, D), xs[0])
+            n_tot = [x.shape[0] * x.shape[1] * sync.world for x in xs]      # every rank holds the same number of rows
+            for i, x in enumerate(xs):
+                ops.bn_sync_stat(x, None, n_tot[i], stats[0, i])
+            sync.all_reduce(stats[0])
+            for i, x in enumerate(xs):
+                ops.bn_sync_stat(x, stats[0, i], n_tot[i], stats[1, i])
+            sync.all_reduce(stats[1])
         for i, x in enumerate(xs):
             m = cfg["mods"][i]
             sm = _new((D,), x) if cfg["training"] else None
             si = _new((D,), x) if cfg["training"] else None
-            ops.bn_concat_fwd(x, out, f_off, m["pack"].w, m["pack"].b, m["running_mean"], m["running_var"],
-                              m["nbt"], sm, si, cfg["training"], cfg.get("momentum", 0.1), cfg.get("eps", 1e-5))
+            if sync is not None:
+                ops.bn_concat_fwd_sync(x, out, f_off, m["pack"].w, m["pack"].b, m["running_mean"], m["running_var"], m["nbt"],
+                                       sm, si, stats[0, i], stats[1, i], n_tot[i], cfg.get("momentum", 0.1), cfg.get("eps", 1e-5))
+            else:
+                ops.bn_concat_fwd(x, out, f_off, m["pack"].w, m["pack"].b, m["running_mean"], m["running_var"],
+                                  m["nbt"], sm, si, cfg["training"], cfg.get("momentum", 0.1), cfg.get("eps", 1e-5))
             saves.append((x, f_off, sm, si))
             f_off += x.shape[1]
-        ctx.cfg, ctx.saves, ctx.n_mod = cfg, saves, n_mod
+        ctx.cfg, ctx.saves, ctx.n_mod, ctx.sync = cfg, saves, n_mod, sync
         return out
 
     @staticmethod
@@ -119,10 +139,21 @@ class BNConcatFn(Function):
             raise L.NacfLibraryError("BNConcatFn.backward in eval mode is not supported")
         dout = dout.contiguous()
         grads: List[Optional[Tensor]] = []
+        sync = ctx.sync
+        if sync is not None:
+            D = ctx.saves[0][0].shape[2]
+            sums = _new((ctx.n_mod, 2, D), dout)
+            for i, (x, f_off, sm, si) in enumerate(ctx.saves):
+                pk: Pack = cfg["mods"][i]["pack"]
+                ops.bn_sync_bwd_stat(dout, x, f_off, sm, si, sums[i], pk.gw, pk.gb, beta=1.0)     # local dW / db
+            sync.all_reduce(sums)
         for i, (x, f_off, sm, si) in enumerate(ctx.saves):
             pk: Pack = cfg["mods"][i]["pack"]
             dx = torch.empty_like(x)
-            ops.bn_concat_bwd(dout, x, dx, f_off, pk.w, sm, si, pk.gw, pk.gb, beta=1.0)
+            if sync is not None:
+                ops.bn_concat_bwd_sync(dout, x, dx, f_off, pk.w, sm, si, sums[i], x.shape[0] * x.shape[1] * sync.world)
+            else:
+                ops.bn_concat_bwd(dout, x, dx, f_off, pk.w, sm, si, pk.gw, pk.gb, beta=1.0)
             grads.append(dx if ctx.needs_input_grad[2 + i] else None)
         ctx.saves = None
         return (None, None) + tuple(grads) + (None,) * (len(ctx.needs_input_grad) - 2 - ctx.n_mod)

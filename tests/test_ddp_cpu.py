@@ -109,5 +109,118 @@ def test_two_rank_gloo_allreduce_equals_global_batch_gradient():
     assert max(r[2] for r in res) < 2e-6
 
 
+class SyncBNProtocol(torch.autograd.Function):
+    """The data-parallel BatchNorm protocol of runtime/functional.py:BNConcatFn (cfg['sync']) restated with torch ops
+    and torch.distributed collectives, step for step -- each numbered step is one libnacf_hip entry point there:
+      forward   1. S_local = sum_rows x                      (nacf_bn_sync_stat)            -> all-reduce -> S
+                2. Q_local = sum_rows (x - S/n)^2            (nacf_bn_sync_stat, sum given) -> all-reduce -> Q
+                3. y = (x - S/n) / sqrt(Q/n + eps) * w + b   (nacf_bn_concat_fwd_sync);  n = rows of ALL ranks
+      backward  4. [sum dy | sum dy*xhat] over local rows = the LOCAL db | dw (nacf_bn_sync_bwd_stat) -> all-reduce
+                5. dx = w*invstd*(dy - sum_dy/n - xhat*sum_dyx/n)       (nacf_bn_concat_bwd_sync)
+    tests/test_kernels_gpu.py::test_sync_bn_kernels_equal_the_global_batch checks the HIP kernels against the same
+    steps; here the protocol itself is checked: N ranks must reproduce ONE process holding the global batch."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, eps, world):
+        n = x.shape[0] * world
+        S = x.sum(0)
+        dist.all_reduce(S)
+        mean = S / n
+        Q = ((x - mean) ** 2).sum(0)
+        dist.all_reduce(Q)
+        invstd = 1.0 / torch.sqrt(Q / n + eps)
+        xhat = (x - mean) * invstd
+        ctx.save_for_backward(xhat, invstd, w)
+        ctx.n = n
+        return xhat * w + b
+
+    @staticmethod
+    def backward(ctx, dy):
+        xhat, invstd, w = ctx.saved_tensors
+        sums = torch.stack([dy.sum(0), (dy * xhat).sum(0)])
+        db, dw = sums[0].clone(), sums[1].clone()           # LOCAL parameter gradients
+        dist.all_reduce(sums)
+        dx = w * invstd * (dy - sums[0] / ctx.n - xhat * sums[1] / ctx.n)
+        return dx, dw, db, None, None
+
+
+def _sync_worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(1)
+    opt = gold_opt(load_gold("tiny_nacf_train"))
+    sd = {k: (v.double() if v.is_floating_point() else v) for k, v in O.init_state_dict(opt, seed=0).items()}
+    G = 8
+    batch = O.synth_batch(opt, G, 6, seed=1)
+    dbl = lambda t: t.double() if t.is_floating_point() else t
+    batch = {k: ([dbl(f) for f in v] if isinstance(v, list) else dbl(v)) for k, v in batch.items()}
+
+    def grads(lo, hi, bn):
+        keys = O.trainable_keys(sd)
+        leaves = {k: sd[k].clone().requires_grad_(True) for k in keys}
+        work = dict(sd)
+        work.update(leaves)
+        sl = lambda t: t[lo:hi]
+        saved = O.batchnorm_rows
+        O.batchnorm_rows = bn
+        try:
+            res = O.forward_train(work, opt, [sl(f) for f in batch["feats"]], [sl(batch["tokens_1"]), sl(batch["tokens"])],
+                                  sl(batch["category"]), training=True)
+        finally:
+            O.batchnorm_rows = saved
+        loss, _ = O.criterion(opt, res, [sl(batch["labels_1"]), sl(batch["labels"])], sl(batch["tgt_length"]))
+        loss.backward()
+        return {k: (leaves[k].grad if leaves[k].grad is not None else torch.zeros_like(leaves[k])) for k in keys}, work
+
+    def bn_sync(sd_, name, x, training, new_stats=None, eps=1e-5, momentum=0.1):
+        B, T, D = x.shape
+        y = SyncBNProtocol.apply(x.reshape(B * T, D), sd_[name + ".weight"], sd_[name + ".bias"], eps, world)
+        return y.reshape(B, T, D)
+    lo, hi = shard_range(G, rank, world)
+    g, _ = grads(lo, hi, bn_sync)                           # this rank's shard, global-batch statistics
+    flat = torch.cat([g[k].reshape(-1) for k in sorted(g)])
+    dist.all_reduce(flat)                                   # the gradient all-reduce of runtime/ddp.py
+    flat /= world
+    err_sync = err_local = 0.0
+    if rank == 0:
+        full, _ = grads(0, G, O.batchnorm_rows)             # ONE process, whole batch, training-mode BatchNorm
+        ref = torch.cat([full[k].reshape(-1) for k in sorted(full)])
+        err_sync = float((flat - ref).abs().max() / ref.abs().max())
+    # without the protocol (per-rank statistics) the same reduction does NOT give the global-batch gradient
+    g2, _ = grads(lo, hi, O.batchnorm_rows)
+    flat2 = torch.cat([g2[k].reshape(-1) for k in sorted(g2)])
+    dist.all_reduce(flat2)
+    flat2 /= world
+    if rank == 0:
+        err_local = float((flat2 - ref).abs().max() / ref.abs().max())
+    out.put((rank, err_sync, err_local))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _run_sync(world):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_sync_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=300) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    return [r for r in res if r[0] == 0][0]
+
+
+def test_sync_bn_protocol_world_2_and_4_equal_the_single_process_global_batch():
+    """training-mode BatchNorm under data parallelism (models/joint_representation.py:43-45): with the
+    sync protocol the all-reduced gradient of N ranks equals the gradient of one process on the global batch to
+    round-off (double); with per-rank statistics it does not"""
+    for world in (2, 4):
+        _, err_sync, err_local = _run_sync(world)
+        assert err_sync < 1e-10, (world, err_sync)
+        assert err_local > 1e-4, (world, err_local)
+
+
 def test_shard_range():
     assert [shard_range(1024, r, 8) for r in (0, 7)] == [(0, 128), (896, 1024)]

@@ -903,3 +903,72 @@ def test_bench_shape_linear_fwd_dx_dw_vs_fp64(dev, M, N, K, what):
     ops.linear_bwd_weight(dzd, xd, dw, db, beta=0.0)
     _close64(dw, dz.double().t() @ x.double(), M, what + " dW")
     _close64(db, dz.double().sum(0), M, what + " db")
+
+
+@pytest.mark.parametrize("world", [2, 4])
+@pytest.mark.parametrize("B,Fr,D", [(8, 6, 64), (16, 60, 512), (8, 7, 100)])
+def test_sync_bn_kernels_equal_the_global_batch(dev, B, Fr, D, world):
+    """data-parallel BatchNorm (nacf_bn_sync_stat / _concat_fwd_sync / _sync_bwd_stat / _concat_bwd_sync): the batch is
+    cut into `world` shards that are processed as `world` ranks would, the exchanged vectors are summed by hand (the
+    all-reduce), and every shard's output, dx and the summed dw / db must equal the single-process kernels on the
+    whole batch -- and fp64 BatchNorm (models/joint_representation.py:43-45)"""
+    ops, _ = _ops()
+    M_total, f_off = Fr + 5, 3
+    x = rnd(B, Fr, D, seed=1).to(dev) * 2 + 0.5
+    w, b = (rnd(D, seed=2) + 1.5).to(dev), rnd(D, seed=3).to(dev)
+    dout = rnd(B, M_total, D, seed=4).to(dev)
+    # single process, whole batch
+    out0 = torch.zeros(B, M_total, D, device=dev)
+    rm0, rv0 = torch.zeros(D, device=dev), torch.ones(D, device=dev)
+    nbt0 = torch.zeros((), dtype=torch.int64, device=dev)
+    sm0, si0 = torch.empty(D, device=dev), torch.empty(D, device=dev)
+    ops.bn_concat_fwd(x, out0, f_off, w, b, rm0, rv0, nbt0, sm0, si0, True)
+    dx0, dw0, db0 = torch.empty_like(x), torch.zeros(D, device=dev), torch.zeros(D, device=dev)
+    ops.bn_concat_bwd(dout, x, dx0, f_off, w, sm0, si0, dw0, db0, beta=0.0)
+    # `world` ranks
+    per = B // world
+    xs = [x[r * per:(r + 1) * per].contiguous() for r in range(world)]
+    douts = [dout[r * per:(r + 1) * per].contiguous() for r in range(world)]
+    n_total = B * Fr
+    S_loc = [torch.empty(D, device=dev) for _ in range(world)]
+    for r in range(world):
+        ops.bn_sync_stat(xs[r], None, n_total, S_loc[r])
+    S = torch.stack(S_loc).sum(0)                                   # all-reduce
+    Q_loc = [torch.empty(D, device=dev) for _ in range(world)]
+    for r in range(world):
+        ops.bn_sync_stat(xs[r], S, n_total, Q_loc[r])
+    Q = torch.stack(Q_loc).sum(0)                                   # all-reduce
+    outs, saves, stats = [], [], []
+    for r in range(world):
+        o = torch.zeros(per, M_total, D, device=dev)
+        rm, rv = torch.zeros(D, device=dev), torch.ones(D, device=dev)
+        nbt = torch.zeros((), dtype=torch.int64, device=dev)
+        sm, si = torch.empty(D, device=dev), torch.empty(D, device=dev)
+        ops.bn_concat_fwd_sync(xs[r], o, f_off, w, b, rm, rv, nbt, sm, si, S, Q, n_total)
+        outs.append(o); saves.append((sm, si)); stats.append((rm, rv, nbt))
+    assert err(torch.cat(outs), out0) < 2e-5
+    for rm, rv, nbt in stats:                                       # every rank ends with the GLOBAL running statistics
+        assert err(rm, rm0) < 1e-6 and err(rv, rv0) < 1e-5 and int(nbt) == 1
+    assert float(out0[:, :f_off].abs().max()) == 0 and float(torch.cat(outs)[:, :f_off].abs().max()) == 0
+    sums_loc, dws, dbs = [], [], []
+    for r in range(world):
+        s2 = torch.empty(2, D, device=dev)
+        dw, db = torch.zeros(D, device=dev), torch.zeros(D, device=dev)
+        ops.bn_sync_bwd_stat(douts[r], xs[r], f_off, saves[r][0], saves[r][1], s2, dw, db, beta=0.0)
+        sums_loc.append(s2); dws.append(dw); dbs.append(db)
+    sums = torch.stack(sums_loc).sum(0)                             # all-reduce
+    dxs = []
+    for r in range(world):
+        dx = torch.empty_like(xs[r])
+        ops.bn_concat_bwd_sync(douts[r], xs[r], dx, f_off, w, saves[r][0], saves[r][1], sums, n_total)
+        dxs.append(dx)
+    scale = float(dx0.abs().max())
+    assert err(torch.cat(dxs), dx0) < 2e-5 * max(1.0, scale)
+    assert err(torch.stack(dws).sum(0), dw0) < 1e-4 * max(1.0, float(dw0.abs().max()))      # gradient all-reduce adds the ranks
+    assert err(torch.stack(dbs).sum(0), db0) < 1e-4 * max(1.0, float(db0.abs().max()))
+    # and against fp64 BatchNorm on the whole batch
+    xd = x.double().cpu().reshape(B * Fr, D).requires_grad_(True)
+    y = F.batch_norm(xd, None, None, w.double().cpu(), b.double().cpu(), True, 0.1, 1e-5)
+    assert err(torch.cat(outs)[:, f_off:f_off + Fr].reshape(B * Fr, D), y) < 5e-5
+    y.backward(dout[:, f_off:f_off + Fr].double().cpu().reshape(B * Fr, D))
+    assert err(torch.cat(dxs).reshape(B * Fr, D), xd.grad) < 5e-5 * max(1.0, float(xd.grad.abs().max()))
