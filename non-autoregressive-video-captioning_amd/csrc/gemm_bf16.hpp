@@ -271,6 +271,15 @@ __device__ __forceinline__ bf16x8_t lds_frag(const u32x4* plane, int row, int g)
   return __builtin_bit_cast(bf16x8_t, plane[row * 4 + (g ^ lds_sw(row))]);
 }
 
+// dynamic LDS of a launch in 16-byte chunks (tile images, or the epilogue's reduction scratch if that is larger)
+template <int BM, int BN, int NS, int STAGES, bool ARGMAX>
+constexpr int gemm_bf16_lds_chunks() {
+  const int qst = (STAGES == 2) ? 2 : 1, pst = (STAGES == 1) ? 1 : 2;
+  const int tiles = NS * (qst * BM * 4 + pst * BN * 4);
+  const int red = ARGMAX ? (3 * 2 * BM + 3) / 4 : (BM + 3) / 4;
+  return tiles > red ? tiles : red;
+}
+
 // ---------------------------------------------------------------- kernel
 template <int BM, int BN, int QSRC, int PSRC, int NS, int STAGES, class Epi>
 __global__ __launch_bounds__(256, (BM == 64 ? 3 : 2)) void gemm_bf16_kernel(GemmShape g, Epi epi) {
@@ -285,10 +294,16 @@ __global__ __launch_bounds__(256, (BM == 64 ? 3 : 2)) void gemm_bf16_kernel(Gemm
   static_assert(NS == 1 || NS == 3, "1 = bf16 throughput, 3 = exact fp32 split");
   static_assert(BM % 64 == 0 && BN % 64 == 0, "stager granularity");
   constexpr int QPL = BM * 4, PPL = BN * 4;            // 16-byte chunks per plane
-  constexpr int STAGE = NS * (QPL + PPL);
-  constexpr int RED = Epi::kArgmax ? (3 * WN * BM + 3) / 4 : (BM + 3) / 4;   // epilogue scratch (floats -> chunks)
-  constexpr int SMEM = (STAGES * STAGE > RED) ? STAGES * STAGE : RED;
-  __shared__ u32x4 smem[SMEM];
+  // STAGES: 1 = one LDS image of both operands (two barriers per k-tile); 2 = two images (one barrier);
+  //         3 = one image of Q, TWO of P: the P loads of tile t+2 are issued at the start of the MFMA phase of tile t
+  //             (their address processing overlaps the matrix work) and stored during the staging phase of tile t
+  constexpr int QST = (STAGES == 2) ? 2 : 1, PST = (STAGES == 1) ? 1 : 2;
+  constexpr int QBASE = 0, PBASE = QST * NS * QPL;
+  static_assert(gemm_bf16_lds_chunks<BM, BN, NS, STAGES, Epi::kArgmax>() >= PBASE + PST * NS * PPL, "LDS size helper out of date");
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  u32x4* smem = reinterpret_cast<u32x4*>(smem_raw);
+  auto q_stage = [&](int st) { return smem + QBASE + st * (NS * QPL); };
+  auto p_stage = [&](int st) { return smem + PBASE + st * (NS * PPL); };
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
@@ -350,41 +365,35 @@ __global__ __launch_bounds__(256, (BM == 64 ? 3 : 2)) void gemm_bf16_kernel(Gemm
   const bool p_full = PKC || (n0 + BN <= g.N);
   const bool rows_full = q_full && p_full;
 
-  auto load_tile = [&](int kt, bool idx_ready) {
-#ifdef BF16_EXP_NOLOAD    // timing experiment only: the k-loop re-uses the first tiles' registers
-    if (kt >= 2) return;
-#endif
+  auto load_q = [&](int kt, bool idx_ready) {
     const int k0 = kbeg + kt * BK;
     const bool fast = rows_full && (k0 + BK <= kend);
     if constexpr (QSRC == SRC_F32_KC) { if (fast) qs.load_fast(k0); else qs.load_checked(k0, kend, tid); }
     else { if (fast) qs.load_fast(k0, g.ldq, kmap, idx_ready); else qs.load_checked(k0, kend, g.ldq, kmap); }
-    if constexpr (PSRC == SRC_F32_KC) { if (fast) ps.load_fast(k0); else ps.load_checked(k0, kend, tid); }
-    else if constexpr (PSRC == SRC_F32_MC) { if (fast) ps.load_fast(k0, g.ldp, kmap, idx_ready); else ps.load_checked(k0, kend, g.ldp, kmap); }
-    else ps.load(k0, g.ldpi, g.pimg_plane);      // zero-padded to whole k-tiles, rows clamped: never out of bounds
+    if constexpr (ROWS_ARE_K) { if (kmap && kt + 1 < nk) qs.load_kidx(kbeg + (kt + 1) * BK, Keff, kmap); }   // next tile's rows
   };
-  auto prefetch_kidx = [&](int kt) {      // reduce-row indices of tile kt (row-list dW), one tile ahead of its loads
-    if constexpr (ROWS_ARE_K) {
-      if (kmap && kt < nk) {
-        qs.load_kidx(kbeg + kt * BK, Keff, kmap);
-        ps.load_kidx(kbeg + kt * BK, Keff, kmap);
-      }
+  auto load_p = [&](int kt, bool idx_ready) {
+    const int k0 = kbeg + kt * BK;
+    const bool fast = rows_full && (k0 + BK <= kend);
+    if constexpr (PSRC == SRC_F32_KC) { if (fast) ps.load_fast(k0); else ps.load_checked(k0, kend, tid); }
+    else if constexpr (PSRC == SRC_F32_MC) {
+      if (fast) ps.load_fast(k0, g.ldp, kmap, idx_ready); else ps.load_checked(k0, kend, g.ldp, kmap);
+      if constexpr (ROWS_ARE_K) { if (kmap && kt + 1 < nk) ps.load_kidx(kbeg + (kt + 1) * BK, Keff, kmap); }
     }
+    else ps.load(k0, g.ldpi, g.pimg_plane);      // zero-padded to whole k-tiles, rows clamped: never out of bounds
   };
   const bool do_colsum = ROWS_ARE_K && (g.colsum_part || g.colsum_out) && tile_n == 0;
   f32x4 qsum = {0.f, 0.f, 0.f, 0.f};
-  auto write_tile = [&](int stage) {
-#ifdef BF16_EXP_NOSTORE   // timing experiment only
-    if (stage >= 0 && nk > 1000000) return;
-    { asm volatile("" :: "v"(qs.v[0]), "v"(ps.v[0])); if (kbeg >= 0) return; }
-#endif
-    u32x4* base = smem + stage * STAGE;
-    if constexpr (QSRC == SRC_F32_KC) qs.write(base, tid);
+  auto write_q = [&](int st) {
+    if constexpr (QSRC == SRC_F32_KC) qs.write(q_stage(st), tid);
     else {
-      qs.write(base);
+      qs.write(q_stage(st));
       if (do_colsum) qsum += (qs.v[0] + qs.v[1]) + (qs.v[2] + qs.v[3]);   // every k-tile is written exactly once
     }
-    if constexpr (PSRC == SRC_F32_MC) ps.write(base + NS * QPL);
-    else ps.write(base + NS * QPL, tid);
+  };
+  auto write_p = [&](int st) {
+    if constexpr (PSRC == SRC_F32_MC) ps.write(p_stage(st));
+    else ps.write(p_stage(st), tid);
   };
 
   f32x4 acc[TM][TN];
@@ -393,9 +402,9 @@ __global__ __launch_bounds__(256, (BM == 64 ? 3 : 2)) void gemm_bf16_kernel(Gemm
 #pragma unroll
     for (int b = 0; b < TN; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  auto compute = [&](int stage) {
-    const u32x4* qpl = smem + stage * STAGE;
-    const u32x4* ppl = qpl + NS * QPL;
+  auto compute = [&](int qst, int pst) {
+    const u32x4* qpl = q_stage(qst);
+    const u32x4* ppl = p_stage(pst);
     bf16x8_t pf[TN][NS];
 #pragma unroll
     for (int b = 0; b < TN; ++b)
@@ -429,14 +438,23 @@ __global__ __launch_bounds__(256, (BM == 64 ? 3 : 2)) void gemm_bf16_kernel(Gemm
 
 #ifdef NACF_BF16_TRACE
   unsigned long long tacc[5] = {0, 0, 0, 0, 0};
+  unsigned long long tsub[3] = {0, 0, 0};     // STAGES == 3 staging phase: Q split + stores | Q load issue | P stores
   const unsigned long long t_begin = __builtin_readcyclecounter();
 #endif
   // ---- pipeline: G(t) global -> registers, W(t) registers -> LDS image (convert / split), C(t) fragments + MFMAs
+  if constexpr (ROWS_ARE_K) {
+    if (kmap && nk > 0) { qs.load_kidx(kbeg, Keff, kmap); ps.load_kidx(kbeg, Keff, kmap); }
+  }
   if (nk > 0) {
-    load_tile(0, false);
-    prefetch_kidx(1);
-    write_tile(0);
-    if (nk > 1) { load_tile(1, true); prefetch_kidx(2); }
+    load_q(0, true);
+    load_p(0, true);
+    write_q(0);
+    write_p(0);
+    if (nk > 1) {
+      load_q(1, true);
+      load_p(1, true);
+      if constexpr (STAGES == 3) write_p(1);      // P runs two tiles ahead: tile 1 is stored now, tile 2 loaded in C(0)
+    }
   }
   __syncthreads();
 #pragma nounroll
@@ -448,17 +466,17 @@ __global__ __launch_bounds__(256, (BM == 64 ? 3 : 2)) void gemm_bf16_kernel(Gemm
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #endif
       BF16_T(t1);
-      if (kt + 1 < nk) write_tile((kt + 1) & 1);
-      if (kt + 2 < nk) { load_tile(kt + 2, true); prefetch_kidx(kt + 3); }
+      if (kt + 1 < nk) { write_q((kt + 1) & 1); write_p((kt + 1) & 1); }
+      if (kt + 2 < nk) { load_q(kt + 2, true); load_p(kt + 2, true); }
       BF16_T(t2);
-      compute(kt & 1);
+      compute(kt & 1, kt & 1);
       BF16_T(t3);
       __syncthreads();
       BF16_T(t4);
       BF16_TACC(2, t0, t1); BF16_TACC(3, t1, t2); BF16_TACC(0, t2, t3); BF16_TACC(1, t3, t4);
-    } else {
+    } else if constexpr (STAGES == 1) {
       BF16_T(t0);
-      compute(0);
+      compute(0, 0);
       BF16_T(t1);
       __syncthreads();
       BF16_T(t2);
@@ -467,8 +485,44 @@ __global__ __launch_bounds__(256, (BM == 64 ? 3 : 2)) void gemm_bf16_kernel(Gemm
 #endif
       BF16_T(t3);
       if (kt + 1 < nk) {
-        write_tile(0);
-        if (kt + 2 < nk) { load_tile(kt + 2, true); prefetch_kidx(kt + 3); }
+        write_q(0);
+        write_p(0);
+        if (kt + 2 < nk) { load_q(kt + 2, true); load_p(kt + 2, true); }
+      }
+      BF16_T(t4);
+      __syncthreads();
+      BF16_T(t5);
+      BF16_TACC(0, t0, t1); BF16_TACC(1, t1, t2); BF16_TACC(2, t2, t3); BF16_TACC(3, t3, t4); BF16_TACC(4, t4, t5);
+    } else {
+      // one Q image, two P images.  The P registers are free during C(kt) (tile kt+1 sits in LDS already), so the
+      // loads of tile kt+2 are issued FIRST: the texture addresser works through them while the MFMAs run, and the
+      // staging phase only converts / stores (plus the four Q loads)
+      BF16_T(t0);
+      if (kt + 2 < nk) load_p(kt + 2, true);
+      compute(0, kt & 1);
+      BF16_T(t1);
+      __syncthreads();
+      BF16_T(t2);
+#ifdef NACF_BF16_TRACE
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+      BF16_T(t3);
+      if (kt + 1 < nk) {
+        write_q(0);
+#ifdef NACF_BF16_TRACE
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#endif
+        BF16_T(t3a);
+        if (kt + 2 < nk) {
+          load_q(kt + 2, true);
+          BF16_T(t3b);
+          write_p(kt & 1);             // tile kt+2 into the image C(kt) has just released
+#ifdef NACF_BF16_TRACE
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          const unsigned long long t3c = __builtin_readcyclecounter();
+          tsub[0] += t3a - t3; tsub[1] += t3b - t3a; tsub[2] += t3c - t3b;
+#endif
+        }
       }
       BF16_T(t4);
       __syncthreads();
@@ -482,7 +536,7 @@ __global__ __launch_bounds__(256, (BM == 64 ? 3 : 2)) void gemm_bf16_kernel(Gemm
     for (int i = 0; i < 5; ++i) o[i] = tacc[i];
     o[5] = __builtin_readcyclecounter() - t_begin;
     o[6] = (unsigned long long)nk;
-    o[7] = wall_clock64();
+    o[7] = (tsub[0] << 42) | (tsub[1] << 21) | tsub[2];      // three 21-bit sums (cycles / 16 would overflow less; fine for nk <= 64)
   }
 #endif
 

@@ -5,6 +5,10 @@
 #pragma once
 #include "gemm_bf16.hpp"
 
+#ifndef NACF_BF16_EXACT128_STAGES
+#define NACF_BF16_EXACT128_STAGES 3     // LDS staging of the exact mode's 128x128 tile: 1 | 3 (gemm_bf16.hpp "STAGES")
+#endif
+
 void launch_bf16_linear(GemmShape g, const EpiLinear& epi, int tile, int ns, hipStream_t s);              // y = x W^T
 void launch_bf16_argmax(GemmShape g, const EpiArgmax& epi, int tile, int ns, hipStream_t s);              // + soft-max stats
 void launch_bf16_dx(GemmShape g, const EpiStore& epi, int splits, int tile, int ns, hipStream_t s);       // dX = dZ W
@@ -14,20 +18,35 @@ void launch_wimage_refresh(const WImageDesc* descs, int n_desc, int n_tiles, int
 const char* bf16_last_kernel_name();
 void bf16_note_kernel(int tile, int qsrc, int psrc, int ns, int stages, const char* epi);
 
+template <int BM, int QSRC, int PSRC, int NS, int STAGES, class Epi>
+inline void launch_bf16_one(const GemmShape& g, const Epi& epi, dim3 grid, hipStream_t s) {
+  constexpr size_t bytes = (size_t)gemm_bf16_lds_chunks<BM, BM, NS, STAGES, Epi::kArgmax>() * 16;
+  auto kern = gemm_bf16_kernel<BM, BM, QSRC, PSRC, NS, STAGES, Epi>;
+  if constexpr (bytes > 48 * 1024) {          // above the default dynamic-LDS limit: raise it once per kernel
+    static bool raised = false;
+    if (!raised) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+      raised = true;
+    }
+  }
+  hipLaunchKernelGGL(kern, grid, dim3(256), bytes, s, g, epi);
+}
+
 template <int QSRC, int PSRC, class Epi>
 inline void launch_bf16_any(GemmShape g, const Epi& epi, int splits, int tile, int ns, hipStream_t s, const char* epi_name) {
   const int t = tile == 0 ? 128 : 64;
   g.tiles_m = cdiv(g.M, t);
   g.tiles_n = cdiv(g.N, t);
   dim3 grid((g.tiles_m + (g.zero_dead ? 1 : 0)) * g.tiles_n, 1, splits);
-  // LDS images: two where they fit in 48 KB (one barrier per k-tile), one for the exact mode's 128x128 tile
+  // LDS images: two of each operand where they fit (one barrier per k-tile); the exact mode's 128x128 tile keeps one
+  // image of Q and two of P (72 KB, two workgroups per CU): P is loaded during the MFMA phase, two tiles ahead
   if (ns == 1) {
-    if (tile == 0) hipLaunchKernelGGL((gemm_bf16_kernel<128, 128, QSRC, PSRC, 1, 2, Epi>), grid, dim3(256), 0, s, g, epi);
-    else hipLaunchKernelGGL((gemm_bf16_kernel<64, 64, QSRC, PSRC, 1, 2, Epi>), grid, dim3(256), 0, s, g, epi);
+    if (tile == 0) launch_bf16_one<128, QSRC, PSRC, 1, 2, Epi>(g, epi, grid, s);
+    else launch_bf16_one<64, QSRC, PSRC, 1, 2, Epi>(g, epi, grid, s);
     bf16_note_kernel(t, QSRC, PSRC, 1, 2, epi_name);
   } else {
-    if (tile == 0) hipLaunchKernelGGL((gemm_bf16_kernel<128, 128, QSRC, PSRC, 3, 1, Epi>), grid, dim3(256), 0, s, g, epi);
-    else hipLaunchKernelGGL((gemm_bf16_kernel<64, 64, QSRC, PSRC, 3, 2, Epi>), grid, dim3(256), 0, s, g, epi);
-    bf16_note_kernel(t, QSRC, PSRC, 3, tile == 0 ? 1 : 2, epi_name);
+    if (tile == 0) launch_bf16_one<128, QSRC, PSRC, 3, NACF_BF16_EXACT128_STAGES, Epi>(g, epi, grid, s);
+    else launch_bf16_one<64, QSRC, PSRC, 3, 2, Epi>(g, epi, grid, s);
+    bf16_note_kernel(t, QSRC, PSRC, 3, tile == 0 ? NACF_BF16_EXACT128_STAGES : 2, epi_name);
   }
 }

@@ -19,6 +19,7 @@ import math
 import torch
 
 from ..config import Constants
+from ..runtime import ops
 from ..runtime.functional import FusedVocabXentFn, FusedVocabXentMultiFn, KLDivMeanFn, LossCombineFn
 
 
@@ -158,7 +159,7 @@ class Criterion(object):
         lang_terms = None
         if both is not None and all(labels[i].shape == labels[0].shape for i in range(n_pass)):
             lang_slots = [t for kind, _, t in plan['slots'] if kind == 'lang']
-            lab_all = torch.cat([labels[i].reshape(-1) for i in range(n_pass)])
+            lab_all = ops.stacked_rows([labels[i].contiguous() for i in range(n_pass)]).reshape(-1)
             lang_terms = FusedVocabXentMultiFn.apply(
                 both.reshape(-1, both.shape[-1]), dict(pack=pack, outs=[slab[t * S:t * S + 5] for t in lang_slots]),
                 lab_all, tuple((i == 0 and self.vw) for i in range(n_pass)), *params)

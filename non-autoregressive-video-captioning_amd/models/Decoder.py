@@ -179,7 +179,7 @@ class BertDecoderDisentangled(nn.Module):
             # visual-word pass + caption pass: one launch sequence over 2B rows
             assert len(tgt_seq) == 2
             B = tgt_seq[0].shape[0]
-            both = torch.cat([tgt_seq[0], tgt_seq[1]], dim=0)
+            both = ops.stacked_rows([tgt_seq[0], tgt_seq[1]])       # a view when the two passes are adjacent in memory
             kwargs = dict(kwargs, row_map=('mod', enc_output.shape[0]))
             hidden, embs = self.forward_(both, enc_output, category, **kwargs)[:2]
             h0, h1 = HalvesFn.apply(hidden)

@@ -15,6 +15,7 @@ import torch
 import torch.nn as nn
 
 from ..config import Constants
+from ..runtime import ops
 from ..runtime.functional import MeanTimeFn, VocabLogProbFn
 from ..runtime.state import FlatParams, Runtime
 
@@ -112,8 +113,12 @@ class Seq2Seq(nn.Module):
         self.flat.sync_images()
         enc_streams, _ = self.encoder([f.contiguous() for f in feats])
         with torch.no_grad():  # mean-over-time hidden: only LSTM decoders consume it (seq2seq.py:66-68)
-            hid = [MeanTimeFn.apply(s.detach()) for s in enc_streams]
-            enc_hidden = torch.stack(hid, dim=0).mean(0)
+            s0 = enc_streams[0]
+            hid = torch.empty(len(enc_streams), s0.shape[0], s0.shape[2], dtype=s0.dtype, device=s0.device)
+            for i, s_ in enumerate(enc_streams):
+                ops.mean_time_fwd(s_.detach().contiguous(), hid[i])
+            # mean over the modalities (models/joint_representation.py:27) with the same kernel: [1, n_mod, B*D]
+            enc_hidden = ops.mean_time_fwd(hid.view(1, hid.shape[0], -1), torch.empty_like(hid[0]).view(1, -1)).view_as(hid[0])
         if self.joint_representation_learner is not None:
             enc_output, enc_hidden = self.joint_representation_learner(enc_streams, enc_hidden)
         else:

@@ -248,6 +248,13 @@ class TrainStep(object):
                 else:
                     self.static[k] = list(self.static[k])
                     self.static[k][i] = t.clone()
+            # the two decoding passes of NACF / ARB2 are batched as 2B rows: keep their tokens (and labels) back to
+            # back in ONE buffer so that the model takes a view instead of concatenating every step
+            for first, second in (('tokens_1', 'tokens'), ('labels_1', 'labels')):
+                a, b = self.static.get(first), self.static.get(second)
+                if torch.is_tensor(a) and torch.is_tensor(b) and a.shape == b.shape and a.dtype == b.dtype:
+                    pair = torch.stack([a, b])
+                    self.static[first], self.static[second] = pair[0], pair[1]
             self.sig = _signature(batch, self.keys)
             self.loss = torch.zeros((), device=next(iter(_tensors(batch, self.keys).values())).device)
         self.n_steps += 1

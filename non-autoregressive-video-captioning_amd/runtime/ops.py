@@ -218,6 +218,21 @@ class RngState:
         L.check(L.load().nacf_rng_advance(_ptr(self.state), _stream()), "nacf_rng_advance")
 
 
+def stacked_rows(parts):
+    """torch.cat(parts, dim=0) of equal-shape contiguous tensors -- WITHOUT a copy when they already sit back to back
+    in one storage (the step engine allocates the two NACF passes' tokens / labels that way): the decoder batches
+    both passes as 2B rows every step, and a copy kernel per step is pure overhead."""
+    a = parts[0]
+    ok = all(t.is_contiguous() and t.shape == a.shape and t.dtype == a.dtype and t.device == a.device for t in parts)
+    if ok:
+        step = a.numel() * a.element_size()
+        ok = all(t.untyped_storage().data_ptr() == a.untyped_storage().data_ptr() and
+                 t.data_ptr() == a.data_ptr() + i * step for i, t in enumerate(parts))
+    if ok:
+        return torch.as_strided(a, (len(parts) * a.shape[0],) + tuple(a.shape[1:]), a.stride())
+    return torch.cat(list(parts), dim=0)
+
+
 # ---------------------------------------------------------------- live-row lists
 class RowSet:
     """Device-side list of the live (non-<pad>) activation slots; see nacf_rowset in nacf_hip.h."""

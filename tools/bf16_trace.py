@@ -39,8 +39,10 @@ a.record(); f(); b.record()
 torch.cuda.synchronize()
 assert raw.nacf_debug_bf16_trace(ctypes.c_void_p(0)) == 0
 print(L.load().nacf_gemm_last_kernel().decode())
-t = buf.cpu().numpy().reshape(-1, 8)
-t = t[t[:, 5] != 0].astype(np.float64)
+raw8 = buf.cpu().numpy().reshape(-1, 8)
+raw8 = raw8[raw8[:, 5] != 0]
+sub = raw8[:, 7].astype(np.uint64)
+t = raw8.astype(np.float64)
 nk = t[:, 6].max()
 print("kernel %.1f us (with stamps), %d workgroups, %d k-tiles each" % (a.elapsed_time(b) * 1e3, len(t), nk))
 names = ["compute", "barrier after compute", "wait global loads", "convert + LDS stores + next loads", "barrier after stores"]
@@ -50,5 +52,9 @@ for i, n in enumerate(names):
     v = t[:, i] / nk
     print("  %-34s per k-tile: p50 %6.0f  p10 %6.0f  p90 %6.0f   (%4.1f %% of the workgroup's life)" % (n, np.percentile(v, 50), np.percentile(v, 10), np.percentile(v, 90), 100 * t[:, i].sum() / tot.sum()))
 print("  outside the k-loop (prologue + epilogue): %4.1f %%" % (100 * (1 - t[:, :5].sum() / tot.sum())))
+if int(sub.max()) > 0:      # STAGES == 3 kernels: the staging phase in three parts
+    parts = [(sub >> np.uint64(42)) & np.uint64((1 << 21) - 1), (sub >> np.uint64(21)) & np.uint64((1 << 21) - 1), sub & np.uint64((1 << 21) - 1)]
+    for n, v in zip(["Q split + LDS stores (drained)", "Q load issue", "P LDS stores (drained)"], parts):
+        print("    staging: %-32s per k-tile p50 %6.0f" % (n, np.percentile(v.astype(np.float64) / nk, 50)))
 if imgs is not None:
     imgs.close()
