@@ -365,16 +365,16 @@ __global__ __launch_bounds__(256, (BM == 64 ? 3 : 2)) void gemm_bf16_kernel(Gemm
   const bool p_full = PKC || (n0 + BN <= g.N);
   const bool rows_full = q_full && p_full;
 
-  auto load_q = [&](int kt, bool idx_ready) {
+  auto load_q = [&](int kt, bool idx_ready, bool steady = false) {
     const int k0 = kbeg + kt * BK;
-    const bool fast = rows_full && (k0 + BK <= kend);
+    const bool fast = steady || (rows_full && (k0 + BK <= kend));
     if constexpr (QSRC == SRC_F32_KC) { if (fast) qs.load_fast(k0); else qs.load_checked(k0, kend, tid); }
     else { if (fast) qs.load_fast(k0, g.ldq, kmap, idx_ready); else qs.load_checked(k0, kend, g.ldq, kmap); }
     if constexpr (ROWS_ARE_K) { if (kmap && kt + 1 < nk) qs.load_kidx(kbeg + (kt + 1) * BK, Keff, kmap); }   // next tile's rows
   };
-  auto load_p = [&](int kt, bool idx_ready) {
+  auto load_p = [&](int kt, bool idx_ready, bool steady = false) {
     const int k0 = kbeg + kt * BK;
-    const bool fast = rows_full && (k0 + BK <= kend);
+    const bool fast = steady || (rows_full && (k0 + BK <= kend));
     if constexpr (PSRC == SRC_F32_KC) { if (fast) ps.load_fast(k0); else ps.load_checked(k0, kend, tid); }
     else if constexpr (PSRC == SRC_F32_MC) {
       if (fast) ps.load_fast(k0, g.ldp, kmap, idx_ready); else ps.load_checked(k0, kend, g.ldp, kmap);
@@ -457,8 +457,27 @@ __global__ __launch_bounds__(256, (BM == 64 ? 3 : 2)) void gemm_bf16_kernel(Gemm
     }
   }
   __syncthreads();
+  int kt_first = 0;
+#ifndef NACF_BF16_TRACE
+  if constexpr (STAGES == 2) {
+    // STEADY iterations (tile kt+2 exists and is an interior tile of fully populated row tiles): one straight-line
+    // block -- stores of tile kt+1, unguarded loads of tile kt+2, fragments + MFMAs of tile kt -- so that the scheduler
+    // may slide the staging instructions of the OTHER LDS image into the shadows of this tile's MFMAs.  A launch of
+    // less than one round of workgroups (the decoder's 512-wide GEMMs) has nobody else to hide them behind.
+    const int n_steady = rows_full ? min(nk - 2, (kend - kbeg) / BK - 2) : 0;
 #pragma nounroll
-  for (int kt = 0; kt < nk; ++kt) {
+    for (; kt_first < n_steady; ++kt_first) {
+      write_q((kt_first + 1) & 1);
+      write_p((kt_first + 1) & 1);
+      load_q(kt_first + 2, true, true);
+      load_p(kt_first + 2, true, true);
+      compute(kt_first & 1, kt_first & 1);
+      __syncthreads();
+    }
+  }
+#endif
+#pragma nounroll
+  for (int kt = kt_first; kt < nk; ++kt) {
     if constexpr (STAGES == 2) {
       // W(kt+1) goes into the image C(kt-1) read (a barrier ago); G(kt+2) has all of C(kt) to land
       BF16_T(t0);

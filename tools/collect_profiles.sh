@@ -1,8 +1,8 @@
 #!/bin/bash
-# Collect everything profiles/ holds for one round, on the GPU box:  tools/collect_profiles.sh r01
+# Collect everything profiles/ holds for one round, on the GPU box:  tools/collect_profiles.sh r02
 # (run through gpurun; results land in gpurun_out/profiles_<round>/ and are then copied into profiles/ by hand)
 set -u
-R=${1:-r01}
+R=${1:-r02}
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
 OUT=$ROOT/gpurun_out/profiles_$R
 mkdir -p $OUT
@@ -13,16 +13,20 @@ python $ROOT/bench.py > $OUT/${R}_bench.json 2> $OUT/bench.err
 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_stats -o b -- python $ROOT/bench.py > $OUT/${R}_bench_under_rocprof.json 2> /dev/null
 cp /tmp/prof_stats/b_kernel_stats.csv $OUT/${R}_bench_kernel_stats.csv
 # 2b. the training leg alone: every launch of a kernel class then has the shapes the bench's roofline object times
-rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_train -o b -- python $ROOT/bench.py --no-decode --no-compare --no-cpu-baseline > $OUT/${R}_train_only_bench.json 2> /dev/null
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_train -o b -- python $ROOT/bench.py --no-decode --no-compare --no-cpu-baseline --no-loader > $OUT/${R}_train_only_bench.json 2> /dev/null
 cp /tmp/prof_train/b_kernel_stats.csv $OUT/${R}_train_only_kernel_stats.csv
 # 3. HBM traffic counters, separate passes (FETCH_SIZE and WRITE_SIZE do not fit one pass)
 for c in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --kernel-trace --output-format csv --pmc $c -d /tmp/prof_$c -o b -- python $ROOT/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-decode --graph off > /dev/null 2>&1
+  rocprofv3 --kernel-trace --output-format csv --pmc $c -d /tmp/prof_$c -o b -- python $ROOT/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-decode --no-compare --no-loader --graph off > /dev/null 2>&1
 done
 python $ROOT/tools/pmc_traffic.py /tmp/prof_FETCH_SIZE/b_counter_collection.csv /tmp/prof_WRITE_SIZE/b_counter_collection.csv $OUT/${R}_pmc_traffic.json
-# 4. GEMM microbenchmarks + attainable MFMA peak
-python $ROOT/tools/gemm_bench.py --iters 20 > $OUT/${R}_gemm_microbench.txt 2> /dev/null
+# 4. GEMM microbenchmarks (three arithmetic modes, weights from pre-split images as in the model) + attainable MFMA peak
+python $ROOT/tools/gemm_bench.py --iters 20 --modes f32,bf16x3,bf16 --images > $OUT/${R}_gemm_microbench.txt 2> /dev/null
 $ROOT/tools/mfma_peak 20000 > $OUT/${R}_mfma_peak.txt 2>&1
-# 5. SQ / GRBM counters of the vocabulary GEMM at K = 512 (the model's shape) and K = 8192
-$ROOT/tools/pmc_gemm.sh 0:5120:10547:512,0:5120:10547:8192 128 2>/dev/null | grep "^pass" > $OUT/${R}_gemm_pmc_counters.txt
+# 5. SQ / GRBM counters of the vocabulary GEMM at K = 512 (the model's shape) and K = 8192, exact and throughput mode
+{ for m in bf16x3 bf16; do echo "== mode $m"; $ROOT/tools/pmc_gemm.sh 0:5120:10547:512,0:5120:10547:8192 128 $m --images 2>/dev/null | grep "^pass"; done; } > $OUT/${R}_gemm_pmc_counters.txt
+# 6. per-phase shader-clock cycles inside the bf16 kernels (needs the trace build: make -C .../csrc trace)
+if [ -f $ROOT/non-autoregressive-video-captioning_amd/libnacf_hip_trace.so ]; then
+  { for m in bf16x3 bf16; do for shp in 15360:1024:512 5120:10547:512; do echo "== mode $m shape $shp tile 128"; NACF_GEMM_MODE=$m python $ROOT/tools/bf16_trace.py $shp 128 --images 2>/dev/null; done; done; } > $OUT/${R}_bf16_phase_trace.txt
+fi
 ls -la $OUT
