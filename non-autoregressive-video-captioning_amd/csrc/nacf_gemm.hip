@@ -91,10 +91,10 @@ int pick_tile_bf16(int kind, int M, int N, int splits, bool has_rows, int ns, bo
   if (kind == 0) {
     // throughput mode: the small-tile kernel runs 7-8 workgroups per CU and hides a row list's edge work and a
     // transcendental epilogue (tanh|sigmoid, gelu) far better: 64x64 unless the launch is huge (the vocabulary)
-    thr = has_rows ? (ns == 1 ? 1500 : 400) : 200;
+    thr = has_rows ? (ns == 1 ? 1500 : 400) : (ns == 1 ? 300 : 200);
     if (heavy_epilogue && ns == 1) thr = 1L << 40;
   } else {
-    thr = (ns == 1) ? 90 : (has_rows ? 300 : 200);
+    thr = (ns == 1) ? 300 : (has_rows ? 300 : 200);      // tools/gemm_bench.py --modes bf16x3,bf16 --tiles 64,128,auto --images
   }
   return big >= thr ? 0 : 1;
 }
