@@ -140,18 +140,46 @@ struct StageF32KC {
       v[u] = t;
     }
   }
-  __device__ __forceinline__ void write(u32x4* plane0, int tid) const {
+  // split() + store() = write(), in two steps so that the conversion can run one pipeline phase before the LDS stores
+  u32x2 w[U][NS];
+  __device__ __forceinline__ void split_unit(int u) {
+    uint32_t wa[NS], wb[NS];
+    bf16_split2<NS>(v[u][0], v[u][1], wa);
+    bf16_split2<NS>(v[u][2], v[u][3], wb);
+#pragma unroll
+    for (int p = 0; p < NS; ++p) w[u][p] = u32x2{wa[p], wb[p]};
+  }
+  __device__ __forceinline__ void split() {
+#pragma unroll
+    for (int u = 0; u < U; ++u) split_unit(u);
+  }
+  // the same split in 7 * 2U single steps (1-2 vector instructions each) for hand-interleaving with matrix
+  // instructions; IN PLACE: v is consumed.  pair = (unit, half), step 0..6; both fold to constants when unrolled
+  static constexpr int PAIRS = 2 * U;
+  __device__ __forceinline__ void split_step(int pair, int step) {
+    if constexpr (NS == 3) {
+      const int u = pair >> 1, h = pair & 1;
+      float a = v[u][2 * h], b = v[u][2 * h + 1];
+      if (step == 0) w[u][0][h] = bf16_pack_top(a, b);
+      else if (step == 1 || step == 4) v[u][2 * h] = a - f32_top16(a);
+      else if (step == 2 || step == 5) v[u][2 * h + 1] = b - f32_top16(b);
+      else if (step == 3) w[u][1][h] = bf16_pack_top(a, b);
+      else w[u][2][h] = bf16_pack_top(a, b);
+    }
+  }
+  __device__ __forceinline__ void store(u32x4* plane0, int tid) const {
     u32x2* p8 = reinterpret_cast<u32x2*>(plane0);
     const int j = tid & 7;
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const int row = (tid >> 3) + 32 * u;
-      uint32_t wa[NS], wb[NS];
-      bf16_split2<NS>(v[u][0], v[u][1], wa);
-      bf16_split2<NS>(v[u][2], v[u][3], wb);
 #pragma unroll
-      for (int p = 0; p < NS; ++p) p8[(p * (R * 4) + row * 4 + ((j >> 1) ^ lds_sw(row))) * 2 + (j & 1)] = u32x2{wa[p], wb[p]};
+      for (int p = 0; p < NS; ++p) p8[(p * (R * 4) + row * 4 + ((j >> 1) ^ lds_sw(row))) * 2 + (j & 1)] = w[u][p];
     }
+  }
+  __device__ __forceinline__ void write(u32x4* plane0, int tid) {
+    split();
+    store(plane0, tid);
   }
 };
 
@@ -212,20 +240,44 @@ struct StageF32MC {
       v[j] = t;
     }
   }
-  __device__ __forceinline__ void write(u32x4* plane0) const {
+  u32x2 w[4][NS];
+  __device__ __forceinline__ void split() {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      uint32_t wa[NS], wb[NS];
+      bf16_split2<NS>(v[0][e], v[1][e], wa);
+      bf16_split2<NS>(v[2][e], v[3][e], wb);
+#pragma unroll
+      for (int p = 0; p < NS; ++p) w[e][p] = u32x2{wa[p], wb[p]};
+    }
+  }
+  static constexpr int PAIRS = 8;
+  __device__ __forceinline__ void split_step(int pair, int step) {     // see StageF32KC::split_step
+    if constexpr (NS == 3) {
+      const int e = pair >> 1, h = pair & 1;
+      float a = v[2 * h][e], b = v[2 * h + 1][e];
+      if (step == 0) w[e][0][h] = bf16_pack_top(a, b);
+      else if (step == 1 || step == 4) v[2 * h][e] = a - f32_top16(a);
+      else if (step == 2 || step == 5) v[2 * h + 1][e] = b - f32_top16(b);
+      else if (step == 3) w[e][1][h] = bf16_pack_top(a, b);
+      else w[e][2][h] = bf16_pack_top(a, b);
+    }
+  }
+  __device__ __forceinline__ void store(u32x4* plane0) const {
     if (active) {
       u32x2* p8 = reinterpret_cast<u32x2*>(plane0);
       const int c = mq >> 1, half = mq & 1;
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         const int row = 4 * rq + e;
-        uint32_t wa[NS], wb[NS];
-        bf16_split2<NS>(v[0][e], v[1][e], wa);
-        bf16_split2<NS>(v[2][e], v[3][e], wb);
 #pragma unroll
-        for (int p = 0; p < NS; ++p) p8[(p * (R * 4) + row * 4 + (c ^ lds_sw(row))) * 2 + half] = u32x2{wa[p], wb[p]};
+        for (int p = 0; p < NS; ++p) p8[(p * (R * 4) + row * 4 + (c ^ lds_sw(row))) * 2 + half] = w[e][p];
       }
     }
+  }
+  __device__ __forceinline__ void write(u32x4* plane0) {
+    split();
+    store(plane0);
   }
 };
 
@@ -391,6 +443,10 @@ __global__ __launch_bounds__(256, (BM == 64 ? 3 : 2)) void gemm_bf16_kernel(Gemm
       if (do_colsum) qsum += (qs.v[0] + qs.v[1]) + (qs.v[2] + qs.v[3]);   // every k-tile is written exactly once
     }
   };
+  auto store_q = [&](int st) {          // second half of write_q (the STAGES == 3 steady loop splits in compute_split)
+    if constexpr (QSRC == SRC_F32_KC) qs.store(q_stage(st), tid);
+    else qs.store(q_stage(st));
+  };
   auto write_p = [&](int st) {
     if constexpr (PSRC == SRC_F32_MC) ps.write(p_stage(st));
     else ps.write(p_stage(st), tid);
@@ -436,6 +492,55 @@ __global__ __launch_bounds__(256, (BM == 64 ? 3 : 2)) void gemm_bf16_kernel(Gemm
     }
   };
 
+  // C(kt) with the split of the Q registers (tile kt+1) threaded through it BY HAND: after every matrix instruction
+  // one split step (1-2 full-rate vector instructions), pinned there by a scheduling fence -- the matrix pipe takes 16
+  // cycles per instruction and the issue port is free for 12 of them, so the conversion costs no time of its own.
+  // The Q fragments of row block a+1 are fetched a block ahead (the fences stop the compiler from hoisting them).
+  auto compute_split = [&](int pst, int kt_next) {     // kt_next: the Q tile to load once the registers are split
+    static_assert(NS == 3 || STAGES != 3, "hand schedule is for the three-term kernels");
+    if constexpr (NS == 3 && QSRC != SRC_BF16_KC) {
+      if constexpr (QSRC != SRC_F32_KC) { if (do_colsum) qsum += (qs.v[0] + qs.v[1]) + (qs.v[2] + qs.v[3]); }
+      const u32x4* qpl = q_stage(0);
+      const u32x4* ppl = p_stage(pst);
+      bf16x8_t pf[TN][NS], qf[2][NS];
+#pragma unroll
+      for (int b = 0; b < TN; ++b)
+#pragma unroll
+        for (int p = 0; p < NS; ++p) pf[b][p] = lds_frag(ppl + p * PPL, wn * WTN + b * 16 + li, lg);
+#pragma unroll
+      for (int p = 0; p < NS; ++p) qf[0][p] = lds_frag(qpl + p * QPL, wm * WTM + li, lg);
+      constexpr int NSTEP = 7 * decltype(qs)::PAIRS;
+      constexpr int TP[6] = {2, 0, 1, 1, 0, 0}, TQ[6] = {0, 2, 1, 0, 1, 0};     // six cross terms, smallest first
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int a = 0; a < TM; ++a) {
+        if (a + 1 < TM) {
+#pragma unroll
+          for (int p = 0; p < NS; ++p) qf[(a + 1) & 1][p] = lds_frag(qpl + p * QPL, wm * WTM + (a + 1) * 16 + li, lg);
+        }
+#pragma unroll
+        for (int t = 0; t < 6; ++t) {
+#pragma unroll
+          for (int b = 0; b < TN; ++b) {
+            acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pf[b][TP[t]], qf[a & 1][TQ[t]], acc[a][b], 0, 0, 0);
+            constexpr int NSLOT = TM * 6 * TN;
+            const int slot = (a * 6 + t) * TN + b;
+            if (slot < NSTEP) qs.split_step(slot / 7, slot % 7);
+            if (slot == NSTEP) load_q(kt_next, true, true);
+            if constexpr (PSRC == SRC_F32_MC) {
+              // a row-contiguous fp32 P (dW): its registers hold tile kt+2, split in the LAST slots; tile kt+3 is
+              // requested after the loop
+              constexpr int PSTEP = 7 * decltype(ps)::PAIRS;
+              const int ps_slot = slot - (NSLOT - PSTEP);
+              if (ps_slot >= 0) ps.split_step(ps_slot / 7, ps_slot % 7);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        }
+      }
+    }
+  };
+
 #ifdef NACF_BF16_TRACE
   unsigned long long tacc[5] = {0, 0, 0, 0, 0};
   unsigned long long tsub[3] = {0, 0, 0};     // STAGES == 3 staging phase: Q split + stores | Q load issue | P stores
@@ -458,6 +563,7 @@ __global__ __launch_bounds__(256, (BM == 64 ? 3 : 2)) void gemm_bf16_kernel(Gemm
   }
   __syncthreads();
   int kt_first = 0;
+  bool p_preloaded = false;      // the steady loop left tile kt_first+2 of P in the registers
 #ifndef NACF_BF16_TRACE
   if constexpr (STAGES == 2) {
     // STEADY iterations (tile kt+2 exists and is an interior tile of fully populated row tiles): one straight-line
@@ -476,6 +582,36 @@ __global__ __launch_bounds__(256, (BM == 64 ? 3 : 2)) void gemm_bf16_kernel(Gemm
     }
   }
 #endif
+  if constexpr (STAGES == 3 && NS == 3) {
+    // STEADY iterations of the one-Q-image pipeline.  Invariant at the top of iteration kt: the Q image holds tile kt,
+    // the P images tiles kt and kt+1, the Q registers the raw fp32 of tile kt+1 (and, for a converted P, the P
+    // registers the raw tile kt+2).  The split of those registers into bf16 planes is pure VALU work with no LDS
+    // dependence: compute_split threads it through the MFMAs of tile kt; only the stores wait for the barrier.  The
+    // raw registers are free as soon as they are split, so the next loads go out most of an MFMA phase earlier too.
+    constexpr bool PSHADOW = (PSRC == SRC_F32_MC);
+    constexpr int AHEAD = PSHADOW ? 3 : 2;
+    const int n_steady = rows_full ? min(nk - AHEAD, (kend - kbeg) / BK - AHEAD) : 0;
+    if constexpr (PSHADOW) {
+      if (n_steady > 0) { load_p(2, true, true); p_preloaded = true; }
+    }
+#pragma nounroll
+    for (; kt_first < n_steady; ++kt_first) {
+      BF16_T(t0);
+      if constexpr (!PSHADOW) load_p(kt_first + 2, true, true);
+      compute_split(kt_first & 1, kt_first + 2);
+      if constexpr (PSHADOW) load_p(kt_first + 3, true, true);
+      BF16_T(t1);
+      __syncthreads();
+      BF16_T(t2);
+      store_q(0);
+      if constexpr (PSHADOW) ps.store(p_stage(kt_first & 1));
+      else write_p(kt_first & 1);
+      BF16_T(t4);
+      __syncthreads();
+      BF16_T(t5);
+      BF16_TACC(0, t0, t1); BF16_TACC(1, t1, t2); BF16_TACC(3, t2, t4); BF16_TACC(4, t4, t5);
+    }
+  }
 #pragma nounroll
   for (int kt = kt_first; kt < nk; ++kt) {
     if constexpr (STAGES == 2) {
@@ -517,7 +653,7 @@ __global__ __launch_bounds__(256, (BM == 64 ? 3 : 2)) void gemm_bf16_kernel(Gemm
       // loads of tile kt+2 are issued FIRST: the texture addresser works through them while the MFMAs run, and the
       // staging phase only converts / stores (plus the four Q loads)
       BF16_T(t0);
-      if (kt + 2 < nk) load_p(kt + 2, true);
+      if (kt + 2 < nk && !(p_preloaded && kt == kt_first)) load_p(kt + 2, true);
       compute(0, kt & 1);
       BF16_T(t1);
       __syncthreads();
@@ -551,11 +687,15 @@ __global__ __launch_bounds__(256, (BM == 64 ? 3 : 2)) void gemm_bf16_kernel(Gemm
   }
 #ifdef NACF_BF16_TRACE
   if (g_bf16_trace && tid == 0) {
-    unsigned long long* o = g_bf16_trace + ((size_t)blockIdx.z * gridDim.x + blockIdx.x) * 8;
+    unsigned long long* o = g_bf16_trace + ((size_t)blockIdx.z * gridDim.x + blockIdx.x) * 16;
     for (int i = 0; i < 5; ++i) o[i] = tacc[i];
-    o[5] = __builtin_readcyclecounter() - t_begin;
+    const unsigned long long t_loop_end = __builtin_readcyclecounter();
+    o[5] = t_loop_end - t_begin;
     o[6] = (unsigned long long)nk;
     o[7] = (tsub[0] << 42) | (tsub[1] << 21) | tsub[2];      // three 21-bit sums (cycles / 16 would overflow less; fine for nk <= 64)
+    o[8] = t_begin;                                           // absolute stamps: the timeline of workgroups per CU
+    o[9] = t_loop_end;
+    o[11] = ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32) | __builtin_amdgcn_s_getreg((31 << 11) | 4);   // XCC_ID | HW_ID
   }
 #endif
 
@@ -597,6 +737,14 @@ __global__ __launch_bounds__(256, (BM == 64 ? 3 : 2)) void gemm_bf16_kernel(Gemm
   } else {
     argmax_epilogue<BM, BN, WM, WN, TM, TN>(reinterpret_cast<float*>(smem), g, epi, acc, m0, n0, Meff, tile_n, wm, wn, li, lg, tid);
   }
+#ifdef NACF_BF16_TRACE
+  if (g_bf16_trace && tid == 0) {
+    const unsigned long long t_issued = __builtin_readcyclecounter();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // the epilogue's stores have left this wave
+    g_bf16_trace[((size_t)blockIdx.z * gridDim.x + blockIdx.x) * 16 + 10] = __builtin_readcyclecounter();
+    g_bf16_trace[((size_t)blockIdx.z * gridDim.x + blockIdx.x) * 16 + 12] = t_issued;
+  }
+#endif
 }
 
 // ---------------------------------------------------------------- weight images

@@ -354,11 +354,31 @@ struct EpiLinear {
     const bool any_drop = (ep.p_drop1 > 0.f) || (ep.p_drop2 > 0.f);
     DropRng rng;
     if (any_drop) rng.init(ep.rng_state);
-    fast_body<0, TM, TN>(acc, mphys, ncol, N, bias, res, dead, rng);
+    // ONE uniform dispatch on (activation, dropout) up front, then a straight-line body per combination: with the
+    // tests inside the TM x TN unrolled body every sub-tile drags its own copy of every activation and of the Philox
+    // rounds along (72 k instructions for a 128 x 128 tile), and the walk over those mostly skipped copies costs the
+    // workgroup ~14 k cycles of instruction-cache misses -- as much as four k-tiles of matrix work.
+    if (!any_drop) {
+      switch (ep.act) {
+        case NACF_ACT_NONE: fast_body<0, TM, TN, NACF_ACT_NONE, false>(acc, mphys, ncol, N, bias, res, dead, rng); break;
+        case NACF_ACT_RELU: fast_body<0, TM, TN, NACF_ACT_RELU, false>(acc, mphys, ncol, N, bias, res, dead, rng); break;
+        case NACF_ACT_GELU_NEW: fast_body<0, TM, TN, NACF_ACT_GELU_NEW, false>(acc, mphys, ncol, N, bias, res, dead, rng); break;
+        case NACF_ACT_TANH: fast_body<0, TM, TN, NACF_ACT_TANH, false>(acc, mphys, ncol, N, bias, res, dead, rng); break;
+        case NACF_ACT_SIGMOID: fast_body<0, TM, TN, NACF_ACT_SIGMOID, false>(acc, mphys, ncol, N, bias, res, dead, rng); break;
+        case NACF_ACT_TANH_SIGMOID: fast_body<0, TM, TN, NACF_ACT_TANH_SIGMOID, false>(acc, mphys, ncol, N, bias, res, dead, rng); break;
+        default: fast_body<0, TM, TN, NACF_ACT_GELU_ERF, false>(acc, mphys, ncol, N, bias, res, dead, rng); break;
+      }
+    } else if (ep.act == NACF_ACT_NONE) {
+      fast_body<0, TM, TN, NACF_ACT_NONE, true>(acc, mphys, ncol, N, bias, res, dead, rng);
+    } else if (ep.act == NACF_ACT_RELU) {
+      fast_body<0, TM, TN, NACF_ACT_RELU, true>(acc, mphys, ncol, N, bias, res, dead, rng);
+    } else {
+      fast_body<0, TM, TN, -1, true>(acc, mphys, ncol, N, bias, res, dead, rng);      // rare: every test stays inside
+    }
   }
   // compile-time recursion over the TM x TN sub-tiles (a `#pragma unroll` loop over this body is declined by
-  // the optimiser and the register arrays end up in scratch)
-  template <int IDX, int TM, int TN>
+  // the optimiser and the register arrays end up in scratch).  ACT: the activation, or -1 = read ep.act per element.
+  template <int IDX, int TM, int TN, int ACT, bool DROP>
   __device__ __forceinline__ void fast_body(f32x4 (&acc)[TM][TN], const int (&mphys)[TM], const int (&ncol)[TN], int N,
                                             const f32x4 (&bias)[TN], const f32x4 (&res)[TM][TN], const bool (&dead)[TM],
                                             const DropRng& rng) const {
@@ -367,19 +387,26 @@ struct EpiLinear {
       const int n = ncol[b];
       f32x4 v = acc[a][b] + bias[b];
       if (ep.preact) *reinterpret_cast<f32x4*>(ep.preact + (int64_t)mphys[a] * ep.ld_preact + n) = v;
-      if (ep.act != NACF_ACT_NONE) {
-        v[0] = apply_act(ep.act, v[0], n, ep.act_split);
-        v[1] = apply_act(ep.act, v[1], n + 1, ep.act_split);
-        v[2] = apply_act(ep.act, v[2], n + 2, ep.act_split);
-        v[3] = apply_act(ep.act, v[3], n + 3, ep.act_split);
+      if constexpr (ACT != NACF_ACT_NONE) {
+        const int act = ACT < 0 ? ep.act : ACT;
+        if (ACT >= 0 || act != NACF_ACT_NONE) {
+          v[0] = apply_act(act, v[0], n, ep.act_split);
+          v[1] = apply_act(act, v[1], n + 1, ep.act_split);
+          v[2] = apply_act(act, v[2], n + 2, ep.act_split);
+          v[3] = apply_act(act, v[3], n + 3, ep.act_split);
+        }
       }
-      const uint64_t grp = ((uint64_t)mphys[a] * (uint64_t)N + (uint64_t)n) >> 2;
-      if (ep.p_drop1 > 0.f) v *= rng.keep4(grp, ep.salt1, ep.p_drop1);
-      v += res[a][b];
-      if (ep.p_drop2 > 0.f) v *= rng.keep4(grp, ep.salt2, ep.p_drop2);
+      if constexpr (DROP) {
+        const uint64_t grp = ((uint64_t)mphys[a] * (uint64_t)N + (uint64_t)n) >> 2;
+        if (ep.p_drop1 > 0.f) v *= rng.keep4(grp, ep.salt1, ep.p_drop1);
+        v += res[a][b];
+        if (ep.p_drop2 > 0.f) v *= rng.keep4(grp, ep.salt2, ep.p_drop2);
+      } else {
+        v += res[a][b];
+      }
       if (dead[a]) v = f32x4{0.f, 0.f, 0.f, 0.f};
       *reinterpret_cast<f32x4*>(Y + (int64_t)mphys[a] * ldy + n) = v;
-      fast_body<IDX + 1, TM, TN>(acc, mphys, ncol, N, bias, res, dead, rng);
+      fast_body<IDX + 1, TM, TN, ACT, DROP>(acc, mphys, ncol, N, bias, res, dead, rng);
     }
   }
 };

@@ -39,8 +39,9 @@ a.record(); f(); b.record()
 torch.cuda.synchronize()
 assert raw.nacf_debug_bf16_trace(ctypes.c_void_p(0)) == 0
 print(L.load().nacf_gemm_last_kernel().decode())
-raw8 = buf.cpu().numpy().reshape(-1, 8)
-raw8 = raw8[raw8[:, 5] != 0]
+raw16 = buf.cpu().numpy().reshape(-1, 16)
+raw16 = raw16[raw16[:, 5] != 0]
+raw8 = raw16[:, :8]
 sub = raw8[:, 7].astype(np.uint64)
 t = raw8.astype(np.float64)
 nk = t[:, 6].max()
@@ -56,5 +57,39 @@ if int(sub.max()) > 0:      # STAGES == 3 kernels: the staging phase in three pa
     parts = [(sub >> np.uint64(42)) & np.uint64((1 << 21) - 1), (sub >> np.uint64(21)) & np.uint64((1 << 21) - 1), sub & np.uint64((1 << 21) - 1)]
     for n, v in zip(["Q split + LDS stores (drained)", "Q load issue", "P LDS stores (drained)"], parts):
         print("    staging: %-32s per k-tile p50 %6.0f" % (n, np.percentile(v.astype(np.float64) / nk, 50)))
+# ---- timeline: how many workgroups share a CU, and what happens outside the k-loop
+t0 = raw16[:, 8].min()
+beg, lend, end = (raw16[:, 8] - t0).astype(np.float64), (raw16[:, 9] - t0).astype(np.float64), (raw16[:, 10] - t0).astype(np.float64)
+hw = raw16[:, 11].astype(np.uint64)
+hwid, xcc = hw & np.uint64(0xffffffff), (hw >> np.uint64(32)) & np.uint64(0xf)
+cu = ((xcc << np.uint64(16)) | (((hwid >> np.uint64(13)) & np.uint64(7)) << np.uint64(8)) | (((hwid >> np.uint64(12)) & np.uint64(1)) << np.uint64(4)) | ((hwid >> np.uint64(8)) & np.uint64(15))).astype(np.int64)
+# the shader clock counters of the 8 XCDs have different origins: align each XCD to its own first workgroup
+for x in set(xcc.tolist()):
+    sel = xcc == x
+    o = beg[sel].min()
+    beg[sel] -= o; lend[sel] -= o; end[sel] -= o
+issued = (raw16[:, 12] - t0).astype(np.float64)
+for x in set(xcc.tolist()):
+    sel = xcc == x
+    issued[sel] -= (raw16[sel, 8] - t0).astype(np.float64).min()
+span = end.max()
+order = np.argsort(beg)
+nq = 4
+print("  epilogue by start-time quartile: " + "  ".join("q%d: issue %.0f + drain %.0f" % (i, np.median((issued - lend)[order[i * len(order) // nq:(i + 1) * len(order) // nq]]),
+      np.median((end - issued)[order[i * len(order) // nq:(i + 1) * len(order) // nq]])) for i in range(nq)))
+print("timeline: kernel span %.0f cycles (%.1f us at 2.1 GHz); %d distinct CUs; epilogue p50 %.0f cycles (p90 %.0f); prologue+loop p50 %.0f"
+      % (span, span / 2.1e3, len(set(cu.tolist())), np.percentile(end - lend, 50), np.percentile(end - lend, 90), np.percentile(lend - beg, 50)))
+print("  resident workgroups per CU, time-averaged: %.2f   (sum of lifetimes / (CUs * span))" % ((end - beg).sum() / (len(set(cu.tolist())) * span)))
+starts = np.sort(beg)
+q = [0, 10, 25, 50, 75, 90, 100]
+print("  workgroup start times (cycles): " + "  ".join("p%d %.0f" % (x, np.percentile(starts, x)) for x in q))
+print("  workgroup end   times (cycles): " + "  ".join("p%d %.0f" % (x, np.percentile(end, x)) for x in q))
+per = {}
+for c, b0, e0 in zip(cu.tolist(), beg.tolist(), end.tolist()):
+    per.setdefault(c, []).append((b0, e0))
+ncu = np.array([len(v) for v in per.values()])
+print("  workgroups per CU: min %d  median %d  max %d" % (ncu.min(), np.median(ncu), ncu.max()))
+c0 = sorted(per.items())[0]
+print("  one CU's workgroups (start, end): " + "  ".join("(%.0f, %.0f)" % x for x in sorted(c0[1])))
 if imgs is not None:
     imgs.close()
