@@ -40,6 +40,7 @@
 // 128x128 tile (48 KB per image) uses one image and two barriers -- a k-tile there is 96 MFMAs per wave, and two
 // to three workgroups per CU cover each other's barriers.
 #pragma once
+#include <type_traits>
 #include "gemm_f32.hpp"
 
 typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
@@ -292,7 +293,8 @@ struct StageBF16KC {
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const int q = tid + 256 * u;
-      ptr[u] = img + (int64_t)min(r0 + (q >> 2), rmax - 1) * 32 + (q & 3) * 8;
+      const int64_t rowoff = (int64_t)min(r0 + (q >> 2), rmax - 1) * 32;
+      ptr[u] = img + rowoff + (q & 3) * 8;
     }
   }
   // kt_stride: elements between consecutive k-tiles (= rows of the registered matrix * 32)
@@ -496,7 +498,9 @@ __global__ __launch_bounds__(256, (BM == 64 ? 3 : 2)) void gemm_bf16_kernel(Gemm
   // one split step (1-2 full-rate vector instructions), pinned there by a scheduling fence -- the matrix pipe takes 16
   // cycles per instruction and the issue port is free for 12 of them, so the conversion costs no time of its own.
   // The Q fragments of row block a+1 are fetched a block ahead (the fences stop the compiler from hoisting them).
-  auto compute_split = [&](int pst, int kt_next) {     // kt_next: the Q tile to load once the registers are split
+  // q_slot0: matrix-instruction slot of the first Q split step; kt_next >= 0: request that Q tile once the registers are split
+  auto compute_split = [&](int pst, int kt_next, auto q_slot0_c) {
+    constexpr int Q0 = decltype(q_slot0_c)::value;
     static_assert(NS == 3 || STAGES != 3, "hand schedule is for the three-term kernels");
     if constexpr (NS == 3 && QSRC != SRC_BF16_KC) {
       if constexpr (QSRC != SRC_F32_KC) { if (do_colsum) qsum += (qs.v[0] + qs.v[1]) + (qs.v[2] + qs.v[3]); }
@@ -525,8 +529,9 @@ __global__ __launch_bounds__(256, (BM == 64 ? 3 : 2)) void gemm_bf16_kernel(Gemm
             acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pf[b][TP[t]], qf[a & 1][TQ[t]], acc[a][b], 0, 0, 0);
             constexpr int NSLOT = TM * 6 * TN;
             const int slot = (a * 6 + t) * TN + b;
-            if (slot < NSTEP) qs.split_step(slot / 7, slot % 7);
-            if (slot == NSTEP) load_q(kt_next, true, true);
+            static_assert(Q0 + NSTEP <= NSLOT, "split steps past the last matrix instruction");
+            if (slot >= Q0 && slot < Q0 + NSTEP) qs.split_step((slot - Q0) / 7, (slot - Q0) % 7);
+            if (slot == Q0 + NSTEP || (Q0 + NSTEP == NSLOT && slot == NSLOT - 1)) { if (kt_next >= 0) load_q(kt_next, true, true); }
             if constexpr (PSRC == SRC_F32_MC) {
               // a row-contiguous fp32 P (dW): its registers hold tile kt+2, split in the LAST slots; tile kt+3 is
               // requested after the loop
@@ -538,6 +543,50 @@ __global__ __launch_bounds__(256, (BM == 64 ? 3 : 2)) void gemm_bf16_kernel(Gemm
           }
         }
       }
+    }
+  };
+
+  // the same for the two-image pipelines (STAGES == 2, the 64 x 64 exact tile): everything of tile kt+1 -- P stores, the
+  // Q split and its stores, the loads of tile kt+2 -- shares one straight-line block with the MFMAs of tile kt.  Term
+  // outermost: an accumulator comes back after TM * TN matrix instructions (the per-accumulator order of the six terms,
+  // and with it every bit of the result, is that of compute()).
+  auto compute_split2 = [&](int kt) {
+    if constexpr (NS == 3 && STAGES == 2 && QSRC != SRC_BF16_KC) {
+      const int cur = kt & 1, nxt = cur ^ 1;
+      write_p(nxt);
+      load_p(kt + 2, true, true);
+      if constexpr (QSRC != SRC_F32_KC) { if (do_colsum) qsum += (qs.v[0] + qs.v[1]) + (qs.v[2] + qs.v[3]); }
+      const u32x4* qpl = q_stage(cur);
+      const u32x4* ppl = p_stage(cur);
+      bf16x8_t pf[TN][NS], qf[TM][NS];
+#pragma unroll
+      for (int b = 0; b < TN; ++b)
+#pragma unroll
+        for (int p = 0; p < NS; ++p) pf[b][p] = lds_frag(ppl + p * PPL, wn * WTN + b * 16 + li, lg);
+#pragma unroll
+      for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int p = 0; p < NS; ++p) qf[a][p] = lds_frag(qpl + p * QPL, wm * WTM + a * 16 + li, lg);
+      constexpr int NSTEP = 7 * decltype(qs)::PAIRS, NSLOT = 6 * TM * TN;
+      constexpr int TP[6] = {2, 0, 1, 1, 0, 0}, TQ[6] = {0, 2, 1, 0, 1, 0};
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int t = 0; t < 6; ++t) {
+#pragma unroll
+        for (int a = 0; a < TM; ++a) {
+#pragma unroll
+          for (int b = 0; b < TN; ++b) {
+            acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pf[b][TP[t]], qf[a][TQ[t]], acc[a][b], 0, 0, 0);
+            const int slot = (t * TM + a) * TN + b;
+#pragma unroll
+            for (int i = 0; i < NSTEP; ++i)
+              if (i * NSLOT / NSTEP == slot) qs.split_step(i / 7, i % 7);
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        }
+      }
+      store_q(nxt);
+      load_q(kt + 2, true, true);
     }
   };
 
@@ -573,11 +622,15 @@ __global__ __launch_bounds__(256, (BM == 64 ? 3 : 2)) void gemm_bf16_kernel(Gemm
     const int n_steady = rows_full ? min(nk - 2, (kend - kbeg) / BK - 2) : 0;
 #pragma nounroll
     for (; kt_first < n_steady; ++kt_first) {
-      write_q((kt_first + 1) & 1);
-      write_p((kt_first + 1) & 1);
-      load_q(kt_first + 2, true, true);
-      load_p(kt_first + 2, true, true);
-      compute(kt_first & 1, kt_first & 1);
+      if constexpr (NS == 3 && BM == 64 && PSRC == SRC_BF16_KC) {      // (dW's two converted operands measure slower this way)
+        compute_split2(kt_first);
+      } else {
+        write_q((kt_first + 1) & 1);
+        write_p((kt_first + 1) & 1);
+        load_q(kt_first + 2, true, true);
+        load_p(kt_first + 2, true, true);
+        compute(kt_first & 1, kt_first & 1);
+      }
       __syncthreads();
     }
   }
@@ -598,7 +651,7 @@ __global__ __launch_bounds__(256, (BM == 64 ? 3 : 2)) void gemm_bf16_kernel(Gemm
     for (; kt_first < n_steady; ++kt_first) {
       BF16_T(t0);
       if constexpr (!PSHADOW) load_p(kt_first + 2, true, true);
-      compute_split(kt_first & 1, kt_first + 2);
+      compute_split(kt_first & 1, kt_first + 2, std::integral_constant<int, 0>{});
       if constexpr (PSHADOW) load_p(kt_first + 3, true, true);
       BF16_T(t1);
       __syncthreads();
