@@ -393,7 +393,14 @@ __global__ __launch_bounds__(256, (BM == 64 ? 3 : 2)) void gemm_bf16_kernel(Gemm
   const int xq = nwg >> 3, xr = nwg & 7;
   const int xcd = bid & 7, slot = bid >> 3;
   const int logical = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + slot;
-  const int tile_m = logical / g.tiles_n, tile_n = logical % g.tiles_n;
+  int tile_m = logical / g.tiles_n, tile_n = logical % g.tiles_n;
+  if (g.group_n > 0) {
+    const int per = tiles_m_live * g.group_n;
+    const int grp = logical / per, r = logical - grp * per;
+    const int gn = min(g.group_n, g.tiles_n - grp * g.group_n);
+    tile_m = r / gn;
+    tile_n = grp * g.group_n + (r - tile_m * gn);
+  }
   const int m0 = tile_m * BM, n0 = tile_n * BN;
 
   const int z = blockIdx.z;

@@ -79,6 +79,11 @@ struct GemmShape {
   const unsigned short* Pimg;
   int64_t ldpi;
   int64_t pimg_plane;
+  // bf16 kernels: tile order inside an XCD's run.  0: n fastest over ALL column tiles (one row tile's X stays in L2, the
+  // whole of P streams past once per row tile).  g > 0: column tiles in groups of g, inside a group n fastest, then m --
+  // a group's slice of P (g * BN rows) stays in the XCD's 4 MB L2 while X streams past once per group: for a wide P
+  // (the vocabulary: 83 column tiles) that is tiles_n / g passes over X instead of tiles_m / 8 passes over P.
+  int group_n = 0;
 };
 
 __device__ __forceinline__ int lds_sw(int row) { return (-(row >> 2)) & 3; }
