@@ -64,7 +64,7 @@ int nacf_version(void);
  * included).  nacf_abi_count() returns the value the LIBRARY was built with; the ctypes loader
  * (runtime/lib.py:load) refuses a library whose count differs from its own signature table, so a stale
  * libnacf_hip.so next to a newer Python package fails at import time, not at the first missing symbol. */
-#define NACF_ABI_COUNT 70
+#define NACF_ABI_COUNT 73
 int nacf_abi_count(void);
 
 /* ---- batch construction (reference: dataloader.py) ----------------------------------------
@@ -172,6 +172,17 @@ int nacf_linear_bwd_weight(const float* dZ, int64_t lddz, const float* X, int64_
                            float* dW, int64_t lddw, float* db, int M, int N, int K,
                            float beta, void* ws, size_t ws_bytes, const nacf_rowset* rows,
                            nacf_stream_t stream);
+
+/* Deferred split-K combines.  Between nacf_dw_group_begin() and nacf_dw_group_flush(), nacf_linear_bwd_weight still
+ * launches its GEMM at once but QUEUES the combine of its partial slabs (and of the bias-gradient partials); flush
+ * runs every queued combine in one launch (same slab order as the per-call kernel: bit-identical sums).  Contract for
+ * the caller while a group is open: each call gets its own `ws` region, left untouched until the flush; one dW target
+ * is queued at most once (a second call for the same dW returns NACF_EINVAL -- flush first); dW / db are not read by
+ * anything else before the flush.  The queue holds 32 combines and flushes itself (on the calling stream) when full.
+ * nacf_dw_group_pending: queued combines, or -1 when no group is open.  One group at a time per process. */
+int nacf_dw_group_begin(void);
+int nacf_dw_group_flush(nacf_stream_t stream);
+int nacf_dw_group_pending(void);
 
 /* Which GEMM kernel a call will launch (for profiling / roofline bookkeeping):
  * kind 0 = linear_fwd (also vocab_argmax), 1 = linear_bwd_data, 2 = linear_bwd_weight,

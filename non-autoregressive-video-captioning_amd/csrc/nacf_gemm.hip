@@ -3,6 +3,7 @@
 #include "gemm_f32.hpp"
 #include "gemm_bf16_launch.hpp"
 #include <stdlib.h>
+#include <mutex>
 #include <string.h>
 #include <vector>
 
@@ -156,14 +157,14 @@ __global__ void splitk_reduce_rows_kernel(const float* __restrict__ slabs, int64
 // for the bias-gradient partials the dW GEMM left in part[z][n] (db[n] = beta*db[n] + sum_z part[z][n]).
 // VEC: cols % 4 == 0 and 16-byte aligned rows -> float4 per thread.
 template <bool VEC>
-__global__ void splitk_reduce_kernel(const float* __restrict__ slabs, int64_t slab_stride, int splits,
-                                     float* __restrict__ dst, int64_t ldd, int rows, int cols, float beta,
-                                     const float* __restrict__ part, float* __restrict__ db) {
-  const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+__device__ __forceinline__ void splitk_reduce_body(const float* __restrict__ slabs, int64_t slab_stride, int splits,
+                                                   float* __restrict__ dst, int64_t ldd, int rows, int cols, float beta,
+                                                   const float* __restrict__ part, float* __restrict__ db, int64_t gid,
+                                                   int64_t gstride) {
   if constexpr (VEC) {
     const int c4n = cols >> 2;
     const int64_t total = (int64_t)rows * c4n;
-    for (int64_t idx = gid; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+    for (int64_t idx = gid; idx < total; idx += gstride) {
       const int r = (int)(idx / c4n), c = (int)(idx % c4n) * 4;
       const float* sp = slabs + (int64_t)r * cols + c;
       f32x4 acc = *reinterpret_cast<const f32x4*>(sp);
@@ -173,7 +174,7 @@ __global__ void splitk_reduce_kernel(const float* __restrict__ slabs, int64_t sl
     }
   } else {
     const int64_t total = (int64_t)rows * cols;
-    for (int64_t idx = gid; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+    for (int64_t idx = gid; idx < total; idx += gstride) {
       const int r = (int)(idx / cols), c = (int)(idx % cols);
       float acc = 0.f;
       for (int zz = 0; zz < splits; ++zz) acc += slabs[(int64_t)zz * slab_stride + idx];
@@ -182,12 +183,52 @@ __global__ void splitk_reduce_kernel(const float* __restrict__ slabs, int64_t sl
     }
   }
   if (db) {
-    for (int64_t n = gid; n < rows; n += (int64_t)gridDim.x * blockDim.x) {
+    for (int64_t n = gid; n < rows; n += gstride) {
       float acc = 0.f;
       for (int zz = 0; zz < splits; ++zz) acc += part[(int64_t)zz * rows + n];
       db[n] = (beta != 0.f) ? acc + beta * db[n] : acc;
     }
   }
+}
+
+template <bool VEC>
+__global__ void splitk_reduce_kernel(const float* __restrict__ slabs, int64_t slab_stride, int splits,
+                                     float* __restrict__ dst, int64_t ldd, int rows, int cols, float beta,
+                                     const float* __restrict__ part, float* __restrict__ db) {
+  splitk_reduce_body<VEC>(slabs, slab_stride, splits, dst, ldd, rows, cols, beta, part, db,
+                          (int64_t)blockIdx.x * blockDim.x + threadIdx.x, (int64_t)gridDim.x * blockDim.x);
+}
+
+// ---- deferred combines (nacf_dw_group_begin / _flush): the split-K combines of up to DW_GROUP_MAX dW GEMMs in ONE
+// launch.  Every combine is a ~5-10 us kernel of its own otherwise (12 per NACF training step); their sums do not
+// depend on each other, only on their own GEMM, so they can all wait for the end of the backward pass.  The
+// arithmetic of each combine is exactly splitk_reduce_kernel's (same slab order), so results are bit-identical.
+constexpr int DW_GROUP_MAX = 32;
+struct DwReduceDesc {
+  const float* slabs;
+  float* dst;
+  const float* part;
+  float* db;
+  int64_t slab_stride, ldd;
+  int splits, rows, cols, vec;
+  float beta;
+  int block0;        // first block of this combine in the grouped launch
+};
+struct DwReduceTable {
+  int n;
+  int block_end;
+  DwReduceDesc d[DW_GROUP_MAX];
+};
+__global__ void dw_group_reduce_kernel(DwReduceTable t) {
+  int e = 0;
+#pragma unroll 1
+  while (e + 1 < t.n && (int)blockIdx.x >= t.d[e + 1].block0) ++e;
+  const DwReduceDesc& d = t.d[e];
+  const int nblk = (e + 1 < t.n ? t.d[e + 1].block0 : t.block_end) - d.block0;
+  const int64_t gid = (int64_t)((int)blockIdx.x - d.block0) * blockDim.x + threadIdx.x;
+  const int64_t gstride = (int64_t)nblk * blockDim.x;
+  if (d.vec) splitk_reduce_body<true>(d.slabs, d.slab_stride, d.splits, d.dst, d.ldd, d.rows, d.cols, d.beta, d.part, d.db, gid, gstride);
+  else splitk_reduce_body<false>(d.slabs, d.slab_stride, d.splits, d.dst, d.ldd, d.rows, d.cols, d.beta, d.part, d.db, gid, gstride);
 }
 
 // merge the per-tile (max, idx, sumexp) partials and apply the decode bookkeeping
@@ -495,6 +536,38 @@ static int bwd_weight_splits(int M, int N, int K, bool has_rows, int* tile_out) 
   return s;
 }
 
+// host side of the deferred combines.  One training step at a time; the autograd worker thread queues, the thread that
+// drives the step begins and flushes -- hence a mutex, not thread_local state.
+static std::mutex g_dw_group_mu;
+static bool g_dw_group_on = false;
+static DwReduceTable g_dw_group = {};
+
+static int dw_group_flush_locked(hipStream_t s) {
+  if (g_dw_group.n > 0) {
+    hipLaunchKernelGGL(dw_group_reduce_kernel, dim3(g_dw_group.block_end), dim3(256), 0, s, g_dw_group);
+    g_dw_group.n = 0;
+    g_dw_group.block_end = 0;
+    NACF_LAUNCH_CHECK("nacf_dw_group_flush");
+  }
+  return NACF_OK;
+}
+
+int nacf_dw_group_begin(void) {
+  std::lock_guard<std::mutex> lk(g_dw_group_mu);
+  NACF_CHECK(g_dw_group.n == 0, NACF_EINVAL, "nacf_dw_group_begin: %d combines of the previous group were never flushed", g_dw_group.n);
+  g_dw_group_on = true;
+  return NACF_OK;
+}
+int nacf_dw_group_flush(nacf_stream_t stream) {
+  std::lock_guard<std::mutex> lk(g_dw_group_mu);
+  g_dw_group_on = false;
+  return dw_group_flush_locked(as_hip(stream));
+}
+int nacf_dw_group_pending(void) {
+  std::lock_guard<std::mutex> lk(g_dw_group_mu);
+  return g_dw_group_on ? g_dw_group.n : -1;
+}
+
 size_t nacf_linear_bwd_weight_workspace(int M, int N, int K) {
   int tile;
   const int a = bwd_weight_splits(M, N, K, false, &tile), b = bwd_weight_splits(M, N, K, true, &tile);
@@ -555,6 +628,21 @@ int nacf_linear_bwd_weight(const float* dZ, int64_t lddz, const float* X, int64_
   if (real_splits > 1) {
     const bool v4 = (K % 4 == 0) && (lddw % 4 == 0) && aligned16(dW) && aligned16(slabs);
     const int64_t total = (int64_t)N * (v4 ? K / 4 : K);
+    {
+      std::lock_guard<std::mutex> lk(g_dw_group_mu);
+      if (g_dw_group_on) {
+        // deferred: the caller keeps `ws` untouched until nacf_dw_group_flush and never queues one dW twice
+        if (g_dw_group.n == DW_GROUP_MAX) { const int rc = dw_group_flush_locked(s); if (rc != NACF_OK) return rc; }
+        for (int i = 0; i < g_dw_group.n; ++i)
+          NACF_CHECK(g_dw_group.d[i].dst != dW, NACF_EINVAL, "nacf_linear_bwd_weight: this dW already has a deferred combine pending (flush first)");
+        DwReduceDesc& d = g_dw_group.d[g_dw_group.n++];
+        d.slabs = slabs; d.dst = dW; d.part = db ? part : nullptr; d.db = db; d.slab_stride = (int64_t)N * K; d.ldd = lddw;
+        d.splits = real_splits; d.rows = N; d.cols = K; d.vec = v4 ? 1 : 0; d.beta = beta; d.block0 = g_dw_group.block_end;
+        const int64_t want = (total + 1023) / 1024;          // ~4 elements (float4s) per thread
+        g_dw_group.block_end += (int)(want < 1 ? 1 : (want > 2048 ? 2048 : want));
+        return NACF_OK;
+      }
+    }
     const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
     if (v4)
       hipLaunchKernelGGL(splitk_reduce_kernel<true>, dim3(blocks), dim3(256), 0, s, slabs, (int64_t)N * K, real_splits, dW,

@@ -24,6 +24,8 @@ import sys
 
 import torch
 
+from . import ops
+
 
 BATCH_KEYS = ('feats', 'feats_a', 'feats_m', 'feats_i', 'tokens', 'tokens_1', 'labels', 'labels_1', 'category',
               'length_target')         # what misc/run.py:get_forword_results reads from a batch
@@ -78,19 +80,24 @@ class TrainStep(object):
         loss = self.crit.get_loss(self.forward(b))
         if self.staged and self.three is None:
             self.three = self.hsplit is not None and bool(getattr(self.model, '_cut_head', None))
-        if self.staged and self.three:
-            self._hold['hcut'], self._hold['hgrads'] = self.ddp.backward_head(loss)
-        elif self.staged:
-            self._hold['cut'], self._hold['grads'] = self.ddp.backward_to_cut(loss)
-        else:
-            loss.backward()
+        # every backward stage queues the split-K combines of its weight-gradient GEMMs and runs them in one launch at
+        # its end (ops.dw_group): a stage's gradient bucket is complete -- ready for its all-reduce -- when it returns
+        with ops.dw_group():
+            if self.staged and self.three:
+                self._hold['hcut'], self._hold['hgrads'] = self.ddp.backward_head(loss)
+            elif self.staged:
+                self._hold['cut'], self._hold['grads'] = self.ddp.backward_to_cut(loss)
+            else:
+                loss.backward()
         self.loss.copy_(loss.detach())
 
     def _mid(self):
-        self._hold['cut'], self._hold['grads'] = self.ddp.backward_mid(self._hold['hcut'], self._hold['hgrads'])
+        with ops.dw_group():
+            self._hold['cut'], self._hold['grads'] = self.ddp.backward_mid(self._hold['hcut'], self._hold['hgrads'])
 
     def _back(self):
-        self.ddp.backward_from_cut(self._hold['cut'], self._hold['grads'])
+        with ops.dw_group():
+            self.ddp.backward_from_cut(self._hold['cut'], self._hold['grads'])
 
     def _update(self, part=None):
         """part None: every parameter; 0: the late bucket flat[split:] (starts the step), 1: the rest flat[:split]"""

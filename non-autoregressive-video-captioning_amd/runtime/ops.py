@@ -6,6 +6,7 @@ computation below is a libnacf_hip kernel launched on torch's current stream.
 from __future__ import annotations
 
 import ctypes
+import os
 from typing import Optional
 
 import torch
@@ -323,6 +324,87 @@ def linear_bwd_data(dz: Tensor, w: Tensor, dx: Tensor, beta: float = 0.0, rows: 
     return dx
 
 
+class _DwGroup:
+    """Deferred split-K combines of the weight-gradient GEMMs of one backward pass (nacf_dw_group_*, include/nacf_hip.h).
+
+    While a group is open every linear_bwd_weight call launches its GEMM at once but leaves the combine of its partial
+    slabs for `flush`, which runs them all in ONE launch (12 ~10 us kernels per NACF step otherwise).  Each call gets its
+    own slice of a dedicated grow-only buffer (the slabs must survive until the flush); a second gradient for the same dW
+    (a layer applied twice) flushes first, so its read-modify-write sees the first one's result."""
+
+    def __init__(self):
+        self.ws = _Workspace()
+        self.active = False
+        self.offset = 0
+        self.targets = set()
+        self.device = None
+
+    def begin(self):
+        if self.active:
+            self.flush()
+        L.check(L.load().nacf_dw_group_begin(), "nacf_dw_group_begin")
+        self.active, self.offset = True, 0
+        self.targets.clear()
+
+    def flush(self):
+        if self.active:
+            self.active = False
+            self.targets.clear()
+            self.offset = 0
+            L.check(L.load().nacf_dw_group_flush(_stream()), "nacf_dw_group_flush")
+
+    def _restart(self):
+        self.flush()
+        self.begin()
+
+    def region(self, need: int, dw: Tensor) -> Tensor:
+        key = dw.data_ptr()
+        if key in self.targets:
+            self._restart()
+        need = (int(need) + 255) // 256 * 256
+        buf = self.ws.buf.get(dw.device.index if dw.device.index is not None else torch.cuda.current_device())
+        if buf is None or self.offset + need > buf.numel():
+            # queued combines point into the old buffer: run them before it is replaced by a larger one
+            if self.offset > 0:
+                self._restart()
+            have = 0 if buf is None else buf.numel()
+            buf = self.ws.get(max(need, 2 * have, 64 << 20), dw.device)
+        elif torch.cuda.is_current_stream_capturing():
+            self.ws.get(1, dw.device)          # mark the buffer as seen by a capture (never freed from now on)
+        self.targets.add(key)
+        out = buf[self.offset:self.offset + need]
+        self.offset += need
+        return out
+
+
+DW_GROUP = _DwGroup()
+
+
+class dw_group:
+    """with ops.dw_group(): <a backward pass>  -- combines deferred inside, all run when the block exits"""
+
+    def __enter__(self):
+        if os.environ.get("NACF_DW_GROUP", "1") != "0":      # tuning switch: 0 = every combine right behind its GEMM
+            DW_GROUP.begin()
+        return DW_GROUP
+
+    def __exit__(self, et, ev, tb):
+        if et is None:
+            DW_GROUP.flush()
+        else:                                  # a failed backward: drop the queue, keep the original error
+            DW_GROUP.active = False
+            L.load().nacf_dw_group_flush(_stream())
+        return False
+
+
+def dw_group_begin() -> None:
+    DW_GROUP.begin()
+
+
+def dw_group_flush() -> None:
+    DW_GROUP.flush()
+
+
 def linear_bwd_weight(dz: Tensor, x: Tensor, dw: Tensor, db: Optional[Tensor], beta: float = 1.0,
                       rows: Optional[RowSet] = None) -> None:
     _chk_f32(dz, x, dw, db)
@@ -331,7 +413,7 @@ def linear_bwd_weight(dz: Tensor, x: Tensor, dw: Tensor, db: Optional[Tensor], b
     assert M == M2 and dw.shape == (N, K), (dz.shape, x.shape, dw.shape)
     lib = L.load()
     need = lib.nacf_linear_bwd_weight_workspace(M, N, K)
-    ws = WORKSPACE.get(need, dz.device)
+    ws = DW_GROUP.region(need, dw) if DW_GROUP.active else WORKSPACE.get(need, dz.device)
     tok = PROFILER.begin(2, M, N, K, "EpiStore", rows)
     L.check(lib.nacf_linear_bwd_weight(_ptr(dz), lddz, _ptr(x), ldx, _ptr(dw), dw.stride(0), _ptr(db), M, N, K,
                                        float(beta), _ptr(ws), ws.numel(), _rs(rows), _stream()),

@@ -972,3 +972,44 @@ def test_sync_bn_kernels_equal_the_global_batch(dev, B, Fr, D, world):
     assert err(torch.cat(outs)[:, f_off:f_off + Fr].reshape(B * Fr, D), y) < 5e-5
     y.backward(dout[:, f_off:f_off + Fr].double().cpu().reshape(B * Fr, D))
     assert err(torch.cat(dxs).reshape(B * Fr, D), xd.grad) < 5e-5 * max(1.0, float(xd.grad.abs().max()))
+
+
+def test_deferred_dw_combines_are_bit_identical(dev):
+    """ops.dw_group(): the split-K combines of many weight-gradient GEMMs run in one launch at the end -- same sums bit
+    for bit as the per-call combine; a second gradient for the same dW is serialised; more than 32 queued combines
+    flush themselves; the slabs of every queued combine survive until the flush (own workspace slices)."""
+    from nacf_amd.runtime import lib as L, ops
+    g = torch.Generator().manual_seed(3)
+    r = lambda *s: (torch.rand(*s, generator=g) * 2 - 1).to(dev)
+    shapes = [(2980, 512, 512), (2980, 2048, 512), (2980, 512, 2048), (7680, 512, 2048), (5120, 1536, 512), (777, 96, 200),
+              (3000, 20, 512)]
+    probs = [(r(M, N), r(M, K), r(N, K), r(N)) for M, N, K in shapes]
+    ref = []
+    for dz, x, w0, b0 in probs:
+        dw, db = w0.clone(), b0.clone()
+        ops.linear_bwd_weight(dz, x, dw, db, beta=1.0)
+        ops.linear_bwd_weight(dz, x, dw, db, beta=1.0)          # the layer applied twice: accumulates
+        ref.append((dw, db))
+    torch.cuda.synchronize()
+    out = [(w0.clone(), b0.clone()) for _, _, w0, b0 in probs]
+    with ops.dw_group():
+        for (dz, x, _, _), (dw, db) in zip(probs, out):
+            ops.linear_bwd_weight(dz, x, dw, db, beta=1.0)
+        assert L.load().nacf_dw_group_pending() > 0
+        for (dz, x, _, _), (dw, db) in zip(probs, out):          # same targets again: the group restarts by itself
+            ops.linear_bwd_weight(dz, x, dw, db, beta=1.0)
+    assert L.load().nacf_dw_group_pending() == -1
+    torch.cuda.synchronize()
+    for (a, b), (c, d), shp in zip(ref, out, shapes):
+        assert torch.equal(a, c) and torch.equal(b, d), shp
+    # more combines than the queue holds
+    many = [(r(1500, 64), r(1500, 64)) for _ in range(40)]
+    dws_ref = [torch.zeros(64, 64, device=dev) for _ in many]
+    dws = [torch.zeros(64, 64, device=dev) for _ in many]
+    for (dz, x), dw in zip(many, dws_ref):
+        ops.linear_bwd_weight(dz, x, dw, None, beta=0.0)
+    with ops.dw_group():
+        for (dz, x), dw in zip(many, dws):
+            ops.linear_bwd_weight(dz, x, dw, None, beta=0.0)
+    torch.cuda.synchronize()
+    assert all(torch.equal(a, b) for a, b in zip(dws_ref, dws))
