@@ -168,9 +168,11 @@ def roofline_from(summ, n_prof, mode, prefer_single=True):
           "all_gemm_tflops": round(all_tf, 2), "all_gemm_frac_of_mode_peak": round(all_tf / MODE_PEAK[mode], 4),
           # rocprofv3 --pmc on this kernel family (profiles/r02_gemm_pmc_counters.txt) and the per-phase cycle stamps of
           # tools/bf16_trace.py (profiles/r02_bf16_phase_trace.txt): the matrix pipe is NOT what limits K = 512 launches
-          "limiter": "per k-tile the staging phase (global-load issue ~32 B/clk/CU, operand split, LDS stores) is longer "
-                     "than the MFMA phase and two 128x128 workgroups fit a CU: SQ_VALU_MFMA_BUSY ~45 % of active cycles; "
-                     "`bound` names the roof the kernel is priced against, not a saturated unit"}
+          "limiter": "K = 512 launches: a workgroup spends ~20 % of its life in prologue + epilogue (no MFMA), per k-tile "
+                     "the LDS store phase (48 KB at ~80 B/clk/CU) and barriers add ~900 cycles to a 2000-2300 cycle MFMA "
+                     "phase (floor 1536), and only two 128x128 workgroups fit a CU: SQ_VALU_MFMA_BUSY ~53 % of active "
+                     "cycles (exact mode; ~20 % in the bf16 mode); `bound` names the roof the kernel is priced against, "
+                     "not a saturated unit"}
     tab = newest_traffic_table()
     if tab is not None:
         path, age_h, data = tab
