@@ -64,7 +64,7 @@ int nacf_version(void);
  * included).  nacf_abi_count() returns the value the LIBRARY was built with; the ctypes loader
  * (runtime/lib.py:load) refuses a library whose count differs from its own signature table, so a stale
  * libnacf_hip.so next to a newer Python package fails at import time, not at the first missing symbol. */
-#define NACF_ABI_COUNT 73
+#define NACF_ABI_COUNT 74
 int nacf_abi_count(void);
 
 /* ---- batch construction (reference: dataloader.py) ----------------------------------------
@@ -173,16 +173,24 @@ int nacf_linear_bwd_weight(const float* dZ, int64_t lddz, const float* X, int64_
                            float beta, void* ws, size_t ws_bytes, const nacf_rowset* rows,
                            nacf_stream_t stream);
 
-/* Deferred split-K combines.  Between nacf_dw_group_begin() and nacf_dw_group_flush(), nacf_linear_bwd_weight still
- * launches its GEMM at once but QUEUES the combine of its partial slabs (and of the bias-gradient partials); flush
- * runs every queued combine in one launch (same slab order as the per-call kernel: bit-identical sums).  Contract for
- * the caller while a group is open: each call gets its own `ws` region, left untouched until the flush; one dW target
- * is queued at most once (a second call for the same dW returns NACF_EINVAL -- flush first); dW / db are not read by
- * anything else before the flush.  The queue holds 32 combines and flushes itself (on the calling stream) when full.
- * nacf_dw_group_pending: queued combines, or -1 when no group is open.  One group at a time per process. */
-int nacf_dw_group_begin(void);
+/* Grouped weight gradients.  Between nacf_dw_group_begin(defer_gemm) and nacf_dw_group_flush(stream):
+ *   defer_gemm = 0: nacf_linear_bwd_weight launches its GEMM at once but QUEUES the combine of its partial slabs (and of
+ *     the bias-gradient partials); the flush runs every queued combine in one launch.
+ *   defer_gemm = 1: the GEMM itself is queued too (calls that the 128x128 bf16 kernel serves: bf16 / bf16x3 mode,
+ *     16-byte addressable operands, N, K >= 128; the others behave as with 0).  The flush launches all queued GEMMs as
+ *     ONE grid per 16 problems (a device-side table of problems, longest reduce walks first) with reduce splits chosen
+ *     for the group as a whole -- 1-4 instead of the 8-17 a lone launch needs to fill 256 CUs -- then the combines.
+ * Sums are taken in a fixed order either way (slab index), so results are deterministic; with defer_gemm = 1 the split
+ * count differs from the ungrouped call's, so they are equal to it only to rounding.
+ * Contract for the caller while a group is open: each call gets its own `ws` region, untouched until the flush; with
+ * defer_gemm = 1 dZ, X and the row set are untouched until the flush as well; one dW target is queued at most once (a
+ * second call for the same dW returns NACF_EINVAL -- flush first); dW / db are not read before the flush.
+ * nacf_dw_group_pending: queued GEMMs + combines, or -1 when no group is open.  nacf_dw_group_stats: grouped GEMM
+ * launches and their workgroups at the last flush.  One group at a time per process. */
+int nacf_dw_group_begin(int defer_gemm);
 int nacf_dw_group_flush(nacf_stream_t stream);
 int nacf_dw_group_pending(void);
+int nacf_dw_group_stats(int* launches, int* workgroups);
 
 /* Which GEMM kernel a call will launch (for profiling / roofline bookkeeping):
  * kind 0 = linear_fwd (also vocab_argmax), 1 = linear_bwd_data, 2 = linear_bwd_weight,

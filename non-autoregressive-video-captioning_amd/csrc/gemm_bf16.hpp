@@ -335,8 +335,10 @@ constexpr int gemm_bf16_lds_chunks() {
 }
 
 // ---------------------------------------------------------------- kernel
+// The body of one workgroup: output tile `bid` (XCD-remapped below) of reduce split `z` out of `nz`.  Shared by the plain
+// launch (one problem per grid: bid = blockIdx.x, z = blockIdx.z) and the grouped launch (a table of problems per grid).
 template <int BM, int BN, int QSRC, int PSRC, int NS, int STAGES, class Epi>
-__global__ __launch_bounds__(256, (BM == 64 ? 3 : 2)) void gemm_bf16_kernel(GemmShape g, Epi epi) {
+__device__ __forceinline__ void gemm_bf16_body(const GemmShape& g, const Epi& epi, const int bid, const int z, const int nz) {
   constexpr int BK = 32;
   constexpr int WM = 2, WN = 2;
   constexpr int WTM = BM / WM, WTN = BN / WN;
@@ -373,11 +375,10 @@ __global__ __launch_bounds__(256, (BM == 64 ? 3 : 2)) void gemm_bf16_kernel(Gemm
   }
   const int tiles_m_live = (Meff + BM - 1) / BM;
   const int nwg = tiles_m_live * g.tiles_n;
-  const int bid = blockIdx.x;
   if (bid >= nwg) {
     // workgroups past the live tiles zero-fill the dead rows of the output (nacf_rowset.zero_dead)
     if constexpr (!ROWS_ARE_K) {
-      if (g.zero_dead && g.rows && blockIdx.z == 0) {
+      if (g.zero_dead && g.rows && z == 0) {
         const int dt = bid - nwg;
         const int j0 = (dt / g.tiles_n) * BM, c0 = (dt % g.tiles_n) * BN;
         const int n_dead = g.M - Meff;
@@ -403,10 +404,9 @@ __global__ __launch_bounds__(256, (BM == 64 ? 3 : 2)) void gemm_bf16_kernel(Gemm
   }
   const int m0 = tile_m * BM, n0 = tile_n * BN;
 
-  const int z = blockIdx.z;
   int kps = g.k_per_split;
-  if (ROWS_ARE_K && g.count && gridDim.z > 1) {
-    kps = (((Keff + (int)gridDim.z - 1) / (int)gridDim.z) + BK - 1) / BK * BK;   // re-balance over the LIVE rows
+  if (ROWS_ARE_K && g.count && nz > 1) {
+    kps = (((Keff + nz - 1) / nz) + BK - 1) / BK * BK;   // re-balance over the LIVE rows
     if (kps < BK) kps = BK;
   }
   const int kbeg = z * kps;
@@ -805,6 +805,38 @@ __global__ __launch_bounds__(256, (BM == 64 ? 3 : 2)) void gemm_bf16_kernel(Gemm
     g_bf16_trace[((size_t)blockIdx.z * gridDim.x + blockIdx.x) * 16 + 12] = t_issued;
   }
 #endif
+}
+
+template <int BM, int BN, int QSRC, int PSRC, int NS, int STAGES, class Epi>
+__global__ __launch_bounds__(256, (BM == 64 ? 3 : 2)) void gemm_bf16_kernel(GemmShape g, Epi epi) {
+  gemm_bf16_body<BM, BN, QSRC, PSRC, NS, STAGES, Epi>(g, epi, (int)blockIdx.x, (int)blockIdx.z, (int)gridDim.z);
+}
+
+// ---------------------------------------------------------------- grouped launch
+// Several INDEPENDENT problems of one kernel type in a single grid: workgroup range [wg0[p], wg0[p + 1]) belongs to
+// problem p, laid out as nz[p] reduce splits of gx[p] workgroups each (gx a multiple of 8, so that the XCD a workgroup
+// lands on -- blockIdx.x & 7 -- is the one the body's tile remap assumes; surplus workgroups return at once).  Built for
+// the weight-gradient GEMMs of a backward pass: launched one at a time each has to split its reduce dimension 8-17 ways
+// to fill 256 CUs; launched together 1-4 ways do, with k-loops that much longer and that many fewer slabs to combine.
+constexpr int GEMM_GROUP_MAX = 16;
+template <class Epi>
+struct GemmGroup {
+  int n;
+  int wg0[GEMM_GROUP_MAX + 1];
+  int gx[GEMM_GROUP_MAX];
+  int nz[GEMM_GROUP_MAX];
+  GemmShape g[GEMM_GROUP_MAX];
+  Epi e[GEMM_GROUP_MAX];
+};
+template <int BM, int BN, int QSRC, int PSRC, int NS, int STAGES, class Epi>
+__global__ __launch_bounds__(256, (BM == 64 ? 3 : 2)) void gemm_bf16_group_kernel(GemmGroup<Epi> t) {
+  int p = 0;
+#pragma unroll 1
+  while (p + 1 < t.n && (int)blockIdx.x >= t.wg0[p + 1]) ++p;
+  const int local = (int)blockIdx.x - t.wg0[p];
+  const int gx = t.gx[p];
+  const int z = local / gx;
+  gemm_bf16_body<BM, BN, QSRC, PSRC, NS, STAGES, Epi>(t.g[p], t.e[p], local - z * gx, z, t.nz[p]);
 }
 
 // ---------------------------------------------------------------- weight images

@@ -14,6 +14,7 @@ void launch_bf16_linear(GemmShape g, const EpiLinear& epi, int tile, int ns, hip
 void launch_bf16_argmax(GemmShape g, const EpiArgmax& epi, int tile, int ns, hipStream_t s);              // + soft-max stats
 void launch_bf16_dx(GemmShape g, const EpiStore& epi, int splits, int tile, int ns, hipStream_t s);       // dX = dZ W
 void launch_bf16_dw(GemmShape g, const EpiStore& epi, int splits, int tile, int ns, hipStream_t s);       // dW = dZ^T X
+void launch_bf16_dw_group(const GemmGroup<EpiStore>& t, int ns, hipStream_t s);                            // grouped dW (128x128 tiles)
 void launch_wimage_refresh(const WImageDesc* descs, int n_desc, int n_tiles, int ns, hipStream_t s);
 // "gemm_bf16_kernel<BM, BN, QSRC, PSRC, NS, STAGES, Epi>" of the launch the calling thread made last (profiling aid)
 const char* bf16_last_kernel_name();

@@ -4,6 +4,7 @@
 #include "gemm_bf16_launch.hpp"
 #include <stdlib.h>
 #include <mutex>
+#include <algorithm>
 #include <string.h>
 #include <vector>
 
@@ -542,7 +543,145 @@ static std::mutex g_dw_group_mu;
 static bool g_dw_group_on = false;
 static DwReduceTable g_dw_group = {};
 
+// GEMMs deferred as well (nacf_dw_group_begin(1)): what nacf_linear_bwd_weight was asked to do, replayed at the flush
+struct DwGemmItem {
+  const float* dZ; const float* X; float* dW; float* db; float* ws;
+  int64_t lddz, ldx, lddw;
+  size_t ws_bytes;
+  int M, N, K, has_rs;
+  float beta;
+  nacf_rowset rs;
+};
+static std::vector<DwGemmItem> g_dw_items;
+static int g_dw_defer_gemm = 0;
+static int g_dw_last_group_launches = 0, g_dw_last_group_wgs = 0;
+
+static int dw_combine_push_locked(float* slabs, float* dW, int64_t lddw, const float* part, float* db, int N, int K, int real_splits,
+                                  float beta, hipStream_t s);
+static int dw_group_flush_locked(hipStream_t s);
+
+// Launch every queued weight-gradient GEMM in grouped grids.  Splits: with W = sum of (output tiles x k-tiles) over the
+// group, a workgroup should walk about W / target k-tiles (target = NACF_DW_GROUP_WGS, default 1024 = two rounds of the
+// 512 resident 128x128 workgroups), never fewer than 24; a problem gets ceil(its k-tiles / that) splits.  Longest walks
+// first in the grid, so that the short ones fill the tail.
+static int dw_items_launch_locked(hipStream_t s) {
+  const int n = (int)g_dw_items.size();
+  g_dw_last_group_launches = 0;
+  g_dw_last_group_wgs = 0;
+  if (n == 0) return NACF_OK;
+  static const int target_env = [] { const char* e = getenv("NACF_DW_GROUP_WGS"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 0; }();
+  const int mode = gemm_mode();
+  // measured on the NACF step (bench.py, B = 128): exact mode 1024: 2.91 ms, 1280: 2.89, 1536: 2.90, 3072: 2.93;
+  // throughput mode (its k-tiles are 3x shorter, the fixed cost of a split weighs less) 1024: 2.30, 1536: 2.12, 4096: 2.08
+  const int target = target_env > 0 ? target_env : (mode == NACF_GEMM_BF16 ? 4096 : 1280);
+  std::vector<int> kt(n), tiles(n), sp(n), order(n);
+  long W = 0;
+  for (int i = 0; i < n; ++i) {
+    const DwGemmItem& it = g_dw_items[i];
+    const int m_eff = it.has_rs ? (int)((long)it.M * 29 / 50) : it.M;
+    kt[i] = cdiv(m_eff > 0 ? m_eff : 1, 32);
+    tiles[i] = cdiv(it.N, 128) * cdiv(it.K, 128);
+    W += (long)kt[i] * tiles[i];
+    order[i] = i;
+  }
+  long walk = (W + target - 1) / target;
+  if (walk < 24) walk = 24;
+  for (int i = 0; i < n; ++i) {
+    const DwGemmItem& it = g_dw_items[i];
+    const size_t fixed = (size_t)64 * it.N * sizeof(float) + 256;
+    long max_s = it.ws_bytes > fixed ? (long)((it.ws_bytes - fixed) / ((size_t)it.N * it.K * sizeof(float))) : 1;
+    if (max_s > 64) max_s = 64;
+    if (max_s < 1) max_s = 1;
+    long sps = (kt[i] + walk - 1) / walk;
+    if (sps > max_s) sps = max_s;
+    if (sps < 1) sps = 1;
+    sp[i] = (int)sps;
+  }
+  std::sort(order.begin(), order.end(), [&](int a, int b) {
+    const long wa = (long)kt[a] * sp[b], wb = (long)kt[b] * sp[a];      // kt / sp, longest first
+    return wa != wb ? wa > wb : a < b;
+  });
+  int done = 0;
+  while (done < n) {
+    if (g_dw_group.n + GEMM_GROUP_MAX > DW_GROUP_MAX) {
+      // room for this chunk's combines: everything queued so far belongs to GEMMs that are already in the stream
+      hipLaunchKernelGGL(dw_group_reduce_kernel, dim3(g_dw_group.block_end), dim3(256), 0, s, g_dw_group);
+      g_dw_group.n = 0;
+      g_dw_group.block_end = 0;
+      NACF_LAUNCH_CHECK("nacf_dw_group_flush(combine, between chunks)");
+    }
+    GemmGroup<EpiStore> t = {};
+    int wg = 0;
+    for (; done < n && t.n < GEMM_GROUP_MAX; ++done) {
+      const DwGemmItem& it = g_dw_items[order[done]];
+      const int i = order[done];
+      GemmShape g = {};
+      g.Q = it.dZ; g.P = it.X; g.ldq = it.lddz; g.ldp = it.ldx; g.M = it.N; g.N = it.K; g.K = it.M;
+      g.k_per_split = cdiv(cdiv(it.M, sp[i]), 32) * 32;
+      set_rows(g, it.has_rs ? &it.rs : nullptr);
+      g.tiles_m = cdiv(g.M, 128);
+      g.tiles_n = cdiv(g.N, 128);
+      const int real = cdiv(it.M, g.k_per_split);
+      float* slabs = it.ws;
+      float* part = slabs + (real > 1 ? (size_t)real * it.N * it.K : 0);
+      EpiStore epi;
+      if (real > 1) {
+        epi.C = slabs; epi.ldc = it.K; epi.beta = 0.f; epi.slab_stride = (int64_t)it.N * it.K; epi.vec_out = (it.K % 4 == 0) ? 1 : 0;
+      } else {
+        epi.C = it.dW; epi.ldc = it.lddw; epi.beta = it.beta; epi.slab_stride = 0;
+        epi.vec_out = ((it.lddw % 4 == 0) && aligned16(it.dW)) ? 1 : 0;
+      }
+      if (it.db) {
+        if (real > 1) g.colsum_part = part;
+        else { g.colsum_out = it.db; g.colsum_beta = it.beta; }
+      }
+      const int gx = (tiles[i] + 7) / 8 * 8;
+      t.g[t.n] = g; t.e[t.n] = epi; t.gx[t.n] = gx; t.nz[t.n] = real; t.wg0[t.n] = wg;
+      wg += gx * real;
+      ++t.n;
+      if (real > 1) {
+        const int rc = dw_combine_push_locked(slabs, it.dW, it.lddw, it.db ? part : nullptr, it.db, it.N, it.K, real, it.beta, s);
+        if (rc != NACF_OK) return rc;
+      }
+    }
+    t.wg0[t.n] = wg;
+    launch_bf16_dw_group(t, mode, s);
+    g_last_was_bf16 = true;
+    NACF_LAUNCH_CHECK("nacf_dw_group_flush(grouped gemm)");
+    ++g_dw_last_group_launches;
+    g_dw_last_group_wgs += wg;
+  }
+  g_dw_items.clear();
+  return NACF_OK;
+}
+
+static int dw_combine_push_locked(float* slabs, float* dW, int64_t lddw, const float* part, float* db, int N, int K, int real_splits,
+                                  float beta, hipStream_t s) {
+  const bool v4 = (K % 4 == 0) && (lddw % 4 == 0) && aligned16(dW) && aligned16(slabs);
+  const int64_t total = (int64_t)N * (v4 ? K / 4 : K);
+  if (g_dw_group.n == DW_GROUP_MAX) {
+    // NOTE: only legal when every GEMM whose combine is queued has been launched -- true for the immediate-GEMM mode; the
+    // deferred-GEMM flush queues at most GEMM_GROUP_MAX combines per grouped launch and launches before the next chunk
+    hipLaunchKernelGGL(dw_group_reduce_kernel, dim3(g_dw_group.block_end), dim3(256), 0, s, g_dw_group);
+    g_dw_group.n = 0;
+    g_dw_group.block_end = 0;
+    NACF_LAUNCH_CHECK("nacf_dw_group(combine, queue full)");
+  }
+  for (int i = 0; i < g_dw_group.n; ++i)
+    NACF_CHECK(g_dw_group.d[i].dst != dW, NACF_EINVAL, "nacf_linear_bwd_weight: this dW already has a deferred combine pending (flush first)");
+  DwReduceDesc& d = g_dw_group.d[g_dw_group.n++];
+  d.slabs = slabs; d.dst = dW; d.part = part; d.db = db; d.slab_stride = (int64_t)N * K; d.ldd = lddw;
+  d.splits = real_splits; d.rows = N; d.cols = K; d.vec = v4 ? 1 : 0; d.beta = beta; d.block0 = g_dw_group.block_end;
+  const int64_t want = (total + 1023) / 1024;          // ~4 elements (float4s) per thread
+  g_dw_group.block_end += (int)(want < 1 ? 1 : (want > 2048 ? 2048 : want));
+  return NACF_OK;
+}
+
 static int dw_group_flush_locked(hipStream_t s) {
+  {
+    const int rc = dw_items_launch_locked(s);
+    if (rc != NACF_OK) return rc;
+  }
   if (g_dw_group.n > 0) {
     hipLaunchKernelGGL(dw_group_reduce_kernel, dim3(g_dw_group.block_end), dim3(256), 0, s, g_dw_group);
     g_dw_group.n = 0;
@@ -552,10 +691,18 @@ static int dw_group_flush_locked(hipStream_t s) {
   return NACF_OK;
 }
 
-int nacf_dw_group_begin(void) {
+int nacf_dw_group_begin(int defer_gemm) {
   std::lock_guard<std::mutex> lk(g_dw_group_mu);
-  NACF_CHECK(g_dw_group.n == 0, NACF_EINVAL, "nacf_dw_group_begin: %d combines of the previous group were never flushed", g_dw_group.n);
+  NACF_CHECK(g_dw_group.n == 0 && g_dw_items.empty(), NACF_EINVAL,
+             "nacf_dw_group_begin: %d combines / %d GEMMs of the previous group were never flushed", g_dw_group.n, (int)g_dw_items.size());
   g_dw_group_on = true;
+  g_dw_defer_gemm = defer_gemm ? 1 : 0;
+  return NACF_OK;
+}
+int nacf_dw_group_stats(int* launches, int* workgroups) {
+  std::lock_guard<std::mutex> lk(g_dw_group_mu);
+  if (launches) *launches = g_dw_last_group_launches;
+  if (workgroups) *workgroups = g_dw_last_group_wgs;
   return NACF_OK;
 }
 int nacf_dw_group_flush(nacf_stream_t stream) {
@@ -565,7 +712,7 @@ int nacf_dw_group_flush(nacf_stream_t stream) {
 }
 int nacf_dw_group_pending(void) {
   std::lock_guard<std::mutex> lk(g_dw_group_mu);
-  return g_dw_group_on ? g_dw_group.n : -1;
+  return g_dw_group_on ? g_dw_group.n + (int)g_dw_items.size() : -1;
 }
 
 size_t nacf_linear_bwd_weight_workspace(int M, int N, int K) {
@@ -597,6 +744,22 @@ int nacf_linear_bwd_weight(const float* dZ, int64_t lddz, const float* X, int64_
   const bool bf16 = mode != NACF_GEMM_F32 && vec;
   const int splits = bf16 ? bwd_weight_splits_bf16(M, N, K, rs != nullptr, &tile) : bwd_weight_splits(M, N, K, rs != nullptr, &tile);
   hipStream_t s = as_hip(stream);
+  if (bf16 && N >= 128 && K >= 128 && forced_tile() != 1) {
+    std::lock_guard<std::mutex> lk(g_dw_group_mu);
+    if (g_dw_group_on && g_dw_defer_gemm) {
+      // the whole GEMM waits for the flush (grouped launch): dZ / X / the row set / ws stay untouched until then
+      for (const DwGemmItem& it : g_dw_items)
+        NACF_CHECK(it.dW != dW, NACF_EINVAL, "nacf_linear_bwd_weight: this dW already has a deferred GEMM pending (flush first)");
+      for (int i = 0; i < g_dw_group.n; ++i)
+        NACF_CHECK(g_dw_group.d[i].dst != dW, NACF_EINVAL, "nacf_linear_bwd_weight: this dW already has a deferred combine pending (flush first)");
+      DwGemmItem it = {};
+      it.dZ = dZ; it.X = X; it.dW = dW; it.db = db; it.ws = reinterpret_cast<float*>(ws); it.lddz = lddz; it.ldx = ldx; it.lddw = lddw;
+      it.ws_bytes = ws_bytes; it.M = M; it.N = N; it.K = K; it.has_rs = rs ? 1 : 0; it.beta = beta;
+      if (rs) it.rs = *rs;
+      g_dw_items.push_back(it);
+      return NACF_OK;
+    }
+  }
   // dW[n][k] = sum_m dZ[m][n] X[m][k]: output rows = n (Q = dZ, MC: element (n, m) at dZ[m*lddz + n]),
   // output cols = k (P = X, MC: element (k, m) at X[m*ldx + k]), reduce = m (through the live-row list if given)
   GemmShape g = {};
@@ -630,18 +793,8 @@ int nacf_linear_bwd_weight(const float* dZ, int64_t lddz, const float* X, int64_
     const int64_t total = (int64_t)N * (v4 ? K / 4 : K);
     {
       std::lock_guard<std::mutex> lk(g_dw_group_mu);
-      if (g_dw_group_on) {
-        // deferred: the caller keeps `ws` untouched until nacf_dw_group_flush and never queues one dW twice
-        if (g_dw_group.n == DW_GROUP_MAX) { const int rc = dw_group_flush_locked(s); if (rc != NACF_OK) return rc; }
-        for (int i = 0; i < g_dw_group.n; ++i)
-          NACF_CHECK(g_dw_group.d[i].dst != dW, NACF_EINVAL, "nacf_linear_bwd_weight: this dW already has a deferred combine pending (flush first)");
-        DwReduceDesc& d = g_dw_group.d[g_dw_group.n++];
-        d.slabs = slabs; d.dst = dW; d.part = db ? part : nullptr; d.db = db; d.slab_stride = (int64_t)N * K; d.ldd = lddw;
-        d.splits = real_splits; d.rows = N; d.cols = K; d.vec = v4 ? 1 : 0; d.beta = beta; d.block0 = g_dw_group.block_end;
-        const int64_t want = (total + 1023) / 1024;          // ~4 elements (float4s) per thread
-        g_dw_group.block_end += (int)(want < 1 ? 1 : (want > 2048 ? 2048 : want));
-        return NACF_OK;
-      }
+      // deferred: the caller keeps `ws` untouched until nacf_dw_group_flush and never queues one dW twice
+      if (g_dw_group_on) return dw_combine_push_locked(slabs, dW, lddw, db ? part : nullptr, db, N, K, real_splits, beta, s);
     }
     const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
     if (v4)

@@ -69,7 +69,8 @@ SIGNATURES = {
     "nacf_wimage_unregister": (c_int, [_P, _L]),
     "nacf_wimage_refresh": (c_int, [_P, _I, _I, _I, _P]),
     "nacf_linear_bwd_weight": (c_int, [_P, _L, _P, _L, _P, _L, _P, _I, _I, _I, _F, _P, _S, _RS, _P]),
-    "nacf_dw_group_begin": (c_int, []),
+    "nacf_dw_group_begin": (c_int, [_I]),
+    "nacf_dw_group_stats": (c_int, [_P, _P]),
     "nacf_dw_group_flush": (c_int, [_P]),
     "nacf_dw_group_pending": (c_int, []),
     "nacf_epilogue_bwd": (c_int, [_P, _L, _P, _L, _P, _L, _I, _I, _I, _EP, _P]),

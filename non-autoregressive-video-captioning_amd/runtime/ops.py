@@ -335,14 +335,18 @@ class _DwGroup:
     def __init__(self):
         self.ws = _Workspace()
         self.active = False
+        self.defer_gemm = False
         self.offset = 0
         self.targets = set()
+        self.keep = []           # operands of deferred GEMMs: alive (and unmodified) until the flush has launched them
         self.device = None
 
-    def begin(self):
+    def begin(self, defer_gemm: bool = True):
         if self.active:
             self.flush()
-        L.check(L.load().nacf_dw_group_begin(), "nacf_dw_group_begin")
+        # the GEMM profiler times one launch per call: keep the GEMMs where they are while it is on
+        self.defer_gemm = bool(defer_gemm) and not PROFILER.enabled
+        L.check(L.load().nacf_dw_group_begin(int(self.defer_gemm)), "nacf_dw_group_begin")
         self.active, self.offset = True, 0
         self.targets.clear()
 
@@ -351,11 +355,15 @@ class _DwGroup:
             self.active = False
             self.targets.clear()
             self.offset = 0
-            L.check(L.load().nacf_dw_group_flush(_stream()), "nacf_dw_group_flush")
+            try:
+                L.check(L.load().nacf_dw_group_flush(_stream()), "nacf_dw_group_flush")
+            finally:
+                self.keep.clear()
 
     def _restart(self):
+        d = self.defer_gemm
         self.flush()
-        self.begin()
+        self.begin(d)
 
     def region(self, need: int, dw: Tensor) -> Tensor:
         key = dw.data_ptr()
@@ -383,9 +391,13 @@ DW_GROUP = _DwGroup()
 class dw_group:
     """with ops.dw_group(): <a backward pass>  -- combines deferred inside, all run when the block exits"""
 
+    def __init__(self, defer_gemm: bool = True):
+        self.defer_gemm = defer_gemm
+
     def __enter__(self):
-        if os.environ.get("NACF_DW_GROUP", "1") != "0":      # tuning switch: 0 = every combine right behind its GEMM
-            DW_GROUP.begin()
+        mode = os.environ.get("NACF_DW_GROUP", "2")          # tuning switch: 0 = off, 1 = combines only, 2 = GEMMs too
+        if mode != "0":
+            DW_GROUP.begin(self.defer_gemm and mode != "1")
         return DW_GROUP
 
     def __exit__(self, et, ev, tb):
@@ -394,11 +406,12 @@ class dw_group:
         else:                                  # a failed backward: drop the queue, keep the original error
             DW_GROUP.active = False
             L.load().nacf_dw_group_flush(_stream())
+            DW_GROUP.keep.clear()
         return False
 
 
-def dw_group_begin() -> None:
-    DW_GROUP.begin()
+def dw_group_begin(defer_gemm: bool = True) -> None:
+    DW_GROUP.begin(defer_gemm)
 
 
 def dw_group_flush() -> None:
@@ -414,6 +427,8 @@ def linear_bwd_weight(dz: Tensor, x: Tensor, dw: Tensor, db: Optional[Tensor], b
     lib = L.load()
     need = lib.nacf_linear_bwd_weight_workspace(M, N, K)
     ws = DW_GROUP.region(need, dw) if DW_GROUP.active else WORKSPACE.get(need, dz.device)
+    if DW_GROUP.active and DW_GROUP.defer_gemm:
+        DW_GROUP.keep.append((dz, x, rows, dw, db))
     tok = PROFILER.begin(2, M, N, K, "EpiStore", rows)
     L.check(lib.nacf_linear_bwd_weight(_ptr(dz), lddz, _ptr(x), ldx, _ptr(dw), dw.stride(0), _ptr(db), M, N, K,
                                        float(beta), _ptr(ws), ws.numel(), _rs(rows), _stream()),

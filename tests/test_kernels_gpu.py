@@ -992,7 +992,7 @@ def test_deferred_dw_combines_are_bit_identical(dev):
         ref.append((dw, db))
     torch.cuda.synchronize()
     out = [(w0.clone(), b0.clone()) for _, _, w0, b0 in probs]
-    with ops.dw_group():
+    with ops.dw_group(defer_gemm=False):
         for (dz, x, _, _), (dw, db) in zip(probs, out):
             ops.linear_bwd_weight(dz, x, dw, db, beta=1.0)
         assert L.load().nacf_dw_group_pending() > 0
@@ -1008,8 +1008,77 @@ def test_deferred_dw_combines_are_bit_identical(dev):
     dws = [torch.zeros(64, 64, device=dev) for _ in many]
     for (dz, x), dw in zip(many, dws_ref):
         ops.linear_bwd_weight(dz, x, dw, None, beta=0.0)
-    with ops.dw_group():
+    with ops.dw_group(defer_gemm=False):
         for (dz, x), dw in zip(many, dws):
             ops.linear_bwd_weight(dz, x, dw, None, beta=0.0)
     torch.cuda.synchronize()
     assert all(torch.equal(a, b) for a, b in zip(dws_ref, dws))
+
+
+def test_grouped_dw_gemms(dev):
+    """ops.dw_group() with the GEMMs deferred too: all weight-gradient GEMMs of a backward pass in one grid per 16 problems
+    (device-side problem table, splits chosen for the group).  Against float64: as accurate as the one-at-a-time launches;
+    live-row lists, bias gradients, accumulation (beta = 1), problems the grouped kernel does not take (N < 128: launched
+    at once), more than 16 problems, a dW queued twice (the group restarts), and run-to-run bit-identity."""
+    import ctypes
+    from nacf_amd.runtime import lib as L, ops
+    g = torch.Generator().manual_seed(11)
+    r = lambda *s: (torch.rand(*s, generator=g) * 2 - 1).to(dev)
+    shapes = [(5120, 512, 512), (5120, 2048, 512), (5120, 512, 2048), (7680, 512, 2048), (5120, 1536, 512), (15360, 1024, 512),
+              (5120, 10547, 512), (3000, 20, 512), (128, 512, 512), (2000, 130, 260)]
+    probs = []
+    for i, (M, N, K) in enumerate(shapes):
+        dz, x = r(M, ops.vocab_ld(N))[:, :N], r(M, K)
+        rows = None
+        if i in (0, 1, 6):                                         # decoder-style live-row lists (~58 % live)
+            tok = (torch.rand(M, generator=g) < 0.58).to(dev).long()
+            rows = ops.rowset_build(tokens=tok)                   # tokens != <pad> (0) are live
+        probs.append((dz, x, r(N, K), r(N), rows))
+    lib = L.load()
+
+    def run(grouped):
+        out = [(w0.clone(), b0.clone()) for _, _, w0, b0, _ in probs]
+        if grouped:
+            with ops.dw_group():
+                for (dz, x, _, _, rows), (dw, db) in zip(probs, out):
+                    ops.linear_bwd_weight(dz, x, dw, db, beta=1.0, rows=rows)
+                pending = lib.nacf_dw_group_pending()
+            nl, nw = ctypes.c_int(0), ctypes.c_int(0)
+            lib.nacf_dw_group_stats(ctypes.byref(nl), ctypes.byref(nw))
+            seen.append((pending, nl.value, nw.value))
+        else:
+            for (dz, x, _, _, rows), (dw, db) in zip(probs, out):
+                ops.linear_bwd_weight(dz, x, dw, db, beta=1.0, rows=rows)
+        torch.cuda.synchronize()
+        return out
+
+    seen = []
+    one = run(False)
+    run(True)                     # sizes the group's slab buffer (a growth flushes what is queued: fewer per launch)
+    grp, grp2 = run(True), run(True)
+    if ops.gemm_mode() != 0:       # (the fp32-MFMA family launches one GEMM per call; only its combines are grouped)
+        assert seen[-1][0] >= 8 and seen[-1][1] == 1 and seen[-1][2] > 0, seen      # 8 of the 10 problems in ONE grid
+    for (dz, x, w0, b0, rows), (a, ab), (c, cb), (d, db_) in zip(probs, one, grp, grp2):
+        assert torch.equal(c, d) and torch.equal(cb, db_)          # deterministic
+        dz64, x64 = dz.double(), x.double()
+        if rows is not None:
+            live = rows.rows[:int(rows.count)].long()
+            dz64, x64 = dz64[live], x64[live]
+        ref = w0.double() + dz64.t() @ x64
+        refb = b0.double() + dz64.sum(0)
+        scale = float(ref.abs().max())
+        e_one, e_grp = float((a.double() - ref).abs().max()) / scale, float((c.double() - ref).abs().max()) / scale
+        assert e_grp <= max(2e-6, 1.5 * e_one), (tuple(dz.shape), e_one, e_grp)
+        assert float((cb.double() - refb).abs().max()) <= 1e-5 * float(refb.abs().max()) + 1e-4
+    # two chunks (more than 16 problems) and a repeated target
+    many = [(r(2048, 128), r(2048, 256)) for _ in range(20)]
+    ref = [dz.double().t() @ x.double() for dz, x in many]
+    dws = [torch.zeros(128, 256, device=dev) for _ in many]
+    with ops.dw_group():
+        for (dz, x), dw in zip(many, dws):
+            ops.linear_bwd_weight(dz, x, dw, None, beta=0.0)
+        ops.linear_bwd_weight(many[0][0], many[0][1], dws[0], None, beta=1.0)      # the same dW again: twice the product
+    torch.cuda.synchronize()
+    ref[0] = 2 * ref[0]
+    for a, b in zip(ref, dws):
+        assert float((a - b.double()).abs().max()) <= 2e-6 * float(a.abs().max())
