@@ -190,6 +190,11 @@ def roofline_from(summ, n_prof, mode, prefer_single=True):
 
 def bench_decode(model, dev, feats, category, n_batches, with_roofline=True, mode="bf16x3"):
     from nacf_amd.models.Translator import Translator
+    from nacf_amd import synthetic as O
+    # decode the SEEDED INITIAL weights, not whatever the training legs left behind: at random init the predicted
+    # lengths / re-masked slots -- and with them the executed work per caption -- move with the last bits of the
+    # weights, so a decode of the trained-for-N-steps model is a different workload after every kernel change
+    model.load_state_dict(O.init_state_dict(model.opt, seed=0))
     model.eval()
     B = feats[0].shape[0]
     tr = Translator(model, dict(model.opt), device=dev)
@@ -206,7 +211,7 @@ def bench_decode(model, dev, feats, category, n_batches, with_roofline=True, mod
         hyp = dec_once()
     torch.cuda.synchronize()
     ddt = (time.perf_counter() - t1) / n_batches
-    out = {"captions_per_s": round(B / ddt, 1), "ms_per_batch": round(ddt * 1e3, 2), "batch": B,
+    out = {"captions_per_s": round(B / ddt, 1), "ms_per_batch": round(ddt * 1e3, 2), "batch": B, "weights": "seeded init (seed 0)",
            "paradigm": "mp+ct" if model.opt.get("use_ct") else "mp", "iterations": 5, "length_beam_size": 6,
            "width": int(hyp.shape[1]), "hipgraph": any(k[0] != "seen" for k in getattr(model, "_nacf_decode_graphs", {}))}
     if with_roofline:
