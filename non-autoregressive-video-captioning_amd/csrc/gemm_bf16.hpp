@@ -99,6 +99,10 @@ __device__ __forceinline__ void bf16_split2(float a, float b, uint32_t (&w)[NS])
   }
 }
 
+#ifndef NACF_X3_DEEP
+#define NACF_X3_DEEP 1
+#endif
+
 // ---------------------------------------------------------------- staging: global -> registers -> LDS planes
 // An LDS plane of R rows is R*4 16-byte chunks: chunk (row, c) at plane[row * 4 + (c ^ lds_sw(row))].
 
@@ -557,12 +561,13 @@ __device__ __forceinline__ void gemm_bf16_body(const GemmShape& g, const Epi& ep
   // Q split and its stores, the loads of tile kt+2 -- shares one straight-line block with the MFMAs of tile kt.  Term
   // outermost: an accumulator comes back after TM * TN matrix instructions (the per-accumulator order of the six terms,
   // and with it every bit of the result, is that of compute()).
-  auto compute_split2 = [&](int kt) {
-    if constexpr (NS == 3 && STAGES == 2 && QSRC != SRC_BF16_KC) {
+  // QS / PS: the register set that holds tile kt+1; `ahead` = how many tiles further the set is re-loaded for (2: the one
+  // register set of the general pipeline; 3: two sets alternate, every load has TWO iterations to land -- see the loop)
+  auto compute_split2 = [&](int kt, auto& QS, auto& PS, int ahead) {
+    if constexpr (NS == 3 && STAGES == 2 && QSRC == SRC_F32_KC && PSRC == SRC_BF16_KC) {
       const int cur = kt & 1, nxt = cur ^ 1;
-      write_p(nxt);
-      load_p(kt + 2, true, true);
-      if constexpr (QSRC != SRC_F32_KC) { if (do_colsum) qsum += (qs.v[0] + qs.v[1]) + (qs.v[2] + qs.v[3]); }
+      PS.write(p_stage(nxt), tid);
+      PS.load(kbeg + (kt + ahead) * BK, g.ldpi, g.pimg_plane);
       const u32x4* qpl = q_stage(cur);
       const u32x4* ppl = p_stage(cur);
       bf16x8_t pf[TN][NS], qf[TM][NS];
@@ -587,13 +592,13 @@ __device__ __forceinline__ void gemm_bf16_body(const GemmShape& g, const Epi& ep
             const int slot = (t * TM + a) * TN + b;
 #pragma unroll
             for (int i = 0; i < NSTEP; ++i)
-              if (i * NSLOT / NSTEP == slot) qs.split_step(i / 7, i % 7);
+              if (i * NSLOT / NSTEP == slot) QS.split_step(i / 7, i % 7);
             __builtin_amdgcn_sched_barrier(0);
           }
         }
       }
-      store_q(nxt);
-      load_q(kt + 2, true, true);
+      QS.store(q_stage(nxt), tid);
+      QS.load_fast(kbeg + (kt + ahead) * BK);
     }
   };
 
@@ -627,10 +632,33 @@ __device__ __forceinline__ void gemm_bf16_body(const GemmShape& g, const Epi& ep
     // may slide the staging instructions of the OTHER LDS image into the shadows of this tile's MFMAs.  A launch of
     // less than one round of workgroups (the decoder's 512-wide GEMMs) has nobody else to hide them behind.
     const int n_steady = rows_full ? min(nk - 2, (kend - kbeg) / BK - 2) : 0;
+    if constexpr (NS == 3 && BM == 64 && QSRC == SRC_F32_KC && PSRC == SRC_BF16_KC && NACF_X3_DEEP) {
+      // The 64 x 64 launches of the decoder layers are under one round of workgroups (<= 3 per CU): nothing hides a
+      // global load but the workgroup's own next iteration, and an iteration (24 MFMAs per wave) is shorter than the
+      // load latency under load -- the k-loop ran at one memory latency per k-tile.  Two register sets, alternating:
+      // iteration kt consumes tile kt+1 from one set and re-loads that set with tile kt+3, so every load has two
+      // iterations to land.  Unrolled by two (the sets are distinct variables); an even count keeps tile kt+1 in qs / ps
+      // for the general loop that follows.
+      int n_deep = rows_full ? min(nk - 3, (kend - kbeg) / BK - 3) : 0;
+      n_deep &= ~1;
+      if (n_deep > 0) {
+        auto qs2 = qs;
+        auto ps2 = ps;
+        qs2.load_fast(kbeg + 2 * BK);
+        ps2.load(kbeg + 2 * BK, g.ldpi, g.pimg_plane);
+#pragma nounroll
+        for (; kt_first < n_deep; kt_first += 2) {
+          compute_split2(kt_first, qs, ps, 3);
+          __syncthreads();
+          compute_split2(kt_first + 1, qs2, ps2, 3);
+          __syncthreads();
+        }
+      }
+    }
 #pragma nounroll
     for (; kt_first < n_steady; ++kt_first) {
-      if constexpr (NS == 3 && BM == 64 && PSRC == SRC_BF16_KC) {      // (dW's two converted operands measure slower this way)
-        compute_split2(kt_first);
+      if constexpr (NS == 3 && BM == 64 && QSRC == SRC_F32_KC && PSRC == SRC_BF16_KC) {   // (dW's two converted operands measure slower this way)
+        compute_split2(kt_first, qs, ps, 2);
       } else {
         write_q((kt_first + 1) & 1);
         write_p((kt_first + 1) & 1);
