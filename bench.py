@@ -170,7 +170,7 @@ def roofline_from(summ, n_prof, mode, prefer_single=True):
           # tools/bf16_trace.py (profiles/r02_bf16_phase_trace.txt): the matrix pipe is NOT what limits K = 512 launches
           "limiter": "K = 512 launches: a workgroup spends ~20 % of its life in prologue + epilogue (no MFMA), per k-tile "
                      "the LDS store phase (48 KB at ~80 B/clk/CU) and barriers add ~900 cycles to a 2000-2300 cycle MFMA "
-                     "phase (floor 1536), and only two 128x128 workgroups fit a CU: SQ_VALU_MFMA_BUSY ~53 % of active "
+                     "phase (floor 1536), and only two 128x128 workgroups fit a CU: SQ_VALU_MFMA_BUSY ~55 % of active "
                      "cycles (exact mode; ~20 % in the bf16 mode); `bound` names the roof the kernel is priced against, "
                      "not a saturated unit"}
     tab = newest_traffic_table()
