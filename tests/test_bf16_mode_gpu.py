@@ -75,7 +75,7 @@ def test_bf16_mode_tracks_the_fp32_accurate_path(dev, restore_mode):
 
 
 def test_bf16_mode_trains_under_the_graph_engine(dev, restore_mode):
-    """a few hipGraph-replayed steps in the throughput mode: the loss falls, every launch was a bf16 kernel, the
+    """BASELINE configs[1] at its own shapes: hipGraph-replayed steps in the throughput mode: the loss falls, every launch was a bf16 kernel, the
     optimiser state is fp32 and the checkpointed weights are the fp32 masters (not the bf16 images)"""
     import nacf_amd
     from nacf_amd import synthetic as S
@@ -84,12 +84,13 @@ def test_bf16_mode_trains_under_the_graph_engine(dev, restore_mode):
     from nacf_amd.misc.run import get_forword_results
     from nacf_amd.runtime import lib as L
     from nacf_amd.runtime.engine import TrainStep
-    opt = nacf_amd.opts.make_opt("NAB", "MSRVTT", with_category=True, max_len=20, vocab_size=2000, n_frames=16, fused_loss=True,
+    # BASELINE.json configs[1]: NAB, bf16 compute / fp32 master weights, batch 64, seq_len 20, MSRVTT shapes
+    opt = nacf_amd.opts.make_opt("NAB", "MSRVTT", with_category=True, max_len=20, vocab_size=10547, n_frames=60, fused_loss=True,
                                  learning_rate=2e-3)
     model = _model(opt, dev, "bf16")
     model.train()
     crit, optim = get_criterion(model.opt), get_optimizer(model.opt, model)
-    b = S.synth_batch(opt, 32, 16, seed=2)
+    b = S.synth_batch(opt, 64, 60, seed=2)
     batch = {"feats": [f.to(dev) for f in b["feats"]], "tokens": b["tokens"].to(dev), "labels": b["labels"].to(dev),
              "category": b["category"].to(dev), "length_target": b["tgt_length"].to(dev)}
     engine = TrainStep(model, crit, optim, lambda bb: get_forword_results(model.opt, model, bb, dev), graph="on")
