@@ -20,6 +20,7 @@ of hipGraphs cut at those points (`_capture_stage`), and the replay issues the c
 
 A batch whose shapes differ from the captured ones (the ragged tail of an epoch) runs launch by launch.
 """
+import os
 import sys
 
 import torch
@@ -64,7 +65,12 @@ class TrainStep(object):
         self.multi = ddp is not None and (ddp.world > 1 or ddp.force)
         self.split = ddp.bucket_split() if self.multi else None
         self.staged = self.split is not None
-        self.hsplit = ddp.head_split() if self.staged else None      # three buckets when the vocabulary projection is a tail
+        # Two backward stages (decoder side incl. the vocabulary projection | encoder side) by default: each stage's
+        # weight-gradient GEMMs run as ONE grouped launch at its end (ops.dw_group), and a group has to be large to need
+        # few reduce splits -- a third stage for the vocabulary projection alone (NACF_DDP_STAGES=3: its bucket leaves
+        # one stage earlier) costs more in the grouped launches than the earlier all-reduce start gains at one rank
+        three_ok = self.staged and os.environ.get("NACF_DDP_STAGES", "2") == "3"
+        self.hsplit = ddp.head_split() if three_ok else None
         self.three = None                   # decided at the first step (needs model._cut_head of a fused-loss forward)
         self.grad_scale = ddp.grad_scale if self.multi else 1.0
         self.static = self.sig = None
