@@ -518,12 +518,16 @@ __device__ __forceinline__ void gemm_bf16_body(const GemmShape& g, const Epi& ep
       const u32x4* qpl = q_stage(0);
       const u32x4* ppl = p_stage(pst);
       bf16x8_t pf[TN][NS], qf[2][NS];
+      // fragment reads in the order the terms need them (LDS returns data in order): the first matrix instruction waits
+      // for 5 of the 15 reads instead of for 13 -- all four waves start their phase with 18 KB of reads each
+      constexpr int PORD[3] = {2, 0, 1}, QORD[3] = {0, 2, 1};
 #pragma unroll
-      for (int b = 0; b < TN; ++b)
+      for (int o = 0; o < 3; ++o) {
+        qf[0][QORD[o]] = lds_frag(qpl + QORD[o] * QPL, wm * WTM + li, lg);
 #pragma unroll
-        for (int p = 0; p < NS; ++p) pf[b][p] = lds_frag(ppl + p * PPL, wn * WTN + b * 16 + li, lg);
-#pragma unroll
-      for (int p = 0; p < NS; ++p) qf[0][p] = lds_frag(qpl + p * QPL, wm * WTM + li, lg);
+        for (int b = 0; b < TN; ++b) pf[b][PORD[o]] = lds_frag(ppl + PORD[o] * PPL, wn * WTN + b * 16 + li, lg);
+        __builtin_amdgcn_sched_barrier(0);
+      }
       constexpr int NSTEP = 7 * decltype(qs)::PAIRS;
       constexpr int TP[6] = {2, 0, 1, 1, 0, 0}, TQ[6] = {0, 2, 1, 0, 1, 0};     // six cross terms, smallest first
       __builtin_amdgcn_sched_barrier(0);
