@@ -168,11 +168,11 @@ def roofline_from(summ, n_prof, mode, prefer_single=True):
           "all_gemm_tflops": round(all_tf, 2), "all_gemm_frac_of_mode_peak": round(all_tf / MODE_PEAK[mode], 4),
           # rocprofv3 --pmc on this kernel family (profiles/r02_gemm_pmc_counters.txt) and the per-phase cycle stamps of
           # tools/bf16_trace.py (profiles/r02_bf16_phase_trace.txt): the matrix pipe is NOT what limits K = 512 launches
-          "limiter": "K = 512 launches: a workgroup spends ~20 % of its life in prologue + epilogue (no MFMA), per k-tile "
-                     "the LDS store phase (48 KB at ~80 B/clk/CU) and barriers add ~900 cycles to a 2000-2300 cycle MFMA "
-                     "phase (floor 1536), and only two 128x128 workgroups fit a CU: SQ_VALU_MFMA_BUSY ~55 % of active "
-                     "cycles (exact mode; ~20 % in the bf16 mode); `bound` names the roof the kernel is priced against, "
-                     "not a saturated unit"}
+          "limiter": "LDS bandwidth: per 128x128 k-tile a workgroup reads 96 KB of bf16x3 fragments (24 ds_read_b128 per "
+                     "wave, 768 cycles at the 128 B/clk/CU the LDS delivers, tools/probes/compute_phase.hip) and stores 48 KB "
+                     "(~600 cycles) against 1536 cycles of MFMAs, shared by both resident workgroups; plus ~20 % of a K = 512 "
+                     "workgroup's life in prologue + epilogue: SQ_VALU_MFMA_BUSY ~55 % of active cycles (exact mode; ~20 % in "
+                     "the bf16 mode); `bound` names the roof the kernel is priced against, not a saturated unit"}
     tab = newest_traffic_table()
     if tab is not None:
         path, age_h, data = tab
