@@ -64,7 +64,7 @@ int nacf_version(void);
  * included).  nacf_abi_count() returns the value the LIBRARY was built with; the ctypes loader
  * (runtime/lib.py:load) refuses a library whose count differs from its own signature table, so a stale
  * libnacf_hip.so next to a newer Python package fails at import time, not at the first missing symbol. */
-#define NACF_ABI_COUNT 74
+#define NACF_ABI_COUNT 76
 int nacf_abi_count(void);
 
 /* ---- batch construction (reference: dataloader.py) ----------------------------------------
@@ -191,6 +191,18 @@ int nacf_dw_group_begin(int defer_gemm);
 int nacf_dw_group_flush(nacf_stream_t stream);
 int nacf_dw_group_pending(void);
 int nacf_dw_group_stats(int* launches, int* workgroups);
+
+/* Grouped forward / dX GEMMs of INDEPENDENT problems.  The reference runs the modalities of the visual encoder one after
+ * the other (models/Encoder.py:47-59: `for i in range(self.num_feats)`); each stream's Linear(2048 -> 512) is 120 big
+ * output tiles at 128 videos -- half an MI355X.  Between nacf_wide_group_begin() and nacf_wide_group_flush(stream),
+ * nacf_linear_fwd / nacf_linear_bwd_data calls that the wide-wave-tile kernel serves (csrc/gemm_bf16_wide.hpp: bf16x3
+ * mode, registered weight image, K % 64 == 0, K >= 128, no reduce split, enough tiles) are QUEUED and the flush launches
+ * the queued problems of each kind as one grid; every other call launches at once, as without a group.  Each problem's
+ * arithmetic is exactly that of its own launch (bit-identical results).  Contract while a group is open: the queued
+ * calls' operands and outputs are untouched until the flush, and none of them reads what another one (or anything
+ * launched in between) writes.  The flush returns the number of GEMMs it launched (>= 0) or a negative error code. */
+int nacf_wide_group_begin(void);
+int nacf_wide_group_flush(nacf_stream_t stream);
 
 /* Which GEMM kernel a call will launch (for profiling / roofline bookkeeping):
  * kind 0 = linear_fwd (also vocab_argmax), 1 = linear_bwd_data, 2 = linear_bwd_weight,

@@ -406,7 +406,9 @@ int nacf_linear_fwd(const float* X, int64_t ldx, const float* W, int64_t ldw, fl
   const int mode = gemm_mode();
   if (mode != NACF_GEMM_F32 && vec) {          // bf16 matrix cores (16-byte addressable operands only)
     find_image(W, ldw, N, K, mode, g);
-    launch_bf16_linear(g, epi, pick_tile_bf16(0, M, N, 1, rs != nullptr, mode, heavy), mode, as_hip(stream));
+    const bool heavy_w = heavy || epi.ep.p_drop1 > 0.f || epi.ep.p_drop2 > 0.f;      // nothing overlaps the wide kernel's epilogue
+    if (!(mode == NACF_GEMM_BF16X3 && launch_wide_linear(g, epi, rs != nullptr, heavy_w, as_hip(stream))))
+      launch_bf16_linear(g, epi, pick_tile_bf16(0, M, N, 1, rs != nullptr, mode, heavy), mode, as_hip(stream));
     g_last_was_bf16 = true;
   } else {
     launch_gemm<true, true, EpiLinear>(g, epi, 1, pick_tile(M, N, 1, rs != nullptr, heavy), vec, as_hip(stream));
@@ -473,7 +475,8 @@ int nacf_linear_bwd_data(const float* dZ, int64_t lddz, const float* W, int64_t 
   }
   if (bf16) {
     find_image_t(W, ldw, N, K, mode, g);       // P = W^T image [K, N] when registered, else the fp32 W read transposed
-    launch_bf16_dx(g, epi, real_splits, pick_tile_bf16(1, M, K, real_splits, rs != nullptr, mode), mode, s);
+    if (!(mode == NACF_GEMM_BF16X3 && launch_wide_dx(g, epi, real_splits, rs != nullptr, s)))
+      launch_bf16_dx(g, epi, real_splits, pick_tile_bf16(1, M, K, real_splits, rs != nullptr, mode), mode, s);
     g_last_was_bf16 = true;
   } else {
     launch_gemm<true, false, EpiStore>(g, epi, real_splits, pick_tile(M, K, real_splits, rs != nullptr), vec, s);

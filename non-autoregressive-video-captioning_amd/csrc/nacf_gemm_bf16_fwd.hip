@@ -9,6 +9,8 @@ void bf16_note_kernel(int tile, int qsrc, int psrc, int ns, int stages, const ch
            stages, epi);
 }
 
+void bf16_note_wide(const char* name) { snprintf(g_last_kernel, sizeof(g_last_kernel), "%s", name); }
+
 void launch_bf16_linear(GemmShape g, const EpiLinear& epi, int tile, int ns, hipStream_t s) {
   if (g.Pimg) launch_bf16_any<SRC_F32_KC, SRC_BF16_KC, EpiLinear>(g, epi, 1, tile, ns, s, "EpiLinear");
   else launch_bf16_any<SRC_F32_KC, SRC_F32_KC, EpiLinear>(g, epi, 1, tile, ns, s, "EpiLinear");

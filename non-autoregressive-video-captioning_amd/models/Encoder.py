@@ -10,7 +10,7 @@ HighWay's w1|w2 packed into one [2D, D] GEMM.
 """
 import torch.nn as nn
 
-from ..runtime.functional import EncoderStreamFn
+from ..runtime.functional import EncoderStreamFn, EncoderStreamsFn
 
 __all__ = ('Encoder_HighWay',)
 
@@ -41,6 +41,7 @@ class Encoder_HighWay(nn.Module):
             self.add_module('Encoder_%s' % char.upper(), seq)
             self.streams.append(seq)
         self.num_feats = len(self.modality)
+        self.joint_streams = bool(opt.get('encoder_joint_streams', True))     # nacf_amd option: False = one autograd node per modality
         self._cfg = None
 
     # --- flat-buffer binding -------------------------------------------------
@@ -62,8 +63,11 @@ class Encoder_HighWay(nn.Module):
 
     def forward(self, input_feats):
         assert self.num_feats == len(input_feats)
-        outs = []
-        for cfg, x in zip(self._cfg, input_feats):
-            c = dict(cfg, training=self.training, rng=self._rt.rng(x.device))
-            outs.append(EncoderStreamFn.apply(x, c, *cfg['params']))
+        cs = [dict(cfg, training=self.training, rng=self._rt.rng(x.device)) for cfg, x in zip(self._cfg, input_feats)]
+        if self.num_feats > 1 and self.joint_streams:
+            # layer by layer across the modalities: their independent GEMMs share launches (EncoderStreamsFn)
+            params = [p for cfg in self._cfg for p in cfg['params']]
+            outs = list(EncoderStreamsFn.apply(cs, self.num_feats, *input_feats, *params))
+        else:
+            outs = [EncoderStreamFn.apply(x, c, *cfg['params']) for cfg, c, x in zip(self._cfg, cs, input_feats)]
         return outs, None  # hiddens (mean over time) are produced lazily by Seq2Seq.encode

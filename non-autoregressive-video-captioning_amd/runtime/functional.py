@@ -89,6 +89,67 @@ class EncoderStreamFn(Function):
         return (dx, None) + (None,) * (len(ctx.needs_input_grad) - 2)
 
 
+class EncoderStreamsFn(Function):
+    """All modalities of the visual encoder in ONE autograd node: the same kernels as EncoderStreamFn per modality
+    (models/Encoder.py:9-25,47-66), but layer by layer across the modalities, so that the streams' independent GEMMs of
+    a layer can share a launch (ops.wide_group: at 128 videos one stream's Linear(2048 -> 512) is 120 big output tiles,
+    half of the chip).  Results per stream are bit-identical to EncoderStreamFn.
+
+    apply(cfgs, n_mod, x_0 .. x_{n-1}, *params of stream 0, *params of stream 1, ...) -> out_0 .. out_{n-1}"""
+
+    @staticmethod
+    def forward(ctx, cfgs, n_mod, *args):
+        xs = args[:n_mod]
+        st = []
+        for x, cfg in zip(xs, cfgs):
+            B, F, Din = x.shape
+            D = cfg["lin"].w.shape[0]
+            st.append(dict(shape=(B, F, Din), D=D, x2=_c2d(x, B * F, Din), h=_new((B * F, D), x), tg=_new((B * F, 2 * D), x),
+                           out=_new((B * F, D), x), p=cfg["p"] if cfg["training"] else 0.0))
+        with ops.wide_group():
+            for s_, cfg in zip(st, cfgs):
+                ops.linear_fwd(s_["x2"], cfg["lin"].w, s_["h"], ops.Epi(bias=cfg["lin"].b))
+        with ops.wide_group():
+            for s_, cfg in zip(st, cfgs):
+                ops.linear_fwd(s_["h"], cfg["hw"].w, s_["tg"], ops.Epi(bias=cfg["hw"].b, act=L.ACT_TANH_SIGMOID, act_split=s_["D"]))
+        for s_, cfg in zip(st, cfgs):
+            ops.highway_mix_fwd(s_["h"], s_["tg"], s_["out"], s_["p"], cfg["salt"], cfg["rng"])
+        ctx.cfgs, ctx.st, ctx.n_mod = cfgs, st, n_mod
+        ctx.n_params = [len(cfg["params"]) for cfg in cfgs]
+        outs = tuple(s_["out"].view(s_["shape"][0], s_["shape"][1], s_["D"]) for s_ in st)
+        for s_ in st:
+            del s_["out"]
+        return outs
+
+    @staticmethod
+    def backward(ctx, *douts):
+        cfgs, st, n_mod = ctx.cfgs, ctx.st, ctx.n_mod
+        for s_, dout in zip(st, douts):
+            B, F, Din = s_["shape"]
+            D = s_["D"]
+            s_["d2"] = _c2d(dout, B * F, D)
+            s_["dh"] = _new((B * F, D), s_["d2"])
+            s_["dp"] = _new((B * F, 2 * D), s_["d2"])
+        for s_, cfg in zip(st, cfgs):
+            ops.highway_mix_bwd(s_["d2"], s_["h"], s_["tg"], s_["dh"], s_["dp"], s_["p"], cfg["salt"], cfg["rng"])
+        with ops.wide_group():
+            for s_, cfg in zip(st, cfgs):
+                ops.linear_bwd_data(s_["dp"], cfg["hw"].w, s_["dh"], beta=1.0)
+        dxs = []
+        for i, (s_, cfg) in enumerate(zip(st, cfgs)):
+            ops.linear_bwd_weight(s_["dp"], s_["h"], cfg["hw"].gw, cfg["hw"].gb, beta=1.0)
+            ops.linear_bwd_weight(s_["dh"], s_["x2"], cfg["lin"].gw, cfg["lin"].gb, beta=1.0)
+            dx = None
+            if ctx.needs_input_grad[2 + i]:
+                B, F, Din = s_["shape"]
+                dx = _new((B * F, Din), s_["d2"])
+                ops.linear_bwd_data(s_["dh"], cfg["lin"].w, dx)
+                dx = dx.view(B, F, Din)
+            dxs.append(dx)
+        ctx.st = None
+        return (None, None) + tuple(dxs) + (None,) * sum(ctx.n_params)
+
+
 class BNConcatFn(Function):
     """per-modality BatchNorm1d over B*F rows + temporal concat
     (models/joint_representation.py:40-51).

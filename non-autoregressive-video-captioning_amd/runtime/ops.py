@@ -410,6 +410,22 @@ class dw_group:
         return False
 
 
+class wide_group:
+    """with ops.wide_group(): <forward / dX GEMMs of INDEPENDENT problems>  -- those the wide-tile kernel serves are queued
+    and launched as one grid when the block exits (nacf_wide_group_*, include/nacf_hip.h); everything else launches at
+    once.  Inside the block nothing may read what a queued GEMM writes."""
+
+    def __enter__(self):
+        L.check(L.load().nacf_wide_group_begin(), "nacf_wide_group_begin")
+        return self
+
+    def __exit__(self, exc_type, exc, tb):
+        rc = L.load().nacf_wide_group_flush(_stream())
+        if exc_type is None and rc < 0:
+            L.check(rc, "nacf_wide_group_flush")
+        return False
+
+
 def dw_group_begin(defer_gemm: bool = True) -> None:
     DW_GROUP.begin(defer_gemm)
 
