@@ -109,7 +109,7 @@ int flush_one(std::vector<std::pair<GemmShape, Epi>>& v, const char* name, hipSt
 // K >= 128), 16-byte addressable activations whose extent fits 32-bit byte offsets.  Worthwhile (tools/probes/wide_gemm.hip,
 // 1x MI355X, exact mode, old -> wide): 7680x512x2048 105 -> 91 us with 64-row tiles (120 big tiles: the 128-row tile fills
 // half the chip, 120 us); 2688x2048x512 48 -> 42; 7680x1024x512 53 -> 50; 15360x1024x512 97 -> 94; 15360x512x1024 94 -> 87;
-// the vocabulary (756 tiles, K = 512) ties.  One workgroup per CU means nothing overlaps a workgroup's epilogue, so
+// the vocabulary (756 tiles, K = 512) ties (and has no wide soft-max epilogue instantiated).  One workgroup per CU means nothing overlaps a workgroup's epilogue, so
 // transcendental / dropout epilogues stay with the 2-per-CU kernels unless the reduce dimension is long.
 int wide_pick(const GemmShape& g, int splits, bool has_rows, int ns, bool heavy_epilogue) {
   const int forced = wide_env();
@@ -120,8 +120,12 @@ int wide_pick(const GemmShape& g, int splits, bool has_rows, int ns, bool heavy_
   if (forced == 1 || forced == 2) return forced;
   if (heavy_epilogue && kps < 2048) return 0;
   const long t2 = tiles_of(g, 128, splits, has_rows), t1 = tiles_of(g, 64, splits, has_rows);
+  // With a live-row list the host does not know how many row tiles survive, and one workgroup per CU makes a partly
+  // filled last round expensive (decode, 8921 live of 14592 rows x 1024: 280 workgroups = 1.1 rounds, 0.111 vs 0.081 ms
+  // on the 128x128 kernel; x 1536: 0.148 vs 0.109): only launches of >= 4 estimated rounds take the wide kernel then.
+  if (has_rows) return t2 >= 1024 ? 2 : 0;
   if (t2 >= 160) return 2;
-  if (t1 >= 160 && kps >= 1024) return 1;
+  if (t1 >= 160 && kps >= 1024 && splits == 1) return 1;       // (with reduce splits the 64-row tile lost: 0.068 vs 0.061 ms)
   return 0;
 }
 

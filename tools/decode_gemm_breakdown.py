@@ -23,7 +23,7 @@ once(); torch.cuda.synchronize()
 ops.PROFILER.enabled = False
 import collections
 agg = collections.OrderedDict()
-for name, shape, a, e, single, rows in ops.PROFILER.records:
+for name, shape, a, e, single, rows, _kind in ops.PROFILER.records:
     M, N, K = shape
     live = min(M, int(rows.count)) if rows is not None else M
     k = (name[16:40], shape)
