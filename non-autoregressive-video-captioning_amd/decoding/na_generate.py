@@ -62,7 +62,7 @@ def _generate_graphed(opt, model, teacher_model, enc, t_enc, category, tgt_vocab
             'no_candidate_decision', 'collect_best_candidate_iterative_results', 'collect_last',
             'not_only_best_candidate')
     flat = getattr(model, 'flat', None)          # the graph holds raw pointers into the parameter buffer
-    key = (None if flat is None else flat.data.data_ptr(), ops.gemm_mode(), tuple(e.shape), tuple(pl.shape), None if category is None else tuple(category.shape), int(length_bias),
+    key = (None if flat is None else (flat.data.data_ptr(), flat.image_epoch), ops.gemm_mode(), tuple(e.shape), tuple(pl.shape), None if category is None else tuple(category.shape), int(length_bias),
            id(teacher_model) if te is not None else None, None if te is None else tuple(te[0].shape),
            tuple(str(opt.get(k)) for k in keys))
     cache = model.__dict__.setdefault('_nacf_decode_graphs', {})

@@ -37,6 +37,7 @@ class FusedAdam(object):
     def step(self, grad_scale=1.0, lo=None, hi=None, bump=True):
         """lo / hi: update only flat[lo:hi] (one gradient bucket of the data-parallel step); exactly one part of a
         step passes bump=True, and it must come first"""
+        self.model.flat.touch()      # (weight images are rebuilt at the next forward entry)
         if self._flat is not self.model.flat:   # model moved (.to/.cuda) after the optimiser was built
             if torch.cuda.is_current_stream_capturing():
                 raise RuntimeError('nacf_amd: the model was re-homed during a hipGraph capture')

@@ -65,11 +65,13 @@ class BertDecoder(nn.Module):
         return self.embedding.nacf_groups() + [g for l in self.layer for g in l.nacf_groups()]
 
     def nacf_bind(self, flat, rt):
+        self.__dict__['_flat'] = flat       # (not a sub-module / parameter: keep it out of nn.Module's bookkeeping)
         self.embedding.nacf_bind(flat, rt)
         for l in self.layer:
             l.nacf_bind(flat, rt)
 
     def project_memory(self, enc_output):
+        self._flat.ensure_images()          # a direct call on cached encoder outputs: the weights may have moved on
         return [l.project_memory(enc_output) for l in self.layer]
 
     @staticmethod
@@ -87,6 +89,7 @@ class BertDecoder(nn.Module):
         return val, Bv
 
     def forward(self, tgt_seq, enc_output=None, category=None, signals=None, tags=None, **kwargs):
+        self._flat.ensure_images()
         decoding_type = kwargs.get('decoding_type', self.decoding_type)
         output_attentions = kwargs.get('output_attentions', False)
         if isinstance(enc_output, list):

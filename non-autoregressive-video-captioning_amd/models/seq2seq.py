@@ -138,8 +138,14 @@ class Seq2Seq(nn.Module):
             inputs_for_decoder['enc_output'] = inputs_for_decoder['enc_output'][0]
         return inputs_for_decoder
 
+    def load_state_dict(self, *args, **kwargs):
+        out = super().load_state_dict(*args, **kwargs)
+        self.flat.touch()
+        return out
+
     def vocab_logprobs(self, hidden):
         """tgt_word_prj + log_softmax on [.., L, D] hidden states -> [.., L, V] log-probs"""
+        self.flat.ensure_images()
         shape = hidden.shape
         params = [p for p in self.tgt_word_prj.parameters()]
         lp = VocabLogProbFn.apply(hidden.reshape(-1, shape[-1]), dict(pack=self._vocab_pack), *params)

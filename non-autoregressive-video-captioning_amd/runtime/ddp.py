@@ -65,6 +65,7 @@ class DataParallel(object):
         if self.world == 1 and not self.force:
             return
         dist.broadcast(self.model.flat.data, src, group=self.group)
+        self.model.flat.touch()
         for b in self.model.buffers():
             dist.broadcast(b, src, group=self.group)
 

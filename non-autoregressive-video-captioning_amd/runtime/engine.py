@@ -228,6 +228,12 @@ class TrainStep(object):
         self.count_delta = [a - b for a, b in zip(self.crit._loss_cnt, before)]
         self.crit._loss_cnt = before
         self.graphs = (front, mid, back, upd)
+        self._graph_images = self._image_state()
+
+    def _image_state(self):
+        """what the captured launches bake in besides the static buffers: the GEMM mode and the weight-image set"""
+        flat = getattr(self.model, 'flat', None)
+        return (ops.gemm_mode(), None if flat is None else flat.image_epoch)
 
     def _replay(self):
         front, mid, back, upd = self.graphs
@@ -283,6 +289,13 @@ class TrainStep(object):
             for k, v in batch.items():                  # everything else (video ids, sample indices ...) rides along
                 if (k, None) not in dst and (k, 0) not in dst:
                     self.static[k] = v
+        if self.graphs is not None and self._image_state() != self._graph_images:
+            # the process-wide GEMM mode changed, or the weight images were replaced (an eager forward in another mode):
+            # the graphs would refresh and read the retired image set.  Drop them; this step runs launch by launch and
+            # builds the new images, the next one re-captures.
+            self.graphs = None
+            self._hold.clear()
+            self.n_steps = min(self.n_steps, self.eager_steps)
         if self.graphs is None and self.graph_mode != 'off' and self.n_steps > self.eager_steps:
             if self._graph_ready():
                 try:

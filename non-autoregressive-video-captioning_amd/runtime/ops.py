@@ -372,11 +372,15 @@ class _DwGroup:
         need = (int(need) + 255) // 256 * 256
         buf = self.ws.buf.get(dw.device.index if dw.device.index is not None else torch.cuda.current_device())
         if buf is None or self.offset + need > buf.numel():
-            # queued combines point into the old buffer: run them before it is replaced by a larger one
+            # queued combines point into the buffer: run them first -- the restart also rewinds the offset, after which
+            # the region may fit the buffer as it is (growing it is an allocation: refused under a stream capture)
             if self.offset > 0:
                 self._restart()
-            have = 0 if buf is None else buf.numel()
-            buf = self.ws.get(max(need, 2 * have, 64 << 20), dw.device)
+            if buf is None or need > buf.numel():
+                have = 0 if buf is None else buf.numel()
+                buf = self.ws.get(max(need, 2 * have, 64 << 20), dw.device)
+            elif torch.cuda.is_current_stream_capturing():
+                self.ws.get(1, dw.device)
         elif torch.cuda.is_current_stream_capturing():
             self.ws.get(1, dw.device)          # mark the buffer as seen by a capture (never freed from now on)
         self.targets.add(key)

@@ -62,6 +62,15 @@ class FlatParams:
         self.params: List[nn.Parameter] = [p for g in layout for p in g]
         self.image_specs: List[tuple] = []      # (offset, N, K, want_transposed) of every GEMM weight (pack(..., image=))
         self.images = None                      # ops.WeightImages of the bf16 GEMM modes
+        # captured hipGraphs bake the images' addresses in (the refresh launch and every GEMM's P operand): replaced image
+        # sets are RETIRED (unregistered, memory kept) rather than freed, and every replacement bumps `image_epoch`, which
+        # the graph owners (runtime/engine.py:TrainStep, decoding/na_generate.py) compare before a replay
+        self.image_epoch = 0
+        self._retired_images: List[object] = []
+        # `version` counts writes to the fp32 master weights that went through this package (optimiser step,
+        # load_state_dict, broadcast); `images_version` is the version the images were last built from
+        self.version = 0
+        self.images_version = -1
         with torch.no_grad():
             for p in self.params:
                 o, n = self.offset[id(p)], p.numel()
@@ -93,16 +102,38 @@ class FlatParams:
         mode = ops.gemm_mode()
         if mode == 0 or not self.data.is_cuda:
             if self.images is not None:
-                self.images.close()
-                self.images = None
+                self._retire_images()
             return
         if self.images is None or self.images.ns != mode or self.images.flat.data_ptr() != self.data.data_ptr():
             if torch.cuda.is_current_stream_capturing():
                 raise RuntimeError("nacf_amd: weight images must exist before a hipGraph capture (run a warm-up step)")
             if self.images is not None:
-                self.images.close()
+                self._retire_images()
             self.images = ops.WeightImages(self.data, self.image_specs, mode)
+            self.image_epoch += 1
         self.images.refresh()
+        self.images_version = self.version
+
+    def _retire_images(self) -> None:
+        self.images.close()                          # unregister: no new launch finds them
+        self._retired_images.append(self.images)     # ... but a graph captured earlier may still read / refresh them
+        self.images = None
+        self.image_epoch += 1
+
+    def touch(self) -> None:
+        """the fp32 master weights were written (optimiser step, load_state_dict, parameter broadcast)"""
+        self.version += 1
+
+    def ensure_images(self) -> None:
+        """entry points that run GEMMs WITHOUT going through Seq2Seq.encode (a direct model.decoder(...) /
+        vocab_logprobs / Translator call on cached encoder outputs): rebuild the images if the weights changed since
+        they were built.  Writes that bypass this package (`p.data.mul_(..)`) are not seen: call model.flat.touch()."""
+        from . import ops
+        if not self.data.is_cuda or torch.cuda.is_current_stream_capturing():
+            return
+        stale = self.images is None or self.images.ns != ops.gemm_mode() or self.images_version != self.version
+        if ops.gemm_mode() != 0 and stale:
+            self.sync_images()
 
     def pack(self, ws: Sequence[nn.Parameter], bs: Optional[Sequence[nn.Parameter]] = None,
              image: Optional[str] = None) -> Pack:

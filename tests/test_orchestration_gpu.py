@@ -211,3 +211,77 @@ def test_rank_sharded_loaders_partition_the_global_batch(dev, tmp_path):
         assert torch.equal(g["sample_index"], torch.cat([a["sample_index"], b["sample_index"]]))
         assert torch.equal(g["length_target"][:4], a["length_target"]) and torch.equal(g["category"][4:], b["category"])
         assert torch.equal(g["feats"][1][4:], b["feats"][1]) or True      # frame draws depend on the batch row
+
+
+def test_captured_step_survives_a_gemm_mode_switch(dev):
+    """a captured step bakes the weight images' addresses in.  An eager forward in another GEMM mode
+    between two replays replaces the image set; the engine must notice (image epoch), drop its graphs, rebuild and
+    re-capture -- and the trajectory must be the uninterrupted one, bit for bit."""
+    from nacf_amd.misc.crit import get_criterion
+    from nacf_amd.misc.optim import get_optimizer
+    from nacf_amd.misc.run import get_forword_results
+    from nacf_amd.runtime.engine import TrainStep
+    from nacf_amd.runtime import ops
+    g = load_gold("tiny_nacf_trajectory")
+    opt = gold_opt(g)
+    batches = _gold_batches(g, dev)
+    finals, losses = [], []
+    for interrupt in (False, True):
+        ops.set_gemm_mode("bf16x3")
+        model = _model(opt, dev, fused_loss=True)
+        model.train()
+        crit, optim = get_criterion(model.opt), get_optimizer(model.opt, model)
+        engine = TrainStep(model, crit, optim, lambda b, m=model: get_forword_results(m.opt, m, b, dev), graph="on")
+        ls = []
+        for i in range(6):
+            engine(batches[i % len(batches)])
+            ls.append(float(engine.loss))
+            if interrupt and i == 3:
+                assert engine.captured
+                epoch = model.flat.image_epoch
+                ops.set_gemm_mode("f32")
+                model.eval()
+                with torch.no_grad():
+                    model.encode(feats=batches[0]["feats"])            # eager, fp32 mode: the image set is retired
+                model.train()
+                ops.set_gemm_mode("bf16x3")
+                assert model.flat.image_epoch > epoch
+        assert engine.captured
+        losses.append(ls)
+        finals.append(model.flat.data.clone())
+    assert losses[0] == losses[1]
+    assert torch.equal(finals[0], finals[1])
+
+
+def test_direct_decoder_calls_see_updated_weights(dev):
+    """ADVICE round 2: in the bf16 GEMM modes the GEMMs read weight images that used to be rebuilt in Seq2Seq.encode only;
+    a direct model.decoder(...) / vocab_logprobs / Translator call on CACHED encoder outputs after an optimiser step or
+    load_state_dict must not use the old weights."""
+    import nacf_amd
+    from nacf_amd import synthetic as S
+    from nacf_amd.models.Translator import Translator
+    from nacf_amd.runtime import ops
+    ops.set_gemm_mode("bf16x3")
+    opt = nacf_amd.opts.make_opt("NACF", "MSRVTT", with_category=True, max_len=12, vocab_size=200, n_frames=8, dim_hidden=128,
+                                 num_attention_heads=4, intermediate_size=256, dim_i=64, dim_m=64)
+    model = _model(opt, dev, seed=3)
+    model.eval()
+    b = S.synth_batch(model.opt, 6, 8, seed=5)
+    feats, cat, tok = [f.to(dev) for f in b["feats"]], b["category"].to(dev), b["tokens"].to(dev)
+    dopt = dict(model.opt, paradigm="mp", use_ct=True, iterations=3, length_beam_size=3, beam_alpha=1.0, decode_graph="off")
+    with torch.no_grad():
+        enc = model.encode(feats=feats)
+        h0 = model.decoder(tok, enc_output=enc["enc_output"], category=cat)[0].clone()
+        # new weights through load_state_dict, NO encode() afterwards
+        sd2 = {k: (v * 1.5 if v.is_floating_point() and "running" not in k else v) for k, v in model.state_dict().items()}
+        model.load_state_dict(sd2)
+        h1 = model.decoder(tok, enc_output=enc["enc_output"], category=cat)[0].clone()
+        lp1 = model.vocab_logprobs(h1).clone()
+        hyp1, _ = Translator(model, dopt, device=dev).translate_batch(enc, cat, None, None)
+        # the same calls after an explicit rebuild of the images
+        model.flat.sync_images()
+        h2 = model.decoder(tok, enc_output=enc["enc_output"], category=cat)[0]
+        lp2 = model.vocab_logprobs(h2)
+        hyp2, _ = Translator(model, dopt, device=dev).translate_batch(enc, cat, None, None)
+    assert not torch.equal(h0, h1)
+    assert torch.equal(h1, h2) and torch.equal(lp1, lp2) and torch.equal(hyp1, hyp2)
