@@ -372,15 +372,17 @@ class _DwGroup:
         need = (int(need) + 255) // 256 * 256
         buf = self.ws.buf.get(dw.device.index if dw.device.index is not None else torch.cuda.current_device())
         if buf is None or self.offset + need > buf.numel():
-            # queued combines point into the buffer: run them first -- the restart also rewinds the offset, after which
-            # the region may fit the buffer as it is (growing it is an allocation: refused under a stream capture)
+            # queued combines point into the buffer: run them before it is replaced (the restart rewinds the offset)
             if self.offset > 0:
                 self._restart()
-            if buf is None or need > buf.numel():
+            if torch.cuda.is_current_stream_capturing() and buf is not None and need <= buf.numel():
+                # under a stream capture growing is an allocation (refused); the rewound buffer holds this region
+                self.ws.get(1, dw.device)
+            else:
+                # outside a capture grow, so that the NEXT pass fits the whole group in one piece (one grouped launch
+                # per backward stage instead of one per restart)
                 have = 0 if buf is None else buf.numel()
                 buf = self.ws.get(max(need, 2 * have, 64 << 20), dw.device)
-            elif torch.cuda.is_current_stream_capturing():
-                self.ws.get(1, dw.device)
         elif torch.cuda.is_current_stream_capturing():
             self.ws.get(1, dw.device)          # mark the buffer as seen by a capture (never freed from now on)
         self.targets.add(key)
