@@ -44,6 +44,17 @@ METRIC = "training videos/sec (whole node) + NA-decode captions/sec, NACF MSRVTT
 PEAK_F32_MFMA_TFLOPS = 157.3          # v_mfma_f32_16x16x4_f32
 PEAK_BF16_MFMA_TFLOPS = 2500.0        # v_mfma_f32_16x16x32_bf16 / 32x32x16
 MODE_PEAK = {"f32": PEAK_F32_MFMA_TFLOPS, "bf16": PEAK_BF16_MFMA_TFLOPS, "bf16x3": PEAK_BF16_MFMA_TFLOPS / 6.0}
+# what keeps each kernel family below its roof (rocprofv3 --pmc, tools/bf16_trace.py, tools/probes/*: DESIGN.md section 4)
+LIMITER_128 = ("LDS bandwidth: per 128x128 k-tile a workgroup reads 96 KB of bf16x3 fragments (24 ds_read_b128 per wave, 768 cycles "
+               "at the 128 B/clk/CU the LDS delivers, tools/probes/compute_phase.hip) and stores 48 KB (~600 cycles) against 1536 "
+               "cycles of MFMAs, shared by both resident workgroups; plus ~20 % of a K = 512 workgroup's life in prologue + "
+               "epilogue: SQ_VALU_MFMA_BUSY ~55 % of active cycles (exact mode; ~20 % in the bf16 mode); `bound` names the roof "
+               "the kernel is priced against, not a saturated unit")
+LIMITER_WIDE = ("inside the k-loop the matrix pipe is 93 % busy (3250-3310 cycles per k-tile of 96 v_mfma_f32_32x32x16_bf16 = 3072; "
+                "64-row tiles 81 %: tools/probes/wide_gemm.hip stamps); what is left is outside it: one workgroup per CU, so "
+                "nothing overlaps its prologue (~4 k cycles: DMA latency + the first operand split) and epilogue (10-14 k cycles, "
+                "HBM-write bound when all CUs store at once) -- 23 % of a K = 512 workgroup's life -- nor a partly filled last "
+                "round, and the chip clocks ~1.9 GHz with every CU issuing matrix instructions")
 MODE_NOTE = {
     "f32": "fp32 MFMA (v_mfma_f32_16x16x4_f32), 157.3 TFLOP/s dense",
     "bf16": "bf16 MFMA on operands rounded to bf16, fp32 accumulate, 2500 TFLOP/s dense",
@@ -134,6 +145,23 @@ def gemm_profile(run_once, n_prof=3):
     return summ
 
 
+def group_profile(run_once, n_prof=3):
+    """the grouped launches of the REAL step (weight-gradient group, encoder-stream group): groups stay on, every grouped
+    launch is bracketed by HIP events on the launch stream (ops.GemmProfiler.group_span)"""
+    from nacf_amd.runtime import ops
+    ops.PROFILER.group_records = []
+    ops.PROFILER.group_enabled = True
+    try:
+        for _ in range(n_prof):
+            run_once()
+        torch.cuda.synchronize()
+    finally:
+        ops.PROFILER.group_enabled = False
+    summ = ops.PROFILER.group_summary()
+    ops.PROFILER.group_records = []
+    return summ
+
+
 def newest_traffic_table():
     """profiles/r*_pmc_traffic.json with the newest mtime (PMC counters cannot be collected inside this process; the
     table comes from separate rocprofv3 --pmc passes of this same command, tools/pmc_traffic.py)"""
@@ -147,15 +175,22 @@ def newest_traffic_table():
         return None
 
 
-def roofline_from(summ, n_prof, mode, prefer_single=True):
-    """dominant kernel = the GEMM kernel class with the largest total time whose spans are ONE kernel each (spans of
-    dW entry points also contain the split-K combine: listed in the table, not chosen)"""
+def roofline_from(summ, n_prof, mode, prefer_single=True, groups=None):
+    """dominant kernel = the GEMM kernel class with the largest time per pass whose spans are ONE kernel each (spans of
+    dW entry points also contain the split-K combine: listed in the table, not chosen).  `groups`: the grouped launches
+    of the real step (group_profile); the classes they absorb are launched one at a time in `summ`, so the by-time
+    dominant kernel of the REAL step is the larger of the two views' maxima -- in the NACF step the grouped dW kernel."""
     cands = [(k, v) for k, v in summ.items() if v["single"]] if prefer_single else list(summ.items())
     if not cands:
         cands = list(summ.items())
+    if groups:
+        cands = cands + list(groups.items())
     name, r = max(cands, key=lambda kv: kv[1]["ms"])
-    family = "bf16" if name.startswith("gemm_bf16") else "f32"
-    ns = 3 if (family == "bf16" and ", 3, " in name) else 1
+    family = "f32" if name.startswith("gemm_f32") else "bf16"
+    if name.startswith("gemm_wide"):
+        ns = 3                       # the wide kernels exist in the exact mode only
+    else:
+        ns = 3 if (family == "bf16" and ", 3, " in name) else 1
     kmode = "f32" if family == "f32" else ("bf16x3" if ns == 3 else "bf16")
     peak = MODE_PEAK[kmode]
     achieved = r["flops"] / (r["ms"] * 1e-3) / 1e12
@@ -163,16 +198,17 @@ def roofline_from(summ, n_prof, mode, prefer_single=True):
     all_tf = sum(v["flops"] for v in summ.values()) / n_prof / (gemm_ms * 1e-3) / 1e12
     rl = {"bound": "mfma", "kernel": name, "achieved": round(achieved, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
           "frac": round(achieved / peak, 4), "traffic": None, "peak_basis": MODE_NOTE[kmode],
+          # the same achieved rate against the two hardware peaks, so that the mode roof (2500/6) is explicit: useful flops vs
+          # the fp32 matrix instruction's peak, and EXECUTED bf16 matrix flops (6 per useful one in the exact mode) vs 2.5 PF
+          "frac_vs_fp32_mfma_peak": round(achieved / PEAK_F32_MFMA_TFLOPS, 4),
+          "executed_bf16_frac": round(achieved * (6.0 if kmode == "bf16x3" else 1.0) / PEAK_BF16_MFMA_TFLOPS, 4) if kmode != "f32" else None,
+          "is_grouped_launch": bool(groups and name in groups),
           "launches_per_pass": r["calls"] // n_prof, "avg_launch_ms": round(r["ms"] / r["calls"], 4),
           "flops_per_pass": r["flops"] / n_prof, "all_gemm_ms_per_pass": round(gemm_ms, 3),
           "all_gemm_tflops": round(all_tf, 2), "all_gemm_frac_of_mode_peak": round(all_tf / MODE_PEAK[mode], 4),
           # rocprofv3 --pmc on this kernel family (profiles/r02_gemm_pmc_counters.txt) and the per-phase cycle stamps of
           # tools/bf16_trace.py (profiles/r02_bf16_phase_trace.txt): the matrix pipe is NOT what limits K = 512 launches
-          "limiter": "LDS bandwidth: per 128x128 k-tile a workgroup reads 96 KB of bf16x3 fragments (24 ds_read_b128 per "
-                     "wave, 768 cycles at the 128 B/clk/CU the LDS delivers, tools/probes/compute_phase.hip) and stores 48 KB "
-                     "(~600 cycles) against 1536 cycles of MFMAs, shared by both resident workgroups; plus ~20 % of a K = 512 "
-                     "workgroup's life in prologue + epilogue: SQ_VALU_MFMA_BUSY ~55 % of active cycles (exact mode; ~20 % in "
-                     "the bf16 mode); `bound` names the roof the kernel is priced against, not a saturated unit"}
+          "limiter": LIMITER_WIDE if name.startswith("gemm_wide") else LIMITER_128}
     tab = newest_traffic_table()
     if tab is not None:
         path, age_h, data = tab
@@ -368,18 +404,19 @@ def bench_cpu(opt, sd, O, B, F_, budget_s=18.0):
             return ORACLE.train_step(sd_c, dict(opt), cbatch["feats"], [cbatch["tokens_1"], cbatch["tokens"]], cbatch["category"],
                                      [cbatch["labels_1"], cbatch["labels"]], cbatch["tgt_length"], st,
                                      lr=opt["learning_rate"], training=True)
-        step()                                           # warm-up
+        for _ in range(N_WARM):                          # >= 3 warm-ups, >= 10 timed
+            step()
         ts = []
-        t_all = time.perf_counter()
-        while len(ts) < min_steps or (time.perf_counter() - t_all < budget and len(ts) < 10):
+        for _ in range(N_TIMED):
             t0 = time.perf_counter()
             step()
             ts.append(time.perf_counter() - t0)
-        return cb / statistics.median(ts), len(ts)
+        return cb / statistics.median(ts), len(ts), [round(cb / max(ts), 2), round(cb / min(ts), 2)]
+    N_WARM, N_TIMED = 3, 10
     ncpu = os.cpu_count()
     all_threads = torch.get_num_threads()
-    v_all, n_all = train_leg(B, all_threads, budget_s, 2)
-    v_one, n_one = train_leg(8, 1, budget_s * 0.6, 2)
+    v_all, n_all, spread_all = train_leg(B, all_threads, budget_s, 2)
+    v_one, n_one, spread_one = train_leg(8, 1, budget_s * 0.6, 2)
     torch.set_num_threads(all_threads)
     # NA decode (mask-predict + coarse templates, T = 5, lbs = 6), batch 32
     db = O.synth_batch(opt, 32, F_, seed=2)
@@ -389,22 +426,26 @@ def bench_cpu(opt, sd, O, B, F_, budget_s=18.0):
         with torch.no_grad():
             enc = ORACLE.encode(sd, opt, db["feats"], training=False)
             return ORACLE.generate(sd, opt, dec, enc, db["category"])
-    dstep()
+    for _ in range(N_WARM):
+        dstep()
     ts = []
-    t_all = time.perf_counter()
-    while len(ts) < 2 or (time.perf_counter() - t_all < budget_s * 0.5 and len(ts) < 10):
+    for _ in range(N_TIMED):
         t0 = time.perf_counter()
         dstep()
         ts.append(time.perf_counter() - t0)
     return {"value": round(v_all, 2), "unit": "videos/s", "cores": all_threads, "kind": "port",
-            "sample": "NACF train step (fwd+loss+bwd+clip+Adam, dropout 0.5) of %d videos, same shapes as the GPU leg: 1 warm-up + "
-                      "%d timed steps, median; oracle = plain eager PyTorch fp32" % (B, n_all),
+            "sample": "NACF train step (fwd+loss+bwd+clip+Adam, dropout 0.5) of %d videos, same shapes as the GPU leg: %d warm-ups + "
+                      "%d timed steps, median; oracle = plain eager PyTorch fp32" % (B, N_WARM, n_all),
+            "spread_min_max": spread_all,       # slowest / fastest timed step, videos/s: the box's other tenants move this 2-3x
             "cpu_model": cpu_model_name(), "logical_cpus": ncpu,
             "one_thread": {"value": round(v_one, 3), "unit": "videos/s", "cores": 1,
-                           "sample": "same step, 8 videos, 1 warm-up + %d timed steps, median" % n_one},
+                           "spread_min_max": spread_one,
+                           "sample": "same step on an 8-video batch (a 128-video step takes ~5 s on one thread: 13 of them would "
+                                     "not fit the default run), %d warm-ups + %d timed steps, median" % (N_WARM, n_one)},
             "decode": {"value": round(32 / statistics.median(ts), 2), "unit": "captions/s", "cores": all_threads,
-                       "sample": "oracle encode + generate (mp + coarse templates, T=5, lbs=6) of 32 videos: 1 warm-up + %d timed, "
-                                 "median" % len(ts)}}
+                       "spread_min_max": [round(32 / max(ts), 2), round(32 / min(ts), 2)],
+                       "sample": "oracle encode + generate (mp + coarse templates, T=5, lbs=6) of 32 videos: %d warm-ups + %d timed, "
+                                 "median" % (N_WARM, len(ts))}}
 
 
 def main():
@@ -494,7 +535,20 @@ def main():
             crit.get_loss(engine.forward(engine.static)).backward()
             optim._optimizer.step(grad_scale=1.0)
         summ = gemm_profile(eager_step)
-        roofline, gemm_table = roofline_from(summ, 3, mode)
+
+        def grouped_step():         # the same step as the engine runs it: weight-gradient GEMMs grouped per backward pass
+            optim.zero_grad()
+            loss_ = crit.get_loss(engine.forward(engine.static))
+            with ops.dw_group():
+                loss_.backward()
+            optim._optimizer.step(grad_scale=1.0)
+        groups = group_profile(grouped_step) if mode != "f32" else None
+        roofline, gemm_table = roofline_from(summ, 3, mode, groups=groups)
+        if groups:
+            gemm_table.update({k + " [grouped launch of the real step]":
+                               {"calls_per_pass": v["calls"] // 3, "problems_per_pass": v["problems"] // 3,
+                                "ms_per_pass": round(v["ms"] / 3, 3), "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2),
+                                "span_is_one_kernel": True} for k, v in groups.items()})
 
         feats, category = batch["feats"], batch["category"]
         decode = None

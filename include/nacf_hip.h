@@ -64,7 +64,7 @@ int nacf_version(void);
  * included).  nacf_abi_count() returns the value the LIBRARY was built with; the ctypes loader
  * (runtime/lib.py:load) refuses a library whose count differs from its own signature table, so a stale
  * libnacf_hip.so next to a newer Python package fails at import time, not at the first missing symbol. */
-#define NACF_ABI_COUNT 76
+#define NACF_ABI_COUNT 77
 int nacf_abi_count(void);
 
 /* ---- batch construction (reference: dataloader.py) ----------------------------------------
@@ -189,6 +189,8 @@ int nacf_linear_bwd_weight(const float* dZ, int64_t lddz, const float* X, int64_
  * launches and their workgroups at the last flush.  One group at a time per process. */
 int nacf_dw_group_begin(int defer_gemm);
 int nacf_dw_group_flush(nacf_stream_t stream);
+/* launches the queued GEMMs only (returns how many problems; < 0 = error); the combines wait for nacf_dw_group_flush */
+int nacf_dw_group_launch_gemms(nacf_stream_t stream);
 int nacf_dw_group_pending(void);
 int nacf_dw_group_stats(int* launches, int* workgroups);
 
@@ -200,7 +202,8 @@ int nacf_dw_group_stats(int* launches, int* workgroups);
  * the queued problems of each kind as one grid; every other call launches at once, as without a group.  Each problem's
  * arithmetic is exactly that of its own launch (bit-identical results).  Contract while a group is open: the queued
  * calls' operands and outputs are untouched until the flush, and none of them reads what another one (or anything
- * launched in between) writes.  The flush returns the number of GEMMs it launched (>= 0) or a negative error code. */
+ * launched in between) writes.  The flush returns the number of GEMMs it launched (>= 0) or a negative error code.
+ * nacf_gemm_last_kernel() reads "gemm_wide_queued" after a call that was queued. */
 int nacf_wide_group_begin(void);
 int nacf_wide_group_flush(nacf_stream_t stream);
 

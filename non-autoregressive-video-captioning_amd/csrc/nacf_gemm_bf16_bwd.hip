@@ -27,5 +27,8 @@ static void launch_dw_group_one(const GemmGroup<EpiStore>& t, hipStream_t s) {
 void launch_bf16_dw_group(const GemmGroup<EpiStore>& t, int ns, hipStream_t s) {
   if (ns == 1) launch_dw_group_one<1, 2>(t, s);
   else launch_dw_group_one<3, NACF_BF16_EXACT128_STAGES>(t, s);
-  bf16_note_kernel(128, SRC_F32_MC, SRC_F32_MC, ns == 1 ? 1 : 3, ns == 1 ? 2 : NACF_BF16_EXACT128_STAGES, "EpiStore");
+  char name[96];
+  snprintf(name, sizeof(name), "gemm_bf16_group_kernel<128, 128, %d, %d, %d, %d, EpiStore>", SRC_F32_MC, SRC_F32_MC, ns == 1 ? 1 : 3,
+           ns == 1 ? 2 : NACF_BF16_EXACT128_STAGES);
+  bf16_note_wide(name);        // (sets the "last kernel" string verbatim: rocprofv3's name of the grouped kernel)
 }

@@ -136,7 +136,7 @@ static bool launch_wide_any(const GemmShape& g, const Epi& epi, int splits, bool
   if (!mt) return false;
   if (queue && splits == 1) {
     std::lock_guard<std::mutex> lk(g_wide_mu);
-    if (g_wide_group_on) { queue->push_back({g, epi}); return true; }
+    if (g_wide_group_on) { queue->push_back({g, epi}); bf16_note_wide("gemm_wide_queued"); return true; }
   }
   if (mt == 2) launch_wide_one<2, Epi>(g, epi, splits, s); else launch_wide_one<1, Epi>(g, epi, splits, s);
   note(mt, name, false);

@@ -72,6 +72,7 @@ SIGNATURES = {
     "nacf_dw_group_begin": (c_int, [_I]),
     "nacf_dw_group_stats": (c_int, [_P, _P]),
     "nacf_dw_group_flush": (c_int, [_P]),
+    "nacf_dw_group_launch_gemms": (c_int, [_P]),
     "nacf_dw_group_pending": (c_int, []),
     "nacf_wide_group_begin": (c_int, []),
     "nacf_wide_group_flush": (c_int, [_P]),

@@ -88,6 +88,35 @@ class GemmProfiler:
     def __init__(self):
         self.enabled = False
         self.records = []
+        # grouped launches (the weight-gradient group, the encoder streams' wide group) as the REAL step runs them: with
+        # `group_enabled` the groups stay on and every grouped launch is bracketed by events (`enabled` must be off: it
+        # turns the grouping off to time one launch per call)
+        self.group_enabled = False
+        self.group_records = []      # (kernel name, [(M, N, K, rows)], event a, event b)
+
+    def group_span(self, problems, launch):
+        """run `launch()` (one grouped launch of `problems`), timed when group_enabled"""
+        if not self.group_enabled:
+            return launch()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        out = launch()
+        b.record()
+        name = (L.load().nacf_gemm_last_kernel() or b"?").decode()
+        self.group_records.append((name, list(problems), a, b))
+        return out
+
+    def group_summary(self):
+        out = {}
+        for name, problems, a, b in self.group_records:
+            r = out.setdefault(name, dict(calls=0, flops=0.0, ms=0.0, problems=0, single=True))
+            r["calls"] += 1
+            r["ms"] += a.elapsed_time(b)
+            r["problems"] += len(problems)
+            for M, N, K, rows in problems:
+                m_live = min(M, int(rows.count)) if rows is not None else M
+                r["flops"] += 2.0 * m_live * N * K
+        return out
 
     def _splits(self, kind, M, N, K, flags=0):
         tile, splits = ctypes.c_int(0), ctypes.c_int(0)
@@ -305,6 +334,7 @@ def linear_fwd(x: Tensor, w: Tensor, out: Tensor, epi: Optional[Epi] = None, row
     L.check(L.load().nacf_linear_fwd(_ptr(x), ldx, _ptr(w), ldw, _ptr(out), out.stride(0), M, N, K,
                                      ctypes.byref(ep), _rs(rows, zero_dead), _stream()), "nacf_linear_fwd")
     PROFILER.end(tok)
+    wide_group.note(M, N, K, rows)
     return out
 
 
@@ -321,6 +351,7 @@ def linear_bwd_data(dz: Tensor, w: Tensor, dx: Tensor, beta: float = 0.0, rows: 
                                      float(beta), _ptr(ws), ws.numel(), _rs(rows, zero_dead), _stream()),
             "nacf_linear_bwd_data")
     PROFILER.end(tok)
+    wide_group.note(M, N, K, rows)
     return dx
 
 
@@ -356,6 +387,10 @@ class _DwGroup:
             self.targets.clear()
             self.offset = 0
             try:
+                if PROFILER.group_enabled and self.defer_gemm and self.keep:
+                    probs = [(dz.shape[0], dz.shape[1], x.shape[1], rows) for dz, x, rows, _dw, _db in self.keep]
+                    PROFILER.group_span(probs, lambda: L.check(min(0, L.load().nacf_dw_group_launch_gemms(_stream())),
+                                                               "nacf_dw_group_launch_gemms"))
                 L.check(L.load().nacf_dw_group_flush(_stream()), "nacf_dw_group_flush")
             finally:
                 self.keep.clear()
@@ -421,15 +456,32 @@ class wide_group:
     and launched as one grid when the block exits (nacf_wide_group_*, include/nacf_hip.h); everything else launches at
     once.  Inside the block nothing may read what a queued GEMM writes."""
 
+    current = None
+
     def __enter__(self):
+        self.queued = []
+        if PROFILER.enabled:             # the per-call profiler times one launch per call: no grouping while it is on
+            return self
         L.check(L.load().nacf_wide_group_begin(), "nacf_wide_group_begin")
+        wide_group.current = self
         return self
 
     def __exit__(self, exc_type, exc, tb):
-        rc = L.load().nacf_wide_group_flush(_stream())
+        if wide_group.current is not self:
+            return False
+        wide_group.current = None
+        rc = PROFILER.group_span(self.queued, lambda: L.load().nacf_wide_group_flush(_stream())) if self.queued \
+            else L.load().nacf_wide_group_flush(_stream())
         if exc_type is None and rc < 0:
             L.check(rc, "nacf_wide_group_flush")
         return False
+
+    @staticmethod
+    def note(M, N, K, rows):
+        """called after a forward / dX GEMM entry point: remember the problem if the library queued it"""
+        g = wide_group.current
+        if g is not None and (L.load().nacf_gemm_last_kernel() or b"") == b"gemm_wide_queued":
+            g.queued.append((M, N, K, rows))
 
 
 def dw_group_begin(defer_gemm: bool = True) -> None:
