@@ -72,6 +72,9 @@ class TieRecorder:
         return False
 
 
+_ORACLE_CACHE = {}
+
+
 @pytest.mark.parametrize("graph", ["off", "on"])
 @pytest.mark.parametrize("B", [32, 128])
 def test_full_size_na_decode_vs_oracle(dev, B, graph):
@@ -95,13 +98,17 @@ def test_full_size_na_decode_vs_oracle(dev, B, graph):
         if graph == "on":       # the replayed graph, not only the capture run
             hyp2, (it_tok2, _) = tr.translate_batch(enc, cat, None, None)
             assert torch.equal(hyp, hyp2) and torch.equal(it_tok, it_tok2)
-    # the oracle on the host cores, recording where its own decisions were numerically tied
-    o_enc = O.encode(sd, opt, b["feats"], training=False)
-    assert maxerr(enc["enc_output"], o_enc["enc_output"]) < 2e-4 and maxerr(enc["pred_length"], o_enc["pred_length"]) < 2e-4
+    # the oracle on the host cores, recording where its own decisions were numerically tied (once per batch size: the
+    # graph on / off cases share it)
     lbs = dec["length_beam_size"]
-    col = []
-    with TieRecorder(B * lbs) as rec:
-        o_hyp, o_all, o_lp, o_beam = O.generate(sd, opt, dec, o_enc, b["category"], None, col)
+    if B not in _ORACLE_CACHE:
+        o_enc = O.encode(sd, opt, b["feats"], training=False)
+        col = []
+        with TieRecorder(B * lbs) as rec:
+            o_res = O.generate(sd, opt, dec, o_enc, b["category"], None, col)
+        _ORACLE_CACHE[B] = (o_enc, col, rec, o_res)
+    o_enc, col, rec, (o_hyp, o_all, o_lp, o_beam) = _ORACLE_CACHE[B]
+    assert maxerr(enc["enc_output"], o_enc["enc_output"]) < 2e-4 and maxerr(enc["pred_length"], o_enc["pred_length"]) < 2e-4
     o_tok = torch.stack([c[0] for c in col], 1)
     o_prob = torch.stack([c[1] for c in col], 1)
     assert o_tok.shape == tuple(it_tok.shape), (o_tok.shape, it_tok.shape)
