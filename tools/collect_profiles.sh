@@ -2,7 +2,7 @@
 # Collect everything profiles/ holds for one round, on the GPU box:  tools/collect_profiles.sh r02
 # (run through gpurun; results land in gpurun_out/profiles_<round>/ and are then copied into profiles/ by hand)
 set -u
-R=${1:-r02}
+R=${1:-r03}
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
 OUT=$ROOT/gpurun_out/profiles_$R
 mkdir -p $OUT
@@ -22,9 +22,18 @@ done
 python $ROOT/tools/pmc_traffic.py /tmp/prof_FETCH_SIZE/b_counter_collection.csv /tmp/prof_WRITE_SIZE/b_counter_collection.csv $OUT/${R}_pmc_traffic.json
 # 4. GEMM microbenchmarks (three arithmetic modes, weights from pre-split images as in the model) + attainable MFMA peak
 python $ROOT/tools/gemm_bench.py --iters 20 --modes f32,bf16x3,bf16 --images > $OUT/${R}_gemm_microbench.txt 2> /dev/null
+python $ROOT/tools/gemm_bench.py --iters 20 --modes bf16x3 --tiles 128,wide1,wide2,auto --images --only fwd >> $OUT/${R}_gemm_microbench.txt 2> /dev/null
+python $ROOT/tools/gemm_bench.py --iters 20 --modes bf16x3 --tiles 128,wide1,wide2,auto --images --only dX >> $OUT/${R}_gemm_microbench.txt 2> /dev/null
 $ROOT/tools/mfma_peak 20000 > $OUT/${R}_mfma_peak.txt 2>&1
 # 5. SQ / GRBM counters of the vocabulary GEMM at K = 512 (the model's shape) and K = 8192, exact and throughput mode
-{ for m in bf16x3 bf16; do echo "== mode $m"; $ROOT/tools/pmc_gemm.sh 0:5120:10547:512,0:5120:10547:8192 128 $m --images 2>/dev/null | grep "^pass"; done; } > $OUT/${R}_gemm_pmc_counters.txt
+{ for m in bf16x3 bf16; do echo "== mode $m"; $ROOT/tools/pmc_gemm.sh 0:5120:10547:512,0:5120:10547:8192 128 $m --images 2>/dev/null | grep "^pass"; done;
+  echo "== mode bf16x3, wide kernel (128 x 256 tiles; csrc/gemm_bf16_wide.hpp)"; $ROOT/tools/pmc_gemm.sh 0:5120:10547:512,0:7680:512:2048,0:15360:1024:512 wide2 bf16x3 --images 2>/dev/null | grep "^pass"; } > $OUT/${R}_gemm_pmc_counters.txt
+# 5b. the wide kernel's phase stamps + ablations (tools/probes/wide_gemm.hip; built by hand, see its header)
+for b in 1 2; do
+  if [ -x $ROOT/tools/probes/wide_gemm$b ]; then
+    { echo "== wide kernel, MT=$b (workgroup tile $((64*b)) x 256)"; for shp in "7680 512 2048" "15360 1024 512" "2304 10547 512" "15360 512 1024"; do $ROOT/tools/probes/wide_gemm$b $shp 10 | grep -v "by col\|by row\|entries off"; done; } >> $OUT/${R}_wide_gemm_probe.txt 2>&1
+  fi
+done
 # 6. per-phase shader-clock cycles inside the bf16 kernels (needs the trace build: make -C .../csrc trace)
 if [ -f $ROOT/non-autoregressive-video-captioning_amd/libnacf_hip_trace.so ]; then
   { for m in bf16x3 bf16; do for shp in 15360:1024:512 5120:10547:512; do echo "== mode $m shape $shp tile 128"; NACF_GEMM_MODE=$m python $ROOT/tools/bf16_trace.py $shp 128 --images 2>/dev/null; done; done; } > $OUT/${R}_bf16_phase_trace.txt

@@ -18,10 +18,10 @@ def main():
         for r in csv.DictReader(open(os.path.join(base, "trace_%s.csv" % i))):
             dur[r["Dispatch_Id"]] = int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
         for r in csv.DictReader(open(path)):
-            if "gemm_f32_kernel" not in r["Kernel_Name"] and "gemm_bf16_kernel" not in r["Kernel_Name"]:
+            if not any(k in r["Kernel_Name"] for k in ("gemm_f32_kernel", "gemm_bf16_kernel", "gemm_wide_kernel")):
                 continue
             d = per[(i, r["Dispatch_Id"])]
-            d["kernel"] = r["Kernel_Name"].split("(")[0][5:60]
+            d["kernel"] = r["Kernel_Name"].split("(")[0][5:64]
             d["grid"] = r["Grid_Size"]
             d["us"] = dur.get(r["Dispatch_Id"], 0) / 1e3
             d[r["Counter_Name"]] = float(r["Counter_Value"])
