@@ -44,6 +44,7 @@ template <int MT> struct Geo {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 #ifdef WIDE_TRACE
+__device__ int g_wide_skew = 0;      // tuning: start delay of workgroup b = ((b >> 3) & 7) * g_wide_skew * 64 cycles
 __device__ unsigned long long* g_wide_trace = nullptr;     // tuning builds: [workgroup][4] shader-clock stamps of wave 0
 #define WIDE_MARK(i) do { if (g_wide_trace && tid == 0) g_wide_trace[(size_t)bid * 4 + (i)] = __builtin_readcyclecounter(); } while (0)
 #else
@@ -379,6 +380,9 @@ __device__ __forceinline__ void gemm_wide_body(const GemmShape& g, const Epi& ep
     for_each_ic(slot, std::make_integer_sequence<int, NSLOT>{});
   };
 
+#ifdef WIDE_TRACE
+  for (int i = 0, n = ((bid >> 3) & 7) * g_wide_skew; i < n; ++i) __builtin_amdgcn_s_sleep(1);
+#endif
   WIDE_MARK(0);
   {
     // ---- prologue: P(0), Q(0), Q(1), Q(2) and the first half of P(1) requested together; Q(0) is split with nothing to

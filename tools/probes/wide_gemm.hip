@@ -116,10 +116,16 @@ int main(int argc, char** argv) {
     CK(hipMemcpy(h.data(), tr, h.size() * 8, hipMemcpyDeviceToHost));
     double pro = 0, loop = 0, epi = 0; const int n = (int)h.size() / 4;
     for (int i = 0; i < n; ++i) { pro += h[4 * i + 1] - h[4 * i]; loop += h[4 * i + 2] - h[4 * i + 1]; epi += h[4 * i + 3] - h[4 * i + 2]; }
-    printf("  %-28s median %.1f us = %.1f TF | per workgroup: prologue %.0f, loop %.0f (%.0f per k-tile; 3072 = MFMA), epilogue %.0f cycles\n", name,
-           tt[reps / 2] * 1e3, fl / (tt[reps / 2] * 1e-3) * 1e-12, pro / n, loop / n, loop / n / (K / 32), epi / n);
+    printf("  %-28s median %.1f us = %.1f TF | per workgroup: prologue %.0f, loop %.0f (%.0f per k-tile; %d = MFMA), epilogue %.0f cycles\n", name,
+           tt[reps / 2] * 1e3, fl / (tt[reps / 2] * 1e-3) * 1e-12, pro / n, loop / n, loop / n / (K / 32), 1536 * WMT, epi / n);
   };
   variant("wide", wide::gemm_wide_kernel<WMT, EpiStore, 0>);
+  for (int skew : {8, 16, 32, 64}) {
+    CK(hipMemcpyToSymbol(HIP_SYMBOL(wide::g_wide_skew), &skew, sizeof(skew)));
+    char nm[64]; snprintf(nm, sizeof(nm), "wide, start skew %d x 64 cycles", skew);
+    variant(nm, wide::gemm_wide_kernel<WMT, EpiStore, 0>);
+  }
+  { int z = 0; CK(hipMemcpyToSymbol(HIP_SYMBOL(wide::g_wide_skew), &z, sizeof(z))); }
   variant("wide, no DMA in loop", wide::gemm_wide_kernel<WMT, EpiStore, 1>);
   variant("wide, no split", wide::gemm_wide_kernel<WMT, EpiStore, 2>);
   variant("wide, no DMA, no split", wide::gemm_wide_kernel<WMT, EpiStore, 3>);
