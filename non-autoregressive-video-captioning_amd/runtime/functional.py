@@ -261,15 +261,16 @@ class LengthHeadFn(Function):
         cfg = ctx.cfg
         p1: Pack = cfg["l1"]
         p2: Pack = cfg["l2"]
-        dz = torch.empty_like(ctx.logp)
-        ops.log_softmax_rows_bwd(dlogp.contiguous(), ctx.logp, dz)
-        dh = torch.empty_like(ctx.h)
-        ops.linear_bwd_data(dz, p2.w, dh)
-        ops.linear_bwd_weight(dz, ctx.h, p2.gw, p2.gb, beta=1.0)
-        ops.epilogue_bwd(dh, dh, None, ctx.epi)
-        dpooled = torch.empty_like(ctx.pooled)
-        ops.linear_bwd_data(dh, p1.w, dpooled)
-        ops.linear_bwd_weight(dh, ctx.pooled, p1.gw, p1.gb, beta=1.0)
+        with ops.aux_workspace():       # may run on a side stream next to the decoder's backward (models/seq2seq.py)
+            dz = torch.empty_like(ctx.logp)
+            ops.log_softmax_rows_bwd(dlogp.contiguous(), ctx.logp, dz)
+            dh = torch.empty_like(ctx.h)
+            ops.linear_bwd_data(dz, p2.w, dh)
+            ops.linear_bwd_weight(dz, ctx.h, p2.gw, p2.gb, beta=1.0)
+            ops.epilogue_bwd(dh, dh, None, ctx.epi)
+            dpooled = torch.empty_like(ctx.pooled)
+            ops.linear_bwd_data(dh, p1.w, dpooled)
+            ops.linear_bwd_weight(dh, ctx.pooled, p1.gw, p1.gb, beta=1.0)
         return (dpooled, None) + (None,) * (len(ctx.needs_input_grad) - 2)
 
 

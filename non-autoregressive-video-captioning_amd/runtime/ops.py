@@ -77,6 +77,27 @@ class _Workspace:
 
 
 WORKSPACE = _Workspace()
+# a second buffer for work that runs on a SIDE stream next to the main one (the length head, models/seq2seq.py): two
+# streams must not share split-K scratch.  Selected by `with ops.aux_workspace():` around the launches (forward and
+# backward bodies of the side-stream Function: autograd runs a device's backward nodes one after the other in one thread)
+WORKSPACE_AUX = _Workspace()
+_AUX_DEPTH = 0
+
+
+class aux_workspace:
+    def __enter__(self):
+        global _AUX_DEPTH
+        _AUX_DEPTH += 1
+        return self
+
+    def __exit__(self, *a):
+        global _AUX_DEPTH
+        _AUX_DEPTH -= 1
+        return False
+
+
+def _ws() -> _Workspace:
+    return WORKSPACE_AUX if _AUX_DEPTH > 0 else WORKSPACE
 
 
 class GemmProfiler:
@@ -345,7 +366,7 @@ def linear_bwd_data(dz: Tensor, w: Tensor, dx: Tensor, beta: float = 0.0, rows: 
     N2, K, ldw = _rows2d(w)
     assert N == N2 and dx.shape == (M, K)
     lib = L.load()
-    ws = WORKSPACE.get(lib.nacf_linear_bwd_data_workspace(M, N, K), dz.device)
+    ws = _ws().get(lib.nacf_linear_bwd_data_workspace(M, N, K), dz.device)
     tok = PROFILER.begin(1, M, N, K, "EpiStore", rows)
     L.check(lib.nacf_linear_bwd_data(_ptr(dz), lddz, _ptr(w), ldw, _ptr(dx), dx.stride(0), M, N, K,
                                      float(beta), _ptr(ws), ws.numel(), _rs(rows, zero_dead), _stream()),
@@ -500,7 +521,7 @@ def linear_bwd_weight(dz: Tensor, x: Tensor, dw: Tensor, db: Optional[Tensor], b
     assert M == M2 and dw.shape == (N, K), (dz.shape, x.shape, dw.shape)
     lib = L.load()
     need = lib.nacf_linear_bwd_weight_workspace(M, N, K)
-    ws = DW_GROUP.region(need, dw) if DW_GROUP.active else WORKSPACE.get(need, dz.device)
+    ws = DW_GROUP.region(need, dw) if DW_GROUP.active else _ws().get(need, dz.device)
     if DW_GROUP.active and DW_GROUP.defer_gemm:
         DW_GROUP.keep.append((dz, x, rows, dw, db))
     tok = PROFILER.begin(2, M, N, K, "EpiStore", rows)
