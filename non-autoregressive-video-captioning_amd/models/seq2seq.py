@@ -16,8 +16,36 @@ import torch.nn as nn
 
 from ..config import Constants
 from ..runtime import ops
-from ..runtime.functional import MeanTimeFn, VocabLogProbFn
+from ..runtime.functional import MeanTimeFn, MemoryFanoutFn, VocabLogProbFn
 from ..runtime.state import FlatParams, Runtime
+
+
+class LazyResults(dict):
+    """the result dict of Seq2Seq.encode / forward with values that are computed on first access (`d[k]`, `d.get(k)`,
+    `k in d`); they are not listed by keys() / items() / a plain dict(d) copy until then"""
+
+    def __init__(self, *a, **kw):
+        super().__init__(*a, **kw)
+        self._lazy = {}
+
+    def lazy(self, key, fn):
+        self._lazy[key] = fn
+
+    def __missing__(self, key):
+        fn = self._lazy.pop(key, None)
+        if fn is None:
+            raise KeyError(key)
+        self[key] = v = fn()
+        return v
+
+    def get(self, key, default=None):
+        try:
+            return self[key]
+        except KeyError:
+            return default
+
+    def __contains__(self, key):
+        return dict.__contains__(self, key) or key in self._lazy
 
 
 class Seq2Seq(nn.Module):
@@ -105,25 +133,33 @@ class Seq2Seq(nn.Module):
 
     # ------------------------------------------------------------- reference surface
     def encode(self, feats, defer_join=False, **kwargs):
-        results = {}
+        results = LazyResults()
         if self.opt.get('automatic_mask', False):
             raise NotImplementedError('nacf_amd: automatic_mask is not built')
         # bf16 GEMM modes: the weight images follow the fp32 master weights at every forward entry (one launch; the
         # forward's and the backward's GEMMs then read images of exactly the weights an fp32 kernel would read)
         self.flat.sync_images()
         enc_streams, _ = self.encoder([f.contiguous() for f in feats])
-        with torch.no_grad():  # mean-over-time hidden: only LSTM decoders consume it (seq2seq.py:66-68)
-            s0 = enc_streams[0]
-            hid = torch.empty(len(enc_streams), s0.shape[0], s0.shape[2], dtype=s0.dtype, device=s0.device)
-            for i, s_ in enumerate(enc_streams):
-                ops.mean_time_fwd(s_.detach().contiguous(), hid[i])
-            # mean over the modalities (models/joint_representation.py:27) with the same kernel: [1, n_mod, B*D]
-            enc_hidden = ops.mean_time_fwd(hid.view(1, hid.shape[0], -1), torch.empty_like(hid[0]).view(1, -1)).view_as(hid[0])
+        def enc_hidden_fn(streams=[s_.detach() for s_ in enc_streams]):
+            # mean-over-time hidden of every stream, then the mean over the modalities (models/Encoder.py:51,
+            # models/joint_representation.py:27).  Only RNN decoders consume it (seq2seq.py:66-68) and none is built here,
+            # so it is computed on first ACCESS (`results['enc_hidden']`), not in every step: three launches less.
+            with torch.no_grad():
+                s0 = streams[0]
+                hid = torch.empty(len(streams), s0.shape[0], s0.shape[2], dtype=s0.dtype, device=s0.device)
+                for i, s_ in enumerate(streams):
+                    ops.mean_time_fwd(s_.contiguous(), hid[i])
+                return ops.mean_time_fwd(hid.view(1, hid.shape[0], -1), torch.empty_like(hid[0]).view(1, -1)).view_as(hid[0])
+        enc_hidden = None
         if self.joint_representation_learner is not None:
             enc_output, enc_hidden = self.joint_representation_learner(enc_streams, enc_hidden)
         else:
             enc_output = torch.cat(enc_streams, dim=1)
-        pooled = MeanTimeFn.apply(enc_output)
+        if self.training and torch.is_tensor(enc_output) and enc_output.requires_grad:
+            results['_enc_root'] = enc_output          # (the staged backward cuts here: upstream of memory AND pooled)
+            enc_output, pooled = MemoryFanoutFn.apply(enc_output)
+        else:
+            pooled = MeanTimeFn.apply(enc_output)
         if self.auxiliary_task_predictor is not None:
             # The length head (two 128-row GEMMs, a row soft-max; ~55 us forward, ~75 us backward of launch-latency-sized
             # kernels) depends on the pooled memory only: in training it runs on a SIDE stream next to the decoder -- a
@@ -148,7 +184,7 @@ class Seq2Seq(nn.Module):
             else:
                 results.update(self.auxiliary_task_predictor(enc_output=enc_output, pooled=pooled))
         results['enc_output'] = enc_output
-        results['enc_hidden'] = enc_hidden
+        results.lazy('enc_hidden', enc_hidden_fn)
         results['_pooled_memory'] = pooled
         return results
 
@@ -198,7 +234,7 @@ class Seq2Seq(nn.Module):
             # the encoder/decoder boundary, for the staged backward of runtime/ddp.py: every path from the loss to an
             # encoder / fusion parameter goes through enc_output (the pooled memory and the length head hang off it),
             # so the gradients of everything downstream are complete before the encoder's backward starts
-            eo = results['enc_output']
+            eo = results.get('_enc_root', results['enc_output'])
             self._cut = [t for t in (eo if isinstance(eo, (list, tuple)) else [eo]) if t.requires_grad]
         inputs_for_decoder = self.prepare_inputs_for_decoder(results, category)
         hidden_states, embs, *_ = self.decoder(tgt_tokens, decoding_type=decoding_type, want_embs=False,
