@@ -649,6 +649,7 @@ def main():
                           "parallelism": "dp%d" % world, "hipgraph": bool(use_graph), "live_row_gemms": True,
                           "sync_bn": bool(model.opt.get("sync_bn", False)),
                           "overlapped_allreduce": bool(staged),
+                          "graph_collectives": bool(getattr(engine, "graph_collectives", False)),
                           "gradient_buckets": (3 if engine.three else 2) if staged else 1},
                "timing": extra_timing, "rank_losses": rank_losses,
                "roofline": roofline, "cpu_baseline": cpu, "decode": decode, "train_L30": l30,

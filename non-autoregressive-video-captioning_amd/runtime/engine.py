@@ -73,6 +73,12 @@ class TrainStep(object):
         self.hsplit = ddp.head_split() if three_ok else None
         self.three = None                   # decided at the first step (needs model._cut_head of a fused-loss forward)
         self.grad_scale = ddp.grad_scale if self.multi else 1.0
+        # NACF_DDP_GRAPH_COLLECTIVES=1: capture the RCCL calls INSIDE the step graph (torch.distributed's NCCL/RCCL process
+        # group is capturable: its internal stream forks from / joins the capturing stream through events), so that an
+        # N > 1 step is ONE graph launch like the single-GPU step instead of 4-7 graphs with host-issued collectives
+        # between them (+0.16 .. +0.27 ms per 2.8 ms step at one rank).  Off by default: it has only ever run with a
+        # 1-rank group (no multi-GPU node here) -- flip it the moment one exists (tools/scale_check.sh).
+        self.graph_collectives = self.multi and os.environ.get("NACF_DDP_GRAPH_COLLECTIVES", "0") == "1"
         self.static = self.sig = None
         self.loss = None                    # device scalar: the last step's loss
         self.n_steps = 0
@@ -146,7 +152,7 @@ class TrainStep(object):
             self.ddp.all_reduce_gradients()
         self._update()
 
-    def _capture_stage(self, fn, pool, mode):
+    def _capture_stage(self, fn, pool, mode, breaks=True):
         """Run `fn` under stream capture.  The result is a launch SEQUENCE: hipGraphs cut wherever the code reached a
         collective inside forward / backward (DataParallel.all_reduce: the SyncBN statistics) -- RCCL calls are never
         captured, the replay issues them between the graphs.  All graphs share one memory pool (the autograd graph
@@ -174,7 +180,7 @@ class TrainStep(object):
             end()
             seq.append(t)
             begin()
-        if self.ddp is not None:
+        if self.ddp is not None and breaks:
             self.ddp._capture_break = brk
         begin()
         try:
@@ -207,6 +213,23 @@ class TrainStep(object):
         pool = [None]
         side = torch.cuda.Stream(device=dev)
         side.wait_stream(torch.cuda.current_stream(dev))
+        if self.graph_collectives:
+            def whole():
+                self._front(self.static)
+                if self.staged:
+                    self._reduce_around(self._mid, self._back, lambda: self._update(0), lambda: self._update(1))
+                    self._hold.clear()
+                else:
+                    self.ddp.all_reduce_gradients()
+                    self._update()
+            with torch.cuda.stream(side):
+                one = self._capture_stage(whole, pool, 'relaxed', breaks=False)
+            torch.cuda.current_stream(dev).wait_stream(side)
+            self.count_delta = [a - b for a, b in zip(self.crit._loss_cnt, before)]
+            self.crit._loss_cnt = before
+            self.graphs = (one, None, None, None)
+            self._graph_images = self._image_state()
+            return
         with torch.cuda.stream(side):
             def front_fn():
                 self._front(self.static)
@@ -239,7 +262,9 @@ class TrainStep(object):
         front, mid, back, upd = self.graphs
         run = self._run_seq
         run(front)
-        if self.staged:
+        if self.graph_collectives:
+            pass                    # the one graph holds the reductions and the update
+        elif self.staged:
             self._reduce_around((lambda: run(mid)) if mid is not None else None, lambda: run(back),
                                 lambda: run(upd[0]), lambda: run(upd[1]))
         else:

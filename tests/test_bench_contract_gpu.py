@@ -55,3 +55,7 @@ def test_multi_rank_launch_sequence_with_one_rank_group(dev):
     # the three-stage variant (the vocabulary projection's bucket leaves a stage earlier) stays selectable
     three = run({"NACF_BENCH_FORCE_DIST": "1", "NACF_DDP_STAGES": "3", "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": "29579"})
     assert three["config"]["gradient_buckets"] == 3 and abs(three["final_loss"] - single["final_loss"]) < 2e-3
+    # NACF_DDP_GRAPH_COLLECTIVES=1: the RCCL calls captured INSIDE one step graph -- the same training, bit for bit
+    one = run({"NACF_BENCH_FORCE_DIST": "1", "NACF_DDP_GRAPH_COLLECTIVES": "1", "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": "29580"})
+    assert one["config"]["hipgraph"] is True and one["final_loss"] == multi["final_loss"]
+    assert one["config"].get("graph_collectives") is True and not multi["config"].get("graph_collectives")

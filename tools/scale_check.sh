@@ -41,3 +41,15 @@ if n > 1:
     assert max(losses) - min(losses) < 0.25 * abs(sum(losses) / n), "rank losses diverge"
     print("OK")
 PY
+# the same N-rank run with the RCCL calls captured inside ONE step graph (runtime/engine.py, NACF_DDP_GRAPH_COLLECTIVES=1):
+# at one rank it halves the launch overhead of the N > 1 sequence; it has never run with N > 1 -- this is the run that tells
+if [ "$N" -gt 1 ]; then
+  NACF_DDP_GRAPH_COLLECTIVES=1 NCCL_DEBUG=${NCCL_DEBUG:-VERSION} timeout 900 python -m torch.distributed.run --nnodes=1 --nproc-per-node $N \
+    --master-addr 127.0.0.1 --master-port $((29700 + $N)) bench.py --gpus $N --steps 50 --warmup 5 --no-compare --no-loader > $OUT/n${N}_graph.log 2>&1 \
+    && tail -1 $OUT/n${N}_graph.log | python -c "
+import json, sys
+d = json.loads(sys.stdin.read()); one = json.load(open('$OUT/n1.json'))
+print('%d ranks, collectives inside the step graph: %9.1f videos/s  %.3f ms/step  efficiency %.3f  losses %s' % (
+    d['n_gpus'], d['value'], d['ms_per_step'], d['value'] / (d['n_gpus'] * one['value']), d.get('rank_losses')))" \
+    || { echo "graph-captured collectives FAILED at $N ranks (keep NACF_DDP_GRAPH_COLLECTIVES=0):"; tail -15 $OUT/n${N}_graph.log; }
+fi
