@@ -64,7 +64,7 @@ int nacf_version(void);
  * included).  nacf_abi_count() returns the value the LIBRARY was built with; the ctypes loader
  * (runtime/lib.py:load) refuses a library whose count differs from its own signature table, so a stale
  * libnacf_hip.so next to a newer Python package fails at import time, not at the first missing symbol. */
-#define NACF_ABI_COUNT 77
+#define NACF_ABI_COUNT 79
 int nacf_abi_count(void);
 
 /* ---- batch construction (reference: dataloader.py) ----------------------------------------
@@ -305,6 +305,23 @@ int nacf_bn_concat_bwd(const float* dOut, const float* x, float* dx, int B, int 
                        const float* save_mean, const float* save_invstd,
                        float* dweight, float* dbias, float beta,
                        void* ws, size_t ws_bytes, nacf_stream_t stream);
+
+/* Every modality of one joint representation in the same launches (models/joint_representation.py:40-51 loops over the
+ * modalities; each of the BatchNorm kernels is a latency-bound chain of row loads, so two modalities side by side cost
+ * what one does).  n_mod <= 4; the array arguments are HOST arrays of n_mod entries (device pointers / ints), an array
+ * that is absent for every modality may be NULL.  Same results as n_mod calls of nacf_bn_concat_fwd / _bwd.
+ * ws: n_mod * nacf_bn_workspace(rows, D) bytes. */
+int nacf_bn_concat_fwd_multi(int n_mod, const float* const* x, float* out, int B, const int* F, int D, int M_total,
+                             const int* f_off, const float* const* weight, const float* const* bias,
+                             float* const* running_mean, float* const* running_var, int64_t* const* num_batches_tracked,
+                             float* const* save_mean, float* const* save_invstd,
+                             int training, float momentum, float eps,
+                             void* ws, size_t ws_bytes, nacf_stream_t stream);
+int nacf_bn_concat_bwd_multi(int n_mod, const float* dOut, const float* const* x, float* const* dx, int B, const int* F, int D,
+                             int M_total, const int* f_off, const float* const* weight,
+                             const float* const* save_mean, const float* const* save_invstd,
+                             float* const* dweight, float* const* dbias, float beta,
+                             void* ws, size_t ws_bytes, nacf_stream_t stream);
 
 /* Data-parallel ("synchronised") BatchNorm: models/joint_representation.py:43-45 computes batch statistics over ALL
  * B*F rows of the batch; with the batch sharded over ranks the same two-pass statistics are formed over the global batch
@@ -576,9 +593,10 @@ int nacf_adam_step(float* param, const float* grad, float* exp_avg, float* exp_a
                    float beta1, float beta2, float eps, float weight_decay,
                    float grad_clip, float grad_scale, nacf_stream_t stream);
 /* The same update over a PART of the flat buffers (data-parallel training updates the parameters whose gradient
- * bucket has been reduced while the other bucket is still in flight): bump != 0 increments step_count first -- exactly
- * one part of a step does. */
-int nacf_adam_step_part(float* param, const float* grad, float* exp_avg, float* exp_avg_sq,
+ * bucket has been reduced while the other bucket is still in flight).  `bump` is a bit set: 1 = increment step_count first
+ * (exactly one part of a step does), 2 = leave the gradient ZEROED behind (the next step's optimizer.zero_grad() of
+ * misc/run.py:254 folded into this walk: the step engine then skips its fill of the gradient buffer). */
+int nacf_adam_step_part(float* param, float* grad, float* exp_avg, float* exp_avg_sq,
                         int64_t n, const float* lr, int64_t* step_count,
                         float beta1, float beta2, float eps, float weight_decay,
                         float grad_clip, float grad_scale, int bump, nacf_stream_t stream);

@@ -241,29 +241,50 @@ __device__ __forceinline__ f32x4 bn_sum_parts(const float* __restrict__ part, in
     for (int s = rg; s < S; s += 16) t += *reinterpret_cast<const f32x4*>(part + (int64_t)s * D + c);
   return bn_fold16(t, red, rg, c4);
 }
-__global__ __launch_bounds__(256) void bn_partial_sum_v4_kernel(const float* __restrict__ x, int rows, int D, int rows_per,
-                                                                float* __restrict__ part) {
+// One launch serves every modality of a joint representation (blockIdx.z): each of these kernels is a chain of ~15
+// dependent row loads per thread, bound by latency, not by the 2 x 16 MB it moves -- two modalities side by side cost
+// what one does.
+constexpr int BN_MAX_MODS = 4;
+struct BnMod {
+  const float* x; float* dx;
+  int F, f_off, rows_per, S;      // S: row slabs this launch walks (grid.y)
+  int SP; float n_stat;           // slabs of partials to fold (1: an already folded / all-reduced vector), rows behind them
+  const float* w; const float* b;
+  float* running_mean; float* running_var; int64_t* nbt;
+  float* save_mean; float* save_invstd;
+  float* dweight; float* dbias;
+  const float* part_in0; const float* part_in1; float* part_out0; float* part_out1;
+};
+struct BnMods { BnMod m[BN_MAX_MODS]; };
+
+__global__ __launch_bounds__(256) void bn_partial_sum_v4_kernel(BnMods t, int B, int D) {
   __shared__ f32x4 red[16][16];
+  const BnMod& m = t.m[blockIdx.z];
+  if ((int)blockIdx.y >= m.S) return;
   const int c4 = threadIdx.x & 15, rg = threadIdx.x >> 4;
   const int c = blockIdx.x * 64 + c4 * 4;
-  const int r0 = blockIdx.y * rows_per, r1 = min(rows, r0 + rows_per);
+  const int rows = B * m.F;
+  const int r0 = blockIdx.y * m.rows_per, r1 = min(rows, r0 + m.rows_per);
+  const float* __restrict__ x = m.x;
   f32x4 acc = {0.f, 0.f, 0.f, 0.f};
   if (c < D) {
 #pragma unroll 4
     for (int r = r0 + rg; r < r1; r += 16) acc += *reinterpret_cast<const f32x4*>(x + (int64_t)r * D + c);
   }
-  const f32x4 t = bn_fold16(acc, red, rg, c4);
-  if (rg == 0 && c < D) *reinterpret_cast<f32x4*>(part + (int64_t)blockIdx.y * D + c) = t;
+  const f32x4 tt = bn_fold16(acc, red, rg, c4);
+  if (rg == 0 && c < D) *reinterpret_cast<f32x4*>(m.part_out0 + (int64_t)blockIdx.y * D + c) = tt;
 }
-__global__ __launch_bounds__(256) void bn_partial_sqdev_v4_kernel(const float* __restrict__ x, int rows, int D, int rows_per, int S,
-                                                                  const float* __restrict__ part_sum, float* __restrict__ part_sq,
-                                                                  float n_stat) {
+__global__ __launch_bounds__(256) void bn_partial_sqdev_v4_kernel(BnMods t, int B, int D) {
   __shared__ f32x4 red[16][16];
+  const BnMod& m = t.m[blockIdx.z];
+  if ((int)blockIdx.y >= m.S) return;
   const int c4 = threadIdx.x & 15, rg = threadIdx.x >> 4;
   const int c = blockIdx.x * 64 + c4 * 4;
-  const int r0 = blockIdx.y * rows_per, r1 = min(rows, r0 + rows_per);
+  const int rows = B * m.F;
+  const int r0 = blockIdx.y * m.rows_per, r1 = min(rows, r0 + m.rows_per);
+  const float* __restrict__ x = m.x;
   f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-  const f32x4 mean = bn_sum_parts(part_sum, S, D, c, c < D, red, rg, c4) / n_stat;
+  const f32x4 mean = bn_sum_parts(m.part_in0, m.SP, D, c, c < D, red, rg, c4) / m.n_stat;
   if (c < D) {
 #pragma unroll 4
     for (int r = r0 + rg; r < r1; r += 16) {
@@ -271,26 +292,25 @@ __global__ __launch_bounds__(256) void bn_partial_sqdev_v4_kernel(const float* _
       acc += dv * dv;
     }
   }
-  const f32x4 t = bn_fold16(acc, red, rg, c4);
-  if (rg == 0 && c < D) *reinterpret_cast<f32x4*>(part_sq + (int64_t)blockIdx.y * D + c) = t;
+  const f32x4 tt = bn_fold16(acc, red, rg, c4);
+  if (rg == 0 && c < D) *reinterpret_cast<f32x4*>(m.part_out1 + (int64_t)blockIdx.y * D + c) = tt;
 }
-__global__ __launch_bounds__(256) void bn_apply_v4_kernel(const float* __restrict__ x, float* __restrict__ out, int B, int F, int D,
-                                                          int M_total, int f_off, const float* __restrict__ w,
-                                                          const float* __restrict__ b, float* __restrict__ running_mean,
-                                                          float* __restrict__ running_var, int64_t* __restrict__ nbt,
-                                                          float* __restrict__ save_mean, float* __restrict__ save_invstd,
-                                                          int training, float momentum, float eps, int S,
-                                                          const float* __restrict__ part_sum, const float* __restrict__ part_sq,
-                                                          int rows_per, float n_stat) {
+__global__ __launch_bounds__(256) void bn_apply_v4_kernel(BnMods t, float* __restrict__ out, int B, int D, int M_total,
+                                                          int training, float momentum, float eps) {
+  const BnMod& m = t.m[blockIdx.z];
+  if ((int)blockIdx.y >= m.S) return;
   const int c4 = threadIdx.x & 15, rg = threadIdx.x >> 4;
   const int c = blockIdx.x * 64 + c4 * 4;
   __shared__ f32x4 red[16][16];
+  const int F = m.F, f_off = m.f_off;
   const int rows = B * F;
-  const int r0 = blockIdx.y * rows_per, r1 = min(rows, r0 + rows_per);
+  const float n_stat = m.n_stat;
+  const int r0 = blockIdx.y * m.rows_per, r1 = min(rows, r0 + m.rows_per);
+  const float* __restrict__ x = m.x;
   f32x4 sm = {0.f, 0.f, 0.f, 0.f}, sq = {0.f, 0.f, 0.f, 0.f};
   if (training) {            // block-uniform: every thread takes part in the folds
-    sm = bn_sum_parts(part_sum, S, D, c, c < D, red, rg, c4);
-    sq = bn_sum_parts(part_sq, S, D, c, c < D, red, rg, c4);
+    sm = bn_sum_parts(m.part_in0, m.SP, D, c, c < D, red, rg, c4);
+    sq = bn_sum_parts(m.part_in1, m.SP, D, c, c < D, red, rg, c4);
   }
   if (c >= D) return;
   f32x4 mean, invstd;
@@ -303,20 +323,20 @@ __global__ __launch_bounds__(256) void bn_apply_v4_kernel(const float* __restric
       const f32x4 var_u = sq / (n_stat > 1.f ? n_stat - 1.f : 1.f);
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        if (running_mean) running_mean[c + e] = (1.f - momentum) * running_mean[c + e] + momentum * mean[e];
-        if (running_var) running_var[c + e] = (1.f - momentum) * running_var[c + e] + momentum * var_u[e];
-        if (save_mean) save_mean[c + e] = mean[e];
-        if (save_invstd) save_invstd[c + e] = invstd[e];
+        if (m.running_mean) m.running_mean[c + e] = (1.f - momentum) * m.running_mean[c + e] + momentum * mean[e];
+        if (m.running_var) m.running_var[c + e] = (1.f - momentum) * m.running_var[c + e] + momentum * var_u[e];
+        if (m.save_mean) m.save_mean[c + e] = mean[e];
+        if (m.save_invstd) m.save_invstd[c + e] = invstd[e];
       }
-      if (nbt && c == 0) nbt[0] += 1;
+      if (m.nbt && c == 0) m.nbt[0] += 1;
     }
   } else {
 #pragma unroll
-    for (int e = 0; e < 4; ++e) { mean[e] = running_mean[c + e]; invstd[e] = 1.0f / sqrtf(running_var[c + e] + eps); }
+    for (int e = 0; e < 4; ++e) { mean[e] = m.running_mean[c + e]; invstd[e] = 1.0f / sqrtf(m.running_var[c + e] + eps); }
   }
   f32x4 ww = {1.f, 1.f, 1.f, 1.f}, bb = {0.f, 0.f, 0.f, 0.f};
-  if (w) ww = *reinterpret_cast<const f32x4*>(w + c);
-  if (b) bb = *reinterpret_cast<const f32x4*>(b + c);
+  if (m.w) ww = *reinterpret_cast<const f32x4*>(m.w + c);
+  if (m.b) bb = *reinterpret_cast<const f32x4*>(m.b + c);
 #pragma unroll 4
   for (int r = r0 + rg; r < r1; r += 16) {
     const int bi = r / F, f = r % F;
@@ -324,19 +344,19 @@ __global__ __launch_bounds__(256) void bn_apply_v4_kernel(const float* __restric
     *reinterpret_cast<f32x4*>(out + ((int64_t)bi * M_total + f_off + f) * D + c) = (v - mean) * invstd * ww + bb;
   }
 }
-__global__ __launch_bounds__(256) void bn_bwd_partial_v4_kernel(const float* __restrict__ dOut, const float* __restrict__ x, int B,
-                                                                int F, int D, int M_total, int f_off,
-                                                                const float* __restrict__ save_mean,
-                                                                const float* __restrict__ save_invstd, int rows_per,
-                                                                float* __restrict__ part_dy, float* __restrict__ part_dyx) {
+__global__ __launch_bounds__(256) void bn_bwd_partial_v4_kernel(BnMods t, const float* __restrict__ dOut, int B, int D, int M_total) {
   __shared__ f32x4 red[16][16];
+  const BnMod& m = t.m[blockIdx.z];
+  if ((int)blockIdx.y >= m.S) return;
   const int c4 = threadIdx.x & 15, rg = threadIdx.x >> 4;
   const int c = blockIdx.x * 64 + c4 * 4;
+  const int F = m.F, f_off = m.f_off;
   const int rows = B * F;
-  const int r0 = blockIdx.y * rows_per, r1 = min(rows, r0 + rows_per);
+  const int r0 = blockIdx.y * m.rows_per, r1 = min(rows, r0 + m.rows_per);
+  const float* __restrict__ x = m.x;
   f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
   if (c < D) {
-    const f32x4 mean = *reinterpret_cast<const f32x4*>(save_mean + c), invstd = *reinterpret_cast<const f32x4*>(save_invstd + c);
+    const f32x4 mean = *reinterpret_cast<const f32x4*>(m.save_mean + c), invstd = *reinterpret_cast<const f32x4*>(m.save_invstd + c);
 #pragma unroll 4
     for (int r = r0 + rg; r < r1; r += 16) {
       const int bi = r / F, f = r % F;
@@ -348,35 +368,36 @@ __global__ __launch_bounds__(256) void bn_bwd_partial_v4_kernel(const float* __r
   const f32x4 t0 = bn_fold16(a0, red, rg, c4);
   const f32x4 t1 = bn_fold16(a1, red, rg, c4);
   if (rg == 0 && c < D) {
-    *reinterpret_cast<f32x4*>(part_dy + (int64_t)blockIdx.y * D + c) = t0;
-    *reinterpret_cast<f32x4*>(part_dyx + (int64_t)blockIdx.y * D + c) = t1;
+    *reinterpret_cast<f32x4*>(m.part_out0 + (int64_t)blockIdx.y * D + c) = t0;
+    *reinterpret_cast<f32x4*>(m.part_out1 + (int64_t)blockIdx.y * D + c) = t1;
   }
 }
-__global__ __launch_bounds__(256) void bn_bwd_apply_v4_kernel(const float* __restrict__ dOut, const float* __restrict__ x,
-                                                              float* __restrict__ dx, int B, int F, int D, int M_total, int f_off,
-                                                              const float* __restrict__ w, const float* __restrict__ save_mean,
-                                                              const float* __restrict__ save_invstd, float* __restrict__ dweight,
-                                                              float* __restrict__ dbias, float beta, int S, int rows_per,
-                                                              const float* __restrict__ part_dy, const float* __restrict__ part_dyx,
-                                                              float n_stat) {
+__global__ __launch_bounds__(256) void bn_bwd_apply_v4_kernel(BnMods t, const float* __restrict__ dOut, int B, int D, int M_total,
+                                                              float beta) {
+  const BnMod& m = t.m[blockIdx.z];
+  if ((int)blockIdx.y >= m.S) return;
   const int c4 = threadIdx.x & 15, rg = threadIdx.x >> 4;
   const int c = blockIdx.x * 64 + c4 * 4;
+  const int F = m.F, f_off = m.f_off;
   const int rows = B * F;
-  const int r0 = blockIdx.y * rows_per, r1 = min(rows, r0 + rows_per);
+  const float n_stat = m.n_stat;
+  const int r0 = blockIdx.y * m.rows_per, r1 = min(rows, r0 + m.rows_per);
+  const float* __restrict__ x = m.x;
+  float* __restrict__ dx = m.dx;
   __shared__ f32x4 red[16][16];
-  const f32x4 sdy = bn_sum_parts(part_dy, S, D, c, c < D, red, rg, c4);
-  const f32x4 sdyx = bn_sum_parts(part_dyx, S, D, c, c < D, red, rg, c4);
+  const f32x4 sdy = bn_sum_parts(m.part_in0, m.SP, D, c, c < D, red, rg, c4);
+  const f32x4 sdyx = bn_sum_parts(m.part_in1, m.SP, D, c, c < D, red, rg, c4);
   if (c >= D) return;
   if (blockIdx.y == 0 && rg == 0) {
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-      if (dweight) dweight[c + e] = (beta != 0.f) ? sdyx[e] + beta * dweight[c + e] : sdyx[e];
-      if (dbias) dbias[c + e] = (beta != 0.f) ? sdy[e] + beta * dbias[c + e] : sdy[e];
+      if (m.dweight) m.dweight[c + e] = (beta != 0.f) ? sdyx[e] + beta * m.dweight[c + e] : sdyx[e];
+      if (m.dbias) m.dbias[c + e] = (beta != 0.f) ? sdy[e] + beta * m.dbias[c + e] : sdy[e];
     }
   }
-  const f32x4 mean = *reinterpret_cast<const f32x4*>(save_mean + c), invstd = *reinterpret_cast<const f32x4*>(save_invstd + c);
+  const f32x4 mean = *reinterpret_cast<const f32x4*>(m.save_mean + c), invstd = *reinterpret_cast<const f32x4*>(m.save_invstd + c);
   f32x4 ww = {1.f, 1.f, 1.f, 1.f};
-  if (w) ww = *reinterpret_cast<const f32x4*>(w + c);
+  if (m.w) ww = *reinterpret_cast<const f32x4*>(m.w + c);
   const float invn = 1.f / n_stat;
 #pragma unroll 4
   for (int r = r0 + rg; r < r1; r += 16) {
@@ -770,7 +791,8 @@ __global__ __launch_bounds__(256) void vocab_logsoftmax_bwd_kernel(const float* 
 }
 
 // ------------------------------------------------------------------ Adam
-__global__ void adam_step_kernel(float* __restrict__ param, const float* __restrict__ grad, float* __restrict__ m,
+template <bool ZERO>
+__global__ void adam_step_kernel(float* __restrict__ param, float* __restrict__ grad, float* __restrict__ m,
                                  float* __restrict__ v, int64_t n, const float* __restrict__ lr_p,
                                  const int64_t* __restrict__ step_p, float b1, float b2, float eps, float wd,
                                  float clip, float gscale) {
@@ -783,6 +805,7 @@ __global__ void adam_step_kernel(float* __restrict__ param, const float* __restr
   const float inv_sqrt_bc2 = 1.f / sqrtf(bc2);
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
     float g = grad[i] * gscale;
+    if (ZERO) grad[i] = 0.f;          // the next step's zero_grad, for 4 of the 32 bytes per parameter this walk moves anyway
     g = fminf(fmaxf(g, -clip), clip);
     const float p = param[i];
     g += wd * p;
@@ -855,40 +878,114 @@ size_t nacf_bn_workspace(int rows, int D) {
   return (size_t)2 * BN_MAX_SLABS * D * sizeof(float) + 256;
 }
 
+// n_mod modalities of one joint representation per launch (x[i]: [B, F[i], D] -> frames f_off[i] .. of out [B, M_total, D]).
+// ws: n_mod * nacf_bn_workspace bytes.  Buffers that are not 16-byte aligned / D % 4 != 0: one modality at a time.
+int nacf_bn_concat_fwd_multi(int n_mod, const float* const* x, float* out, int B, const int* F, int D, int M_total, const int* f_off,
+                             const float* const* weight, const float* const* bias, float* const* running_mean,
+                             float* const* running_var, int64_t* const* num_batches_tracked, float* const* save_mean,
+                             float* const* save_invstd, int training, float momentum, float eps, void* ws, size_t ws_bytes,
+                             nacf_stream_t stream) {
+  NACF_CHECK(n_mod >= 1 && n_mod <= BN_MAX_MODS && x && out && F && f_off && B > 0 && D > 0, NACF_EINVAL, "nacf_bn_concat_fwd_multi: bad argument");
+  const size_t ws_one = nacf_bn_workspace(0, D);
+  NACF_CHECK(ws && ws_bytes >= ws_one * n_mod, NACF_EWORKSPACE, "nacf_bn_concat_fwd_multi: workspace too small");
+  auto at = [](auto* const* arr, int i) { return arr ? arr[i] : nullptr; };
+  bool v4 = (D % 4 == 0) && bn_aligned16(out, ws);
+  BnMods t = {};
+  int S_max = 1;
+  for (int i = 0; i < n_mod; ++i) {
+    NACF_CHECK(x[i] && F[i] > 0 && f_off[i] >= 0 && f_off[i] + F[i] <= M_total, NACF_EINVAL, "nacf_bn_concat_fwd_multi: frame window outside the memory");
+    NACF_CHECK(training || (at(running_mean, i) && at(running_var, i)), NACF_EINVAL, "nacf_bn_concat_fwd_multi: eval mode needs running stats");
+    BnMod& m = t.m[i];
+    m.x = x[i]; m.F = F[i]; m.f_off = f_off[i];
+    bn_split(B * F[i], &m.S, &m.rows_per);
+    m.SP = m.S; m.n_stat = (float)(B * F[i]);
+    m.w = at(weight, i); m.b = at(bias, i);
+    m.running_mean = at(running_mean, i); m.running_var = at(running_var, i); m.nbt = at(num_batches_tracked, i);
+    m.save_mean = at(save_mean, i); m.save_invstd = at(save_invstd, i);
+    float* part = reinterpret_cast<float*>(reinterpret_cast<char*>(ws) + ws_one * i);
+    m.part_out0 = part; m.part_out1 = part + (size_t)BN_MAX_SLABS * D;
+    m.part_in0 = m.part_out0; m.part_in1 = m.part_out1;
+    v4 = v4 && bn_aligned16(m.x, m.w, m.b, m.save_mean, m.save_invstd);
+    if (m.S > S_max) S_max = m.S;
+  }
+  hipStream_t s = as_hip(stream);
+  if (v4) {
+    dim3 grid(cdiv(D, 64), S_max, n_mod);
+    if (training) {
+      hipLaunchKernelGGL(bn_partial_sum_v4_kernel, grid, dim3(256), 0, s, t, B, D);
+      hipLaunchKernelGGL(bn_partial_sqdev_v4_kernel, grid, dim3(256), 0, s, t, B, D);
+    }
+    hipLaunchKernelGGL(bn_apply_v4_kernel, grid, dim3(256), 0, s, t, out, B, D, M_total, training, momentum, eps);
+  } else {
+    for (int i = 0; i < n_mod; ++i) {
+      const BnMod& m = t.m[i];
+      dim3 grid(cdiv(D, 64), m.S);
+      if (training) {
+        hipLaunchKernelGGL(bn_partial_sum_kernel, grid, dim3(256), 0, s, m.x, B * m.F, D, m.rows_per, m.part_out0);
+        hipLaunchKernelGGL(bn_partial_sqdev_kernel, grid, dim3(256), 0, s, m.x, B * m.F, D, m.rows_per, m.S, m.part_in0, m.part_out1, m.n_stat);
+      }
+      hipLaunchKernelGGL(bn_apply_kernel, grid, dim3(256), 0, s, m.x, out, B, m.F, D, M_total, m.f_off, m.w, m.b, m.running_mean,
+                         m.running_var, m.nbt, m.save_mean, m.save_invstd, training, momentum, eps, m.S, m.part_in0, m.part_in1,
+                         m.rows_per, m.n_stat);
+    }
+  }
+  NACF_LAUNCH_CHECK("nacf_bn_concat_fwd_multi");
+  return NACF_OK;
+}
+
 int nacf_bn_concat_fwd(const float* x, float* out, int B, int F, int D, int M_total, int f_off, const float* weight,
                        const float* bias, float* running_mean, float* running_var, int64_t* num_batches_tracked,
                        float* save_mean, float* save_invstd, int training, float momentum, float eps, void* ws,
                        size_t ws_bytes, nacf_stream_t stream) {
   NACF_CHECK(x && out && B > 0 && F > 0 && D > 0, NACF_EINVAL, "nacf_bn_concat_fwd: bad argument");
-  NACF_CHECK(f_off >= 0 && f_off + F <= M_total, NACF_EINVAL, "nacf_bn_concat_fwd: frame window outside the memory");
-  NACF_CHECK(training || (running_mean && running_var), NACF_EINVAL, "nacf_bn_concat_fwd: eval mode needs running stats");
-  NACF_CHECK(ws && ws_bytes >= nacf_bn_workspace(B * F, D), NACF_EWORKSPACE, "nacf_bn_concat_fwd: workspace too small");
-  const int rows = B * F;
-  int S, rows_per;
-  bn_split(rows, &S, &rows_per);
-  float* part_sum = reinterpret_cast<float*>(ws);
-  float* part_sq = part_sum + (size_t)BN_MAX_SLABS * D;
-  hipStream_t s = as_hip(stream);
-  dim3 grid(cdiv(D, 64), S);
-  const bool v4 = (D % 4 == 0) && bn_aligned16(x, out, weight, bias, save_mean, save_invstd, ws);
-  if (v4) {
-    if (training) {
-      hipLaunchKernelGGL(bn_partial_sum_v4_kernel, grid, dim3(256), 0, s, x, rows, D, rows_per, part_sum);
-      hipLaunchKernelGGL(bn_partial_sqdev_v4_kernel, grid, dim3(256), 0, s, x, rows, D, rows_per, S, part_sum, part_sq, (float)rows);
-    }
-    hipLaunchKernelGGL(bn_apply_v4_kernel, grid, dim3(256), 0, s, x, out, B, F, D, M_total, f_off, weight, bias, running_mean,
-                       running_var, num_batches_tracked, save_mean, save_invstd, training, momentum, eps, S, part_sum,
-                       part_sq, rows_per, (float)rows);
-  } else {
-    if (training) {
-      hipLaunchKernelGGL(bn_partial_sum_kernel, grid, dim3(256), 0, s, x, rows, D, rows_per, part_sum);
-      hipLaunchKernelGGL(bn_partial_sqdev_kernel, grid, dim3(256), 0, s, x, rows, D, rows_per, S, part_sum, part_sq, (float)rows);
-    }
-    hipLaunchKernelGGL(bn_apply_kernel, grid, dim3(256), 0, s, x, out, B, F, D, M_total, f_off, weight, bias, running_mean,
-                       running_var, num_batches_tracked, save_mean, save_invstd, training, momentum, eps, S, part_sum,
-                       part_sq, rows_per, (float)rows);
+  return nacf_bn_concat_fwd_multi(1, &x, out, B, &F, D, M_total, &f_off, &weight, &bias, &running_mean, &running_var,
+                                  &num_batches_tracked, &save_mean, &save_invstd, training, momentum, eps, ws, ws_bytes, stream);
+}
+
+int nacf_bn_concat_bwd_multi(int n_mod, const float* dOut, const float* const* x, float* const* dx, int B, const int* F, int D,
+                             int M_total, const int* f_off, const float* const* weight, const float* const* save_mean,
+                             const float* const* save_invstd, float* const* dweight, float* const* dbias, float beta, void* ws,
+                             size_t ws_bytes, nacf_stream_t stream) {
+  NACF_CHECK(n_mod >= 1 && n_mod <= BN_MAX_MODS && dOut && x && dx && F && f_off && save_mean && save_invstd && B > 0 && D > 0,
+             NACF_EINVAL, "nacf_bn_concat_bwd_multi: bad argument");
+  const size_t ws_one = nacf_bn_workspace(0, D);
+  NACF_CHECK(ws && ws_bytes >= ws_one * n_mod, NACF_EWORKSPACE, "nacf_bn_concat_bwd_multi: workspace too small");
+  auto at = [](auto* const* arr, int i) { return arr ? arr[i] : nullptr; };
+  bool v4 = (D % 4 == 0) && bn_aligned16(dOut, ws);
+  BnMods t = {};
+  int S_max = 1;
+  for (int i = 0; i < n_mod; ++i) {
+    NACF_CHECK(x[i] && dx[i] && save_mean[i] && save_invstd[i], NACF_EINVAL, "nacf_bn_concat_bwd_multi: null pointer");
+    NACF_CHECK(F[i] > 0 && f_off[i] >= 0 && f_off[i] + F[i] <= M_total, NACF_EINVAL, "nacf_bn_concat_bwd_multi: bad shape");
+    BnMod& m = t.m[i];
+    m.x = x[i]; m.dx = dx[i]; m.F = F[i]; m.f_off = f_off[i];
+    bn_split(B * F[i], &m.S, &m.rows_per);
+    m.SP = m.S; m.n_stat = (float)(B * F[i]);
+    m.w = at(weight, i);
+    m.save_mean = const_cast<float*>(save_mean[i]); m.save_invstd = const_cast<float*>(save_invstd[i]);
+    m.dweight = at(dweight, i); m.dbias = at(dbias, i);
+    float* part = reinterpret_cast<float*>(reinterpret_cast<char*>(ws) + ws_one * i);
+    m.part_out0 = part; m.part_out1 = part + (size_t)BN_MAX_SLABS * D;
+    m.part_in0 = m.part_out0; m.part_in1 = m.part_out1;
+    v4 = v4 && bn_aligned16(m.x, m.dx, m.w, m.save_mean, m.save_invstd);
+    if (m.S > S_max) S_max = m.S;
   }
-  NACF_LAUNCH_CHECK("nacf_bn_concat_fwd");
+  hipStream_t s = as_hip(stream);
+  if (v4) {
+    dim3 grid(cdiv(D, 64), S_max, n_mod);
+    hipLaunchKernelGGL(bn_bwd_partial_v4_kernel, grid, dim3(256), 0, s, t, dOut, B, D, M_total);
+    hipLaunchKernelGGL(bn_bwd_apply_v4_kernel, grid, dim3(256), 0, s, t, dOut, B, D, M_total, beta);
+  } else {
+    for (int i = 0; i < n_mod; ++i) {
+      const BnMod& m = t.m[i];
+      dim3 grid(cdiv(D, 64), m.S);
+      hipLaunchKernelGGL(bn_bwd_partial_kernel, grid, dim3(256), 0, s, dOut, m.x, B, m.F, D, M_total, m.f_off, m.save_mean,
+                         m.save_invstd, m.rows_per, m.part_out0, m.part_out1);
+      hipLaunchKernelGGL(bn_bwd_apply_kernel, grid, dim3(256), 0, s, dOut, m.x, m.dx, B, m.F, D, M_total, m.f_off, m.w, m.save_mean,
+                         m.save_invstd, m.dweight, m.dbias, beta, m.S, m.rows_per, m.part_in0, m.part_in1, m.n_stat);
+    }
+  }
+  NACF_LAUNCH_CHECK("nacf_bn_concat_bwd_multi");
   return NACF_OK;
 }
 
@@ -896,28 +993,8 @@ int nacf_bn_concat_bwd(const float* dOut, const float* x, float* dx, int B, int 
                        const float* weight, const float* save_mean, const float* save_invstd, float* dweight,
                        float* dbias, float beta, void* ws, size_t ws_bytes, nacf_stream_t stream) {
   NACF_CHECK(dOut && x && dx && save_mean && save_invstd, NACF_EINVAL, "nacf_bn_concat_bwd: null pointer");
-  NACF_CHECK(B > 0 && F > 0 && D > 0 && f_off >= 0 && f_off + F <= M_total, NACF_EINVAL, "nacf_bn_concat_bwd: bad shape");
-  NACF_CHECK(ws && ws_bytes >= nacf_bn_workspace(B * F, D), NACF_EWORKSPACE, "nacf_bn_concat_bwd: workspace too small");
-  const int rows = B * F;
-  int S, rows_per;
-  bn_split(rows, &S, &rows_per);
-  float* part_dy = reinterpret_cast<float*>(ws);
-  float* part_dyx = part_dy + (size_t)BN_MAX_SLABS * D;
-  hipStream_t s = as_hip(stream);
-  dim3 grid(cdiv(D, 64), S);
-  if ((D % 4 == 0) && bn_aligned16(dOut, x, dx, weight, save_mean, save_invstd, ws)) {
-    hipLaunchKernelGGL(bn_bwd_partial_v4_kernel, grid, dim3(256), 0, s, dOut, x, B, F, D, M_total, f_off, save_mean,
-                       save_invstd, rows_per, part_dy, part_dyx);
-    hipLaunchKernelGGL(bn_bwd_apply_v4_kernel, grid, dim3(256), 0, s, dOut, x, dx, B, F, D, M_total, f_off, weight, save_mean,
-                       save_invstd, dweight, dbias, beta, S, rows_per, part_dy, part_dyx, (float)rows);
-  } else {
-    hipLaunchKernelGGL(bn_bwd_partial_kernel, grid, dim3(256), 0, s, dOut, x, B, F, D, M_total, f_off, save_mean,
-                       save_invstd, rows_per, part_dy, part_dyx);
-    hipLaunchKernelGGL(bn_bwd_apply_kernel, grid, dim3(256), 0, s, dOut, x, dx, B, F, D, M_total, f_off, weight, save_mean,
-                       save_invstd, dweight, dbias, beta, S, rows_per, part_dy, part_dyx, (float)rows);
-  }
-  NACF_LAUNCH_CHECK("nacf_bn_concat_bwd");
-  return NACF_OK;
+  return nacf_bn_concat_bwd_multi(1, dOut, &x, &dx, B, &F, D, M_total, &f_off, &weight, &save_mean, &save_invstd, &dweight, &dbias,
+                                  beta, ws, ws_bytes, stream);
 }
 
 // ---- data-parallel (synchronised) BatchNorm: the same two-pass statistics over the GLOBAL batch, cut where the ranks
@@ -932,11 +1009,15 @@ int nacf_bn_sync_stat(const float* x, int rows, int D, const float* sum_global, 
   hipStream_t s = as_hip(stream);
   dim3 grid(cdiv(D, 64), S);
   const bool v4 = (D % 4 == 0) && bn_aligned16(x, sum_global, ws);
+  BnMods t = {};
+  BnMod& m = t.m[0];
+  m.x = x; m.F = rows; m.rows_per = rows_per; m.S = S; m.SP = 1; m.n_stat = (float)n_total;     // B = 1, F = rows
+  m.part_in0 = sum_global; m.part_out0 = part; m.part_out1 = part;
   if (!sum_global) {
-    if (v4) hipLaunchKernelGGL(bn_partial_sum_v4_kernel, grid, dim3(256), 0, s, x, rows, D, rows_per, part);
+    if (v4) hipLaunchKernelGGL(bn_partial_sum_v4_kernel, grid, dim3(256), 0, s, t, 1, D);
     else hipLaunchKernelGGL(bn_partial_sum_kernel, grid, dim3(256), 0, s, x, rows, D, rows_per, part);
   } else {            // squared deviations from the GLOBAL mean = sum_global / n_total (one "slab" of partial sums)
-    if (v4) hipLaunchKernelGGL(bn_partial_sqdev_v4_kernel, grid, dim3(256), 0, s, x, rows, D, rows_per, 1, sum_global, part, (float)n_total);
+    if (v4) hipLaunchKernelGGL(bn_partial_sqdev_v4_kernel, grid, dim3(256), 0, s, t, 1, D);
     else hipLaunchKernelGGL(bn_partial_sqdev_kernel, grid, dim3(256), 0, s, x, rows, D, rows_per, 1, sum_global, part, (float)n_total);
   }
   hipLaunchKernelGGL(bn_fold_parts_kernel, dim3(cdiv(D, 256)), dim3(256), 0, s, part, S, D, out, (float*)nullptr, 0.f);
@@ -956,11 +1037,14 @@ int nacf_bn_concat_fwd_sync(const float* x, float* out, int B, int F, int D, int
   bn_split(rows, &S, &rows_per);
   hipStream_t s = as_hip(stream);
   dim3 grid(cdiv(D, 64), S);
-  if ((D % 4 == 0) && bn_aligned16(x, out, weight, bias, save_mean, save_invstd, sum_global, sqdev_global))
-    hipLaunchKernelGGL(bn_apply_v4_kernel, grid, dim3(256), 0, s, x, out, B, F, D, M_total, f_off, weight, bias, running_mean,
-                       running_var, num_batches_tracked, save_mean, save_invstd, 1, momentum, eps, 1, sum_global, sqdev_global,
-                       rows_per, (float)n_total);
-  else
+  if ((D % 4 == 0) && bn_aligned16(x, out, weight, bias, save_mean, save_invstd, sum_global, sqdev_global)) {
+    BnMods t = {};
+    BnMod& m = t.m[0];
+    m.x = x; m.F = F; m.f_off = f_off; m.rows_per = rows_per; m.S = S; m.SP = 1; m.n_stat = (float)n_total;
+    m.w = weight; m.b = bias; m.running_mean = running_mean; m.running_var = running_var; m.nbt = num_batches_tracked;
+    m.save_mean = save_mean; m.save_invstd = save_invstd; m.part_in0 = sum_global; m.part_in1 = sqdev_global;
+    hipLaunchKernelGGL(bn_apply_v4_kernel, grid, dim3(256), 0, s, t, out, B, D, M_total, 1, momentum, eps);
+  } else
     hipLaunchKernelGGL(bn_apply_kernel, grid, dim3(256), 0, s, x, out, B, F, D, M_total, f_off, weight, bias, running_mean,
                        running_var, num_batches_tracked, save_mean, save_invstd, 1, momentum, eps, 1, sum_global, sqdev_global,
                        rows_per, (float)n_total);
@@ -981,10 +1065,14 @@ int nacf_bn_sync_bwd_stat(const float* dOut, const float* x, int B, int F, int D
   float* part_dyx = part_dy + (size_t)BN_MAX_SLABS * D;
   hipStream_t s = as_hip(stream);
   dim3 grid(cdiv(D, 64), S);
-  if ((D % 4 == 0) && bn_aligned16(dOut, x, save_mean, save_invstd, ws))
-    hipLaunchKernelGGL(bn_bwd_partial_v4_kernel, grid, dim3(256), 0, s, dOut, x, B, F, D, M_total, f_off, save_mean,
-                       save_invstd, rows_per, part_dy, part_dyx);
-  else
+  if ((D % 4 == 0) && bn_aligned16(dOut, x, save_mean, save_invstd, ws)) {
+    BnMods t = {};
+    BnMod& m = t.m[0];
+    m.x = x; m.F = F; m.f_off = f_off; m.rows_per = rows_per; m.S = S;
+    m.save_mean = const_cast<float*>(save_mean); m.save_invstd = const_cast<float*>(save_invstd);
+    m.part_out0 = part_dy; m.part_out1 = part_dyx;
+    hipLaunchKernelGGL(bn_bwd_partial_v4_kernel, grid, dim3(256), 0, s, t, dOut, B, D, M_total);
+  } else
     hipLaunchKernelGGL(bn_bwd_partial_kernel, grid, dim3(256), 0, s, dOut, x, B, F, D, M_total, f_off, save_mean,
                        save_invstd, rows_per, part_dy, part_dyx);
   // the LOCAL sums are this rank's bias / weight gradient (the gradient all-reduce adds the ranks up); the vectors
@@ -1006,11 +1094,14 @@ int nacf_bn_concat_bwd_sync(const float* dOut, const float* x, float* dx, int B,
   bn_split(rows, &S, &rows_per);
   hipStream_t s = as_hip(stream);
   dim3 grid(cdiv(D, 64), S);
-  if ((D % 4 == 0) && bn_aligned16(dOut, x, dx, weight, save_mean, save_invstd, sums2_global))
-    hipLaunchKernelGGL(bn_bwd_apply_v4_kernel, grid, dim3(256), 0, s, dOut, x, dx, B, F, D, M_total, f_off, weight, save_mean,
-                       save_invstd, (float*)nullptr, (float*)nullptr, 0.f, 1, rows_per, sums2_global, sums2_global + D,
-                       (float)n_total);
-  else
+  if ((D % 4 == 0) && bn_aligned16(dOut, x, dx, weight, save_mean, save_invstd, sums2_global)) {
+    BnMods t = {};
+    BnMod& m = t.m[0];
+    m.x = x; m.dx = dx; m.F = F; m.f_off = f_off; m.rows_per = rows_per; m.S = S; m.SP = 1; m.n_stat = (float)n_total;
+    m.w = weight; m.save_mean = const_cast<float*>(save_mean); m.save_invstd = const_cast<float*>(save_invstd);
+    m.part_in0 = sums2_global; m.part_in1 = sums2_global + D;
+    hipLaunchKernelGGL(bn_bwd_apply_v4_kernel, grid, dim3(256), 0, s, t, dOut, B, D, M_total, 0.f);
+  } else
     hipLaunchKernelGGL(bn_bwd_apply_kernel, grid, dim3(256), 0, s, dOut, x, dx, B, F, D, M_total, f_off, weight, save_mean,
                        save_invstd, (float*)nullptr, (float*)nullptr, 0.f, 1, rows_per, sums2_global, sums2_global + D,
                        (float)n_total);
@@ -1147,15 +1238,19 @@ int nacf_vocab_logsoftmax_bwd(const float* dlogp, int64_t ldg, const float* logp
   return NACF_OK;
 }
 
-int nacf_adam_step_part(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, const float* lr,
+int nacf_adam_step_part(float* param, float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, const float* lr,
                         int64_t* step_count, float beta1, float beta2, float eps, float weight_decay, float grad_clip,
                         float grad_scale, int bump, nacf_stream_t stream) {
   NACF_CHECK(param && grad && exp_avg && exp_avg_sq && lr && step_count && n > 0, NACF_EINVAL,
              "nacf_adam_step: bad argument");
   hipStream_t s = as_hip(stream);
-  if (bump) hipLaunchKernelGGL(adam_bump_kernel, dim3(1), dim3(1), 0, s, step_count);
-  hipLaunchKernelGGL(adam_step_kernel, dim3(grid_for(n, 256, 4096)), dim3(256), 0, s, param, grad, exp_avg, exp_avg_sq, n,
-                     lr, step_count, beta1, beta2, eps, weight_decay, grad_clip, grad_scale);
+  if (bump & 1) hipLaunchKernelGGL(adam_bump_kernel, dim3(1), dim3(1), 0, s, step_count);
+  if (bump & 2)
+    hipLaunchKernelGGL(adam_step_kernel<true>, dim3(grid_for(n, 256, 4096)), dim3(256), 0, s, param, grad, exp_avg, exp_avg_sq, n,
+                       lr, step_count, beta1, beta2, eps, weight_decay, grad_clip, grad_scale);
+  else
+    hipLaunchKernelGGL(adam_step_kernel<false>, dim3(grid_for(n, 256, 4096)), dim3(256), 0, s, param, grad, exp_avg, exp_avg_sq, n,
+                       lr, step_count, beta1, beta2, eps, weight_decay, grad_clip, grad_scale);
   NACF_LAUNCH_CHECK("nacf_adam_step");
   return NACF_OK;
 }
@@ -1163,8 +1258,8 @@ int nacf_adam_step_part(float* param, const float* grad, float* exp_avg, float* 
 int nacf_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, const float* lr,
                    int64_t* step_count, float beta1, float beta2, float eps, float weight_decay, float grad_clip,
                    float grad_scale, nacf_stream_t stream) {
-  return nacf_adam_step_part(param, grad, exp_avg, exp_avg_sq, n, lr, step_count, beta1, beta2, eps, weight_decay, grad_clip,
-                             grad_scale, 1, stream);
+  return nacf_adam_step_part(param, const_cast<float*>(grad), exp_avg, exp_avg_sq, n, lr, step_count, beta1, beta2, eps, weight_decay,
+                             grad_clip, grad_scale, 1, stream);
 }
 
 }  // extern "C"

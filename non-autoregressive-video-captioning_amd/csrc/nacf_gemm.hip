@@ -577,6 +577,8 @@ static int dw_items_launch_locked(hipStream_t s) {
   // measured on the NACF step (bench.py, B = 128): exact mode 1024: 2.91 ms, 1280: 2.89, 1536: 2.90, 3072: 2.93;
   // throughput mode (its k-tiles are 3x shorter, the fixed cost of a split weighs less) 1024: 2.30, 1536: 2.12, 4096: 2.08
   const int target = target_env > 0 ? target_env : (mode == NACF_GEMM_BF16 ? 4096 : 1280);
+  // NACF_DW_GROUP_ORDER=0: every split spreads its tiles over the 8 XCDs (round 2); default 1: see GemmGroup
+  static const bool split_major = [] { const char* e = getenv("NACF_DW_GROUP_ORDER"); return !(e && atoi(e) == 0); }();
   std::vector<int> kt(n), tiles(n), sp(n), order(n);
   long W = 0;
   for (int i = 0; i < n; ++i) {
@@ -614,6 +616,7 @@ static int dw_items_launch_locked(hipStream_t s) {
       NACF_LAUNCH_CHECK("nacf_dw_group_flush(combine, between chunks)");
     }
     GemmGroup<EpiStore> t = {};
+    t.order = split_major ? 1 : 0;
     int wg = 0;
     for (; done < n && t.n < GEMM_GROUP_MAX; ++done) {
       const DwGemmItem& it = g_dw_items[order[done]];
@@ -625,6 +628,15 @@ static int dw_items_launch_locked(hipStream_t s) {
       g.tiles_m = cdiv(g.M, 128);
       g.tiles_n = cdiv(g.N, 128);
       const int real = cdiv(it.M, g.k_per_split);
+      if (split_major) {
+        // an XCD's run of `run` consecutive tiles inside one split: as square as the tile grid allows (GemmShape::group_n)
+        const long run = ((long)tiles[i] * real + 7) / 8;
+        if (run < tiles[i]) {
+          int gn = 1;
+          while ((long)(gn + 1) * (gn + 1) <= run) ++gn;
+          if (gn < g.tiles_n) g.group_n = gn;
+        }
+      }
       float* slabs = it.ws;
       float* part = slabs + (real > 1 ? (size_t)real * it.N * it.K : 0);
       EpiStore epi;
@@ -638,9 +650,9 @@ static int dw_items_launch_locked(hipStream_t s) {
         if (real > 1) g.colsum_part = part;
         else { g.colsum_out = it.db; g.colsum_beta = it.beta; }
       }
-      const int gx = (tiles[i] + 7) / 8 * 8;
+      const int gx = split_major ? tiles[i] : (tiles[i] + 7) / 8 * 8;
       t.g[t.n] = g; t.e[t.n] = epi; t.gx[t.n] = gx; t.nz[t.n] = real; t.wg0[t.n] = wg;
-      wg += gx * real;
+      wg += split_major ? (gx * real + 7) / 8 * 8 : gx * real;
       ++t.n;
       if (real > 1) {
         const int rc = dw_combine_push_locked(slabs, it.dW, it.lddw, it.db ? part : nullptr, it.db, it.N, it.K, real, it.beta, s);

@@ -25,18 +25,23 @@ class FusedAdam(object):
         self.exp_avg_sq = torch.zeros_like(flat.data)
         self.step_dev = torch.zeros(1, dtype=torch.int64, device=flat.data.device)
         self.lr_dev = torch.zeros(1, dtype=torch.float32, device=flat.data.device)
+        self._lr_on_dev = 0.0
         self.param_groups = [{'lr': 0.0, 'params': flat.params}]
 
     def set_lr(self, lr):
         self.param_groups[0]['lr'] = lr
-        self.lr_dev.fill_(lr)
+        if lr != self._lr_on_dev:            # (constant after the warm-up: no fill launch per step then)
+            self.lr_dev.fill_(lr)
+            self._lr_on_dev = lr
 
     def zero_grad(self):
         self.model.zero_grad()
 
-    def step(self, grad_scale=1.0, lo=None, hi=None, bump=True):
+    def step(self, grad_scale=1.0, lo=None, hi=None, bump=True, zero_grad=False):
         """lo / hi: update only flat[lo:hi] (one gradient bucket of the data-parallel step); exactly one part of a
-        step passes bump=True, and it must come first"""
+        step passes bump=True, and it must come first.  zero_grad: leave the gradients of the updated range zeroed
+        (runtime/engine.py: the NEXT step's optimizer.zero_grad() for 4 more bytes per parameter of this walk; the
+        reference's optimizer.step() leaves them, so this is off unless the step engine asks)"""
         self.model.flat.touch()      # (weight images are rebuilt at the next forward entry)
         if self._flat is not self.model.flat:   # model moved (.to/.cuda) after the optimiser was built
             if torch.cuda.is_current_stream_capturing():
@@ -48,10 +53,11 @@ class FusedAdam(object):
                 self.exp_avg_sq.copy_(old[1])
                 self.step_dev.copy_(old[2])
             self.lr_dev.fill_(self.param_groups[0]['lr'])
+            self._lr_on_dev = self.param_groups[0]['lr']
         f = self._flat
         sl = slice(lo, hi)
         ops.adam_step(f.data[sl], f.grad[sl], self.exp_avg[sl], self.exp_avg_sq[sl], self.lr_dev, self.step_dev,
-                      self.betas[0], self.betas[1], self.eps, self.wd, self.grad_clip, grad_scale, bump=bump)
+                      self.betas[0], self.betas[1], self.eps, self.wd, self.grad_clip, grad_scale, bump=bump, zero_grad=zero_grad)
 
 
 class ScheduledOptim(object):

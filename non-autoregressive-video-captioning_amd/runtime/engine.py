@@ -79,6 +79,11 @@ class TrainStep(object):
         # between them (+0.16 .. +0.27 ms per 2.8 ms step at one rank).  Off by default: it has only ever run with a
         # 1-rank group (no multi-GPU node here) -- flip it the moment one exists (tools/scale_check.sh).
         self.graph_collectives = self.multi and os.environ.get("NACF_DDP_GRAPH_COLLECTIVES", "0") == "1"
+        # the Adam walk of step i leaves the gradient buffer zeroed for step i + 1 (one fill of 74 MB less per step); between
+        # its steps the engine owns that buffer.  NACF_FUSED_ZERO_GRAD=0: fill at the start of every step as misc/run.py does
+        self.fused_zero_grad = os.environ.get("NACF_FUSED_ZERO_GRAD", "1") != "0"
+        self._grad_clean = False
+        self._one = self._graph_loss = None
         self.static = self.sig = None
         self.loss = None                    # device scalar: the last step's loss
         self.n_steps = 0
@@ -88,7 +93,10 @@ class TrainStep(object):
 
     # ---- the launch sequence -------------------------------------------------------------------------------------
     def _front(self, b):
-        self.adam.zero_grad()
+        # the previous step's Adam walk left the gradients zeroed (FusedAdam.step(zero_grad=True)): no fill then
+        if not self._grad_clean:
+            self.adam.zero_grad()
+        self._grad_clean = False
         loss = self.crit.get_loss(self.forward(b))
         if self.staged and self.three is None:
             self.three = self.hsplit is not None and bool(getattr(self.model, '_cut_head', None))
@@ -100,8 +108,9 @@ class TrainStep(object):
             elif self.staged:
                 self._hold['cut'], self._hold['grads'] = self.ddp.backward_to_cut(loss)
             else:
-                loss.backward()
-        self.loss.copy_(loss.detach())
+                loss.backward(self._one)    # (a resident 1.0: backward() would fill a fresh one every step)
+        # a reference, not a copy: under capture this is the graph's own output buffer, alive as long as it is held here
+        self.loss = loss.detach()
 
     def _mid(self):
         with ops.dw_group():
@@ -113,12 +122,15 @@ class TrainStep(object):
 
     def _update(self, part=None):
         """part None: every parameter; 0: the late bucket flat[split:] (starts the step), 1: the rest flat[:split]"""
+        z = self.fused_zero_grad
         if part is None:
-            self.adam.step(grad_scale=self.grad_scale)
+            self.adam.step(grad_scale=self.grad_scale, zero_grad=z)
         elif part == 0:
-            self.adam.step(grad_scale=self.grad_scale, lo=self.split, hi=None, bump=True)
+            self.adam.step(grad_scale=self.grad_scale, lo=self.split, hi=None, bump=True, zero_grad=z)
         else:
-            self.adam.step(grad_scale=self.grad_scale, lo=0, hi=self.split, bump=False)
+            self.adam.step(grad_scale=self.grad_scale, lo=0, hi=self.split, bump=False, zero_grad=z)
+        if part != 0:
+            self._grad_clean = z          # every part of the flat gradient has been walked
 
     def _reduce_around(self, mid_stage, last_stage, update_late, update_early):
         """Gradient buckets leave as soon as they are complete and travel (RCCL's own stream, in this order) under the
@@ -229,6 +241,7 @@ class TrainStep(object):
             self.crit._loss_cnt = before
             self.graphs = (one, None, None, None)
             self._graph_images = self._image_state()
+            self._graph_loss = self.loss
             return
         with torch.cuda.stream(side):
             def front_fn():
@@ -252,6 +265,7 @@ class TrainStep(object):
         self.crit._loss_cnt = before
         self.graphs = (front, mid, back, upd)
         self._graph_images = self._image_state()
+        self._graph_loss = self.loss
 
     def _image_state(self):
         """what the captured launches bake in besides the static buffers: the GEMM mode and the weight-image set"""
@@ -261,6 +275,7 @@ class TrainStep(object):
     def _replay(self):
         front, mid, back, upd = self.graphs
         run = self._run_seq
+        self.loss = self._graph_loss
         run(front)
         if self.graph_collectives:
             pass                    # the one graph holds the reductions and the update
@@ -301,6 +316,7 @@ class TrainStep(object):
                     self.static[first], self.static[second] = pair[0], pair[1]
             self.sig = _signature(batch, self.keys)
             self.loss = torch.zeros((), device=next(iter(_tensors(batch, self.keys).values())).device)
+            self._one = torch.ones((), device=self.loss.device)
         self.n_steps += 1
         if self.sched is not None:
             self.sched.step_update_learning_rate()      # host counter + one fill of the device-side learning rate

@@ -11,6 +11,8 @@ from __future__ import annotations
 
 from typing import List, Optional
 
+import os
+
 import torch
 from torch.autograd import Function
 
@@ -150,6 +152,9 @@ class EncoderStreamsFn(Function):
         return (None, None) + tuple(dxs) + (None,) * sum(ctx.n_params)
 
 
+_BN_MULTI = os.environ.get("NACF_BN_MULTI", "1") != "0"      # tuning: 0 = one modality per launch (round 2)
+
+
 class BNConcatFn(Function):
     """per-modality BatchNorm1d over B*F rows + temporal concat
     (models/joint_representation.py:40-51).
@@ -178,6 +183,20 @@ class BNConcatFn(Function):
             for i, x in enumerate(xs):
                 ops.bn_sync_stat(x, stats[0, i], n_tot[i], stats[1, i])
             sync.all_reduce(stats[1])
+        mods = cfg["mods"]
+        if sync is None and 1 < n_mod <= 4 and _BN_MULTI:
+            # both modalities in the same launches (nacf_bn_concat_fwd_multi)
+            f_offs, sms, sis = [], [], []
+            for x in xs:
+                f_offs.append(f_off)
+                f_off += x.shape[1]
+                sms.append(_new((D,), x) if cfg["training"] else None)
+                sis.append(_new((D,), x) if cfg["training"] else None)
+            ops.bn_concat_fwd_multi(xs, out, f_offs, [m["pack"].w for m in mods], [m["pack"].b for m in mods],
+                                    [m["running_mean"] for m in mods], [m["running_var"] for m in mods], [m["nbt"] for m in mods],
+                                    sms, sis, cfg["training"], cfg.get("momentum", 0.1), cfg.get("eps", 1e-5))
+            saves = [(x, f_offs[i], sms[i], sis[i]) for i, x in enumerate(xs)]
+            xs = []
         for i, x in enumerate(xs):
             m = cfg["mods"][i]
             sm = _new((D,), x) if cfg["training"] else None
@@ -208,6 +227,15 @@ class BNConcatFn(Function):
                 pk: Pack = cfg["mods"][i]["pack"]
                 ops.bn_sync_bwd_stat(dout, x, f_off, sm, si, sums[i], pk.gw, pk.gb, beta=1.0)     # local dW / db
             sync.all_reduce(sums)
+        if sync is None and 1 < ctx.n_mod <= 4 and _BN_MULTI:
+            dxs = [torch.empty_like(x) for x, _, _, _ in ctx.saves]
+            pks = [cfg["mods"][i]["pack"] for i in range(ctx.n_mod)]
+            ops.bn_concat_bwd_multi(dout, [s_[0] for s_ in ctx.saves], dxs, [s_[1] for s_ in ctx.saves], [pk.w for pk in pks],
+                                    [s_[2] for s_ in ctx.saves], [s_[3] for s_ in ctx.saves], [pk.gw for pk in pks],
+                                    [pk.gb for pk in pks], beta=1.0)
+            grads = [dx if ctx.needs_input_grad[2 + i] else None for i, dx in enumerate(dxs)]
+            ctx.saves = None
+            return (None, None) + tuple(grads) + (None,) * (len(ctx.needs_input_grad) - 2 - ctx.n_mod)
         for i, (x, f_off, sm, si) in enumerate(ctx.saves):
             pk: Pack = cfg["mods"][i]["pack"]
             dx = torch.empty_like(x)

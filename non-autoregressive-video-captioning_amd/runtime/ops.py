@@ -593,6 +593,45 @@ def bn_concat_bwd(dout, x, dx, f_off, weight, save_mean, save_invstd, dweight, d
                                    _ptr(ws), ws.numel(), _stream()), "nacf_bn_concat_bwd")
 
 
+def _ptr_array(ts):
+    """host array of device pointers (NULL for None) for the *_multi entry points"""
+    import ctypes
+    return (ctypes.c_void_p * len(ts))(*[(t.data_ptr() if t is not None else None) for t in ts])
+
+
+def _int_array(vs):
+    import ctypes
+    return (ctypes.c_int * len(vs))(*[int(v) for v in vs])
+
+
+def bn_concat_fwd_multi(xs, out, f_offs, weights, biases, running_means, running_vars, nbts, save_means, save_invstds,
+                        training, momentum=0.1, eps=1e-5):
+    """every modality of a joint representation in the same three launches (nacf_bn_concat_fwd_multi)"""
+    _chk_f32(out, *xs, *weights, *biases, *running_means, *running_vars, *save_means, *save_invstds)
+    B, _, D = xs[0].shape
+    assert all(x.shape[0] == B and x.shape[2] == D and x.is_contiguous() for x in xs)
+    lib = L.load()
+    n = len(xs)
+    ws = WORKSPACE.get(n * lib.nacf_bn_workspace(B * max(x.shape[1] for x in xs), D), out.device)
+    L.check(lib.nacf_bn_concat_fwd_multi(n, _ptr_array(xs), _ptr(out), B, _int_array([x.shape[1] for x in xs]), D, out.shape[1],
+                                         _int_array(f_offs), _ptr_array(weights), _ptr_array(biases), _ptr_array(running_means),
+                                         _ptr_array(running_vars), _ptr_array(nbts), _ptr_array(save_means),
+                                         _ptr_array(save_invstds), int(training), float(momentum), float(eps), _ptr(ws),
+                                         ws.numel(), _stream()), "nacf_bn_concat_fwd_multi")
+
+
+def bn_concat_bwd_multi(dout, xs, dxs, f_offs, weights, save_means, save_invstds, dweights, dbiases, beta=1.0):
+    _chk_f32(dout, *xs, *dxs, *weights, *save_means, *save_invstds, *dweights, *dbiases)
+    B, _, D = xs[0].shape
+    lib = L.load()
+    n = len(xs)
+    ws = WORKSPACE.get(n * lib.nacf_bn_workspace(B * max(x.shape[1] for x in xs), D), dout.device)
+    L.check(lib.nacf_bn_concat_bwd_multi(n, _ptr(dout), _ptr_array(xs), _ptr_array(dxs), B, _int_array([x.shape[1] for x in xs]), D,
+                                         dout.shape[1], _int_array(f_offs), _ptr_array(weights), _ptr_array(save_means),
+                                         _ptr_array(save_invstds), _ptr_array(dweights), _ptr_array(dbiases), float(beta),
+                                         _ptr(ws), ws.numel(), _stream()), "nacf_bn_concat_bwd_multi")
+
+
 def bn_sync_stat(x, sum_global, n_total, out):
     """one pass of the global-batch BatchNorm statistics over this rank's rows (see nacf_bn_sync_stat): the column
     sums (sum_global None) or the squared deviations from the global mean sum_global / n_total"""
@@ -876,13 +915,15 @@ def best_candidate(tokens, probs, teacher, beam, alpha, B, lbs, Lp, out_tokens, 
 
 
 # ---------------------------------------------------------------- optimiser
-def adam_step(param, grad, m, v, lr_dev, step_dev, beta1, beta2, eps, weight_decay, grad_clip, grad_scale, bump=True):
-    """param / grad / m / v may be equal-length slices of the flat buffers; bump: this call starts a new step"""
+def adam_step(param, grad, m, v, lr_dev, step_dev, beta1, beta2, eps, weight_decay, grad_clip, grad_scale, bump=True,
+              zero_grad=False):
+    """param / grad / m / v may be equal-length slices of the flat buffers; bump: this call starts a new step;
+    zero_grad: the gradient slice is left zeroed (the step engine's next zero_grad, folded into this walk)"""
     _chk_f32(param, grad, m, v, lr_dev)
     assert param.numel() == grad.numel() == m.numel() == v.numel() and param.is_contiguous()
     L.check(L.load().nacf_adam_step_part(_ptr(param), _ptr(grad), _ptr(m), _ptr(v), param.numel(), _ptr(lr_dev),
                                          _ptr(step_dev), float(beta1), float(beta2), float(eps), float(weight_decay),
-                                         float(grad_clip), float(grad_scale), int(bool(bump)), _stream()),
+                                         float(grad_clip), float(grad_scale), int(bool(bump)) | (2 if zero_grad else 0), _stream()),
             "nacf_adam_step")
 
 
