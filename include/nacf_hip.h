@@ -64,7 +64,7 @@ int nacf_version(void);
  * included).  nacf_abi_count() returns the value the LIBRARY was built with; the ctypes loader
  * (runtime/lib.py:load) refuses a library whose count differs from its own signature table, so a stale
  * libnacf_hip.so next to a newer Python package fails at import time, not at the first missing symbol. */
-#define NACF_ABI_COUNT 79
+#define NACF_ABI_COUNT 82
 int nacf_abi_count(void);
 
 /* ---- batch construction (reference: dataloader.py) ----------------------------------------
@@ -310,17 +310,23 @@ int nacf_bn_concat_bwd(const float* dOut, const float* x, float* dx, int B, int 
  * modalities; each of the BatchNorm kernels is a latency-bound chain of row loads, so two modalities side by side cost
  * what one does).  n_mod <= 4; the array arguments are HOST arrays of n_mod entries (device pointers / ints), an array
  * that is absent for every modality may be NULL.  Same results as n_mod calls of nacf_bn_concat_fwd / _bwd.
+ * Data-parallel form (see below): stats_global [2][n_mod][D] = (sum | squared deviations) of the GLOBAL batch with
+ * n_total[i] rows behind modality i (HOST array) replaces the local statistics passes (= nacf_bn_concat_fwd_sync per
+ * modality); sums_global [n_mod][2][D] = the all-reduced (sum dy | sum dy*xhat) replaces the local backward sums and
+ * dweight / dbias are not touched (= nacf_bn_concat_bwd_sync).  NULL / NULL otherwise.
  * ws: n_mod * nacf_bn_workspace(rows, D) bytes. */
 int nacf_bn_concat_fwd_multi(int n_mod, const float* const* x, float* out, int B, const int* F, int D, int M_total,
                              const int* f_off, const float* const* weight, const float* const* bias,
                              float* const* running_mean, float* const* running_var, int64_t* const* num_batches_tracked,
                              float* const* save_mean, float* const* save_invstd,
                              int training, float momentum, float eps,
+                             const float* stats_global, const int64_t* n_total,
                              void* ws, size_t ws_bytes, nacf_stream_t stream);
 int nacf_bn_concat_bwd_multi(int n_mod, const float* dOut, const float* const* x, float* const* dx, int B, const int* F, int D,
                              int M_total, const int* f_off, const float* const* weight,
                              const float* const* save_mean, const float* const* save_invstd,
                              float* const* dweight, float* const* dbias, float beta,
+                             const float* sums_global, const int64_t* n_total,
                              void* ws, size_t ws_bytes, nacf_stream_t stream);
 
 /* Data-parallel ("synchronised") BatchNorm: models/joint_representation.py:43-45 computes batch statistics over ALL
@@ -336,6 +342,25 @@ int nacf_bn_concat_bwd_multi(int n_mod, const float* dOut, const float* const* x
  * n_total = rows of ALL ranks.  ws: nacf_bn_workspace(rows, D) bytes. */
 int nacf_bn_sync_stat(const float* x, int rows, int D, const float* sum_global, int64_t n_total, float* out, void* ws,
                       size_t ws_bytes, nacf_stream_t stream);
+/* Forward statistics from ONE exchange instead of two: every rank computes (sum, squared deviations about its OWN mean)
+ * with two nacf_bn_sync_stat calls (the second with its local sum and local row count), the ranks all-GATHER the
+ * [2][n_mod][D] vectors, and this merges them exactly about the global mean (parallel-variance formula, ranks in fixed
+ * order): out [2][n_mod][D] = (global sum | global squared deviations), the operands of nacf_bn_concat_fwd_sync.
+ * gathered: [world][2][n_mod][D]; rows_per_rank: HOST array [n_mod] (every rank holds the same number of rows). */
+int nacf_bn_sync_merge(const float* gathered, int world, int n_mod, int D, const float* rows_per_rank, float* out,
+                       nacf_stream_t stream);
+/* The local halves of the data-parallel statistics for every modality at once:
+ * nacf_bn_sync_local_multi      loc  [2][n_mod][D] = (sum | squared deviations about this rank's OWN mean) -- gathered by
+ *                               the ranks and merged by nacf_bn_sync_merge (3 launches instead of 4 per modality);
+ * nacf_bn_sync_bwd_local_multi  sums [n_mod][2][D] = (sum dy | sum dy*xhat) over this rank's rows, also accumulated (beta)
+ *                               into the LOCAL dbias | dweight (= nacf_bn_sync_bwd_stat per modality, 2 launches).
+ * ws: n_mod * nacf_bn_workspace(rows, D) bytes. */
+int nacf_bn_sync_local_multi(int n_mod, const float* const* x, int B, const int* F, int D, float* loc,
+                             void* ws, size_t ws_bytes, nacf_stream_t stream);
+int nacf_bn_sync_bwd_local_multi(int n_mod, const float* dOut, const float* const* x, int B, const int* F, int D, int M_total,
+                                 const int* f_off, const float* const* save_mean, const float* const* save_invstd,
+                                 float* sums, float* const* dweight, float* const* dbias, float beta,
+                                 void* ws, size_t ws_bytes, nacf_stream_t stream);
 int nacf_bn_concat_fwd_sync(const float* x, float* out, int B, int F, int D, int M_total, int f_off, const float* weight,
                             const float* bias, float* running_mean, float* running_var, int64_t* num_batches_tracked,
                             float* save_mean, float* save_invstd, float momentum, float eps, const float* sum_global,

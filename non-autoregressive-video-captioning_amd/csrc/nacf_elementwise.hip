@@ -420,6 +420,48 @@ __global__ void bn_fold_parts_kernel(const float* __restrict__ part, int S, int 
   if (acc) acc[c] = (beta != 0.f) ? t + beta * acc[c] : t;
 }
 
+// the same for every (modality, statistic) of a joint representation in one launch: grid (cdiv(D, 256), n_mod, 2)
+struct BnFold {
+  const float* part[BN_MAX_MODS][2];
+  int S[BN_MAX_MODS];
+  float* out[BN_MAX_MODS][2];
+  float* acc[BN_MAX_MODS][2];
+};
+__global__ void bn_fold_multi_kernel(BnFold t, int D, float beta) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= D) return;
+  const int mod = blockIdx.y, st = blockIdx.z;
+  const float* __restrict__ part = t.part[mod][st];
+  float v = 0.f;
+  for (int s = 0; s < t.S[mod]; ++s) v += part[(int64_t)s * D + c];
+  if (t.out[mod][st]) t.out[mod][st][c] = v;
+  float* acc = t.acc[mod][st];
+  if (acc) acc[c] = (beta != 0.f) ? v + beta * acc[c] : v;
+}
+
+// data-parallel BatchNorm, forward statistics from ONE exchange: every rank contributes (sum, squared deviations about its
+// OWN mean) of its rows; the parallel-variance merge (Chan et al.) is exact about the global mean:
+//   S = sum_i s_i,  mean = S / N,  Q = sum_i [ q_i + n_i (s_i / n_i - mean)^2 ]        (ranks in fixed order)
+// gathered: [world][2][n_mod][D]; out: [2][n_mod][D] = (S | Q), what nacf_bn_concat_fwd_sync consumes
+struct BnMergeN { float n[BN_MAX_MODS]; };
+__global__ void bn_sync_merge_kernel(const float* __restrict__ gathered, int world, int n_mod, int D, BnMergeN rows,
+                                     float* __restrict__ out) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  const int C = n_mod * D;
+  if (c >= C) return;
+  const float n = rows.n[c / D];
+  float S = 0.f;
+  for (int r = 0; r < world; ++r) S += gathered[(int64_t)r * 2 * C + c];
+  const float mean = S / (n * (float)world);
+  float Q = 0.f;
+  for (int r = 0; r < world; ++r) {
+    const float dm = gathered[(int64_t)r * 2 * C + c] / n - mean;
+    Q += gathered[(int64_t)r * 2 * C + C + c] + n * dm * dm;
+  }
+  out[c] = S;
+  out[C + c] = Q;
+}
+
 // ------------------------------------------------------------------ time mean
 // block = 32 float4 columns x 8 time groups; group tg sums t = tg, tg+8, ...; the 8 partials are combined in
 // fixed order through LDS
@@ -883,9 +925,10 @@ size_t nacf_bn_workspace(int rows, int D) {
 int nacf_bn_concat_fwd_multi(int n_mod, const float* const* x, float* out, int B, const int* F, int D, int M_total, const int* f_off,
                              const float* const* weight, const float* const* bias, float* const* running_mean,
                              float* const* running_var, int64_t* const* num_batches_tracked, float* const* save_mean,
-                             float* const* save_invstd, int training, float momentum, float eps, void* ws, size_t ws_bytes,
-                             nacf_stream_t stream) {
+                             float* const* save_invstd, int training, float momentum, float eps, const float* stats_global,
+                             const int64_t* n_total, void* ws, size_t ws_bytes, nacf_stream_t stream) {
   NACF_CHECK(n_mod >= 1 && n_mod <= BN_MAX_MODS && x && out && F && f_off && B > 0 && D > 0, NACF_EINVAL, "nacf_bn_concat_fwd_multi: bad argument");
+  NACF_CHECK(!stats_global || (n_total && training), NACF_EINVAL, "nacf_bn_concat_fwd_multi: global statistics need n_total and training mode");
   const size_t ws_one = nacf_bn_workspace(0, D);
   NACF_CHECK(ws && ws_bytes >= ws_one * n_mod, NACF_EWORKSPACE, "nacf_bn_concat_fwd_multi: workspace too small");
   auto at = [](auto* const* arr, int i) { return arr ? arr[i] : nullptr; };
@@ -905,13 +948,18 @@ int nacf_bn_concat_fwd_multi(int n_mod, const float* const* x, float* out, int B
     float* part = reinterpret_cast<float*>(reinterpret_cast<char*>(ws) + ws_one * i);
     m.part_out0 = part; m.part_out1 = part + (size_t)BN_MAX_SLABS * D;
     m.part_in0 = m.part_out0; m.part_in1 = m.part_out1;
-    v4 = v4 && bn_aligned16(m.x, m.w, m.b, m.save_mean, m.save_invstd);
+    if (stats_global) {           // data-parallel: (sum | squared deviations) of the GLOBAL batch, n_total[i] rows behind them
+      NACF_CHECK(n_total[i] >= (int64_t)B * F[i], NACF_EINVAL, "nacf_bn_concat_fwd_multi: n_total below the local rows");
+      m.SP = 1; m.n_stat = (float)n_total[i];
+      m.part_in0 = stats_global + (size_t)i * D; m.part_in1 = stats_global + (size_t)(n_mod + i) * D;
+    }
+    v4 = v4 && bn_aligned16(m.x, m.w, m.b, m.save_mean, m.save_invstd, m.part_in0, m.part_in1);
     if (m.S > S_max) S_max = m.S;
   }
   hipStream_t s = as_hip(stream);
   if (v4) {
     dim3 grid(cdiv(D, 64), S_max, n_mod);
-    if (training) {
+    if (training && !stats_global) {
       hipLaunchKernelGGL(bn_partial_sum_v4_kernel, grid, dim3(256), 0, s, t, B, D);
       hipLaunchKernelGGL(bn_partial_sqdev_v4_kernel, grid, dim3(256), 0, s, t, B, D);
     }
@@ -920,12 +968,12 @@ int nacf_bn_concat_fwd_multi(int n_mod, const float* const* x, float* out, int B
     for (int i = 0; i < n_mod; ++i) {
       const BnMod& m = t.m[i];
       dim3 grid(cdiv(D, 64), m.S);
-      if (training) {
+      if (training && !stats_global) {
         hipLaunchKernelGGL(bn_partial_sum_kernel, grid, dim3(256), 0, s, m.x, B * m.F, D, m.rows_per, m.part_out0);
         hipLaunchKernelGGL(bn_partial_sqdev_kernel, grid, dim3(256), 0, s, m.x, B * m.F, D, m.rows_per, m.S, m.part_in0, m.part_out1, m.n_stat);
       }
       hipLaunchKernelGGL(bn_apply_kernel, grid, dim3(256), 0, s, m.x, out, B, m.F, D, M_total, m.f_off, m.w, m.b, m.running_mean,
-                         m.running_var, m.nbt, m.save_mean, m.save_invstd, training, momentum, eps, m.S, m.part_in0, m.part_in1,
+                         m.running_var, m.nbt, m.save_mean, m.save_invstd, training, momentum, eps, m.SP, m.part_in0, m.part_in1,
                          m.rows_per, m.n_stat);
     }
   }
@@ -939,15 +987,17 @@ int nacf_bn_concat_fwd(const float* x, float* out, int B, int F, int D, int M_to
                        size_t ws_bytes, nacf_stream_t stream) {
   NACF_CHECK(x && out && B > 0 && F > 0 && D > 0, NACF_EINVAL, "nacf_bn_concat_fwd: bad argument");
   return nacf_bn_concat_fwd_multi(1, &x, out, B, &F, D, M_total, &f_off, &weight, &bias, &running_mean, &running_var,
-                                  &num_batches_tracked, &save_mean, &save_invstd, training, momentum, eps, ws, ws_bytes, stream);
+                                  &num_batches_tracked, &save_mean, &save_invstd, training, momentum, eps, nullptr, nullptr, ws,
+                                  ws_bytes, stream);
 }
 
 int nacf_bn_concat_bwd_multi(int n_mod, const float* dOut, const float* const* x, float* const* dx, int B, const int* F, int D,
                              int M_total, const int* f_off, const float* const* weight, const float* const* save_mean,
-                             const float* const* save_invstd, float* const* dweight, float* const* dbias, float beta, void* ws,
-                             size_t ws_bytes, nacf_stream_t stream) {
+                             const float* const* save_invstd, float* const* dweight, float* const* dbias, float beta,
+                             const float* sums_global, const int64_t* n_total, void* ws, size_t ws_bytes, nacf_stream_t stream) {
   NACF_CHECK(n_mod >= 1 && n_mod <= BN_MAX_MODS && dOut && x && dx && F && f_off && save_mean && save_invstd && B > 0 && D > 0,
              NACF_EINVAL, "nacf_bn_concat_bwd_multi: bad argument");
+  NACF_CHECK(!sums_global || n_total, NACF_EINVAL, "nacf_bn_concat_bwd_multi: global sums need n_total");
   const size_t ws_one = nacf_bn_workspace(0, D);
   NACF_CHECK(ws && ws_bytes >= ws_one * n_mod, NACF_EWORKSPACE, "nacf_bn_concat_bwd_multi: workspace too small");
   auto at = [](auto* const* arr, int i) { return arr ? arr[i] : nullptr; };
@@ -967,22 +1017,30 @@ int nacf_bn_concat_bwd_multi(int n_mod, const float* dOut, const float* const* x
     float* part = reinterpret_cast<float*>(reinterpret_cast<char*>(ws) + ws_one * i);
     m.part_out0 = part; m.part_out1 = part + (size_t)BN_MAX_SLABS * D;
     m.part_in0 = m.part_out0; m.part_in1 = m.part_out1;
-    v4 = v4 && bn_aligned16(m.x, m.dx, m.w, m.save_mean, m.save_invstd);
+    if (sums_global) {            // data-parallel: [n_mod][2][D] = (sum dy | sum dy * xhat) of the GLOBAL batch; the LOCAL
+                                  // parameter gradients were written by nacf_bn_sync_bwd_local_multi
+      NACF_CHECK(n_total[i] >= (int64_t)B * F[i], NACF_EINVAL, "nacf_bn_concat_bwd_multi: n_total below the local rows");
+      m.SP = 1; m.n_stat = (float)n_total[i];
+      m.part_in0 = sums_global + (size_t)(2 * i) * D; m.part_in1 = sums_global + (size_t)(2 * i + 1) * D;
+      m.dweight = nullptr; m.dbias = nullptr;
+    }
+    v4 = v4 && bn_aligned16(m.x, m.dx, m.w, m.save_mean, m.save_invstd, m.part_in0, m.part_in1);
     if (m.S > S_max) S_max = m.S;
   }
   hipStream_t s = as_hip(stream);
   if (v4) {
     dim3 grid(cdiv(D, 64), S_max, n_mod);
-    hipLaunchKernelGGL(bn_bwd_partial_v4_kernel, grid, dim3(256), 0, s, t, dOut, B, D, M_total);
+    if (!sums_global) hipLaunchKernelGGL(bn_bwd_partial_v4_kernel, grid, dim3(256), 0, s, t, dOut, B, D, M_total);
     hipLaunchKernelGGL(bn_bwd_apply_v4_kernel, grid, dim3(256), 0, s, t, dOut, B, D, M_total, beta);
   } else {
     for (int i = 0; i < n_mod; ++i) {
       const BnMod& m = t.m[i];
       dim3 grid(cdiv(D, 64), m.S);
-      hipLaunchKernelGGL(bn_bwd_partial_kernel, grid, dim3(256), 0, s, dOut, m.x, B, m.F, D, M_total, m.f_off, m.save_mean,
-                         m.save_invstd, m.rows_per, m.part_out0, m.part_out1);
+      if (!sums_global)
+        hipLaunchKernelGGL(bn_bwd_partial_kernel, grid, dim3(256), 0, s, dOut, m.x, B, m.F, D, M_total, m.f_off, m.save_mean,
+                           m.save_invstd, m.rows_per, m.part_out0, m.part_out1);
       hipLaunchKernelGGL(bn_bwd_apply_kernel, grid, dim3(256), 0, s, dOut, m.x, m.dx, B, m.F, D, M_total, m.f_off, m.w, m.save_mean,
-                         m.save_invstd, m.dweight, m.dbias, beta, m.S, m.rows_per, m.part_in0, m.part_in1, m.n_stat);
+                         m.save_invstd, m.dweight, m.dbias, beta, m.SP, m.rows_per, m.part_in0, m.part_in1, m.n_stat);
     }
   }
   NACF_LAUNCH_CHECK("nacf_bn_concat_bwd_multi");
@@ -994,7 +1052,7 @@ int nacf_bn_concat_bwd(const float* dOut, const float* x, float* dx, int B, int 
                        float* dbias, float beta, void* ws, size_t ws_bytes, nacf_stream_t stream) {
   NACF_CHECK(dOut && x && dx && save_mean && save_invstd, NACF_EINVAL, "nacf_bn_concat_bwd: null pointer");
   return nacf_bn_concat_bwd_multi(1, dOut, &x, &dx, B, &F, D, M_total, &f_off, &weight, &save_mean, &save_invstd, &dweight, &dbias,
-                                  beta, ws, ws_bytes, stream);
+                                  beta, nullptr, nullptr, ws, ws_bytes, stream);
 }
 
 // ---- data-parallel (synchronised) BatchNorm: the same two-pass statistics over the GLOBAL batch, cut where the ranks
@@ -1022,6 +1080,109 @@ int nacf_bn_sync_stat(const float* x, int rows, int D, const float* sum_global, 
   }
   hipLaunchKernelGGL(bn_fold_parts_kernel, dim3(cdiv(D, 256)), dim3(256), 0, s, part, S, D, out, (float*)nullptr, 0.f);
   NACF_LAUNCH_CHECK("nacf_bn_sync_stat");
+  return NACF_OK;
+}
+
+// this rank's share of the forward statistics for every modality: loc [2][n_mod][D] = (sum | squared deviations about the
+// rank's OWN mean) over its B * F[i] rows -- three launches; what the ranks all-gather for nacf_bn_sync_merge
+int nacf_bn_sync_local_multi(int n_mod, const float* const* x, int B, const int* F, int D, float* loc, void* ws, size_t ws_bytes,
+                             nacf_stream_t stream) {
+  NACF_CHECK(n_mod >= 1 && n_mod <= BN_MAX_MODS && x && F && loc && B > 0 && D > 0, NACF_EINVAL, "nacf_bn_sync_local_multi: bad argument");
+  const size_t ws_one = nacf_bn_workspace(0, D);
+  NACF_CHECK(ws && ws_bytes >= ws_one * n_mod, NACF_EWORKSPACE, "nacf_bn_sync_local_multi: workspace too small");
+  bool v4 = (D % 4 == 0) && bn_aligned16(ws);
+  BnMods t = {};
+  BnFold f = {};
+  int S_max = 1;
+  for (int i = 0; i < n_mod; ++i) {
+    NACF_CHECK(x[i] && F[i] > 0, NACF_EINVAL, "nacf_bn_sync_local_multi: bad modality");
+    BnMod& m = t.m[i];
+    m.x = x[i]; m.F = F[i];
+    bn_split(B * F[i], &m.S, &m.rows_per);
+    m.SP = m.S; m.n_stat = (float)(B * F[i]);
+    float* part = reinterpret_cast<float*>(reinterpret_cast<char*>(ws) + ws_one * i);
+    m.part_out0 = part; m.part_out1 = part + (size_t)BN_MAX_SLABS * D;
+    m.part_in0 = m.part_out0; m.part_in1 = m.part_out1;
+    f.part[i][0] = m.part_out0; f.part[i][1] = m.part_out1; f.S[i] = m.S;
+    f.out[i][0] = loc + (size_t)i * D; f.out[i][1] = loc + (size_t)(n_mod + i) * D;
+    v4 = v4 && bn_aligned16(m.x);
+    if (m.S > S_max) S_max = m.S;
+  }
+  hipStream_t s = as_hip(stream);
+  if (v4) {
+    dim3 grid(cdiv(D, 64), S_max, n_mod);
+    hipLaunchKernelGGL(bn_partial_sum_v4_kernel, grid, dim3(256), 0, s, t, B, D);
+    hipLaunchKernelGGL(bn_partial_sqdev_v4_kernel, grid, dim3(256), 0, s, t, B, D);
+  } else {
+    for (int i = 0; i < n_mod; ++i) {
+      const BnMod& m = t.m[i];
+      dim3 grid(cdiv(D, 64), m.S);
+      hipLaunchKernelGGL(bn_partial_sum_kernel, grid, dim3(256), 0, s, m.x, B * m.F, D, m.rows_per, m.part_out0);
+      hipLaunchKernelGGL(bn_partial_sqdev_kernel, grid, dim3(256), 0, s, m.x, B * m.F, D, m.rows_per, m.S, m.part_in0, m.part_out1, m.n_stat);
+    }
+  }
+  hipLaunchKernelGGL(bn_fold_multi_kernel, dim3(cdiv(D, 256), n_mod, 2), dim3(256), 0, s, f, D, 0.f);
+  NACF_LAUNCH_CHECK("nacf_bn_sync_local_multi");
+  return NACF_OK;
+}
+
+// this rank's share of the backward sums for every modality: sums [n_mod][2][D] = (sum dy | sum dy * xhat) over its rows,
+// also accumulated (beta) into the LOCAL dbias | dweight -- two launches; the ranks all-reduce `sums`
+int nacf_bn_sync_bwd_local_multi(int n_mod, const float* dOut, const float* const* x, int B, const int* F, int D, int M_total,
+                                 const int* f_off, const float* const* save_mean, const float* const* save_invstd, float* sums,
+                                 float* const* dweight, float* const* dbias, float beta, void* ws, size_t ws_bytes,
+                                 nacf_stream_t stream) {
+  NACF_CHECK(n_mod >= 1 && n_mod <= BN_MAX_MODS && dOut && x && F && f_off && save_mean && save_invstd && sums && B > 0 && D > 0,
+             NACF_EINVAL, "nacf_bn_sync_bwd_local_multi: bad argument");
+  const size_t ws_one = nacf_bn_workspace(0, D);
+  NACF_CHECK(ws && ws_bytes >= ws_one * n_mod, NACF_EWORKSPACE, "nacf_bn_sync_bwd_local_multi: workspace too small");
+  auto at = [](auto* const* arr, int i) { return arr ? arr[i] : nullptr; };
+  bool v4 = (D % 4 == 0) && bn_aligned16(dOut, ws);
+  BnMods t = {};
+  BnFold f = {};
+  int S_max = 1;
+  for (int i = 0; i < n_mod; ++i) {
+    NACF_CHECK(x[i] && save_mean[i] && save_invstd[i] && F[i] > 0 && f_off[i] >= 0 && f_off[i] + F[i] <= M_total, NACF_EINVAL,
+               "nacf_bn_sync_bwd_local_multi: bad modality");
+    BnMod& m = t.m[i];
+    m.x = x[i]; m.F = F[i]; m.f_off = f_off[i];
+    bn_split(B * F[i], &m.S, &m.rows_per);
+    m.save_mean = const_cast<float*>(save_mean[i]); m.save_invstd = const_cast<float*>(save_invstd[i]);
+    float* part = reinterpret_cast<float*>(reinterpret_cast<char*>(ws) + ws_one * i);
+    m.part_out0 = part; m.part_out1 = part + (size_t)BN_MAX_SLABS * D;
+    f.part[i][0] = m.part_out0; f.part[i][1] = m.part_out1; f.S[i] = m.S;
+    f.out[i][0] = sums + (size_t)(2 * i) * D; f.out[i][1] = sums + (size_t)(2 * i + 1) * D;
+    f.acc[i][0] = at(dbias, i); f.acc[i][1] = at(dweight, i);
+    v4 = v4 && bn_aligned16(m.x, m.save_mean, m.save_invstd);
+    if (m.S > S_max) S_max = m.S;
+  }
+  hipStream_t s = as_hip(stream);
+  if (v4) {
+    hipLaunchKernelGGL(bn_bwd_partial_v4_kernel, dim3(cdiv(D, 64), S_max, n_mod), dim3(256), 0, s, t, dOut, B, D, M_total);
+  } else {
+    for (int i = 0; i < n_mod; ++i) {
+      const BnMod& m = t.m[i];
+      hipLaunchKernelGGL(bn_bwd_partial_kernel, dim3(cdiv(D, 64), m.S), dim3(256), 0, s, dOut, m.x, B, m.F, D, M_total, m.f_off,
+                         m.save_mean, m.save_invstd, m.rows_per, m.part_out0, m.part_out1);
+    }
+  }
+  hipLaunchKernelGGL(bn_fold_multi_kernel, dim3(cdiv(D, 256), n_mod, 2), dim3(256), 0, s, f, D, beta);
+  NACF_LAUNCH_CHECK("nacf_bn_sync_bwd_local_multi");
+  return NACF_OK;
+}
+
+int nacf_bn_sync_merge(const float* gathered, int world, int n_mod, int D, const float* rows_per_rank, float* out,
+                       nacf_stream_t stream) {
+  NACF_CHECK(gathered && out && rows_per_rank && world >= 1 && n_mod >= 1 && n_mod <= BN_MAX_MODS && D > 0, NACF_EINVAL,
+             "nacf_bn_sync_merge: bad argument");
+  BnMergeN rows = {};
+  for (int i = 0; i < n_mod; ++i) {
+    NACF_CHECK(rows_per_rank[i] >= 1.f, NACF_EINVAL, "nacf_bn_sync_merge: a modality without rows");
+    rows.n[i] = rows_per_rank[i];
+  }
+  hipLaunchKernelGGL(bn_sync_merge_kernel, dim3(cdiv(n_mod * D, 256)), dim3(256), 0, as_hip(stream), gathered, world, n_mod, D, rows,
+                     out);
+  NACF_LAUNCH_CHECK("nacf_bn_sync_merge");
   return NACF_OK;
 }
 

@@ -33,7 +33,7 @@ import torch.distributed as dist
 from ..config import Constants
 from ..models.Translator import Translator
 from ..opts import persistable
-from ..runtime.ddp import DataParallel
+from ..runtime.ddp import DataParallel, host_broadcast_int
 from ..runtime.engine import TrainStep
 from .cocoeval import COCOScorer
 from .crit import get_criterion
@@ -396,9 +396,8 @@ def train_network_all(opt, model, device, summarywriter=None, **kwargs):
                     say(info)
                 else:
                     stop.fill_(1)
-            if dist.is_initialized():
-                dist.broadcast(stop, 0)
-            if float(stop) > 0:
+            # the verdict travels through the rendezvous store: the idle ranks wait on the host, not inside an RCCL call
+            if host_broadcast_int(int(float(stop) > 0), 'stop_after_epoch_%d' % epoch) > 0:
                 break                        # `tolerence` evaluations in a row without entering the k-best queue
 
     final = None

@@ -33,6 +33,22 @@ def shard_range(global_batch: int, rank: int, world: int):
     return rank * per, (rank + 1) * per
 
 
+def host_broadcast_int(value, tag, src=0, timeout_s=6 * 3600):
+    """`value` of rank `src` on every rank, through the rendezvous store -- a HOST-side wait.  For the long one-sided phases
+    of training (rank 0 decodes and scores the validation split, misc/run.py): a device collective posted by the idle
+    ranks would sit in RCCL's queue for the whole evaluation, in reach of its watchdog timeout."""
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return int(value)
+    from datetime import timedelta
+    store = dist.distributed_c10d._get_default_store()
+    key = 'nacf_amd/host_broadcast/%s' % tag
+    if dist.get_rank() == src:
+        store.set(key, str(int(value)))
+        return int(value)
+    store.wait([key], timedelta(seconds=timeout_s))
+    return int(store.get(key))
+
+
 class DataParallel(object):
     def __init__(self, model, process_group=None, force_collectives=False):
         self.model = model
@@ -56,6 +72,16 @@ class DataParallel(object):
             self._capture_break(t)
         else:
             dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+
+    def all_gather(self, out, t):
+        """out[r] = rank r's `t` (out: [world, *t.shape]), ordered with the current stream; cuts a capture like all_reduce"""
+        self.n_sync_points += 1
+        if self._capture_break is not None:
+            self._capture_break(('gather', out, t))
+        elif t.is_cuda:
+            dist.all_gather_into_tensor(out, t, group=self.group)
+        else:                       # gloo (CPU tests)
+            dist.all_gather(list(out.unbind(0)), t, group=self.group)
 
     @property
     def grad_scale(self):

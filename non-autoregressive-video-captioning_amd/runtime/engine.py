@@ -208,7 +208,9 @@ class TrainStep(object):
         for item in seq:
             if isinstance(item, torch.cuda.CUDAGraph):
                 item.replay()
-            else:                           # a tensor: the collective recorded at this point of the step
+            elif isinstance(item, tuple):   # ('gather', out, t): an all-gather recorded at this point of the step
+                self.ddp.all_gather(item[1], item[2])
+            else:                           # a tensor: the all-reduce recorded at this point of the step
                 self.ddp.all_reduce(item)
 
     def _capture(self):

@@ -152,6 +152,7 @@ class EncoderStreamsFn(Function):
         return (None, None) + tuple(dxs) + (None,) * sum(ctx.n_params)
 
 
+_SYNC_BN_ONE_EXCHANGE = os.environ.get("NACF_SYNC_BN_EXCHANGES", "1") != "2"     # 2 = the two all-reduces of round 2
 _BN_MULTI = os.environ.get("NACF_BN_MULTI", "1") != "0"      # tuning: 0 = one modality per launch (round 2)
 
 
@@ -170,46 +171,54 @@ class BNConcatFn(Function):
         B, _, D = xs[0].shape
         M_total = sum(x.shape[1] for x in xs)
         out = _new((B, M_total, D), xs[0])
-        sync = cfg.get("sync") if cfg["training"] else None
-        saves = []
-        f_off = 0
-        stats = None
+        training = cfg["training"]
+        sync = cfg.get("sync") if training else None
+        mods = cfg["mods"]
+        mom, eps = cfg.get("momentum", 0.1), cfg.get("eps", 1e-5)
+        multi = 1 <= n_mod <= 4 and _BN_MULTI        # every modality in the same launches (nacf_bn_*_multi)
+        f_offs = [sum(x.shape[1] for x in xs[:i]) for i in range(n_mod)]
+        sms = [_new((D,), x) if training else None for x in xs]
+        sis = [_new((D,), x) if training else None for x in xs]
+        stats = n_tot = None
         if sync is not None:
             stats = _new((2, n_mod, D), xs[0])
             n_tot = [x.shape[0] * x.shape[1] * sync.world for x in xs]      # every rank holds the same number of rows
-            for i, x in enumerate(xs):
-                ops.bn_sync_stat(x, None, n_tot[i], stats[0, i])
-            sync.all_reduce(stats[0])
-            for i, x in enumerate(xs):
-                ops.bn_sync_stat(x, stats[0, i], n_tot[i], stats[1, i])
-            sync.all_reduce(stats[1])
-        mods = cfg["mods"]
-        if sync is None and 1 < n_mod <= 4 and _BN_MULTI:
-            # both modalities in the same launches (nacf_bn_concat_fwd_multi)
-            f_offs, sms, sis = [], [], []
-            for x in xs:
-                f_offs.append(f_off)
-                f_off += x.shape[1]
-                sms.append(_new((D,), x) if cfg["training"] else None)
-                sis.append(_new((D,), x) if cfg["training"] else None)
+            if getattr(sync, "all_gather", None) is not None and _SYNC_BN_ONE_EXCHANGE:
+                # one exchange: (sum | squared deviations about the rank's OWN mean) gathered, merged exactly
+                n_loc = [x.shape[0] * x.shape[1] for x in xs]
+                loc = _new((2, n_mod, D), xs[0])
+                if multi:
+                    ops.bn_sync_local_multi(xs, loc)
+                else:
+                    for i, x in enumerate(xs):
+                        ops.bn_sync_stat(x, None, n_loc[i], loc[0, i])
+                    for i, x in enumerate(xs):
+                        ops.bn_sync_stat(x, loc[0, i], n_loc[i], loc[1, i])
+                gathered = _new((sync.world, 2, n_mod, D), xs[0])
+                sync.all_gather(gathered, loc)
+                ops.bn_sync_merge(gathered, n_loc, stats)
+            else:
+                for i, x in enumerate(xs):
+                    ops.bn_sync_stat(x, None, n_tot[i], stats[0, i])
+                sync.all_reduce(stats[0])
+                for i, x in enumerate(xs):
+                    ops.bn_sync_stat(x, stats[0, i], n_tot[i], stats[1, i])
+                sync.all_reduce(stats[1])
+        if multi:
             ops.bn_concat_fwd_multi(xs, out, f_offs, [m["pack"].w for m in mods], [m["pack"].b for m in mods],
                                     [m["running_mean"] for m in mods], [m["running_var"] for m in mods], [m["nbt"] for m in mods],
-                                    sms, sis, cfg["training"], cfg.get("momentum", 0.1), cfg.get("eps", 1e-5))
-            saves = [(x, f_offs[i], sms[i], sis[i]) for i, x in enumerate(xs)]
-            xs = []
-        for i, x in enumerate(xs):
-            m = cfg["mods"][i]
-            sm = _new((D,), x) if cfg["training"] else None
-            si = _new((D,), x) if cfg["training"] else None
-            if sync is not None:
-                ops.bn_concat_fwd_sync(x, out, f_off, m["pack"].w, m["pack"].b, m["running_mean"], m["running_var"], m["nbt"],
-                                       sm, si, stats[0, i], stats[1, i], n_tot[i], cfg.get("momentum", 0.1), cfg.get("eps", 1e-5))
-            else:
-                ops.bn_concat_fwd(x, out, f_off, m["pack"].w, m["pack"].b, m["running_mean"], m["running_var"],
-                                  m["nbt"], sm, si, cfg["training"], cfg.get("momentum", 0.1), cfg.get("eps", 1e-5))
-            saves.append((x, f_off, sm, si))
-            f_off += x.shape[1]
-        ctx.cfg, ctx.saves, ctx.n_mod, ctx.sync = cfg, saves, n_mod, sync
+                                    sms, sis, training, mom, eps, stats_global=stats, n_total=n_tot)
+        else:
+            for i, x in enumerate(xs):
+                m = mods[i]
+                if sync is not None:
+                    ops.bn_concat_fwd_sync(x, out, f_offs[i], m["pack"].w, m["pack"].b, m["running_mean"], m["running_var"],
+                                           m["nbt"], sms[i], sis[i], stats[0, i], stats[1, i], n_tot[i], mom, eps)
+                else:
+                    ops.bn_concat_fwd(x, out, f_offs[i], m["pack"].w, m["pack"].b, m["running_mean"], m["running_var"],
+                                      m["nbt"], sms[i], sis[i], training, mom, eps)
+        ctx.cfg, ctx.n_mod, ctx.sync, ctx.multi = cfg, n_mod, sync, multi
+        ctx.saves = [(x, f_offs[i], sms[i], sis[i]) for i, x in enumerate(xs)]
         return out
 
     @staticmethod
@@ -218,34 +227,33 @@ class BNConcatFn(Function):
         if not cfg["training"]:
             raise L.NacfLibraryError("BNConcatFn.backward in eval mode is not supported")
         dout = dout.contiguous()
-        grads: List[Optional[Tensor]] = []
-        sync = ctx.sync
+        sync, n_mod = ctx.sync, ctx.n_mod
+        xs, f_offs = [s_[0] for s_ in ctx.saves], [s_[1] for s_ in ctx.saves]
+        sms, sis = [s_[2] for s_ in ctx.saves], [s_[3] for s_ in ctx.saves]
+        pks: List[Pack] = [cfg["mods"][i]["pack"] for i in range(n_mod)]
+        dxs = [torch.empty_like(x) for x in xs]
+        sums = n_tot = None
         if sync is not None:
-            D = ctx.saves[0][0].shape[2]
-            sums = _new((ctx.n_mod, 2, D), dout)
-            for i, (x, f_off, sm, si) in enumerate(ctx.saves):
-                pk: Pack = cfg["mods"][i]["pack"]
-                ops.bn_sync_bwd_stat(dout, x, f_off, sm, si, sums[i], pk.gw, pk.gb, beta=1.0)     # local dW / db
-            sync.all_reduce(sums)
-        if sync is None and 1 < ctx.n_mod <= 4 and _BN_MULTI:
-            dxs = [torch.empty_like(x) for x, _, _, _ in ctx.saves]
-            pks = [cfg["mods"][i]["pack"] for i in range(ctx.n_mod)]
-            ops.bn_concat_bwd_multi(dout, [s_[0] for s_ in ctx.saves], dxs, [s_[1] for s_ in ctx.saves], [pk.w for pk in pks],
-                                    [s_[2] for s_ in ctx.saves], [s_[3] for s_ in ctx.saves], [pk.gw for pk in pks],
-                                    [pk.gb for pk in pks], beta=1.0)
-            grads = [dx if ctx.needs_input_grad[2 + i] else None for i, dx in enumerate(dxs)]
-            ctx.saves = None
-            return (None, None) + tuple(grads) + (None,) * (len(ctx.needs_input_grad) - 2 - ctx.n_mod)
-        for i, (x, f_off, sm, si) in enumerate(ctx.saves):
-            pk: Pack = cfg["mods"][i]["pack"]
-            dx = torch.empty_like(x)
-            if sync is not None:
-                ops.bn_concat_bwd_sync(dout, x, dx, f_off, pk.w, sm, si, sums[i], x.shape[0] * x.shape[1] * sync.world)
+            sums = _new((n_mod, 2, xs[0].shape[2]), dout)
+            n_tot = [x.shape[0] * x.shape[1] * sync.world for x in xs]
+            if ctx.multi:
+                ops.bn_sync_bwd_local_multi(dout, xs, f_offs, sms, sis, sums, [pk.gw for pk in pks], [pk.gb for pk in pks], beta=1.0)
             else:
-                ops.bn_concat_bwd(dout, x, dx, f_off, pk.w, sm, si, pk.gw, pk.gb, beta=1.0)
-            grads.append(dx if ctx.needs_input_grad[2 + i] else None)
+                for i, x in enumerate(xs):
+                    ops.bn_sync_bwd_stat(dout, x, f_offs[i], sms[i], sis[i], sums[i], pks[i].gw, pks[i].gb, beta=1.0)     # local dW / db
+            sync.all_reduce(sums)
+        if ctx.multi:
+            ops.bn_concat_bwd_multi(dout, xs, dxs, f_offs, [pk.w for pk in pks], sms, sis, [pk.gw for pk in pks],
+                                    [pk.gb for pk in pks], beta=1.0, sums_global=sums, n_total=n_tot)
+        else:
+            for i, x in enumerate(xs):
+                if sync is not None:
+                    ops.bn_concat_bwd_sync(dout, x, dxs[i], f_offs[i], pks[i].w, sms[i], sis[i], sums[i], n_tot[i])
+                else:
+                    ops.bn_concat_bwd(dout, x, dxs[i], f_offs[i], pks[i].w, sms[i], sis[i], pks[i].gw, pks[i].gb, beta=1.0)
+        grads = [dx if ctx.needs_input_grad[2 + i] else None for i, dx in enumerate(dxs)]
         ctx.saves = None
-        return (None, None) + tuple(grads) + (None,) * (len(ctx.needs_input_grad) - 2 - ctx.n_mod)
+        return (None, None) + tuple(grads) + (None,) * (len(ctx.needs_input_grad) - 2 - n_mod)
 
 
 class MeanTimeFn(Function):

@@ -604,9 +604,17 @@ def _int_array(vs):
     return (ctypes.c_int * len(vs))(*[int(v) for v in vs])
 
 
+def _i64_array(vs):
+    import ctypes
+    return (ctypes.c_int64 * len(vs))(*[int(v) for v in vs])
+
+
 def bn_concat_fwd_multi(xs, out, f_offs, weights, biases, running_means, running_vars, nbts, save_means, save_invstds,
-                        training, momentum=0.1, eps=1e-5):
-    """every modality of a joint representation in the same three launches (nacf_bn_concat_fwd_multi)"""
+                        training, momentum=0.1, eps=1e-5, stats_global=None, n_total=None):
+    """every modality of a joint representation in the same three launches (nacf_bn_concat_fwd_multi);
+    stats_global [2, n_mod, D] + n_total: the data-parallel form (global-batch statistics, one launch)"""
+    _chk_f32(stats_global)
+    assert stats_global is None or (stats_global.is_contiguous() and stats_global.shape == (2, len(xs), xs[0].shape[2]))
     _chk_f32(out, *xs, *weights, *biases, *running_means, *running_vars, *save_means, *save_invstds)
     B, _, D = xs[0].shape
     assert all(x.shape[0] == B and x.shape[2] == D and x.is_contiguous() for x in xs)
@@ -616,12 +624,16 @@ def bn_concat_fwd_multi(xs, out, f_offs, weights, biases, running_means, running
     L.check(lib.nacf_bn_concat_fwd_multi(n, _ptr_array(xs), _ptr(out), B, _int_array([x.shape[1] for x in xs]), D, out.shape[1],
                                          _int_array(f_offs), _ptr_array(weights), _ptr_array(biases), _ptr_array(running_means),
                                          _ptr_array(running_vars), _ptr_array(nbts), _ptr_array(save_means),
-                                         _ptr_array(save_invstds), int(training), float(momentum), float(eps), _ptr(ws),
+                                         _ptr_array(save_invstds), int(training), float(momentum), float(eps),
+                                         _ptr(stats_global), _i64_array(n_total) if n_total is not None else None, _ptr(ws),
                                          ws.numel(), _stream()), "nacf_bn_concat_fwd_multi")
 
 
-def bn_concat_bwd_multi(dout, xs, dxs, f_offs, weights, save_means, save_invstds, dweights, dbiases, beta=1.0):
-    _chk_f32(dout, *xs, *dxs, *weights, *save_means, *save_invstds, *dweights, *dbiases)
+def bn_concat_bwd_multi(dout, xs, dxs, f_offs, weights, save_means, save_invstds, dweights, dbiases, beta=1.0,
+                        sums_global=None, n_total=None):
+    """sums_global [n_mod, 2, D] + n_total: the data-parallel form (dweights / dbiases untouched)"""
+    _chk_f32(dout, sums_global, *xs, *dxs, *weights, *save_means, *save_invstds, *dweights, *dbiases)
+    assert sums_global is None or (sums_global.is_contiguous() and sums_global.shape == (len(xs), 2, xs[0].shape[2]))
     B, _, D = xs[0].shape
     lib = L.load()
     n = len(xs)
@@ -629,7 +641,45 @@ def bn_concat_bwd_multi(dout, xs, dxs, f_offs, weights, save_means, save_invstds
     L.check(lib.nacf_bn_concat_bwd_multi(n, _ptr(dout), _ptr_array(xs), _ptr_array(dxs), B, _int_array([x.shape[1] for x in xs]), D,
                                          dout.shape[1], _int_array(f_offs), _ptr_array(weights), _ptr_array(save_means),
                                          _ptr_array(save_invstds), _ptr_array(dweights), _ptr_array(dbiases), float(beta),
+                                         _ptr(sums_global), _i64_array(n_total) if n_total is not None else None,
                                          _ptr(ws), ws.numel(), _stream()), "nacf_bn_concat_bwd_multi")
+
+
+def bn_sync_local_multi(xs, loc):
+    """loc [2, n_mod, D] = this rank's (sum | squared deviations about its own mean) per modality (nacf_bn_sync_local_multi)"""
+    _chk_f32(loc, *xs)
+    B, _, D = xs[0].shape
+    n = len(xs)
+    assert loc.shape == (2, n, D) and loc.is_contiguous() and all(x.is_contiguous() and x.shape[0] == B and x.shape[2] == D for x in xs)
+    lib = L.load()
+    ws = WORKSPACE.get(n * lib.nacf_bn_workspace(B * max(x.shape[1] for x in xs), D), loc.device)
+    L.check(lib.nacf_bn_sync_local_multi(n, _ptr_array(xs), B, _int_array([x.shape[1] for x in xs]), D, _ptr(loc), _ptr(ws),
+                                         ws.numel(), _stream()), "nacf_bn_sync_local_multi")
+
+
+def bn_sync_bwd_local_multi(dout, xs, f_offs, save_means, save_invstds, sums, dweights, dbiases, beta=1.0):
+    """sums [n_mod, 2, D] = this rank's (sum dy | sum dy*xhat); the same sums accumulate into the LOCAL dbiases | dweights"""
+    _chk_f32(dout, sums, *xs, *save_means, *save_invstds, *dweights, *dbiases)
+    B, _, D = xs[0].shape
+    n = len(xs)
+    assert sums.shape == (n, 2, D) and sums.is_contiguous()
+    lib = L.load()
+    ws = WORKSPACE.get(n * lib.nacf_bn_workspace(B * max(x.shape[1] for x in xs), D), dout.device)
+    L.check(lib.nacf_bn_sync_bwd_local_multi(n, _ptr(dout), _ptr_array(xs), B, _int_array([x.shape[1] for x in xs]), D, dout.shape[1],
+                                             _int_array(f_offs), _ptr_array(save_means), _ptr_array(save_invstds), _ptr(sums),
+                                             _ptr_array(dweights), _ptr_array(dbiases), float(beta), _ptr(ws), ws.numel(),
+                                             _stream()), "nacf_bn_sync_bwd_local_multi")
+
+
+def bn_sync_merge(gathered, rows_per_rank, out):
+    """gathered [world, 2, n_mod, D] of per-rank (sum | squared deviations about the rank's own mean) -> out [2, n_mod, D]
+    (global sum | squared deviations about the global mean); see nacf_bn_sync_merge"""
+    import ctypes
+    _chk_f32(gathered, out)
+    world, two, n_mod, D = gathered.shape
+    assert two == 2 and out.shape == (2, n_mod, D) and gathered.is_contiguous() and out.is_contiguous()
+    rows = (ctypes.c_float * n_mod)(*[float(r) for r in rows_per_rank])
+    L.check(L.load().nacf_bn_sync_merge(_ptr(gathered), world, n_mod, D, rows, _ptr(out), _stream()), "nacf_bn_sync_merge")
 
 
 def bn_sync_stat(x, sum_global, n_total, out):

@@ -938,6 +938,20 @@ def test_sync_bn_kernels_equal_the_global_batch(dev, B, Fr, D, world):
     for r in range(world):
         ops.bn_sync_stat(xs[r], S, n_total, Q_loc[r])
     Q = torch.stack(Q_loc).sum(0)                                   # all-reduce
+    # ONE exchange instead (the default protocol): per rank (sum | squared deviations about its OWN mean), all-gathered,
+    # merged by nacf_bn_sync_merge -- the same S, and Q to fp32 round-off of the two-pass Q and of fp64
+    n_loc = per * Fr
+    gathered = torch.empty(world, 2, 1, D, device=dev)
+    for r in range(world):
+        ops.bn_sync_stat(xs[r], None, n_loc, gathered[r, 0, 0])
+        ops.bn_sync_stat(xs[r], gathered[r, 0, 0], n_loc, gathered[r, 1, 0])
+    merged = torch.empty(2, 1, D, device=dev)
+    ops.bn_sync_merge(gathered, [n_loc], merged)
+    x64 = x.double().reshape(B * Fr, D)
+    Q64 = ((x64 - x64.mean(0)) ** 2).sum(0)
+    assert err(merged[0, 0], S) <= 2e-6 * float(S.abs().max())
+    assert err(merged[1, 0], Q64) <= 3e-6 * float(Q64.max()) and err(Q, Q64) <= 3e-6 * float(Q64.max())
+    S, Q = merged[0, 0].clone(), merged[1, 0].clone()               # what the ranks apply from here on
     outs, saves, stats = [], [], []
     for r in range(world):
         o = torch.zeros(per, M_total, D, device=dev)
@@ -972,6 +986,124 @@ def test_sync_bn_kernels_equal_the_global_batch(dev, B, Fr, D, world):
     assert err(torch.cat(outs)[:, f_off:f_off + Fr].reshape(B * Fr, D), y) < 5e-5
     y.backward(dout[:, f_off:f_off + Fr].double().cpu().reshape(B * Fr, D))
     assert err(torch.cat(dxs).reshape(B * Fr, D), xd.grad) < 5e-5 * max(1.0, float(xd.grad.abs().max()))
+
+
+def test_bn_concat_of_all_modalities_in_one_launch(dev):
+    """nacf_bn_concat_fwd_multi / _bwd_multi: the modalities of a joint representation side by side in the same launches --
+    bit-identical to one nacf_bn_concat_fwd / _bwd call per modality (different frame counts, running statistics,
+    parameter gradients accumulated with beta = 1), training and eval"""
+    ops, _ = _ops()
+    B, D, Fs = 24, 192, [7, 12, 5]
+    M_total = sum(Fs) + 2
+    f_offs = [1, 1 + Fs[0], 1 + Fs[0] + Fs[1]]
+    xs = [(rnd(B, f, D, seed=10 + i) * (1 + i) + 0.3 * i).to(dev) for i, f in enumerate(Fs)]
+    ws = [(rnd(D, seed=20 + i) + 1.5).to(dev) for i in range(3)]
+    bs = [rnd(D, seed=30 + i).to(dev) for i in range(3)]
+    dout = rnd(B, M_total, D, seed=4).to(dev)
+
+    def fresh():
+        return ([torch.full((D,), 0.1 * i, device=dev) for i in range(3)], [torch.full((D,), 1.0 + i, device=dev) for i in range(3)],
+                [torch.zeros((), dtype=torch.int64, device=dev) for _ in range(3)],
+                [torch.empty(D, device=dev) for _ in range(3)], [torch.empty(D, device=dev) for _ in range(3)])
+    for training in (False, True):           # (training last: its saved statistics feed the backward below)
+        rm1, rv1, nbt1, sm1, si1 = fresh()
+        out1 = torch.zeros(B, M_total, D, device=dev)
+        for i in range(3):
+            ops.bn_concat_fwd(xs[i], out1, f_offs[i], ws[i], bs[i], rm1[i], rv1[i], nbt1[i], sm1[i], si1[i], training)
+        rm2, rv2, nbt2, sm2, si2 = fresh()
+        out2 = torch.zeros(B, M_total, D, device=dev)
+        ops.bn_concat_fwd_multi(xs, out2, f_offs, ws, bs, rm2, rv2, nbt2, sm2 if training else [None] * 3,
+                                si2 if training else [None] * 3, training)
+        assert torch.equal(out1, out2)
+        for i in range(3):
+            assert torch.equal(rm1[i], rm2[i]) and torch.equal(rv1[i], rv2[i]) and int(nbt1[i]) == int(nbt2[i]) == int(training)
+            if training:
+                assert torch.equal(sm1[i], sm2[i]) and torch.equal(si1[i], si2[i])
+    dws1 = [rnd(D, seed=40 + i).to(dev) for i in range(3)]
+    dbs1 = [rnd(D, seed=50 + i).to(dev) for i in range(3)]
+    dws2, dbs2 = [t.clone() for t in dws1], [t.clone() for t in dbs1]
+    dx1, dx2 = [torch.empty_like(x) for x in xs], [torch.empty_like(x) for x in xs]
+    for i in range(3):
+        ops.bn_concat_bwd(dout, xs[i], dx1[i], f_offs[i], ws[i], sm1[i], si1[i], dws1[i], dbs1[i], beta=1.0)
+    ops.bn_concat_bwd_multi(dout, xs, dx2, f_offs, ws, sm1, si1, dws2, dbs2, beta=1.0)
+    for i in range(3):
+        assert torch.equal(dx1[i], dx2[i]) and torch.equal(dws1[i], dws2[i]) and torch.equal(dbs1[i], dbs2[i])
+
+
+def test_sync_bn_of_all_modalities_in_one_launch(dev):
+    """the data-parallel BatchNorm entry points for every modality at once (nacf_bn_sync_local_multi, _sync_bwd_local_multi,
+    the stats_global / sums_global forms of nacf_bn_concat_{fwd,bwd}_multi) against the per-modality ones: bit-identical"""
+    ops, _ = _ops()
+    B, D, Fs, world = 16, 128, [9, 4], 4
+    M_total = sum(Fs)
+    f_offs = [0, Fs[0]]
+    xs = [(rnd(B, f, D, seed=10 + i) * (1 + i) + 0.3 * i).to(dev) for i, f in enumerate(Fs)]
+    ws = [(rnd(D, seed=20 + i) + 1.5).to(dev) for i in range(2)]
+    bs = [rnd(D, seed=30 + i).to(dev) for i in range(2)]
+    dout = rnd(B, M_total, D, seed=4).to(dev)
+    n_loc = [B * f for f in Fs]
+    n_tot = [n * world for n in n_loc]
+    loc1 = torch.empty(2, 2, D, device=dev)
+    for i in range(2):
+        ops.bn_sync_stat(xs[i], None, n_loc[i], loc1[0, i])
+        ops.bn_sync_stat(xs[i], loc1[0, i], n_loc[i], loc1[1, i])
+    loc2 = torch.empty(2, 2, D, device=dev)
+    ops.bn_sync_local_multi(xs, loc2)
+    assert torch.equal(loc1, loc2)
+    # pretend `world` ranks hold shifted copies of these rows: any gathered vector will do for the comparison
+    gathered = torch.stack([loc1 * (1 + 0.01 * r) for r in range(world)]).contiguous()
+    stats = torch.empty(2, 2, D, device=dev)
+    ops.bn_sync_merge(gathered, n_loc, stats)
+
+    def fresh():
+        return ([torch.zeros(D, device=dev) for _ in range(2)], [torch.ones(D, device=dev) for _ in range(2)],
+                [torch.zeros((), dtype=torch.int64, device=dev) for _ in range(2)],
+                [torch.empty(D, device=dev) for _ in range(2)], [torch.empty(D, device=dev) for _ in range(2)])
+    rm1, rv1, nbt1, sm1, si1 = fresh()
+    out1 = torch.zeros(B, M_total, D, device=dev)
+    for i in range(2):
+        ops.bn_concat_fwd_sync(xs[i], out1, f_offs[i], ws[i], bs[i], rm1[i], rv1[i], nbt1[i], sm1[i], si1[i], stats[0, i], stats[1, i], n_tot[i])
+    rm2, rv2, nbt2, sm2, si2 = fresh()
+    out2 = torch.zeros(B, M_total, D, device=dev)
+    ops.bn_concat_fwd_multi(xs, out2, f_offs, ws, bs, rm2, rv2, nbt2, sm2, si2, True, stats_global=stats, n_total=n_tot)
+    assert torch.equal(out1, out2)
+    for i in range(2):
+        assert torch.equal(rm1[i], rm2[i]) and torch.equal(rv1[i], rv2[i]) and torch.equal(sm1[i], sm2[i]) and torch.equal(si1[i], si2[i])
+    dws1, dbs1 = [rnd(D, seed=40 + i).to(dev) for i in range(2)], [rnd(D, seed=50 + i).to(dev) for i in range(2)]
+    dws2, dbs2 = [t.clone() for t in dws1], [t.clone() for t in dbs1]
+    sums1, sums2 = torch.empty(2, 2, D, device=dev), torch.empty(2, 2, D, device=dev)
+    for i in range(2):
+        ops.bn_sync_bwd_stat(dout, xs[i], f_offs[i], sm1[i], si1[i], sums1[i], dws1[i], dbs1[i], beta=1.0)
+    ops.bn_sync_bwd_local_multi(dout, xs, f_offs, sm1, si1, sums2, dws2, dbs2, beta=1.0)
+    assert torch.equal(sums1, sums2)
+    for i in range(2):
+        assert torch.equal(dws1[i], dws2[i]) and torch.equal(dbs1[i], dbs2[i])
+    sums_g = (sums1 * world).contiguous()
+    dx1, dx2 = [torch.empty_like(x) for x in xs], [torch.empty_like(x) for x in xs]
+    for i in range(2):
+        ops.bn_concat_bwd_sync(dout, xs[i], dx1[i], f_offs[i], ws[i], sm1[i], si1[i], sums_g[i], n_tot[i])
+    keep_w, keep_b = [t.clone() for t in dws2], [t.clone() for t in dbs2]
+    ops.bn_concat_bwd_multi(dout, xs, dx2, f_offs, ws, sm1, si1, dws2, dbs2, beta=1.0, sums_global=sums_g, n_total=n_tot)
+    for i in range(2):
+        assert torch.equal(dx1[i], dx2[i]) and torch.equal(dws2[i], keep_w[i]) and torch.equal(dbs2[i], keep_b[i])
+
+
+def test_adam_walk_can_leave_the_gradient_zeroed(dev):
+    """nacf_adam_step_part, bump bit 2: the same update, and the gradient slice is zero afterwards (runtime/engine.py skips
+    the next step's fill); without the bit the gradient is left as optimizer.step() of the reference leaves it"""
+    ops, _ = _ops()
+    n = 100_003
+    p0, g0 = rnd(n, seed=1).to(dev), (rnd(n, seed=2) * 8).to(dev)
+    res = []
+    for z in (False, True):
+        p, g = p0.clone(), g0.clone()
+        m, v = torch.zeros(n, device=dev), torch.zeros(n, device=dev)
+        lr, step = torch.full((1,), 1e-3, device=dev), torch.zeros(1, dtype=torch.int64, device=dev)
+        ops.adam_step(p[:70000], g[:70000], m[:70000], v[:70000], lr, step, 0.9, 0.999, 1e-8, 5e-4, 5.0, 0.5, bump=True, zero_grad=z)
+        res.append((p, g, m, v, int(step)))
+    (pa, ga, ma, va, sa), (pb, gb, mb, vb, sb) = res
+    assert torch.equal(pa, pb) and torch.equal(ma, mb) and torch.equal(va, vb) and sa == sb == 1
+    assert torch.equal(ga, g0) and float(gb[:70000].abs().max()) == 0.0 and torch.equal(gb[70000:], g0[70000:])
 
 
 def test_deferred_dw_combines_are_bit_identical(dev):
