@@ -275,72 +275,68 @@ __global__ __launch_bounds__(EMB_THREADS) void layernorm_bwd_kernel(
   }
 }
 
-// dword[tok] += sum of the dE rows carrying `tok`, in ascending row order; the
-// workgroup of the FIRST occurrence of a token does the whole sum.
-__global__ __launch_bounds__(EMB_THREADS) void embed_scatter_word_kernel(const float* __restrict__ dE,
-                                                                          const int64_t* __restrict__ tokens,
-                                                                          float* __restrict__ dword, int n_rows,
-                                                                          int D, int first_tok) {
-  __shared__ int list[EMB_THREADS];
-  __shared__ int wcnt[2];
-  const int me = blockIdx.x;
+// ---- embedding-table gradients: two launches.  Phase A runs the four independent gathers side by side (block ranges
+// of ONE grid: each is a chain of dependent row loads, together they cost what the longest does), phase B the three
+// fixed-order combines.  Every sum keeps the order of the one-kernel-per-table version (ascending rows / chunks / videos).
+constexpr int SCAT_GROUPS = 4;
+constexpr int SCAT_THREADS = SCAT_GROUPS * EMB_THREADS;      // 512: 8 waves
+constexpr int SPECIAL_N = 5;          // ids 1..5: <unk>, <bos>, <eos>, <mask>, <vis>
+constexpr int SCATTER_CHUNK = 128;
+struct ScatShared {
+  int list[SCATTER_CHUNK];
+  int wcnt[2];
+  f32x4 red[SCAT_GROUPS][EMB_MAXJ][EMB_THREADS];
+};
+
+// dword[tok] += sum of the dE rows carrying `tok`, in ascending row order; the WAVE of the FIRST occurrence of a token
+// does the whole sum (one wave per row, no workgroup barrier: 8 rows per workgroup)
+__device__ __forceinline__ void scatter_word_wave(const float* __restrict__ dE, const int64_t* __restrict__ tokens,
+                                                  float* __restrict__ dword, int n_rows, int D, int first_tok, int me) {
+  if (me >= n_rows) return;
+  const int lane = threadIdx.x & 63;
   const int64_t tok = tokens[me];
   if (tok < first_tok) return;  // PAD never gets a gradient; ids < first_tok go through the chunked path
-  for (int base = 0; base < me; base += EMB_THREADS) {
-    const int idx = base + threadIdx.x;
-    const int found = (idx < me && tokens[idx] == tok) ? 1 : 0;
-    if (__syncthreads_or(found)) return;
+  for (int base = 0; base < me; base += 64) {
+    const int idx = base + lane;
+    if (__ballot(idx < me && tokens[idx] == tok) != 0ull) return;
   }
-  f32x4 acc[EMB_MAXJ];
+  constexpr int WJ = 2 * EMB_MAXJ;      // float4 columns per lane
+  f32x4 acc[WJ];
 #pragma unroll
-  for (int j = 0; j < EMB_MAXJ; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  for (int base = me; base < n_rows; base += EMB_THREADS) {
-    const int idx = base + threadIdx.x;
-    const bool match = idx < n_rows && tokens[idx] == tok;
-    const unsigned long long bal = __ballot(match);
-    const int pre = __popcll(bal & ((1ull << lane) - 1ull));
-    if (lane == 0) wcnt[wave] = __popcll(bal);
-    __syncthreads();
-    const int off = (wave == 0) ? 0 : wcnt[0];
-    const int n = wcnt[0] + wcnt[1];
-    if (match) list[off + pre] = idx;
-    __syncthreads();
-    for (int i = 0; i < n; ++i) {
-      const int64_t src = (int64_t)list[i] * D;
+  for (int j = 0; j < WJ; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int base = me; base < n_rows; base += 64) {
+    const int idx = base + lane;
+    unsigned long long bal = __ballot(idx < n_rows && tokens[idx] == tok);
+    while (bal) {
+      const int bit = __builtin_ctzll(bal);
+      bal &= bal - 1ull;
+      const int64_t src = (int64_t)(base + bit) * D;
 #pragma unroll
-      for (int j = 0; j < EMB_MAXJ; ++j) {
-        const int d = (threadIdx.x + EMB_THREADS * j) * 4;
+      for (int j = 0; j < WJ; ++j) {
+        const int d = (lane + 64 * j) * 4;
         if (d < D) acc[j] += *reinterpret_cast<const f32x4*>(dE + src + d);
       }
     }
-    __syncthreads();
   }
 #pragma unroll
-  for (int j = 0; j < EMB_MAXJ; ++j) {
-    const int d = (threadIdx.x + EMB_THREADS * j) * 4;
+  for (int j = 0; j < WJ; ++j) {
+    const int d = (lane + 64 * j) * 4;
     if (d < D) {
       float* o = dword + tok * D + d;
-      f32x4 cur = *reinterpret_cast<f32x4*>(o);
+      const f32x4 cur = *reinterpret_cast<f32x4*>(o);
       *reinterpret_cast<f32x4*>(o) = cur + acc[j];
     }
   }
 }
 
-// The special ids (<unk>, <bos>, <eos>, <mask>, <vis>) label thousands of rows each (every masked /
-// visual-word slot), so their rows are summed chunk-parallel: partial[chunk][tok-1][D] over 128-row
-// chunks, then a fixed-order combine.  grid = (n_chunks, SPECIAL_N)
-constexpr int SPECIAL_N = 5;          // ids 1..5
-constexpr int SCATTER_CHUNK = 128;
-__global__ __launch_bounds__(4 * EMB_THREADS) void embed_scatter_special_partial_kernel(
-    const float* __restrict__ dE, const int64_t* __restrict__ tokens, float* __restrict__ part, int n_rows, int D) {
-  // 4 * EMB_THREADS threads: the first EMB_THREADS list the chunk's rows that hold this token (ascending); group gq
-  // then adds list entries gq, gq+4, ... and the 4 partials fold through LDS in fixed order
-  __shared__ int list[SCATTER_CHUNK];
-  __shared__ int wcnt[2];
-  __shared__ f32x4 red[4][EMB_MAXJ][EMB_THREADS];
-  const int chunk = blockIdx.x;
-  const int64_t tok = blockIdx.y + 1;
+// The special ids label thousands of rows each (every masked / visual-word slot), so their rows are summed
+// chunk-parallel: partial[chunk][tok-1][D] over 128-row chunks, then a fixed-order combine.  The first EMB_THREADS
+// threads list the chunk's rows that hold this token (ascending); group gq then adds list entries gq, gq+4, ... and
+// the 4 partials fold through LDS in fixed order
+__device__ __forceinline__ void scatter_special_partial(ScatShared& sh, const float* __restrict__ dE,
+                                                        const int64_t* __restrict__ tokens, float* __restrict__ part, int n_rows,
+                                                        int D, int chunk, int ti) {
+  const int64_t tok = ti + 1;
   const int t = threadIdx.x % EMB_THREADS, gq = threadIdx.x / EMB_THREADS;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   bool match = false;
@@ -350,17 +346,17 @@ __global__ __launch_bounds__(4 * EMB_THREADS) void embed_scatter_special_partial
     match = idx < n_rows && tokens[idx] == tok;
     const unsigned long long bal = __ballot(match);
     pre = __popcll(bal & ((1ull << lane) - 1ull));
-    if (lane == 0) wcnt[wave] = __popcll(bal);
+    if (lane == 0) sh.wcnt[wave] = __popcll(bal);
   }
   __syncthreads();
-  const int n = wcnt[0] + wcnt[1];
-  if (gq == 0 && match) list[((wave == 0) ? 0 : wcnt[0]) + pre] = chunk * SCATTER_CHUNK + t;
+  const int n = sh.wcnt[0] + sh.wcnt[1];
+  if (gq == 0 && match) sh.list[((wave == 0) ? 0 : sh.wcnt[0]) + pre] = chunk * SCATTER_CHUNK + t;
   __syncthreads();
   f32x4 acc[EMB_MAXJ];
 #pragma unroll
   for (int j = 0; j < EMB_MAXJ; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
-  for (int i = gq; i < n; i += 4) {
-    const int64_t src = (int64_t)list[i] * D;
+  for (int i = gq; i < n; i += SCAT_GROUPS) {
+    const int64_t src = (int64_t)sh.list[i] * D;
 #pragma unroll
     for (int j = 0; j < EMB_MAXJ; ++j) {
       const int d = (t + EMB_THREADS * j) * 4;
@@ -368,43 +364,23 @@ __global__ __launch_bounds__(4 * EMB_THREADS) void embed_scatter_special_partial
     }
   }
 #pragma unroll
-  for (int j = 0; j < EMB_MAXJ; ++j) red[gq][j][t] = acc[j];
+  for (int j = 0; j < EMB_MAXJ; ++j) sh.red[gq][j][t] = acc[j];
   __syncthreads();
   if (gq == 0) {
 #pragma unroll
     for (int j = 0; j < EMB_MAXJ; ++j) {
       const int d = (t + EMB_THREADS * j) * 4;
       if (d < D)
-        *reinterpret_cast<f32x4*>(part + ((int64_t)chunk * SPECIAL_N + blockIdx.y) * D + d) =
-            ((red[0][j][t] + red[1][j][t]) + red[2][j][t]) + red[3][j][t];
+        *reinterpret_cast<f32x4*>(part + ((int64_t)chunk * SPECIAL_N + ti) * D + d) =
+            ((sh.red[0][j][t] + sh.red[1][j][t]) + sh.red[2][j][t]) + sh.red[3][j][t];
     }
   }
 }
 
-// dst[(row0 + blockIdx.x)] (+)= sum_{c < n_parts} part[c][blockIdx.x]  (fixed order)
-__global__ __launch_bounds__(EMB_THREADS) void embed_scatter_combine_kernel(const float* __restrict__ part, int n_parts,
-                                                                             int n_items, float* __restrict__ dst,
-                                                                             int row0, int D, int accumulate) {
-  const int item = blockIdx.x;
-#pragma unroll
-  for (int j = 0; j < EMB_MAXJ; ++j) {
-    const int d = (threadIdx.x + EMB_THREADS * j) * 4;
-    if (d < D) {
-      f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll 4
-      for (int c = 0; c < n_parts; ++c) acc += *reinterpret_cast<const f32x4*>(part + ((int64_t)c * n_items + item) * D + d);
-      float* o = dst + (int64_t)(row0 + item) * D + d;
-      if (accumulate) acc += *reinterpret_cast<const f32x4*>(o);
-      *reinterpret_cast<f32x4*>(o) = acc;
-    }
-  }
-}
-
-// part[pc][l][D] = sum over the rows r of chunk pc of dE[r, l]   grid = (L, n_pchunks)
-__global__ __launch_bounds__(EMB_THREADS) void embed_scatter_pos_partial_kernel(const float* __restrict__ dE,
-                                                                                 float* __restrict__ part, int R, int L,
-                                                                                 int D, int rows_per) {
-  const int l = blockIdx.x, pc = blockIdx.y;
+// part[pc][l][D] = sum over the rows r of chunk pc of dE[r, l]   (the first EMB_THREADS threads of the workgroup)
+__device__ __forceinline__ void scatter_pos_partial(const float* __restrict__ dE, float* __restrict__ part, int R, int L, int D,
+                                                    int rows_per, int l, int pc) {
+  if (threadIdx.x >= EMB_THREADS) return;
   const int r0 = pc * rows_per, r1 = min(R, r0 + rows_per);
   f32x4 acc[EMB_MAXJ];
 #pragma unroll
@@ -424,20 +400,15 @@ __global__ __launch_bounds__(EMB_THREADS) void embed_scatter_pos_partial_kernel(
   }
 }
 
-// vsum[v] = sum over the decoder rows of video v and all positions   grid = n_video, 4 * EMB_THREADS threads:
-// position group gq walks l = gq, gq+4, ... of every matching row; the 4 partials fold through LDS in fixed order
-constexpr int SCAT_GROUPS = 4;
-__global__ __launch_bounds__(SCAT_GROUPS * EMB_THREADS) void embed_scatter_video_kernel(const float* __restrict__ dE,
-                                                                                         float* __restrict__ vsum, int R,
-                                                                                         int L, int D, int vdiv, int vmod) {
-  __shared__ f32x4 red[SCAT_GROUPS][EMB_MAXJ][EMB_THREADS];
-  const int me = blockIdx.x;
+// vsum[v] = sum over the decoder rows of video v and all positions: position group gq walks pairs gq, gq+4, ... of the
+// (row, position) pairs of the video; the 4 partials fold through LDS in fixed order
+__device__ __forceinline__ void scatter_video(ScatShared& sh, const float* __restrict__ dE, float* __restrict__ vsum, int R, int L,
+                                              int D, int vdiv, int vmod, int me) {
   const int t = threadIdx.x % EMB_THREADS, gq = threadIdx.x / EMB_THREADS;
   f32x4 acc[EMB_MAXJ];
 #pragma unroll
   for (int j = 0; j < EMB_MAXJ; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
-  // the rows of video `me` are r = (q * vmod + me) * vdiv + j  (j < vdiv, q = 0, 1, ...): walk the (row, position)
-  // pairs directly, group gq takes pairs gq, gq+4, ...
+  // the rows of video `me` are r = (q * vmod + me) * vdiv + j  (j < vdiv, q = 0, 1, ...)
   const int per_q = vdiv * L;
   const int n_q = (R / vdiv - me + vmod - 1) / vmod;          // number of q with (q*vmod + me) < R/vdiv
   const int n_pairs = (n_q > 0 ? n_q : 0) * per_q;
@@ -453,22 +424,64 @@ __global__ __launch_bounds__(SCAT_GROUPS * EMB_THREADS) void embed_scatter_video
     }
   }
 #pragma unroll
-  for (int j = 0; j < EMB_MAXJ; ++j) red[gq][j][t] = acc[j];
+  for (int j = 0; j < EMB_MAXJ; ++j) sh.red[gq][j][t] = acc[j];
   __syncthreads();
   if (gq == 0) {
 #pragma unroll
     for (int j = 0; j < EMB_MAXJ; ++j) {
       const int d = (t + EMB_THREADS * j) * 4;
-      if (d < D) *reinterpret_cast<f32x4*>(vsum + (int64_t)me * D + d) = ((red[0][j][t] + red[1][j][t]) + red[2][j][t]) + red[3][j][t];
+      if (d < D) *reinterpret_cast<f32x4*>(vsum + (int64_t)me * D + d) = ((sh.red[0][j][t] + sh.red[1][j][t]) + sh.red[2][j][t]) + sh.red[3][j][t];
     }
   }
 }
 
-// dcat[c] += sum of vsum[v] over the videos of category c (ascending v)   grid = n_cat
-__global__ __launch_bounds__(EMB_THREADS) void embed_scatter_cat_kernel(const float* __restrict__ vsum,
-                                                                         const int64_t* __restrict__ category,
-                                                                         float* __restrict__ dcat, int n_video, int D) {
-  const int me = blockIdx.x;
+struct ScatterArgs {
+  const float* dE; const int64_t* tokens; const int64_t* category;
+  float* dword; float* dpos; float* dcat; float* vsum;
+  float* part_special; float* part_pos;
+  int R, L, D, rows, first_tok;
+  int chunks, n_special;        // special ids: grid chunks x n_special
+  int pos_real, pos_rows_per;   // positions: grid L x pos_real
+  int n_video, vdiv, vmod, n_cat;
+  int b_special, b_video, b_pos, b_word;     // phase A: first workgroup of each role (b_word .. grid end: 8 rows each)
+  int c_special, c_pos, c_cat;               // phase B
+};
+
+__global__ __launch_bounds__(SCAT_THREADS) void embed_scatter_gather_kernel(ScatterArgs a) {
+  __shared__ ScatShared sh;
+  const int b = blockIdx.x;
+  if (b >= a.b_word) {
+    scatter_word_wave(a.dE, a.tokens, a.dword, a.rows, a.D, a.first_tok, (b - a.b_word) * (SCAT_THREADS / 64) + (threadIdx.x >> 6));
+  } else if (b >= a.b_pos) {
+    const int i = b - a.b_pos;
+    scatter_pos_partial(a.dE, a.part_pos, a.R, a.L, a.D, a.pos_rows_per, i % a.L, i / a.L);
+  } else if (b >= a.b_video) {
+    scatter_video(sh, a.dE, a.vsum, a.R, a.L, a.D, a.vdiv, a.vmod, b - a.b_video);
+  } else {
+    const int i = b - a.b_special;
+    scatter_special_partial(sh, a.dE, a.tokens, a.part_special, a.rows, a.D, i % a.chunks, i / a.chunks);
+  }
+}
+
+// dst[(row0 + item)] (+)= sum_{c < n_parts} part[c][item]  (fixed order)
+__device__ __forceinline__ void scatter_combine(const float* __restrict__ part, int n_parts, int n_items, float* __restrict__ dst,
+                                                int row0, int D, int accumulate, int item) {
+#pragma unroll
+  for (int j = 0; j < EMB_MAXJ; ++j) {
+    const int d = (threadIdx.x + EMB_THREADS * j) * 4;
+    if (d < D) {
+      f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
+      for (int c = 0; c < n_parts; ++c) acc += *reinterpret_cast<const f32x4*>(part + ((int64_t)c * n_items + item) * D + d);
+      float* o = dst + (int64_t)(row0 + item) * D + d;
+      if (accumulate) acc += *reinterpret_cast<const f32x4*>(o);
+      *reinterpret_cast<f32x4*>(o) = acc;
+    }
+  }
+}
+// dcat[c] += sum of vsum[v] over the videos of category c (ascending v)
+__device__ __forceinline__ void scatter_cat(const float* __restrict__ vsum, const int64_t* __restrict__ category,
+                                            float* __restrict__ dcat, int n_video, int D, int me) {
   f32x4 acc[EMB_MAXJ];
 #pragma unroll
   for (int j = 0; j < EMB_MAXJ; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -485,10 +498,17 @@ __global__ __launch_bounds__(EMB_THREADS) void embed_scatter_cat_kernel(const fl
     const int d = (threadIdx.x + EMB_THREADS * j) * 4;
     if (d < D) {
       float* o = dcat + (int64_t)me * D + d;
-      f32x4 cur = *reinterpret_cast<f32x4*>(o);
+      const f32x4 cur = *reinterpret_cast<f32x4*>(o);
       *reinterpret_cast<f32x4*>(o) = cur + acc[j];
     }
   }
+}
+__global__ __launch_bounds__(EMB_THREADS) void embed_scatter_combine_kernel(ScatterArgs a) {
+  const int b = blockIdx.x;
+  if (b >= a.c_cat) scatter_cat(a.vsum, a.category, a.dcat, a.n_video, a.D, b - a.c_cat);
+  else if (b >= a.c_pos) scatter_combine(a.part_pos, a.pos_real, a.L, a.dpos, 0, a.D, 1, b - a.c_pos);
+  // partial layout is [chunk][SPECIAL_N][D]: n_items = SPECIAL_N, only the first n_special used; dword rows 1..
+  else scatter_combine(a.part_special, a.chunks, SPECIAL_N, a.dword, 1, a.D, 1, b - a.c_special);
 }
 
 __global__ void masked_mean_fwd_kernel(const float* __restrict__ y, const int64_t* __restrict__ tokens,
@@ -778,33 +798,31 @@ int nacf_embed_scatter_bwd(const float* dE, const int64_t* tokens, const int64_t
   float* part_special = reinterpret_cast<float*>(ws);
   float* part_pos = part_special + (size_t)chunks * SPECIAL_N * D;
   float* vsum_ws = part_pos + (size_t)scatter_pos_chunks(R) * L * D;
-  if (dword) {
-    const int n_special = V - 1 < SPECIAL_N ? V - 1 : SPECIAL_N;   // tiny vocabularies
-    if (n_special > 0) {
-      hipLaunchKernelGGL(embed_scatter_special_partial_kernel, dim3(chunks, n_special), dim3(4 * EMB_THREADS), 0, s, dE, tokens,
-                         part_special, rows, D);
-      // partial layout is [chunk][SPECIAL_N][D]: combine with n_items = SPECIAL_N, only the first n_special used
-      hipLaunchKernelGGL(embed_scatter_combine_kernel, dim3(n_special), dim3(EMB_THREADS), 0, s, part_special, chunks,
-                         SPECIAL_N, dword, 1, D, 1);
-    }
-    hipLaunchKernelGGL(embed_scatter_word_kernel, dim3(rows), dim3(EMB_THREADS), 0, s, dE, tokens, dword, rows, D,
-                       1 + n_special);
-  }
-  if (dpos) {
-    const int pch = scatter_pos_chunks(R);
-    const int rows_per = cdiv(R, pch);
-    const int real = cdiv(R, rows_per);
-    hipLaunchKernelGGL(embed_scatter_pos_partial_kernel, dim3(L, real), dim3(EMB_THREADS), 0, s, dE, part_pos, R, L, D,
-                       rows_per);
-    hipLaunchKernelGGL(embed_scatter_combine_kernel, dim3(L), dim3(EMB_THREADS), 0, s, part_pos, real, L, dpos, 0, D, 1);
-  }
-  if (dcat || dadd) {
-    float* vs = dadd ? dadd : vsum_ws;
-    hipLaunchKernelGGL(embed_scatter_video_kernel, dim3(n_video), dim3(SCAT_GROUPS * EMB_THREADS), 0, s, dE, vs, R, L, D, vdiv,
-                       vmod);
-    if (dcat)
-      hipLaunchKernelGGL(embed_scatter_cat_kernel, dim3(n_cat), dim3(EMB_THREADS), 0, s, vs, category, dcat, n_video, D);
-  }
+  ScatterArgs a = {};
+  a.dE = dE; a.tokens = tokens; a.category = category; a.dword = dword; a.dpos = dpos; a.dcat = dcat;
+  a.vsum = dadd ? dadd : vsum_ws; a.part_special = part_special; a.part_pos = part_pos;
+  a.R = R; a.L = L; a.D = D; a.rows = rows;
+  a.chunks = chunks;
+  a.n_special = dword ? (V - 1 < SPECIAL_N ? V - 1 : SPECIAL_N) : 0;   // tiny vocabularies
+  if (a.n_special < 0) a.n_special = 0;
+  a.first_tok = 1 + a.n_special;
+  const int pch = scatter_pos_chunks(R);
+  a.pos_rows_per = cdiv(R, pch);
+  a.pos_real = dpos ? cdiv(R, a.pos_rows_per) : 0;
+  a.n_video = (dcat || dadd) ? n_video : 0; a.vdiv = vdiv; a.vmod = vmod; a.n_cat = dcat ? n_cat : 0;
+  // phase A: special partials | video sums | position partials | words (8 rows per workgroup)
+  a.b_special = 0;
+  a.b_video = a.b_special + chunks * a.n_special;
+  a.b_pos = a.b_video + a.n_video;
+  a.b_word = a.b_pos + L * a.pos_real;
+  const int grid_a = a.b_word + (dword ? cdiv(rows, SCAT_THREADS / 64) : 0);
+  if (grid_a > 0) hipLaunchKernelGGL(embed_scatter_gather_kernel, dim3(grid_a), dim3(SCAT_THREADS), 0, s, a);
+  // phase B: the fixed-order combines
+  a.c_special = 0;
+  a.c_pos = a.c_special + a.n_special;
+  a.c_cat = a.c_pos + (dpos ? L : 0);
+  const int grid_b = a.c_cat + a.n_cat;
+  if (grid_b > 0) hipLaunchKernelGGL(embed_scatter_combine_kernel, dim3(grid_b), dim3(EMB_THREADS), 0, s, a);
   NACF_LAUNCH_CHECK("nacf_embed_scatter_bwd");
   return NACF_OK;
 }
