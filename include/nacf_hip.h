@@ -375,8 +375,9 @@ int nacf_bn_concat_bwd_sync(const float* dOut, const float* x, float* dx, int B,
 /* mean over the time axis: out[b, :] = mean_t x[b, t, :]   (x is [B, T, D]);
  * models/Predictor.py:29, models/Decoder.py:137, models/Encoder.py:51 */
 int nacf_mean_time_fwd(const float* x, float* out, int B, int T, int D, nacf_stream_t stream);
-/* dx[b, t, :] (+)= dOut[b, :] / T */
-int nacf_mean_time_bwd(const float* dOut, float* dx, int B, int T, int D, int accumulate,
+/* dx[b, t, :] (+)= (dOut[b, :] + dOut2[b, :]) / T ; dOut2 may be NULL (the mean has two consumers in the model -- length
+ * head and decoder input enhancement: their gradients are added here, not by a kernel of their own) */
+int nacf_mean_time_bwd(const float* dOut, const float* dOut2, float* dx, int B, int T, int D, int accumulate,
                        nacf_stream_t stream);
 
 /* row-wise log_softmax for narrow rows (length head, N <= 1024),

@@ -494,15 +494,33 @@ __global__ void mean_time_fwd_scalar_kernel(const float* __restrict__ x, float* 
     out[(int64_t)b * D + d] = acc / (float)T;
   }
 }
-__global__ void mean_time_bwd_kernel(const float* __restrict__ dOut, float* __restrict__ dx, int B, int T, int D,
-                                     int accumulate) {
+__global__ void mean_time_bwd_kernel(const float* __restrict__ dOut, const float* __restrict__ dOut2, float* __restrict__ dx, int B,
+                                     int T, int D, int accumulate) {
   const int64_t total = (int64_t)B * T * D;
   const float inv = 1.f / (float)T;
   for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
     const int d = (int)(e % D);
     const int b = (int)(e / ((int64_t)T * D));
-    const float g = dOut[(int64_t)b * D + d] * inv;
+    const float g = (dOut[(int64_t)b * D + d] + (dOut2 ? dOut2[(int64_t)b * D + d] : 0.f)) * inv;
     dx[e] = accumulate ? dx[e] + g : g;
+  }
+}
+
+// float4 form (D % 4 == 0, 16-byte aligned): 32-bit index arithmetic; dOut2 (optional): a second upstream gradient of the
+// mean -- its two consumers' gradients are added here instead of by a separate kernel
+__global__ __launch_bounds__(256) void mean_time_bwd_v4_kernel(const float* __restrict__ dOut, const float* __restrict__ dOut2,
+                                                               float* __restrict__ dx, int B, int T, int D4, int accumulate) {
+  const int rows = B * T;
+  const float inv = 1.f / (float)T;
+  const int total = rows * D4;      // < 2^31 float4s (checked by the launcher)
+  for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) {
+    const int row = e / D4, d4 = e - row * D4;
+    const int b = row / T;
+    f32x4 g = *reinterpret_cast<const f32x4*>(dOut + ((int64_t)b * D4 + d4) * 4);
+    if (dOut2) g += *reinterpret_cast<const f32x4*>(dOut2 + ((int64_t)b * D4 + d4) * 4);
+    g *= inv;
+    f32x4* o = reinterpret_cast<f32x4*>(dx + (int64_t)e * 4);
+    *o = accumulate ? *o + g : g;
   }
 }
 
@@ -1280,10 +1298,14 @@ int nacf_mean_time_fwd(const float* x, float* out, int B, int T, int D, nacf_str
   return NACF_OK;
 }
 
-int nacf_mean_time_bwd(const float* dOut, float* dx, int B, int T, int D, int accumulate, nacf_stream_t stream) {
+int nacf_mean_time_bwd(const float* dOut, const float* dOut2, float* dx, int B, int T, int D, int accumulate, nacf_stream_t stream) {
   NACF_CHECK(dOut && dx && B > 0 && T > 0 && D > 0, NACF_EINVAL, "nacf_mean_time_bwd: bad argument");
-  hipLaunchKernelGGL(mean_time_bwd_kernel, dim3(grid_for((int64_t)B * T * D)), dim3(256), 0, as_hip(stream), dOut, dx, B,
-                     T, D, accumulate);
+  if (D % 4 == 0 && bn_aligned16(dOut, dOut2, dx) && (int64_t)B * T * (D / 4) < (int64_t)1 << 31)
+    hipLaunchKernelGGL(mean_time_bwd_v4_kernel, dim3(grid_for((int64_t)B * T * (D / 4))), dim3(256), 0, as_hip(stream), dOut, dOut2,
+                       dx, B, T, D / 4, accumulate);
+  else
+    hipLaunchKernelGGL(mean_time_bwd_kernel, dim3(grid_for((int64_t)B * T * D)), dim3(256), 0, as_hip(stream), dOut, dOut2, dx, B,
+                       T, D, accumulate);
   NACF_LAUNCH_CHECK("nacf_mean_time_bwd");
   return NACF_OK;
 }

@@ -157,9 +157,9 @@ class Seq2Seq(nn.Module):
             enc_output = torch.cat(enc_streams, dim=1)
         if self.training and torch.is_tensor(enc_output) and enc_output.requires_grad:
             results['_enc_root'] = enc_output          # (the staged backward cuts here: upstream of memory AND pooled)
-            enc_output, pooled = MemoryFanoutFn.apply(enc_output)
+            enc_output, pooled, pooled_dec = MemoryFanoutFn.apply(enc_output)     # (one mean, one handle per consumer)
         else:
-            pooled = MeanTimeFn.apply(enc_output)
+            pooled = pooled_dec = MeanTimeFn.apply(enc_output)
         if self.auxiliary_task_predictor is not None:
             # The length head (two 128-row GEMMs, a row soft-max; ~55 us forward, ~75 us backward of launch-latency-sized
             # kernels) depends on the pooled memory only: in training it runs on a SIDE stream next to the decoder -- a
@@ -185,7 +185,7 @@ class Seq2Seq(nn.Module):
                 results.update(self.auxiliary_task_predictor(enc_output=enc_output, pooled=pooled))
         results['enc_output'] = enc_output
         results.lazy('enc_hidden', enc_hidden_fn)
-        results['_pooled_memory'] = pooled
+        results['_pooled_memory'] = pooled_dec
         return results
 
     def _aux_stream(self, ref):

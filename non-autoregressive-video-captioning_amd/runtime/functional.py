@@ -284,18 +284,24 @@ class MemoryFanoutFn(Function):
         B, T, D = x.shape
         ctx.shape = (B, T, D)
         pooled = ops.mean_time_fwd(x, _new((B, D), x))
-        return x.view_as(x), pooled
+        # the mean as TWO outputs over one buffer, one per consumer (length head | decoder input): autograd then hands their
+        # gradients over separately and the add happens inside nacf_mean_time_bwd, not in a kernel of its own
+        return x.view_as(x), pooled, pooled.view_as(pooled)
 
     @staticmethod
-    def backward(ctx, dmem, dpooled):
-        if dmem is None:
-            dx = _new(ctx.shape, dpooled)
-            ops.mean_time_bwd(dpooled.contiguous(), dx, accumulate=False)
-            return dx
+    def backward(ctx, dmem, dpooled, dpooled2=None):
+        if dpooled is None:
+            dpooled, dpooled2 = dpooled2, None
         if dpooled is None:
             return dmem
+        dpooled = dpooled.contiguous()
+        dpooled2 = dpooled2.contiguous() if dpooled2 is not None else None
+        if dmem is None:
+            dx = _new(ctx.shape, dpooled)
+            ops.mean_time_bwd(dpooled, dx, accumulate=False, dout2=dpooled2)
+            return dx
         dx = dmem.contiguous()
-        ops.mean_time_bwd(dpooled.contiguous(), dx, accumulate=True)      # in place: dmem is this node's alone
+        ops.mean_time_bwd(dpooled, dx, accumulate=True, dout2=dpooled2)      # in place: dmem is this node's alone
         return dx
 
 

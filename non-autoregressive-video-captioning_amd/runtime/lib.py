@@ -98,7 +98,7 @@ SIGNATURES = {
     "nacf_bn_sync_bwd_stat": (c_int, [_P, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _F, _P, _S, _P]),
     "nacf_bn_concat_bwd_sync": (c_int, [_P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _L, _P]),
     "nacf_mean_time_fwd": (c_int, [_P, _P, _I, _I, _I, _P]),
-    "nacf_mean_time_bwd": (c_int, [_P, _P, _I, _I, _I, _I, _P]),
+    "nacf_mean_time_bwd": (c_int, [_P, _P, _P, _I, _I, _I, _I, _P]),
     "nacf_log_softmax_rows": (c_int, [_P, _P, _I, _I, _P]),
     "nacf_log_softmax_rows_bwd": (c_int, [_P, _P, _P, _I, _I, _P]),
     "nacf_kldiv_mean": (c_int, [_P, _P, _P, _P, _P, _F, _I, _I, _P]),

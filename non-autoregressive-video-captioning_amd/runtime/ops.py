@@ -728,10 +728,11 @@ def mean_time_fwd(x, out):
     return out
 
 
-def mean_time_bwd(dout, dx, accumulate=False):
-    _chk_f32(dout, dx)
+def mean_time_bwd(dout, dx, accumulate=False, dout2=None):
+    """dx (+)= (dout + dout2) / T broadcast over time; dout2: the gradient of a second consumer of the mean"""
+    _chk_f32(dout, dout2, dx)
     B, T, D = dx.shape
-    L.check(L.load().nacf_mean_time_bwd(_ptr(dout), _ptr(dx), B, T, D, int(accumulate), _stream()),
+    L.check(L.load().nacf_mean_time_bwd(_ptr(dout), _ptr(dout2), _ptr(dx), B, T, D, int(accumulate), _stream()),
             "nacf_mean_time_bwd")
 
 

@@ -352,6 +352,13 @@ def test_mean_time_logsoftmax_kldiv(dev):
     dx = torch.empty(7, 13, 96, device=dev)
     ops.mean_time_bwd(out, dx)
     assert err(dx, (out.double().cpu() / 13).unsqueeze(1).expand(-1, 13, -1)) < 1e-7
+    # two upstream gradients of the mean (its two consumers) added inside, accumulate on top of dx; float4 and scalar forms
+    for D in (96, 30):
+        g1, g2, base = rnd(7, D, seed=5).to(dev), rnd(7, D, seed=6).to(dev), rnd(7, 13, D, seed=7).to(dev)
+        d2 = base.clone()
+        ops.mean_time_bwd(g1, d2, accumulate=True, dout2=g2)
+        want = base.double().cpu() + ((g1.double().cpu() + g2.double().cpu()) / 13).unsqueeze(1)
+        assert err(d2, want) < 1e-6
     z = rnd(9, 30, seed=2, scale=3).double().requires_grad_(True)
     lp = torch.log_softmax(z, -1)
     tgt = torch.zeros(9, 30, dtype=torch.float64); tgt[torch.arange(9), torch.arange(9) + 4] = 1.0
