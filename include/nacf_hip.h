@@ -448,7 +448,8 @@ int nacf_layernorm_bwd(const float* dOut, const float* xhat, const float* rstd, 
  * query row r reads kv row (r / kv_div) % kv_mod.
  * key_tokens: optional [n_kv... R, Lk] int64 (self-attention: the decoder
  * tokens; key masked when token == PAD, models/Decoder.py:13-22);
- * causal != 0 adds the strict upper-triangular mask (models/Decoder.py:24-39).
+ * causal != 0 adds the strict upper-triangular mask (models/Decoder.py:24-39); causal = 1 + w with w > 0 also masks the
+ * keys k <= q - w (--watch w, models/Decoder.py:27-29: a query sees itself and the w - 1 tokens before it).
  * probs: optional [H, R, Lq, Lk] output (models/bert.py:179). */
 int nacf_attention_fwd(const float* Q, int64_t ldq, const float* K, int64_t ldk,
                        const float* V, int64_t ldv, float* O, int64_t ldo,

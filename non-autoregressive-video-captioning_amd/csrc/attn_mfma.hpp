@@ -143,7 +143,7 @@ __device__ __forceinline__ void softmax_rows(f32x4 (&s)[2][NKT], float sq, const
         const int key = tn * 16 + g * 4 + rr;
         float v = s[tm][tn][rr] / sq;
         if ((padbits >> (tn * 4 + rr)) & 1ull) v = -10e6f;
-        if (causal && key > q) v = -10e6f;
+        if (causal && (key > q || (causal > 1 && key <= q - (causal - 1)))) v = -10e6f;     // causal - 1 = --watch window
         if (key >= Lk) v = -3.0e38f;             // tile padding: contributes exactly 0
         s[tm][tn][rr] = v;
         mx = fmaxf(mx, v);

@@ -556,7 +556,7 @@ __global__ __launch_bounds__(256) void attention_fwd_kernel(const float* __restr
     const float* b = ks + k * ldd;
     for (int d = 0; d < dk; ++d) dot += a[d] * b[d];
     float s = dot / sq;
-    const bool masked = (key_tokens && key_tokens[(int64_t)r * Lk + k] == NACF_PAD) || (causal && k > q);
+    const bool masked = (key_tokens && key_tokens[(int64_t)r * Lk + k] == NACF_PAD) || (causal && (k > q || (causal > 1 && k <= q - (causal - 1))));
     if (masked) s = -10e6f;  // models/bert.py:161: -10e6, not -inf
     ps[idx] = s;
   }
@@ -637,7 +637,7 @@ __global__ __launch_bounds__(256) void attention_bwd_kernel(
       const float* vv = vs + k * ldd;
       for (int d = 0; d < dk; ++d) { dot += a[d] * b[d]; dp += g[d] * vv[d]; }
       float s = dot / sq;
-      const bool masked = (key_tokens && key_tokens[(int64_t)r * Lk + k] == NACF_PAD) || (causal && k > q);
+      const bool masked = (key_tokens && key_tokens[(int64_t)r * Lk + k] == NACF_PAD) || (causal && (k > q || (causal > 1 && k <= q - (causal - 1))));
       if (masked) s = -10e6f;
       ps[idx] = s;
       dps[idx] = dp;

@@ -50,8 +50,7 @@ class BertDecoder(nn.Module):
             # enhance_input=1 (resampling) crashes in the reference itself on torch>=1.2 (Decoder.py:43)
             raise ValueError('enhance_input shoud be either 0 or 2 in nacf_amd')
         self.watch = config.watch
-        if self.watch != 0:
-            raise NotImplementedError('nacf_amd: watch != 0 is not built (reference default 0)')
+        assert self.watch >= 0, 'watch is a window length (models/Decoder.py:28)'
         self.decoding_type = config.decoding_type
         self.pack_rows = bool(getattr(config, 'pack_rows', True))   # skip <pad> slots in the row-wise GEMMs
 
@@ -130,7 +129,7 @@ class BertDecoder(nn.Module):
         for i, layer in enumerate(self.layer):
             kv = memory_kv[i] if memory_kv is not None else layer.project_memory(enc_output)
             last = i == len(self.layer) - 1
-            x2, att = layer.run(x2, tgt_seq, decoding_type == 'ARFormer', kv, M, vdiv, vmod, training,
+            x2, att = layer.run(x2, tgt_seq, (1 + self.watch) if decoding_type == 'ARFormer' else 0, kv, M, vdiv, vmod, training,
                                 output_attentions, rows, pos2, out_rows if last else None)
             if output_attentions:
                 all_attentions = all_attentions + (att,)

@@ -10,7 +10,8 @@ HighWay's w1|w2 packed into one [2D, D] GEMM.
 """
 import torch.nn as nn
 
-from ..runtime.functional import EncoderStreamFn, EncoderStreamsFn
+from ..runtime import lib as L
+from ..runtime.functional import EncoderStreamFn, EncoderStreamsFn, LinearFn
 
 __all__ = ('Encoder_HighWay',)
 
@@ -20,10 +21,10 @@ class HighWay(nn.Module):
 
     def __init__(self, hidden_size, with_gate=True):
         super().__init__()
-        if not with_gate:
-            raise NotImplementedError('nacf_amd: HighWay(with_gate=False) is not built (reference default is gated)')
+        self.with_gate = with_gate
         self.w1 = nn.Linear(hidden_size, hidden_size)
-        self.w2 = nn.Linear(hidden_size, hidden_size)
+        if with_gate:
+            self.w2 = nn.Linear(hidden_size, hidden_size)
 
 
 class Encoder_HighWay(nn.Module):
@@ -48,13 +49,23 @@ class Encoder_HighWay(nn.Module):
     def nacf_groups(self):
         groups = []
         for s in self.streams:
-            groups += [[s[0].weight], [s[0].bias], [s[1].w1.weight, s[1].w2.weight], [s[1].w1.bias, s[1].w2.bias]]
+            if s[1].with_gate:
+                groups += [[s[0].weight], [s[0].bias], [s[1].w1.weight, s[1].w2.weight], [s[1].w1.bias, s[1].w2.bias]]
+            else:
+                groups += [[s[0].weight], [s[0].bias], [s[1].w1.weight], [s[1].w1.bias]]
         return groups
 
     def nacf_bind(self, flat, rt):
         self._rt = rt
         self._cfg = []
         for s in self.streams:
+            if not s[1].with_gate:
+                # opt['gate'] = False (models/Encoder.py:24-25): out = dropout(h + tanh(w1 h)) is ONE Linear with the fused
+                # epilogue tanh -> + residual -> dropout (nacf_linear_fwd); two LinearFn nodes per stream
+                self._cfg.append(dict(gate=False, lin=dict(pack=flat.pack([s[0].weight], [s[0].bias], image='fwd')),
+                                      hw=dict(pack=flat.pack([s[1].w1.weight], [s[1].w1.bias], image='both'), act=L.ACT_TANH,
+                                              p2=self.dropout, salt2=rt.next_salt())))
+                continue
             self._cfg.append(dict(lin=flat.pack([s[0].weight], [s[0].bias], image='fwd'),    # no dX: the features need no gradient
                                   hw=flat.pack([s[1].w1.weight, s[1].w2.weight], [s[1].w1.bias, s[1].w2.bias], image='both'),
                                   p=self.dropout, salt=rt.next_salt(),
@@ -63,6 +74,16 @@ class Encoder_HighWay(nn.Module):
 
     def forward(self, input_feats):
         assert self.num_feats == len(input_feats)
+        if not self._cfg[0].get('gate', True):
+            outs = []
+            for cfg, x, st in zip(self._cfg, input_feats, self.streams):
+                B, F, Din = x.shape
+                rng = self._rt.rng(x.device)
+                h = LinearFn.apply(x.reshape(B * F, Din), None, dict(cfg['lin'], training=self.training, rng=rng),
+                                   st[0].weight, st[0].bias)
+                o = LinearFn.apply(h, h, dict(cfg['hw'], training=self.training, rng=rng), st[1].w1.weight, st[1].w1.bias)
+                outs.append(o.view(B, F, -1))
+            return outs, None
         cs = [dict(cfg, training=self.training, rng=self._rt.rng(x.device)) for cfg, x in zip(self._cfg, input_feats)]
         if self.num_feats > 1 and self.joint_streams:
             # layer by layer across the modalities: their independent GEMMs share launches (EncoderStreamsFn)

@@ -32,7 +32,7 @@ def param_shapes(opt: dict) -> Dict[str, Tuple[int, ...]]:
     for ch in opt["modality"].lower():
         n = f"encoder.Encoder_{ch.upper()}."
         sh[n + "0.weight"] = (d, opt["dim_" + ch]); sh[n + "0.bias"] = (d,)
-        for w in ("w1", "w2"):
+        for w in (("w1", "w2") if opt.get("gate", True) else ("w1",)):     # HighWay(with_gate=False) has no w2 (models/Encoder.py:13-15)
             sh[n + f"1.{w}.weight"] = (d, d); sh[n + f"1.{w}.bias"] = (d,)
     if not opt["no_encoder_bn"]:
         for i in range(len(opt["modality"])):

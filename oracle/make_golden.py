@@ -102,10 +102,12 @@ def opt_blob(opt):
     return np.frombuffer(json.dumps(keep(opt), sort_keys=True).encode(), dtype=np.uint8)
 
 
-def train_case(name, method, extra, V, B, F_, dataset="MSRVTT", beta=(0.35, 0.9)):
-    """forward + loss + backward + clip + Adam, reference vs oracle (dropout 0)."""
+def train_case(name, method, extra, V, B, F_, dataset="MSRVTT", beta=(0.35, 0.9), override=None):
+    """forward + loss + backward + clip + Adam, reference vs oracle (dropout 0).  override: option keys the reference reads
+    from its opt dictionary but has no command-line switch for (e.g. opt['gate'], models/Encoder.py:64)."""
     opt = ref_opt(method, dataset, TINY + list(extra))
     opt["vocab_size"] = V
+    opt.update(override or {})
     sd = O.init_state_dict(opt, seed=0)
     model = ref_model(opt, sd)
     model.train()
@@ -679,6 +681,14 @@ def main():
                                                       "--enhance_input", "0", "--no_encoder_bn", "-tie"],
                    V=101, B=3, F_=6, dataset="Youtube2Text", beta=(0.0, 1.0))
         return
+    if os.environ.get("ONLY_GATE"):
+        train_case("tiny_nab_nogate_train", "NAB", [], V=101, B=3, F_=6, dataset="Youtube2Text", beta=(0.0, 1.0), override={"gate": False})
+        return
+    if os.environ.get("ONLY_WATCH"):
+        train_case("tiny_arb_watch_train", "ARB", ["-wc", "--watch", "3"], V=101, B=3, F_=6)
+        ar_case("tiny_arb_watch_beam", "ARB", ["-wc", "--watch", "3"], V=101, B=4, F_=6, beam_size=3, topk=1, alpha=1.0,
+                eos_boost=EOS_BOOST)
+        return
     if os.environ.get("ONLY_AR"):
         ar_case("tiny_arb2_beam", "ARB2", ["-wc"], V=101, B=3, F_=6)
         ar_case("tiny_arb_beam", "ARB", ["-wc"], V=101, B=3, F_=6)
@@ -696,6 +706,12 @@ def main():
                V=101, B=3, F_=6, dataset="Youtube2Text", beta=(0.0, 1.0))
     train_case("tiny_nacf_ln_train", "NACF", ["-wc", "--with_layernorm", "--norm_type", "ln"], V=101, B=3, F_=6)
     train_case("tiny_nacf_pos_train", "NACF", ["-wc", "--pos_attention"], V=101, B=3, F_=6)
+    # opt['gate'] = False (models/Encoder.py:10-25,64): HighWay without its gate, out = x + tanh(w1 x)
+    train_case("tiny_nab_nogate_train", "NAB", [], V=101, B=3, F_=6, dataset="Youtube2Text", beta=(0.0, 1.0), override={"gate": False})
+    # --watch 3 (opts.py:32): AR self-attention sees the last three tokens only (models/Decoder.py:23-39)
+    train_case("tiny_arb_watch_train", "ARB", ["-wc", "--watch", "3"], V=101, B=3, F_=6)
+    ar_case("tiny_arb_watch_beam", "ARB", ["-wc", "--watch", "3"], V=101, B=4, F_=6, beam_size=3, topk=1, alpha=1.0,
+            eos_boost=EOS_BOOST)
     checkpoint_case()
     data_case()
     trajectory_case()

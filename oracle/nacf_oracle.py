@@ -47,7 +47,7 @@ DEFAULT_OPT = dict(  # opts.py:23-50,116-129 (defaults that shape the model)
     no_encoder_bn=False, norm_type="bn", tie_weights=False,
     fusion="temporal_concat", crit=["lang"], nv_weights=[0.8, 1.0],
     visual_word_generation=False, decoding_type="ARFormer",
-    decoder="BertDecoder", encoder="Encoder_HighWay",
+    decoder="BertDecoder", encoder="Encoder_HighWay", gate=True,
 )
 
 
@@ -89,11 +89,13 @@ def _dropout(x: Tensor, p: float, training: bool) -> Tensor:
 # --------------------------------------------------------------------------
 # encoder side: SURVEY.md section 8a rows 1-4
 # --------------------------------------------------------------------------
-def encoder_stream(sd: SD, name: str, x: Tensor, p: float, training: bool) -> Tensor:
+def encoder_stream(sd: SD, name: str, x: Tensor, p: float, training: bool, gate: bool = True) -> Tensor:
     """One modality of Encoder_HighWay: Linear -> HighWay -> Dropout.
     models/Encoder.py:9-25 (HighWay), :62-66 (Sequential)."""
     h = F.linear(x, sd[f"encoder.{name}.0.weight"], sd[f"encoder.{name}.0.bias"])
     y = torch.tanh(F.linear(h, sd[f"encoder.{name}.1.w1.weight"], sd[f"encoder.{name}.1.w1.bias"]))
+    if not gate:                                                        # models/Encoder.py:24-25 (opt['gate'] = False)
+        return _dropout(h + y, p, training)
     g = torch.sigmoid(F.linear(h, sd[f"encoder.{name}.1.w2.weight"], sd[f"encoder.{name}.1.w2.bias"]))
     out = g * h + (1.0 - g) * y
     return _dropout(out, p, training)
@@ -133,7 +135,7 @@ def encode(sd: SD, opt: dict, feats: Sequence[Tensor], training: bool = False,
     assert len(feats) == len(modality)
     outs, hiddens = [], []
     for ch, x in zip(modality, feats):
-        o = encoder_stream(sd, f"Encoder_{ch.upper()}", x, opt["encoder_dropout"], training)
+        o = encoder_stream(sd, f"Encoder_{ch.upper()}", x, opt["encoder_dropout"], training, gate=opt.get("gate", True))
         outs.append(o)
         hiddens.append(o.mean(1))                      # models/Encoder.py:51
     enc_hidden = torch.stack(hiddens, 0).mean(0)       # joint_representation.py:27
@@ -257,8 +259,11 @@ def decoder_forward(sd: SD, opt: dict, tgt_seq: Tensor, enc_output: Tensor, cate
     if dtype_ == "NARFormer":
         self_mask = key_pad                                             # Decoder.py:105-107
     else:
-        sub = torch.triu(torch.ones(L, L, dtype=torch.bool), diagonal=1)  # Decoder.py:24-39 (watch=0)
-        assert opt["watch"] == 0
+        sub = torch.triu(torch.ones(L, L, dtype=torch.bool), diagonal=1)  # Decoder.py:24-39
+        w = int(opt["watch"])
+        if w != 0 and L >= w:                                           # --watch: only the last `watch` tokens are visible
+            assert w > 0
+            sub = sub | torch.tril(torch.ones(L, L, dtype=torch.bool), diagonal=-w)
         self_mask = key_pad | sub.unsqueeze(0)
     non_pad = tgt_seq.ne(PAD).float().unsqueeze(-1)                     # Decoder.py:9-11
     additional = None

@@ -52,7 +52,7 @@ def test_method_overlays_match_reference_flags():
         nacf_amd.get_model(dict(o, vocab_size=10, decoder="Nope"))
 
 
-@pytest.mark.parametrize("name", ["tiny_nacf_train", "tiny_nab_train", "tiny_arb2_train", "tiny_arb_train",
+@pytest.mark.parametrize("name", ["tiny_nacf_train", "tiny_nab_train", "tiny_arb2_train", "tiny_arb_train", "tiny_arb_watch_train", "tiny_nab_nogate_train",
                                   "tiny_nab_variants_train", "tiny_nacf_ln_train", "tiny_nacf_pos_train"])
 def test_state_dict_contract_and_flat_layout(name):
     g = load_gold(name)
@@ -79,8 +79,12 @@ def test_state_dict_contract_and_flat_layout(name):
     ckv = layer._pk["ckv"]
     assert torch.equal(ckv.w[D:], layer.attend_to_enc_output.self.value.weight)
     assert torch.equal(ckv.b[:D], layer.attend_to_enc_output.self.key.bias)
-    hw = m.encoder._cfg[0]["hw"].w
-    assert torch.equal(hw[D:], m.encoder.Encoder_M[1].w2.weight)
+    if opt.get("gate", True):
+        hw = m.encoder._cfg[0]["hw"].w
+        assert torch.equal(hw[D:], m.encoder.Encoder_M[1].w2.weight)
+    else:                               # HighWay without its gate: w1 alone (models/Encoder.py:13-15)
+        assert not hasattr(m.encoder.Encoder_M[1], "w2")
+        assert torch.equal(m.encoder._cfg[0]["hw"]["pack"].w, m.encoder.Encoder_M[1].w1.weight)
     # zero_grad / re-attach semantics
     for p in m.parameters():
         p.grad = None

@@ -30,7 +30,7 @@ def _tok_labels(opt, b):
     return tokens, labels
 
 
-TRAIN_CASES = ["tiny_nacf_train", "tiny_nab_train", "tiny_arb2_train", "tiny_arb_train", "tiny_nab_variants_train",
+TRAIN_CASES = ["tiny_nacf_train", "tiny_nab_train", "tiny_arb2_train", "tiny_arb_train", "tiny_arb_watch_train", "tiny_nab_nogate_train", "tiny_nab_variants_train",
                "tiny_nacf_ln_train", "tiny_nacf_pos_train"]
 
 
@@ -164,7 +164,7 @@ def test_na_decode_with_ar_teacher_rescoring(dev):
             assert torch.equal(it_tok.cpu(), t(g[v + ".iter_tokens"]).long()), (graph, v)
 
 
-@pytest.mark.parametrize("name", ["tiny_arb2_beam", "tiny_arb_beam", "tiny_arb_beam_eos", "tiny_arb2_beam_eos"])
+@pytest.mark.parametrize("name", ["tiny_arb2_beam", "tiny_arb_beam", "tiny_arb_beam_eos", "tiny_arb2_beam_eos", "tiny_arb_watch_beam"])
 def test_ar_beam_search_vs_reference_golden(dev, name):
     """config-5 comparator: batched device beam search == the reference's per-instance Beam objects"""
     from nacf_amd.models.Translator import Translator

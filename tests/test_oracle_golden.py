@@ -15,7 +15,7 @@ def _tok_labels(opt, b):
     return tokens, labels
 
 
-@pytest.mark.parametrize("name", ["tiny_nacf_train", "tiny_nab_train", "tiny_arb2_train", "tiny_arb_train",
+@pytest.mark.parametrize("name", ["tiny_nacf_train", "tiny_nab_train", "tiny_arb2_train", "tiny_arb_train", "tiny_arb_watch_train", "tiny_nab_nogate_train",
                                   "tiny_nab_variants_train", "tiny_nacf_ln_train", "tiny_nacf_pos_train"])
 def test_train_step_matches_reference(name):
     g = load_gold(name)
@@ -79,7 +79,7 @@ def test_decode_with_teacher_matches_reference():
         assert torch.equal(hyp, t(g[v + ".hyp"])), v
 
 
-@pytest.mark.parametrize("name", ["tiny_arb2_beam", "tiny_arb_beam", "tiny_arb_beam_eos", "tiny_arb2_beam_eos"])
+@pytest.mark.parametrize("name", ["tiny_arb2_beam", "tiny_arb_beam", "tiny_arb_beam_eos", "tiny_arb2_beam_eos", "tiny_arb_watch_beam"])
 def test_ar_beam_matches_reference(name):
     g = load_gold(name)
     opt = gold_opt(g)
