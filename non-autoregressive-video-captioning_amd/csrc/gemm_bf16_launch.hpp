@@ -14,7 +14,8 @@ void launch_bf16_linear(GemmShape g, const EpiLinear& epi, int tile, int ns, hip
 void launch_bf16_argmax(GemmShape g, const EpiArgmax& epi, int tile, int ns, hipStream_t s);              // + soft-max stats
 void launch_bf16_dx(GemmShape g, const EpiStore& epi, int splits, int tile, int ns, hipStream_t s);       // dX = dZ W
 void launch_bf16_dw(GemmShape g, const EpiStore& epi, int splits, int tile, int ns, hipStream_t s);       // dW = dZ^T X
-void launch_bf16_dw_group(const GemmGroup<EpiStore>& t, int ns, hipStream_t s);                            // grouped dW (128x128 tiles)
+void launch_bf16_dw_group(const GemmGroup<EpiStore>& t, int ns, hipStream_t s);
+void launch_widet_dw_group(const GemmGroup<EpiStore>& t, hipStream_t s);                                       // grouped dW, 128x256 tiles, one workgroup per CU (exact mode)                            // grouped dW (128x128 tiles)
 // wide-wave-tile kernels (gemm_bf16_wide.hpp, nacf_gemm_bf16_wide.hip): false = not eligible / not worthwhile, use the others
 bool launch_wide_linear(const GemmShape& g, const EpiLinear& epi, bool has_rows, bool heavy_epilogue, hipStream_t s);
 bool launch_wide_dx(const GemmShape& g, const EpiStore& epi, int splits, bool has_rows, hipStream_t s);

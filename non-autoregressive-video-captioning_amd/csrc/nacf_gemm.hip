@@ -576,16 +576,21 @@ static int dw_items_launch_locked(hipStream_t s) {
   const int mode = gemm_mode();
   // measured on the NACF step (bench.py, B = 128): exact mode 1024: 2.91 ms, 1280: 2.89, 1536: 2.90, 3072: 2.93;
   // throughput mode (its k-tiles are 3x shorter, the fixed cost of a split weighs less) 1024: 2.30, 1536: 2.12, 4096: 2.08
-  const int target = target_env > 0 ? target_env : (mode == NACF_GEMM_BF16 ? 4096 : 1280);
+  // NACF_DW_WIDE=1 (exact mode): the one-workgroup-per-CU weight-gradient kernel (gemm_bf16_widet.hpp): 128 x 256 output
+  // tiles, a workgroup of it does twice the work of a 128 x 128 one, 256 of them are resident
+  const bool widet = mode == NACF_GEMM_BF16X3 && [] { const char* e = getenv("NACF_DW_WIDE"); return e && atoi(e) == 1; }();
+  const int tile_cols = widet ? 256 : 128;
+  const int target = target_env > 0 ? target_env : (mode == NACF_GEMM_BF16 ? 4096 : (widet ? 768 : 1280));
   // NACF_DW_GROUP_ORDER=0: every split spreads its tiles over the 8 XCDs (round 2); default 1: see GemmGroup
-  static const bool split_major = [] { const char* e = getenv("NACF_DW_GROUP_ORDER"); return !(e && atoi(e) == 0); }();
+  static const bool split_major_env = [] { const char* e = getenv("NACF_DW_GROUP_ORDER"); return !(e && atoi(e) == 0); }();
+  const bool split_major = split_major_env || widet;
   std::vector<int> kt(n), tiles(n), sp(n), order(n);
   long W = 0;
   for (int i = 0; i < n; ++i) {
     const DwGemmItem& it = g_dw_items[i];
     const int m_eff = it.has_rs ? (int)((long)it.M * 29 / 50) : it.M;
     kt[i] = cdiv(m_eff > 0 ? m_eff : 1, 32);
-    tiles[i] = cdiv(it.N, 128) * cdiv(it.K, 128);
+    tiles[i] = cdiv(it.N, 128) * cdiv(it.K, tile_cols);
     W += (long)kt[i] * tiles[i];
     order[i] = i;
   }
@@ -626,9 +631,9 @@ static int dw_items_launch_locked(hipStream_t s) {
       g.k_per_split = cdiv(cdiv(it.M, sp[i]), 32) * 32;
       set_rows(g, it.has_rs ? &it.rs : nullptr);
       g.tiles_m = cdiv(g.M, 128);
-      g.tiles_n = cdiv(g.N, 128);
+      g.tiles_n = cdiv(g.N, tile_cols);
       const int real = cdiv(it.M, g.k_per_split);
-      if (split_major) {
+      if (split_major && !widet) {
         // an XCD's run of `run` consecutive tiles inside one split: as square as the tile grid allows (GemmShape::group_n)
         const long run = ((long)tiles[i] * real + 7) / 8;
         if (run < tiles[i]) {
@@ -660,7 +665,8 @@ static int dw_items_launch_locked(hipStream_t s) {
       }
     }
     t.wg0[t.n] = wg;
-    launch_bf16_dw_group(t, mode, s);
+    if (widet) launch_widet_dw_group(t, s);
+    else launch_bf16_dw_group(t, mode, s);
     g_last_was_bf16 = true;
     NACF_LAUNCH_CHECK("nacf_dw_group_flush(grouped gemm)");
     ++g_dw_last_group_launches;

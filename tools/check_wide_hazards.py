@@ -168,6 +168,31 @@ def check(name, lines):
     return bad, spills
 
 
+def inflight_copies(lines):
+    """Registers written by an (inline-assembly) ds_read_b128 hold data only after the next `s_waitcnt lgkmcnt(0)`; the
+    compiler does not know the statement is a load, so under register pressure it may spill (v_accvgpr_write) or move
+    (v_mov) such a register right behind the read -- saving garbage.  Linear scan (the reads and their waits sit in
+    straight-line code): every copy of a register with a read in flight is an error."""
+    pending, out = {}, []
+    for l in lines:
+        t = l.strip()
+        m = re.match(r"ds_read_b128 v\[(\d+):(\d+)\]", t)
+        if m:
+            for r in range(int(m.group(1)), int(m.group(2)) + 1):
+                pending[r] = t
+            continue
+        if t.startswith("s_waitcnt") and "lgkmcnt(0)" in t:
+            pending = {}
+            continue
+        if re.match(r"^\.LBB\d+_\d+:", t):      # (reads and their waits sit in one basic block: a label starts over)
+            pending = {}
+            continue
+        m = re.match(r"v_accvgpr_write_b32 a\d+, v(\d+)", t) or re.match(r"v_mov_b32_e32 v\d+, v(\d+)", t)
+        if m and int(m.group(1)) in pending:
+            out.append(t)
+    return out
+
+
 def loop_copies(lines):
     """accumulator copies between the first two s_barrier of the steady loop body (a rough but stable proxy)"""
     text = "\n".join(lines)
@@ -188,6 +213,12 @@ def main():
         for l in wr[:10]:
             print("   ", l)
         total_bad += len(wr)
+        fl = inflight_copies(lines)
+        if fl:
+            print(f"    {len(fl)} copies of registers whose ds_read has not been waited for:")
+            for l in fl[:6]:
+                print("   ", l)
+        total_bad += len(fl)
         for i, p, d in bad[:10]:
             print(f"   after {d} wait states: {p}")
         total_bad += len(bad)
