@@ -13,13 +13,19 @@ ops.set_gemm_mode("bf16x3")
 SETS = {
     "long k-loop (61440 x 1024 x 2048)": [(61440, 1024, 2048)],
     "enc_lin (7680 x 512 x 2048)": [(7680, 512, 2048)],
+    "hw (7680 x 1024 x 512)": [(7680, 1024, 512)],
+    "kvmem (15360 x 1024 x 512)": [(15360, 1024, 512)],
+    "qkv (5120 x 1536 x 512)": [(5120, 1536, 512)],
+    "proj (5120 x 512 x 512)": [(5120, 512, 512)],
+    "ffn1 (5120 x 2048 x 512)": [(5120, 2048, 512)],
+    "ffn2 (5120 x 512 x 2048)": [(5120, 512, 2048)],
     "NACF step": [(7680, 512, 2048)] * 2 + [(7680, 1024, 512)] * 2 + [(15360, 1024, 512), (5120, 1536, 512), (5120, 512, 512),
-                  (5120, 512, 512), (5120, 512, 512), (5120, 2048, 512), (5120, 512, 2048), (2970, 10547, 512), (128, 512, 512)],
+                  (5120, 512, 512), (5120, 512, 512), (5120, 2048, 512), (5120, 512, 2048), (128, 512, 512)],      # (without the vocabulary projection: it needs a padded pitch and its row list)
 }
 for title, probs in SETS.items():
     ts = [(torch.randn(M, N, device=dev), torch.randn(M, K, device=dev), torch.zeros(N, K, device=dev)) for M, N, K in probs]
     flops = sum(2.0 * M * N * K for M, N, K in probs)
-    for wide, wgs in (("0", None), ("1", None), ("1", "512"), ("1", "1024")):
+    for wide, wgs in (("0", None), ("1", None)):
         os.environ["NACF_DW_WIDE"] = wide
         if wgs: os.environ["NACF_DW_GROUP_WGS"] = wgs
         else: os.environ.pop("NACF_DW_GROUP_WGS", None)
