@@ -567,18 +567,30 @@ static int dw_group_flush_locked(hipStream_t s);
 // group, a workgroup should walk about W / target k-tiles (target = NACF_DW_GROUP_WGS, default 1024 = two rounds of the
 // 512 resident 128x128 workgroups), never fewer than 24; a problem gets ceil(its k-tiles / that) splits.  Longest walks
 // first in the grid, so that the short ones fill the tail.
+static int dw_subset_launch_locked(const std::vector<int>& subset, bool widet, hipStream_t s);
 static int dw_items_launch_locked(hipStream_t s) {
-  const int n = (int)g_dw_items.size();
+  const int n_all = (int)g_dw_items.size();
   g_dw_last_group_launches = 0;
   g_dw_last_group_wgs = 0;
-  if (n == 0) return NACF_OK;
+  if (n_all == 0) return NACF_OK;
+  // NACF_DW_WIDE (exact mode): 1 = every problem on the one-workgroup-per-CU kernel (gemm_bf16_widet.hpp: 128 x 256 output
+  // tiles, a workgroup of it does twice the work of a 128 x 128 one, 256 of them are resident); 2 = the problems WITHOUT a
+  // row list on it (its row-list loop spills), the others on the 128 x 128 group kernel, as two grouped launches
+  const int wide_mode = gemm_mode() == NACF_GEMM_BF16X3 ? [] { const char* e = getenv("NACF_DW_WIDE"); return e ? atoi(e) : 0; }() : 0;
+  std::vector<int> a, b;
+  for (int i = 0; i < n_all; ++i) ((wide_mode == 1 || (wide_mode == 2 && !g_dw_items[i].has_rs)) ? a : b).push_back(i);
+  int rc = NACF_OK;
+  if (!a.empty()) rc = dw_subset_launch_locked(a, true, s);
+  if (rc == NACF_OK && !b.empty()) rc = dw_subset_launch_locked(b, false, s);
+  g_dw_items.clear();
+  return rc;
+}
+static int dw_subset_launch_locked(const std::vector<int>& subset, const bool widet, hipStream_t s) {
+  const int n = (int)subset.size();
   static const int target_env = [] { const char* e = getenv("NACF_DW_GROUP_WGS"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 0; }();
   const int mode = gemm_mode();
   // measured on the NACF step (bench.py, B = 128): exact mode 1024: 2.91 ms, 1280: 2.89, 1536: 2.90, 3072: 2.93;
   // throughput mode (its k-tiles are 3x shorter, the fixed cost of a split weighs less) 1024: 2.30, 1536: 2.12, 4096: 2.08
-  // NACF_DW_WIDE=1 (exact mode): the one-workgroup-per-CU weight-gradient kernel (gemm_bf16_widet.hpp): 128 x 256 output
-  // tiles, a workgroup of it does twice the work of a 128 x 128 one, 256 of them are resident
-  const bool widet = mode == NACF_GEMM_BF16X3 && [] { const char* e = getenv("NACF_DW_WIDE"); return e && atoi(e) == 1; }();
   const int tile_cols = widet ? 256 : 128;
   const int target = target_env > 0 ? target_env : (mode == NACF_GEMM_BF16 ? 4096 : (widet ? 768 : 1280));
   // NACF_DW_GROUP_ORDER=0: every split spreads its tiles over the 8 XCDs (round 2); default 1: see GemmGroup
@@ -587,7 +599,7 @@ static int dw_items_launch_locked(hipStream_t s) {
   std::vector<int> kt(n), tiles(n), sp(n), order(n);
   long W = 0;
   for (int i = 0; i < n; ++i) {
-    const DwGemmItem& it = g_dw_items[i];
+    const DwGemmItem& it = g_dw_items[subset[i]];
     const int m_eff = it.has_rs ? (int)((long)it.M * 29 / 50) : it.M;
     kt[i] = cdiv(m_eff > 0 ? m_eff : 1, 32);
     tiles[i] = cdiv(it.N, 128) * cdiv(it.K, tile_cols);
@@ -597,7 +609,7 @@ static int dw_items_launch_locked(hipStream_t s) {
   long walk = (W + target - 1) / target;
   if (walk < 24) walk = 24;
   for (int i = 0; i < n; ++i) {
-    const DwGemmItem& it = g_dw_items[i];
+    const DwGemmItem& it = g_dw_items[subset[i]];
     const size_t fixed = (size_t)64 * it.N * sizeof(float) + 256;
     long max_s = it.ws_bytes > fixed ? (long)((it.ws_bytes - fixed) / ((size_t)it.N * it.K * sizeof(float))) : 1;
     if (max_s > 64) max_s = 64;
@@ -624,7 +636,7 @@ static int dw_items_launch_locked(hipStream_t s) {
     t.order = split_major ? 1 : 0;
     int wg = 0;
     for (; done < n && t.n < GEMM_GROUP_MAX; ++done) {
-      const DwGemmItem& it = g_dw_items[order[done]];
+      const DwGemmItem& it = g_dw_items[subset[order[done]]];
       const int i = order[done];
       GemmShape g = {};
       g.Q = it.dZ; g.P = it.X; g.ldq = it.lddz; g.ldp = it.ldx; g.M = it.N; g.N = it.K; g.K = it.M;
@@ -672,7 +684,6 @@ static int dw_items_launch_locked(hipStream_t s) {
     ++g_dw_last_group_launches;
     g_dw_last_group_wgs += wg;
   }
-  g_dw_items.clear();
   return NACF_OK;
 }
 

@@ -165,8 +165,9 @@ class Seq2Seq(nn.Module):
             # kernels) depends on the pooled memory only: in training it runs on a SIDE stream next to the decoder -- a
             # parallel branch of the captured step graph.  autograd runs a node's backward on its forward's stream and
             # orders producers / consumers across streams, so the backward overlaps the decoder's too.
-            # opt['aux_side_stream'], default OFF: measured 2.856 vs 2.753 ms per step -- a captured graph with a parallel
-            # branch replays slower on this runtime than the ~130 us of small kernels it takes off the critical path.
+            # opt['aux_side_stream'], default OFF: no difference in an A/B inside one box (2.765 vs 2.766 ms; the "slower" of a
+            # first measurement was box-to-box variance) -- the decoder's launches leave no idle time a parallel branch of
+            # ~130 us of small kernels could fill.
             side = self._aux_stream(enc_output) if (self.training and defer_join is not None) else None
             if side is not None:
                 main = torch.cuda.current_stream(enc_output.device)
