@@ -180,7 +180,7 @@ def newest_traffic_table():
         return None
 
 
-def roofline_from(summ, n_prof, mode, prefer_single=True, groups=None):
+def roofline_from(summ, n_prof, mode, prefer_single=True, groups=None, dec_rows=None):
     """dominant kernel = the GEMM kernel class with the largest time per pass whose spans are ONE kernel each (spans of
     dW entry points also contain the split-K combine: listed in the table, not chosen).  `groups`: the grouped launches
     of the real step (group_profile); the classes they absorb are launched one at a time in `summ`, so the by-time
@@ -223,6 +223,21 @@ def roofline_from(summ, n_prof, mode, prefer_single=True, groups=None):
             rl["traffic"] = int(sum(e["hbm_bytes"] * e["launches_sampled"] for e in hits) / n_l)
             rl["traffic_source"] = "%s (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, bytes/launch; file age %.1f h)" % (
                 os.path.relpath(path, ROOT), age_h)
+    # the GEMMs of the decoder layers alone (attention projections + FFN: what BASELINE's north_star quotes its matrix-core
+    # utilisation target on): every launch over the decoder's rows (sequences x positions x passes) that is not the vocabulary
+    # projection -- forward + dX + dW, one launch at a time
+    if dec_rows:
+        layer = {"flops": 0.0, "ms": 0.0, "calls": 0}
+        for v in summ.values():
+            for (kind, M, N, K), q in v["by_shape"].items():
+                if M == dec_rows and max(N, K) <= 4096:
+                    layer["flops"] += q["flops"]; layer["ms"] += q["ms"]; layer["calls"] += q["calls"]
+        if layer["ms"] > 0:
+            ltf = layer["flops"] / (layer["ms"] * 1e-3) / 1e12
+            rl["decoder_layer_gemms"] = {"what": "attention projections + FFN GEMMs of the decoder layers (fwd + dX + dW over the %d decoder "
+                                                 "rows), launched one at a time" % dec_rows,
+                                         "calls_per_pass": layer["calls"] // n_prof, "ms_per_pass": round(layer["ms"] / n_prof, 3),
+                                         "tflops": round(ltf, 2), "frac_of_mode_peak": round(ltf / MODE_PEAK[mode], 4)}
     table = {k: {"calls_per_pass": v["calls"] // n_prof, "ms_per_pass": round(v["ms"] / n_prof, 3),
                  "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2), "span_is_one_kernel": v["single"]}
              for k, v in summ.items()}
@@ -304,7 +319,7 @@ def bench_nab_bf16(nacf_amd, dev, B, L, V, F_):
             dt = timed_steps(engine, 40) / 40
             summ = gemm_profile(lambda: (optim.zero_grad(), crit.get_loss(engine.forward(engine.static)).backward(),
                                          optim._optimizer.step(grad_scale=1.0)))
-            rl, _ = roofline_from(summ, 3, "bf16")
+            rl, _ = roofline_from(summ, 3, "bf16", dec_rows=B * L)
             dec = bench_decode(model, dev, feats, cat, 10, with_roofline=False)
             res.update({"batch": B, "dtype": "bf16", "train_videos_per_s": round(B / dt, 1), "train_ms_per_step": round(dt * 1e3, 3),
                         "decode_captions_per_s": dec["captions_per_s"], "decode_ms_per_batch": dec["ms_per_batch"], "roofline": rl})
@@ -548,7 +563,7 @@ def main():
                 loss_.backward()
             optim._optimizer.step(grad_scale=1.0)
         groups = group_profile(grouped_step) if mode != "f32" else None
-        roofline, gemm_table = roofline_from(summ, 3, mode, groups=groups)
+        roofline, gemm_table = roofline_from(summ, 3, mode, groups=groups, dec_rows=2 * B * L)
         if groups:
             gemm_table.update({k + " [grouped launch of the real step]":
                                {"calls_per_pass": v["calls"] // 3, "problems_per_pass": v["problems"] // 3,
@@ -624,7 +639,7 @@ def main():
             db_ = timed_steps(eb, 40) / 40
             sb = gemm_profile(lambda: (ob_.zero_grad(), cb_.get_loss(eb.forward(eb.static)).backward(),
                                        ob_._optimizer.step(grad_scale=1.0)))
-            rlb, _ = roofline_from(sb, 3, "bf16")
+            rlb, _ = roofline_from(sb, 3, "bf16", dec_rows=2 * B * L)
             decb = bench_decode(mb, dev, feats, category, 10, with_roofline=False) if not args.no_decode else None
             nacf_bf16 = {"dtype": "bf16", "batch": B, "videos_per_s": round(B / db_, 1), "ms_per_step": round(db_ * 1e3, 3),
                          "final_loss": round(float(eb.loss), 4), "roofline": rlb,
