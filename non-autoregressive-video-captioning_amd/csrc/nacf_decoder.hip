@@ -296,25 +296,40 @@ __device__ __forceinline__ void scatter_word_wave(const float* __restrict__ dE, 
   const int lane = threadIdx.x & 63;
   const int64_t tok = tokens[me];
   if (tok < first_tok) return;  // PAD never gets a gradient; ids < first_tok go through the chunked path
-  for (int base = 0; base < me; base += 64) {
-    const int idx = base + lane;
-    if (__ballot(idx < me && tokens[idx] == tok) != 0ull) return;
+  // both scans walk the token list 256 entries per trip (four independent loads in flight: one load + ballot per trip
+  // is a chain of ~80 dependent L2 round trips per row, 32 us of the launch)
+  for (int base = 0; base < me; base += 256) {
+    int64_t t4[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) t4[u] = tokens[min(base + 64 * u + lane, n_rows - 1)];      // unconditional: all four in flight
+    bool hit = false;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) hit |= (base + 64 * u + lane < me) & (t4[u] == tok);
+    if (__ballot(hit) != 0ull) return;
   }
   constexpr int WJ = 2 * EMB_MAXJ;      // float4 columns per lane
   f32x4 acc[WJ];
 #pragma unroll
   for (int j = 0; j < WJ; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
-  for (int base = me; base < n_rows; base += 64) {
-    const int idx = base + lane;
-    unsigned long long bal = __ballot(idx < n_rows && tokens[idx] == tok);
-    while (bal) {
-      const int bit = __builtin_ctzll(bal);
-      bal &= bal - 1ull;
-      const int64_t src = (int64_t)(base + bit) * D;
+  for (int base = me; base < n_rows; base += 256) {
+    int64_t t4[4];
+    bool m[4];
 #pragma unroll
-      for (int j = 0; j < WJ; ++j) {
-        const int d = (lane + 64 * j) * 4;
-        if (d < D) acc[j] += *reinterpret_cast<const f32x4*>(dE + src + d);
+    for (int u = 0; u < 4; ++u) t4[u] = tokens[min(base + 64 * u + lane, n_rows - 1)];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) m[u] = (base + 64 * u + lane < n_rows) & (t4[u] == tok);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {          // ascending rows: chunk by chunk, bit by bit
+      unsigned long long bal = __ballot(m[u]);
+      while (bal) {
+        const int bit = __builtin_ctzll(bal);
+        bal &= bal - 1ull;
+        const int64_t src = (int64_t)(base + 64 * u + bit) * D;
+#pragma unroll
+        for (int j = 0; j < WJ; ++j) {
+          const int d = (lane + 64 * j) * 4;
+          if (d < D) acc[j] += *reinterpret_cast<const f32x4*>(dE + src + d);
+        }
       }
     }
   }
