@@ -500,13 +500,29 @@ __device__ __forceinline__ void scatter_cat(const float* __restrict__ vsum, cons
   f32x4 acc[EMB_MAXJ];
 #pragma unroll
   for (int j = 0; j < EMB_MAXJ; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
-  for (int v = 0; v < n_video; ++v) {
-    if (category[v] != me) continue;
+  // the videos of this category, ascending: 128 category ids per trip (one load per thread, matches listed through LDS)
+  // instead of one dependent load + branch per video
+  __shared__ int vlist[EMB_THREADS];
+  __shared__ int vcnt[2];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int base = 0; base < n_video; base += EMB_THREADS) {
+    const int v = base + threadIdx.x;
+    const bool match = v < n_video && category[v] == me;
+    const unsigned long long bal = __ballot(match);
+    if (lane == 0) vcnt[wave] = __popcll(bal);
+    __syncthreads();
+    if (match) vlist[(wave == 0 ? 0 : vcnt[0]) + __popcll(bal & ((1ull << lane) - 1ull))] = v;
+    __syncthreads();
+    const int n = vcnt[0] + vcnt[1];
+    for (int i = 0; i < n; ++i) {
+      const int64_t src = (int64_t)vlist[i] * D;
 #pragma unroll
-    for (int j = 0; j < EMB_MAXJ; ++j) {
-      const int d = (threadIdx.x + EMB_THREADS * j) * 4;
-      if (d < D) acc[j] += *reinterpret_cast<const f32x4*>(vsum + (int64_t)v * D + d);
+      for (int j = 0; j < EMB_MAXJ; ++j) {
+        const int d = (threadIdx.x + EMB_THREADS * j) * 4;
+        if (d < D) acc[j] += *reinterpret_cast<const f32x4*>(vsum + src + d);
+      }
     }
+    __syncthreads();
   }
 #pragma unroll
   for (int j = 0; j < EMB_MAXJ; ++j) {
