@@ -21,9 +21,13 @@ for c in FETCH_SIZE WRITE_SIZE; do
 done
 python $ROOT/tools/pmc_traffic.py /tmp/prof_FETCH_SIZE/b_counter_collection.csv /tmp/prof_WRITE_SIZE/b_counter_collection.csv $OUT/${R}_pmc_traffic.json
 # 4. GEMM microbenchmarks (three arithmetic modes, weights from pre-split images as in the model) + attainable MFMA peak
-python $ROOT/tools/gemm_bench.py --iters 20 --modes f32,bf16x3,bf16 --images > $OUT/${R}_gemm_microbench.txt 2> /dev/null
-python $ROOT/tools/gemm_bench.py --iters 20 --modes bf16x3 --tiles 128,wide1,wide2,auto --images --only fwd >> $OUT/${R}_gemm_microbench.txt 2> /dev/null
-python $ROOT/tools/gemm_bench.py --iters 20 --modes bf16x3 --tiles 128,wide1,wide2,auto --images --only dX >> $OUT/${R}_gemm_microbench.txt 2> /dev/null
+# (per-launch HIP events, median of 20; one-off stalls the tool saw go to the top of the file as '#' lines)
+python $ROOT/tools/gemm_bench.py --iters 20 --modes f32,bf16x3,bf16 --images > /tmp/mb.txt 2> /tmp/mb.err
+python $ROOT/tools/gemm_bench.py --iters 20 --modes bf16x3 --tiles 128,wide1,wide2,auto --images --only fwd >> /tmp/mb.txt 2>> /tmp/mb.err
+python $ROOT/tools/gemm_bench.py --iters 20 --modes bf16x3 --tiles 128,wide1,wide2,auto --images --only dX >> /tmp/mb.txt 2>> /tmp/mb.err
+{ echo "# per-launch HIP events, MEDIAN of 20 launches (tools/gemm_bench.py)"; grep "^#" /tmp/mb.err; cat /tmp/mb.txt; } > $OUT/${R}_gemm_microbench.txt
+# 4b. the grouped weight-gradient launch: 128x128 group kernel vs the one-workgroup-per-CU kernel (NACF_DW_WIDE=1), per problem and as the step's mix
+python $ROOT/tools/dw_group_bench.py 10 > $OUT/${R}_dw_group_bench.txt 2> /dev/null
 $ROOT/tools/mfma_peak 20000 > $OUT/${R}_mfma_peak.txt 2>&1
 # 5. SQ / GRBM counters of the vocabulary GEMM at K = 512 (the model's shape) and K = 8192, exact and throughput mode
 { for m in bf16x3 bf16; do echo "== mode $m"; $ROOT/tools/pmc_gemm.sh 0:5120:10547:512,0:5120:10547:8192 128 $m --images 2>/dev/null | grep "^pass"; done;
