@@ -93,6 +93,11 @@ def _worker(rank, world, port, out):
         out.put((same and buckets_ok, (lo, hi), err))
     else:
         out.put((same and buckets_ok, (lo, hi), 0.0))
+    # DataParallel.all_gather (the one exchange of the SyncBN forward statistics): out[r] = rank r's vector
+    mine = torch.full((2, 3), float(rank))
+    gathered = torch.empty(world, 2, 3)
+    ddp.all_gather(gathered, mine)
+    assert all(float(gathered[r].min()) == float(gathered[r].max()) == float(r) for r in range(world))
     # the evaluation verdict of misc/run.py: rank 0's value reaches everybody through the store (no collective posted)
     assert host_broadcast_int(7 if rank == 0 else -1, 'test_a') == 7 and host_broadcast_int(0 if rank == 0 else 5, 'test_b') == 0
     dist.barrier()
