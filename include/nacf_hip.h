@@ -64,7 +64,7 @@ int nacf_version(void);
  * included).  nacf_abi_count() returns the value the LIBRARY was built with; the ctypes loader
  * (runtime/lib.py:load) refuses a library whose count differs from its own signature table, so a stale
  * libnacf_hip.so next to a newer Python package fails at import time, not at the first missing symbol. */
-#define NACF_ABI_COUNT 82
+#define NACF_ABI_COUNT 84
 int nacf_abi_count(void);
 
 /* ---- batch construction (reference: dataloader.py) ----------------------------------------
@@ -517,6 +517,14 @@ int nacf_vocab_lse_fwd(const float* hidden, int64_t ldh, const float* W, int64_t
 int nacf_xent_bwd_lse(const float* logits, int64_t ld, const float* lse, float* dlogits, int64_t ldd, int rows, int V,
                       const int64_t* labels, const float* gscale, float scale, int skip_pad_rows,
                       nacf_stream_t stream);
+/* Several decoding passes back to back in one [n_pass * rows_per_pass, .] batch (the two NACF passes share one
+ * projection launch): the same per pass, in ONE launch each.  exclude_mask / out5 / gscales: HOST arrays of n_pass (<= 4)
+ * entries (out5[i], gscales[i]: device pointers; pass i covers rows [i * rows_per_pass, (i + 1) * rows_per_pass)). */
+int nacf_nll_reduce_multi(const float* label_logp, const int64_t* argmax, const int64_t* labels, int rows_per_pass,
+                          int n_pass, const int* exclude_mask, float* const* out5, nacf_stream_t stream);
+int nacf_xent_bwd_lse_multi(const float* logits, int64_t ld, const float* lse, float* dlogits, int64_t ldd,
+                            int rows_per_pass, int n_pass, int V, const int64_t* labels, const float* const* gscales,
+                            float scale, int skip_pad_rows, nacf_stream_t stream);
 /* Generic log_softmax backward for wide rows (when the caller consumes the
  * log-probs with its own criterion): dlogits = dlogp - exp(logp)*rowsum(dlogp) */
 int nacf_vocab_logsoftmax_bwd(const float* dlogp, int64_t ldg, const float* logp, int64_t ld,

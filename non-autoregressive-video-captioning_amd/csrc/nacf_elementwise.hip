@@ -774,6 +774,36 @@ __global__ void nll_reduce_kernel(const float* __restrict__ label_logp, const in
   if (threadIdx.x == 0) { out5[0] = nll; out5[1] = hit; out5[2] = cnt; out5[3] = sl; out5[4] = sc; }
 }
 
+// several passes that sit back to back in one [n_pass * rows, .] batch (the two NACF decoding passes): one launch, block b
+// = pass b, each with its own exclusion rule and output slot
+constexpr int PASS_MAX = 4;
+struct NllPasses { int exclude[PASS_MAX]; float* out5[PASS_MAX]; };
+__global__ void nll_reduce_multi_kernel(const float* __restrict__ label_logp, const int64_t* __restrict__ argmax,
+                                        const int64_t* __restrict__ labels, int rows_per_pass, NllPasses t) {
+  __shared__ float red[16];
+  const int64_t r0 = (int64_t)blockIdx.x * rows_per_pass;
+  const int exclude_mask = t.exclude[blockIdx.x];
+  float nll = 0.f, hit = 0.f, cnt = 0.f, sl = 0.f, sc = 0.f;
+  for (int r = threadIdx.x; r < rows_per_pass; r += blockDim.x) {
+    const int64_t lab = labels[r0 + r];
+    if (lab != NACF_PAD) {
+      const float lp = label_logp[r0 + r];
+      nll -= lp; sl += lp; sc += 1.f;
+      if (!(exclude_mask && lab == NACF_MASK)) {
+        cnt += 1.f;
+        if (argmax[r0 + r] == lab) hit += 1.f;
+      }
+    }
+  }
+  nll = block_sum(nll, red);
+  hit = block_sum(hit, red);
+  cnt = block_sum(cnt, red);
+  sl = block_sum(sl, red);
+  sc = block_sum(sc, red);
+  float* out5 = t.out5[blockIdx.x];
+  if (threadIdx.x == 0) { out5[0] = nll; out5[1] = hit; out5[2] = cnt; out5[3] = sl; out5[4] = sc; }
+}
+
 __global__ __launch_bounds__(256) void xent_bwd_kernel(const float* __restrict__ logp, int64_t ld,
                                                         float* __restrict__ dlogits, int64_t ldd, int V,
                                                         const int64_t* __restrict__ labels,
@@ -806,15 +836,17 @@ __global__ __launch_bounds__(256) void xent_bwd_kernel(const float* __restrict__
   }
 }
 
+struct XentPasses { const float* g[4]; };
 // the same from RAW logits and the row's log-sum-exp (nacf_vocab_lse_fwd): softmax = exp(z - lse)
 __global__ __launch_bounds__(256) void xent_bwd_lse_kernel(const float* __restrict__ z, int64_t ld,
                                                             const float* __restrict__ lse, float* __restrict__ dlogits,
                                                             int64_t ldd, int V, const int64_t* __restrict__ labels,
                                                             const float* __restrict__ gscale, float scale,
-                                                            int skip_pad_rows) {
+                                                            int skip_pad_rows, int rows_per_pass, XentPasses passes) {
   const int row = blockIdx.x;
   const int64_t lab = labels[row];
   if (skip_pad_rows && lab == NACF_PAD) return;
+  if (rows_per_pass > 0) gscale = passes.g[row / rows_per_pass];      // per-pass upstream gradient (passes back to back)
   const float g = (gscale ? gscale[0] : 1.f) * scale;
   const float* p = z + (int64_t)row * ld;
   float* d = dlogits + (int64_t)row * ldd;
@@ -1407,8 +1439,39 @@ int nacf_xent_bwd_lse(const float* logits, int64_t ld, const float* lse, float* 
                       const int64_t* labels, const float* gscale, float scale, int skip_pad_rows, nacf_stream_t stream) {
   NACF_CHECK(logits && lse && dlogits && labels && rows > 0 && V > 0, NACF_EINVAL, "nacf_xent_bwd_lse: bad argument");
   hipLaunchKernelGGL(xent_bwd_lse_kernel, dim3(rows), dim3(256), 0, as_hip(stream), logits, ld, lse, dlogits, ldd, V, labels,
-                     gscale, scale, skip_pad_rows);
+                     gscale, scale, skip_pad_rows, 0, XentPasses{});
   NACF_LAUNCH_CHECK("nacf_xent_bwd_lse");
+  return NACF_OK;
+}
+
+int nacf_xent_bwd_lse_multi(const float* logits, int64_t ld, const float* lse, float* dlogits, int64_t ldd, int rows_per_pass,
+                            int n_pass, int V, const int64_t* labels, const float* const* gscales, float scale, int skip_pad_rows,
+                            nacf_stream_t stream) {
+  NACF_CHECK(logits && lse && dlogits && labels && gscales && rows_per_pass > 0 && n_pass >= 1 && n_pass <= 4 && V > 0, NACF_EINVAL,
+             "nacf_xent_bwd_lse_multi: bad argument");
+  XentPasses p = {};
+  for (int i = 0; i < n_pass; ++i) {
+    NACF_CHECK(gscales[i], NACF_EINVAL, "nacf_xent_bwd_lse_multi: every pass needs its upstream gradient");
+    p.g[i] = gscales[i];
+  }
+  hipLaunchKernelGGL(xent_bwd_lse_kernel, dim3(rows_per_pass * n_pass), dim3(256), 0, as_hip(stream), logits, ld, lse, dlogits, ldd, V,
+                     labels, (const float*)nullptr, scale, skip_pad_rows, rows_per_pass, p);
+  NACF_LAUNCH_CHECK("nacf_xent_bwd_lse_multi");
+  return NACF_OK;
+}
+
+int nacf_nll_reduce_multi(const float* label_logp, const int64_t* argmax, const int64_t* labels, int rows_per_pass, int n_pass,
+                          const int* exclude_mask, float* const* out5, nacf_stream_t stream) {
+  NACF_CHECK(label_logp && argmax && labels && exclude_mask && out5 && rows_per_pass > 0 && n_pass >= 1 && n_pass <= PASS_MAX, NACF_EINVAL,
+             "nacf_nll_reduce_multi: bad argument");
+  NllPasses t = {};
+  for (int i = 0; i < n_pass; ++i) {
+    NACF_CHECK(out5[i], NACF_EINVAL, "nacf_nll_reduce_multi: null output");
+    t.exclude[i] = exclude_mask[i];
+    t.out5[i] = out5[i];
+  }
+  hipLaunchKernelGGL(nll_reduce_multi_kernel, dim3(n_pass), dim3(1024), 0, as_hip(stream), label_logp, argmax, labels, rows_per_pass, t);
+  NACF_LAUNCH_CHECK("nacf_nll_reduce_multi");
   return NACF_OK;
 }
 

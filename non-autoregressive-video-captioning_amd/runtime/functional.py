@@ -690,12 +690,13 @@ class FusedVocabXentMultiFn(Function):
         argmax = _new((rows,), h, torch.int64)
         ops.vocab_lse_fwd(h, pk.w, pk.b, logits, labels, lse, argmax, label_logp, live)
         outs = cfg.get("outs")
-        stats = []
-        for i in range(S):
-            st = outs[i] if outs is not None else _new((5,), h)
-            sl = slice(i * rp, (i + 1) * rp)
-            ops.nll_reduce(label_logp[sl], argmax[sl], labels[sl], excludes[i], st)
-            stats.append(st)
+        stats = [outs[i] if outs is not None else _new((5,), h) for i in range(S)]
+        if 1 < S <= 4:
+            ops.nll_reduce_multi(label_logp, argmax, labels, excludes, stats)       # every pass in one launch
+        else:
+            for i in range(S):
+                sl = slice(i * rp, (i + 1) * rp)
+                ops.nll_reduce(label_logp[sl], argmax[sl], labels[sl], excludes[i], stats[i])
         ctx.cfg, ctx.h, ctx.logp, ctx.labels, ctx.live, ctx.S, ctx.lse = cfg, h, logits, labels, live, S, lse
         return tuple(stats)
 
@@ -704,12 +705,13 @@ class FusedVocabXentMultiFn(Function):
         pk: Pack = ctx.cfg["pack"]
         rows, V = ctx.logp.shape
         rp = rows // ctx.S
-        for i, g in enumerate(dstats):
-            sl = slice(i * rp, (i + 1) * rp)
-            if g is None:
-                g = torch.zeros(5, dtype=ctx.logp.dtype, device=ctx.logp.device)
-            ops.xent_bwd_lse(ctx.logp[sl], ctx.lse[sl], ctx.logp[sl], V, ctx.labels[sl], g.contiguous(), 1.0,
-                             skip_pad_rows=True)
+        gs = [g.contiguous() if g is not None else torch.zeros(5, dtype=ctx.logp.dtype, device=ctx.logp.device) for g in dstats]
+        if 1 < ctx.S <= 4:
+            ops.xent_bwd_lse_multi(ctx.logp, ctx.lse, ctx.logp, V, ctx.labels, gs, 1.0, skip_pad_rows=True)    # in place, one launch
+        else:
+            for i, g in enumerate(gs):
+                sl = slice(i * rp, (i + 1) * rp)
+                ops.xent_bwd_lse(ctx.logp[sl], ctx.lse[sl], ctx.logp[sl], V, ctx.labels[sl], g, 1.0, skip_pad_rows=True)
         dh = torch.empty_like(ctx.h)
         ops.linear_bwd_data(ctx.logp, pk.w, dh, rows=ctx.live, zero_dead=True)
         ops.linear_bwd_weight(ctx.logp, ctx.h, pk.gw, pk.gb, beta=1.0, rows=ctx.live)

@@ -119,6 +119,8 @@ SIGNATURES = {
     "nacf_xent_bwd": (c_int, [_P, _L, _P, _L, _I, _I, _P, _P, _F, _I, _P]),
     "nacf_vocab_lse_fwd": (c_int, [_P, _L, _P, _L, _P, _I, _I, _I, _P, _L, _P, _P, _P, _P, _P, _S, _RS, _P]),
     "nacf_xent_bwd_lse": (c_int, [_P, _L, _P, _P, _L, _I, _I, _P, _P, _F, _I, _P]),
+    "nacf_xent_bwd_lse_multi": (c_int, [_P, _L, _P, _P, _L, _I, _I, _I, _P, _P, _F, _I, _P]),
+    "nacf_nll_reduce_multi": (c_int, [_P, _P, _P, _I, _I, _P, _P, _P]),
     "nacf_vocab_logsoftmax_bwd": (c_int, [_P, _L, _P, _L, _P, _L, _I, _I, _P]),
     "nacf_vocab_argmax_workspace": (_S, [_I, _I]),
     "nacf_vocab_argmax": (c_int, [_P, _L, _P, _L, _P, _I, _I, _I, _P, _I, _P, _P, _P, _P, _S, _RS, _P]),

@@ -872,6 +872,26 @@ def xent_bwd_lse(logits2d, lse, dlogits2d, V, labels, gscale, scale, skip_pad_ro
                                        int(skip_pad_rows), _stream()), "nacf_xent_bwd_lse")
 
 
+def xent_bwd_lse_multi(logits2d, lse, dlogits2d, V, labels, gscales, scale, skip_pad_rows=False):
+    """the passes of one [n_pass * rows, V] batch in one launch, pass i scaled by gscales[i][0] (nacf_xent_bwd_lse_multi)"""
+    n = len(gscales)
+    rows = logits2d.shape[0]
+    assert rows % n == 0
+    L.check(L.load().nacf_xent_bwd_lse_multi(_ptr(logits2d), logits2d.stride(0), _ptr(lse), _ptr(dlogits2d), dlogits2d.stride(0),
+                                             rows // n, n, V, _ptr(labels), _ptr_array(gscales), float(scale), int(skip_pad_rows),
+                                             _stream()), "nacf_xent_bwd_lse_multi")
+
+
+def nll_reduce_multi(label_logp, argmax, labels, exclude_masks, outs):
+    """per-pass criterion scalars of n_pass passes back to back, one launch (nacf_nll_reduce_multi)"""
+    n = len(outs)
+    rows = label_logp.numel()
+    assert rows % n == 0 and len(exclude_masks) == n
+    L.check(L.load().nacf_nll_reduce_multi(_ptr(label_logp), _ptr(argmax), _ptr(labels), rows // n, n,
+                                           _int_array([int(bool(e)) for e in exclude_masks]), _ptr_array(outs), _stream()),
+            "nacf_nll_reduce_multi")
+
+
 def nll_reduce(label_logp, argmax, labels, exclude_mask, out5):
     rows = label_logp.numel()
     L.check(L.load().nacf_nll_reduce(_ptr(label_logp), _ptr(argmax), _ptr(labels), rows, int(exclude_mask),

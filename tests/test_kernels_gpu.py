@@ -589,6 +589,42 @@ def test_vocab_logsoftmax_nll_xent(dev, rows, V):
     assert err(dz, ref) < 2e-5
 
 
+def test_passes_back_to_back_in_one_launch(dev):
+    """nacf_nll_reduce_multi / nacf_xent_bwd_lse_multi: the decoding passes of one batch (rows back to back) in one launch
+    each -- bit-identical to one nacf_nll_reduce / nacf_xent_bwd_lse call per pass (own exclusion rule, own upstream gradient)"""
+    ops, _ = _ops()
+    rp, n_pass, V = 77, 3, 530
+    rows = rp * n_pass
+    ld = ops.vocab_ld(V)
+    buf = torch.zeros(rows, ld, device=dev)
+    buf[:, :V] = rnd(rows, V, seed=1, scale=4).to(dev)
+    labels = torch.randint(0, 9, (rows,), generator=torch.Generator().manual_seed(2)).to(dev)
+    logits = buf[:, :V]
+    lse = torch.logsumexp(logits.double(), -1).float()
+    am = logits.argmax(-1)
+    ll = (logits.gather(1, labels.view(-1, 1)).squeeze(1) - lse).contiguous()
+    excl = [True, False, True]
+    one = [torch.empty(5, device=dev) for _ in range(n_pass)]
+    for i in range(n_pass):
+        sl = slice(i * rp, (i + 1) * rp)
+        ops.nll_reduce(ll[sl], am[sl], labels[sl], excl[i], one[i])
+    many = [torch.empty(5, device=dev) for _ in range(n_pass)]
+    ops.nll_reduce_multi(ll, am, labels, excl, many)
+    assert all(torch.equal(a, b) for a, b in zip(one, many))
+    gs = [torch.tensor([0.7, 0, 0, 0, 0], device=dev), torch.tensor([-1.3, 0, 0, 0, 0], device=dev), torch.tensor([0.0, 0, 0, 0, 0], device=dev)]
+    d1 = torch.full((rows, ld), 7.0, device=dev)
+    for i in range(n_pass):
+        sl = slice(i * rp, (i + 1) * rp)
+        ops.xent_bwd_lse(logits[sl], lse[sl], d1[sl, :V], V, labels[sl], gs[i], 1.0, skip_pad_rows=True)
+    d2 = torch.full((rows, ld), 7.0, device=dev)
+    ops.xent_bwd_lse_multi(logits, lse, d2[:, :V], V, labels, gs, 1.0, skip_pad_rows=True)
+    assert torch.equal(d1, d2)
+    live = labels.ne(PAD).cpu()
+    ref = (torch.softmax(logits.double().cpu(), -1) - torch.nn.functional.one_hot(labels.cpu(), V).double())
+    scale = torch.tensor([0.7] * rp + [-1.3] * rp + [0.0] * rp, dtype=torch.float64).view(-1, 1)
+    assert err(d2[:, :V][live.to(dev)], (ref * scale)[live]) < 1e-5 and float(d2[~live.to(dev)].sub(7.0).abs().max()) == 0
+
+
 # ------------------------------------------------------------------ decode bookkeeping (bit-exact)
 def test_length_beam_and_canvas(dev):
     ops, _ = _ops()
