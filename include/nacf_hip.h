@@ -64,7 +64,7 @@ int nacf_version(void);
  * included).  nacf_abi_count() returns the value the LIBRARY was built with; the ctypes loader
  * (runtime/lib.py:load) refuses a library whose count differs from its own signature table, so a stale
  * libnacf_hip.so next to a newer Python package fails at import time, not at the first missing symbol. */
-#define NACF_ABI_COUNT 84
+#define NACF_ABI_COUNT 86
 int nacf_abi_count(void);
 
 /* ---- batch construction (reference: dataloader.py) ----------------------------------------
@@ -555,8 +555,19 @@ int nacf_vocab_argmax(const float* hidden, int64_t ldh, const float* W, int64_t 
  * beam_max[0] = max over all (device int32, read back once by the host). */
 int nacf_length_beam(const float* pred_length, int B, int max_len, int lbs, int length_bias,
                      int32_t* beam, int32_t* beam_max, nacf_stream_t stream);
+/* the gold-length beam of opt['load_generated_captions'], decoding/na_generate.py:25-26,118-122:
+ * gold[b] = # non-PAD of tgt_tokens[b, 0..T); beam[b,j] = clamp(gold[b] - (lbs-1)/2 + j, 4, max_len-1), j < lbs;
+ * beam_max[0] = max over all. */
+int nacf_length_beam_gold(const int64_t* tgt_tokens, int B, int T, int max_len, int lbs,
+                          int32_t* beam, int32_t* beam_max, nacf_stream_t stream);
 /* tokens[b*lbs+j, l] = l < beam[b,j] ? MASK : PAD ; width Lp */
 int nacf_canvas_init(const int32_t* beam, int rows, int Lp, int64_t* tokens, nacf_stream_t stream);
+
+/* the canvas under opt['load_generated_captions'], decoding/na_generate.py:42-50:
+ * tokens[b*lbs+j, l] = l < beam[b,j] ? (tgt_tokens[b,l] == PAD ? MASK : tgt_tokens[b,l]) : PAD ; tgt_tokens [rows/lbs, T]
+ * (a slot l >= T inside a candidate's length starts as MASK) */
+int nacf_canvas_init_gold(const int32_t* beam, const int64_t* tgt_tokens, int T, int rows, int lbs, int Lp,
+                          int64_t* tokens, nacf_stream_t stream);
 
 /* select_worst + re-mask, decoding/algorithms.py:206-215,255-260: per row,
  * n = max(1, num_mask_lut[seq_len(row)]) slots of lowest score = probs*teacher

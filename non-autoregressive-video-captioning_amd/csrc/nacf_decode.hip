@@ -38,11 +38,55 @@ __global__ void length_beam_kernel(const float* __restrict__ pred_length, int B,
   if (threadIdx.x == 0) beam_max[0] = red[0];
 }
 
+// gold-length beam (opt['load_generated_captions'], decoding/na_generate.py:25-26,118-122): lbs consecutive lengths around the
+// number of non-<pad> tokens of the given caption, then the same clamp as the predicted beam
+__global__ void length_beam_gold_kernel(const int64_t* __restrict__ tgt_tokens, int B, int T, int max_len, int lbs,
+                                        int32_t* __restrict__ beam, int32_t* __restrict__ beam_max) {
+  __shared__ int red[256];
+  int local_max = 0;
+  for (int b = threadIdx.x; b < B; b += blockDim.x) {
+    const int64_t* t = tgt_tokens + (int64_t)b * T;
+    int gold = 0;
+    for (int i = 0; i < T; ++i) gold += (t[i] != NACF_PAD) ? 1 : 0;
+    const int start = gold - (lbs - 1) / 2;
+    for (int j = 0; j < lbs; ++j) {
+      int len = start + j;
+      if (len < 4) len = 4;                       // decoding/na_generate.py:130-132
+      if (len > max_len - 1) len = max_len - 1;
+      beam[(int64_t)b * lbs + j] = len;
+      local_max = max(local_max, len);
+    }
+  }
+  red[threadIdx.x] = local_max;
+  __syncthreads();
+  for (int o = blockDim.x >> 1; o > 0; o >>= 1) {
+    if (threadIdx.x < o) red[threadIdx.x] = max(red[threadIdx.x], red[threadIdx.x + o]);
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) beam_max[0] = red[0];
+}
+
 __global__ void canvas_init_kernel(const int32_t* __restrict__ beam, int rows, int Lp, int64_t* __restrict__ tokens) {
   const int64_t total = (int64_t)rows * Lp;
   for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
     const int r = (int)(e / Lp), l = (int)(e % Lp);
     tokens[e] = l < beam[r] ? NACF_MASK : NACF_PAD;
+  }
+}
+
+// the canvas of opt['load_generated_captions'] (decoding/na_generate.py:42-50): candidate (b, j) starts from caption b with
+// <pad> -> <mask>, cut to its candidate length
+__global__ void canvas_init_gold_kernel(const int32_t* __restrict__ beam, const int64_t* __restrict__ tgt_tokens, int T, int rows,
+                                        int lbs, int Lp, int64_t* __restrict__ tokens) {
+  const int64_t total = (int64_t)rows * Lp;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+    const int r = (int)(e / Lp), l = (int)(e % Lp);
+    int64_t tok = NACF_PAD;
+    if (l < beam[r]) {
+      tok = l < T ? tgt_tokens[(int64_t)(r / lbs) * T + l] : (int64_t)NACF_MASK;
+      if (tok == NACF_PAD) tok = NACF_MASK;
+    }
+    tokens[e] = tok;
   }
 }
 
@@ -401,6 +445,17 @@ int nacf_length_beam(const float* pred_length, int B, int max_len, int lbs, int 
   return NACF_OK;
 }
 
+int nacf_length_beam_gold(const int64_t* tgt_tokens, int B, int T, int max_len, int lbs, int32_t* beam, int32_t* beam_max,
+                          nacf_stream_t stream) {
+  NACF_CHECK(tgt_tokens && beam && beam_max, NACF_EINVAL, "nacf_length_beam_gold: null pointer");
+  NACF_CHECK(B > 0 && T > 0 && max_len > 4 && max_len <= 64 && lbs > 0 && lbs <= max_len, NACF_EINVAL,
+             "nacf_length_beam_gold: need T > 0, 4 < max_len <= 64 and 0 < lbs <= max_len");
+  hipLaunchKernelGGL(length_beam_gold_kernel, dim3(1), dim3(256), 0, as_hip(stream), tgt_tokens, B, T, max_len, lbs, beam,
+                     beam_max);
+  NACF_LAUNCH_CHECK("nacf_length_beam_gold");
+  return NACF_OK;
+}
+
 int nacf_canvas_init(const int32_t* beam, int rows, int Lp, int64_t* tokens, nacf_stream_t stream) {
   NACF_CHECK(beam && tokens && rows > 0 && Lp > 0, NACF_EINVAL, "nacf_canvas_init: bad argument");
   const int64_t total = (int64_t)rows * Lp;
@@ -408,6 +463,19 @@ int nacf_canvas_init(const int32_t* beam, int rows, int Lp, int64_t* tokens, nac
   if (blocks > 4096) blocks = 4096;
   hipLaunchKernelGGL(canvas_init_kernel, dim3(blocks), dim3(256), 0, as_hip(stream), beam, rows, Lp, tokens);
   NACF_LAUNCH_CHECK("nacf_canvas_init");
+  return NACF_OK;
+}
+
+int nacf_canvas_init_gold(const int32_t* beam, const int64_t* tgt_tokens, int T, int rows, int lbs, int Lp, int64_t* tokens,
+                          nacf_stream_t stream) {
+  NACF_CHECK(beam && tgt_tokens && tokens && rows > 0 && Lp > 0 && T > 0 && lbs > 0 && rows % lbs == 0, NACF_EINVAL,
+             "nacf_canvas_init_gold: bad argument");
+  const int64_t total = (int64_t)rows * Lp;
+  int blocks = (int)((total + 255) / 256);
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(canvas_init_gold_kernel, dim3(blocks), dim3(256), 0, as_hip(stream), beam, tgt_tokens, T, rows, lbs, Lp,
+                     tokens);
+  NACF_LAUNCH_CHECK("nacf_canvas_init_gold");
   return NACF_OK;
 }
 

@@ -23,8 +23,10 @@ def generate(opt, model, teacher_model, encoder_outputs, teacher_encoder_outputs
              dict_mapping, length_bias, **kwargs):
     paradigm = opt.get('paradigm', 'mp')
     assert paradigm in ('mp', 'l2r', 'ef')
-    if opt.get('load_generated_captions', False):
-        raise NotImplementedError('nacf_amd: load_generated_captions (gold length beam) is not built')
+    # opt['load_generated_captions'] (na_generate.py:25-26): the length beam is centred on the given captions' lengths
+    gold = tgt_tokens if opt.get('load_generated_captions', False) else None
+    if gold is not None and not torch.is_tensor(gold):
+        raise ValueError('nacf_amd: load_generated_captions needs tgt_tokens (the captions whose lengths seed the beam)')
     if kwargs.get('output_attentions', False) or opt.get('example', ''):
         raise NotImplementedError('nacf_amd: attention collection / example mode of generate() is not built')
     mode = opt.get('decode_graph', 'auto')
@@ -33,11 +35,11 @@ def generate(opt, model, teacher_model, encoder_outputs, teacher_encoder_outputs
     # ('l2r' / 'ef' read a slot count on the host between passes; a vocabulary remap table is uploaded per call)
     if mode != 'off' and paradigm == 'mp' and not dict_mapping:
         out = _generate_graphed(opt, model, teacher_model, encoder_outputs, teacher_encoder_outputs, category,
-                                tgt_vocab, length_bias, mode)
+                                tgt_vocab, length_bias, mode, gold)
         if out is not None:
             return out
     hyp, lprobs, _ = _generate(opt, model, teacher_model, encoder_outputs, teacher_encoder_outputs, category, tgt_vocab,
-                               dict_mapping, length_bias, None)
+                               dict_mapping, length_bias, None, gold)
     return hyp, lprobs
 
 
@@ -46,7 +48,7 @@ def _enc_tensors(enc):
     return e[0] if isinstance(e, list) else e, enc.get('pred_length'), enc.get('_pooled_memory')
 
 
-def _generate_graphed(opt, model, teacher_model, enc, t_enc, category, tgt_vocab, length_bias, mode):
+def _generate_graphed(opt, model, teacher_model, enc, t_enc, category, tgt_vocab, length_bias, mode, gold=None):
     """The whole decode of one batch -- length beam, canvas, T(+1) decoder passes with fused projection/argmax,
     re-masking, optional teacher scoring, candidate selection -- as ONE hipGraph replay over static inputs.  Inside
     the graph the canvas is max_len-1 slots wide (the length beam's upper clamp, na_generate.py:133): the extra
@@ -64,7 +66,7 @@ def _generate_graphed(opt, model, teacher_model, enc, t_enc, category, tgt_vocab
     flat = getattr(model, 'flat', None)          # the graph holds raw pointers into the parameter buffer
     key = (None if flat is None else (flat.data.data_ptr(), flat.image_epoch), ops.gemm_mode(), tuple(e.shape), tuple(pl.shape), None if category is None else tuple(category.shape), int(length_bias),
            id(teacher_model) if te is not None else None, None if te is None else tuple(te[0].shape),
-           tuple(str(opt.get(k)) for k in keys))
+           tuple(str(opt.get(k)) for k in keys), None if gold is None else tuple(gold.shape))
     cache = model.__dict__.setdefault('_nacf_decode_graphs', {})
     entry = cache.get(key)
     if entry is None:
@@ -74,6 +76,7 @@ def _generate_graphed(opt, model, teacher_model, enc, t_enc, category, tgt_vocab
         W = pl.shape[1] - 1
         st = dict(e=e.clone(), pl=pl.clone(), pooled=None if pooled is None else pooled.clone(),
                   cat=None if category is None else category.clone(),
+                  gold=None if gold is None else gold.to(device=e.device, dtype=torch.int64).contiguous().clone(),
                   te=None if te is None else [None if x is None else x.clone() for x in te])
 
         def run():
@@ -85,7 +88,7 @@ def _generate_graphed(opt, model, teacher_model, enc, t_enc, category, tgt_vocab
                 s_t = {'enc_output': st['te'][0]}
                 if st['te'][2] is not None:
                     s_t['_pooled_memory'] = st['te'][2]
-            return _generate(opt, model, teacher_model, s_enc, s_t, st['cat'], tgt_vocab, {}, length_bias, W)
+            return _generate(opt, model, teacher_model, s_enc, s_t, st['cat'], tgt_vocab, {}, length_bias, W, st['gold'])
         run()                                   # launch by launch once: workspaces, mask-count tables
         dev = e.device
         torch.cuda.synchronize(dev)
@@ -104,6 +107,8 @@ def _generate_graphed(opt, model, teacher_model, enc, t_enc, category, tgt_vocab
         st['pooled'].copy_(pooled)
     if category is not None:
         st['cat'].copy_(category)
+    if gold is not None:
+        st['gold'].copy_(gold)
     if te is not None:
         for dst, src in zip(st['te'], te):
             if src is not None:
@@ -115,7 +120,7 @@ def _generate_graphed(opt, model, teacher_model, enc, t_enc, category, tgt_vocab
 
 
 def _generate(opt, model, teacher_model, encoder_outputs, teacher_encoder_outputs, category, tgt_vocab, dict_mapping,
-              length_bias, fixed_width):
+              length_bias, fixed_width, gold=None):
     paradigm = opt.get('paradigm', 'mp')
     algorithm = algorithms_mapping[paradigm](opt, dict_mapping, tgt_vocab)
     lbs = opt['length_beam_size']
@@ -127,11 +132,20 @@ def _generate(opt, model, teacher_model, encoder_outputs, teacher_encoder_output
 
     beam = torch.empty(B, lbs, dtype=torch.int32, device=dev)
     beam_max = torch.empty(1, dtype=torch.int32, device=dev)
-    ops.length_beam(pred_length, lbs, int(length_bias), beam, beam_max)
+    if gold is not None:        # no length_bias here, as upstream (na_generate.py:118-122)
+        gold = gold.to(device=dev, dtype=torch.int64).contiguous()
+        ops.length_beam_gold(gold, max_len, lbs, beam, beam_max)
+    else:
+        ops.length_beam(pred_length, lbs, int(length_bias), beam, beam_max)
     Lp = int(beam_max.item()) if fixed_width is None else int(fixed_width)
     R = B * lbs
     tokens = torch.empty(R, Lp, dtype=torch.int64, device=dev)
-    ops.canvas_init(beam, R, Lp, tokens)
+    if gold is not None:        # the canvas starts from the given captions (na_generate.py:42-45)
+        if fixed_width is None and gold.shape[1] < Lp:
+            raise ValueError('nacf_amd: tgt_tokens is %d wide, the longest length candidate is %d' % (gold.shape[1], Lp))
+        ops.canvas_init_gold(beam, gold, R, lbs, Lp, tokens)
+    else:
+        ops.canvas_init(beam, R, Lp, tokens)
 
     enc_output = encoder_outputs['enc_output']
     if isinstance(enc_output, list):

@@ -114,10 +114,8 @@ class _Dense(nn.Module):
 class BertLayer(nn.Module):
     def __init__(self, config, is_decoder_layer=True):
         super().__init__()
-        if getattr(config, 'parallel_mlm', False):
-            raise NotImplementedError('nacf_amd: the parallel_mlm variant is not built (reference default off, opts.py:35)')
-        if config.pos_attention and config.with_layernorm:
-            raise NotImplementedError('nacf_amd: pos_attention together with with_layernorm is not built')
+        # parallel_mlm (bert.py:253-254): the self-attention block's BertSelfOutput gets no residual input
+        self.self_residual = not getattr(config, 'parallel_mlm', False)
         if config.attention_probs_dropout_prob != 0.0:
             raise NotImplementedError('nacf_amd: attention_probs_dropout_prob must be 0 (reference default, opts.py:29)')
         if config.hidden_act not in L.ACT_BY_NAME:
@@ -149,7 +147,9 @@ class BertLayer(nn.Module):
              [[m.LayerNorm.bias] for m in (a.output, c.output, self.output)] if self.with_layernorm else []) + \
             ([[pa.self.query.weight, pa.self.key.weight], [pa.self.query.bias, pa.self.key.bias],
               [pa.self.value.weight], [pa.self.value.bias], [pa.output.dense.weight], [pa.output.dense.bias]]
-             if (pa := self.pos_attention) is not None else [])
+             if (pa := self.pos_attention) is not None else []) + \
+            ([[pa.output.LayerNorm.weight], [pa.output.LayerNorm.bias]]
+             if (pa := self.pos_attention) is not None and self.with_layernorm else [])
 
     def nacf_bind(self, flat, rt):
         self._rt = rt
@@ -173,6 +173,8 @@ class BertLayer(nn.Module):
                                         image='both')
             self._pk['pv'] = flat.pack([pa.self.value.weight], [pa.self.value.bias], image='both')
             self._pk['po'] = flat.pack([pa.output.dense.weight], [pa.output.dense.bias], image='both')
+            if self.with_layernorm:
+                self._pk['ln_po'] = flat.pack([pa.output.LayerNorm.weight], [pa.output.LayerNorm.bias])
             self._salt_pos = rt.next_salt()
         self._params = [p for p in self.parameters()]
 
@@ -192,7 +194,7 @@ class BertLayer(nn.Module):
         pk = self._pk
         s = self._salts
         if self.with_layernorm:
-            return self._run_layernorm(x2, tokens, causal, memory_kv, M, vdiv, vmod, training, want_probs, rows)
+            return self._run_layernorm(x2, tokens, causal, memory_kv, M, vdiv, vmod, training, want_probs, rows, pos2)
         if self.pos_attention is not None:
             return self._run_pos(x2, pos2, tokens, causal, memory_kv, M, vdiv, vmod, training, want_probs, rows)
         if out_rows is not None and not torch.is_grad_enabled() and not training:
@@ -204,7 +206,7 @@ class BertLayer(nn.Module):
         h1, h2, h3 = ({}, {}, {}) if link else (None, None, None)
         qkv = LinearFn.apply(x2, None, dict(pack=pk['qkv'], rows=rows, dx_acc=h1), *P)
         att, p_self = SelfAttentionFn.apply(qkv, tokens, int(causal), self.H, want_probs)
-        a = LinearFn.apply(att, x2, dict(pack=pk['so'], p1=self.p, salt1=s[0], row_tokens=tok_flat, rng=rng,
+        a = LinearFn.apply(att, x2 if self.self_residual else None, dict(pack=pk['so'], p1=self.p, salt1=s[0], row_tokens=tok_flat, rng=rng,
                                          training=training, rows=rows, res_sink=h1), *P)
         q = LinearFn.apply(a, None, dict(pack=pk['cq'], rows=rows, dx_acc=h2), *P)
         catt, p_cross = CrossAttentionFn.apply(q, memory_kv, self.H, Lq, M, vdiv, vmod, want_probs)
@@ -236,7 +238,7 @@ class BertLayer(nn.Module):
         att = torch.empty(R * Lq, D, dtype=x2.dtype, device=x2.device)
         p_self = torch.empty(self.H, R, Lq, Lq, dtype=x2.dtype, device=x2.device) if want_probs else None
         ops.attention_fwd(q, kv[:, :D], kv[:, D:], att, tokens, int(causal), p_self, R, self.H, Lq, Lq, D // self.H, 1, R)
-        a = LinearFn.apply(att, x2, dict(pack=pk['so'], **sub), *P)
+        a = LinearFn.apply(att, x2 if self.self_residual else None, dict(pack=pk['so'], **sub), *P)
         cq = LinearFn.apply(a, None, dict(pack=pk['cq'], rows=out_rows), *P)
         catt, p_cross = CrossAttentionFn.apply(cq, memory_kv, self.H, Lq, M, vdiv, vmod, want_probs)
         c = LinearFn.apply(catt, a, dict(pack=pk['co'], **sub), *P)
@@ -244,7 +246,7 @@ class BertLayer(nn.Module):
         y = LinearFn.apply(u, c, dict(pack=pk['f2'], **sub), *P)
         return y, (p_self, p_cross)
 
-    def _run_layernorm(self, x2, tokens, causal, memory_kv, M, vdiv, vmod, training, want_probs, rows):
+    def _run_layernorm(self, x2, tokens, causal, memory_kv, M, vdiv, vmod, training, want_probs, rows, pos2=None):
         """with_layernorm=True (opts.py:36): LayerNorm sits between the residual add and the <pad> mask,
         so the GEMM epilogue stops at the residual and a LayerNorm kernel finishes the block:
            a = LN(dropout(dense(att)) + x) * non_pad                  (BertSelfOutput, bert.py:192-200)
@@ -257,8 +259,16 @@ class BertLayer(nn.Module):
                                              row_tokens=tok_flat)
         qkv = LinearFn.apply(x2, None, dict(pack=pk['qkv'], rows=rows), *P)
         att, p_self = SelfAttentionFn.apply(qkv, tokens, int(causal), self.H, want_probs)
-        a = LinearFn.apply(att, x2, dict(pack=pk['so'], p1=self.p, salt1=s[0], rng=rng, training=training, rows=rows), *P)
+        a = LinearFn.apply(att, x2 if self.self_residual else None, dict(pack=pk['so'], p1=self.p, salt1=s[0], rng=rng, training=training, rows=rows), *P)
         a = LayerNormFn.apply(a, ln('ln_so'), *P)
+        if self.pos_attention is not None:      # pos_attention with LayerNorm: the block of _run_pos, LN before the <pad> mask
+            assert pos2 is not None, 'pos_attention layers need the position embeddings'
+            pqk = LinearFn.apply(pos2, None, dict(pack=pk['pqk'], rows=rows), *P)
+            pv = LinearFn.apply(a, None, dict(pack=pk['pv'], rows=rows), *P)
+            patt = QKVAttentionFn.apply(pqk, pv, tokens, int(causal), self.H)
+            a = LinearFn.apply(patt, pos2, dict(pack=pk['po'], p1=self.p, salt1=self._salt_pos, rng=rng, training=training,
+                                                rows=rows), *P)
+            a = LayerNormFn.apply(a, ln('ln_po'), *P)
         q = LinearFn.apply(a, None, dict(pack=pk['cq'], rows=rows), *P)
         catt, p_cross = CrossAttentionFn.apply(q, memory_kv, self.H, Lq, M, vdiv, vmod, want_probs)
         c = LinearFn.apply(catt, a, dict(pack=pk['co'], p1=self.p, salt1=s[1], rng=rng, training=training, rows=rows), *P)
@@ -281,7 +291,7 @@ class BertLayer(nn.Module):
         common = dict(row_tokens=tok_flat, rng=rng, training=training, rows=rows)
         qkv = LinearFn.apply(x2, None, dict(pack=pk['qkv'], rows=rows), *P)
         att, p_self = SelfAttentionFn.apply(qkv, tokens, int(causal), self.H, want_probs)
-        a = LinearFn.apply(att, x2, dict(pack=pk['so'], p1=self.p, salt1=s[0], **common), *P)
+        a = LinearFn.apply(att, x2 if self.self_residual else None, dict(pack=pk['so'], p1=self.p, salt1=s[0], **common), *P)
         pqk = LinearFn.apply(pos2, None, dict(pack=pk['pqk'], rows=rows), *P)
         pv = LinearFn.apply(a, None, dict(pack=pk['pv'], rows=rows), *P)
         patt = QKVAttentionFn.apply(pqk, pv, tokens, int(causal), self.H)

@@ -125,7 +125,9 @@ SIGNATURES = {
     "nacf_vocab_argmax_workspace": (_S, [_I, _I]),
     "nacf_vocab_argmax": (c_int, [_P, _L, _P, _L, _P, _I, _I, _I, _P, _I, _P, _P, _P, _P, _S, _RS, _P]),
     "nacf_length_beam": (c_int, [_P, _I, _I, _I, _I, _P, _P, _P]),
+    "nacf_length_beam_gold": (c_int, [_P, _I, _I, _I, _I, _P, _P, _P]),
     "nacf_canvas_init": (c_int, [_P, _I, _I, _P, _P]),
+    "nacf_canvas_init_gold": (c_int, [_P, _P, _I, _I, _I, _I, _P, _P]),
     "nacf_select_mask": (c_int, [_P, _P, _P, _P, _I, _I, _I, _P, _P, _P]),
     "nacf_token_replace": (c_int, [_P, _L, _L, _L, _P]),
     "nacf_teacher_probs": (c_int, [_P, _P, _P, _L, _P]),

@@ -933,8 +933,21 @@ def length_beam(pred_length, lbs, length_bias, beam, beam_max):
                                       _stream()), "nacf_length_beam")
 
 
+def length_beam_gold(tgt_tokens, max_len, lbs, beam, beam_max):
+    assert tgt_tokens.dtype == torch.int64 and tgt_tokens.dim() == 2 and tgt_tokens.is_contiguous()
+    B, T = tgt_tokens.shape
+    L.check(L.load().nacf_length_beam_gold(_ptr(tgt_tokens), B, T, max_len, lbs, _ptr(beam), _ptr(beam_max), _stream()),
+            "nacf_length_beam_gold")
+
+
 def canvas_init(beam, rows, Lp, tokens):
     L.check(L.load().nacf_canvas_init(_ptr(beam), rows, Lp, _ptr(tokens), _stream()), "nacf_canvas_init")
+
+
+def canvas_init_gold(beam, tgt_tokens, rows, lbs, Lp, tokens):
+    assert tgt_tokens.dtype == torch.int64 and tgt_tokens.is_contiguous() and tgt_tokens.shape[0] * lbs == rows
+    L.check(L.load().nacf_canvas_init_gold(_ptr(beam), _ptr(tgt_tokens), tgt_tokens.shape[1], rows, lbs, Lp, _ptr(tokens),
+                                           _stream()), "nacf_canvas_init_gold")
 
 
 def select_mask(probs, teacher, pad_tokens, lut, mode, tokens, mask_out):

@@ -176,7 +176,7 @@ def train_case(name, method, extra, V, B, F_, dataset="MSRVTT", beta=(0.35, 0.9)
     return opt, sd
 
 
-def decode_case(name, method, extra, V, B, F_, variants, teacher_method=None, dataset="MSRVTT"):
+def decode_case(name, method, extra, V, B, F_, variants, teacher_method=None, dataset="MSRVTT", gold=False):
     opt = ref_opt(method, dataset, TINY + list(extra))
     opt["vocab_size"] = V
     sd = O.init_state_dict(opt, seed=3)
@@ -190,6 +190,8 @@ def decode_case(name, method, extra, V, B, F_, variants, teacher_method=None, da
     out = {"opt_json": opt_blob(opt), "B": B, "F": F_, "in.category": batch["category"]}
     for i, f in enumerate(batch["feats"]):
         out[f"in.feats{i}"] = f
+    if gold:        # the captions whose lengths seed the beam under opt['load_generated_captions']
+        out["in.gold_tokens"] = batch["tokens"]
     teacher = None
     t_model = None
     if teacher_method is not None:
@@ -216,10 +218,11 @@ def decode_case(name, method, extra, V, B, F_, variants, teacher_method=None, da
         with torch.no_grad():
             hyp, (it_tok, it_prob) = tr.translate_batch(
                 {k: (v.clone() if isinstance(v, torch.Tensor) else v) for k, v in enc.items()},
-                batch["category"], None, {i: str(i) for i in range(V)},
+                batch["category"], batch["tokens"].clone() if gold else None, {i: str(i) for i in range(V)},
                 teacher_encoder_outputs=(t_enc if t_model is not None else None))
         col = []
-        o_hyp, o_all, o_lp, o_beam = O.generate(sd, opt, dec, o_enc, batch["category"], teacher, col)
+        o_hyp, o_all, o_lp, o_beam = O.generate(sd, opt, dec, o_enc, batch["category"], teacher, col,
+                                                gold_tokens=batch["tokens"] if gold else None)
         assert torch.equal(o_hyp, hyp), f"{name}/{vname}: hypotheses differ"
         o_tok = torch.stack([c[0] for c in col], 1)
         o_prob = torch.stack([c[1] for c in col], 1)
@@ -656,6 +659,19 @@ def host_case():
         len(gts), len(dups), len(runs), [len(r["trace"]) for r in runs]))
 
 
+def goldlen_case():
+    """opt['load_generated_captions'] = True (decoding/na_generate.py:25-26,118-122): the length beam is centred on the
+    lengths of the captions handed to translate_batch instead of on the length head's top-k"""
+    decode_case("tiny_nacf_goldlen_decode", "NACF", ["-wc"], V=101, B=4, F_=6, gold=True, variants={
+        "mp_ct_gold": dict(paradigm="mp", use_ct=True, iterations=5, length_beam_size=6, beam_alpha=1.35,
+                           load_generated_captions=True),
+        "mp_gold5": dict(paradigm="mp", use_ct=False, iterations=3, length_beam_size=5, beam_alpha=1.0,
+                         load_generated_captions=True),
+        "ef_gold": dict(paradigm="ef", use_ct=True, q=1, q_iterations=1, length_beam_size=4, beam_alpha=1.0,
+                        load_generated_captions=True),
+    })
+
+
 def main():
     torch.manual_seed(0)
     if os.environ.get("ONLY_HOST"):
@@ -673,6 +689,9 @@ def main():
     if os.environ.get("ONLY_POS"):
         train_case("tiny_nacf_pos_train", "NACF", ["-wc", "--pos_attention"], V=101, B=3, F_=6)
         return
+    if os.environ.get("ONLY_POS_LN"):
+        train_case("tiny_nacf_pos_ln_train", "NACF", ["-wc", "--pos_attention", "--with_layernorm"], V=101, B=3, F_=6)
+        return
     if os.environ.get("ONLY_LN"):
         train_case("tiny_nacf_ln_train", "NACF", ["-wc", "--with_layernorm", "--norm_type", "ln"], V=101, B=3, F_=6)
         return
@@ -683,6 +702,14 @@ def main():
         return
     if os.environ.get("ONLY_GATE"):
         train_case("tiny_nab_nogate_train", "NAB", [], V=101, B=3, F_=6, dataset="Youtube2Text", beta=(0.0, 1.0), override={"gate": False})
+        return
+    if os.environ.get("ONLY_PMLM"):
+        train_case("tiny_nacf_pmlm_train", "NACF", ["-wc"], V=101, B=3, F_=6, override={"parallel_mlm": True})
+        train_case("tiny_nab_pmlm_ln_train", "NAB", ["--with_layernorm"], V=101, B=3, F_=6, dataset="Youtube2Text", beta=(0.0, 1.0),
+                   override={"parallel_mlm": True})
+        return
+    if os.environ.get("ONLY_GOLDLEN"):
+        goldlen_case()
         return
     if os.environ.get("ONLY_WATCH"):
         train_case("tiny_arb_watch_train", "ARB", ["-wc", "--watch", "3"], V=101, B=3, F_=6)
@@ -706,8 +733,13 @@ def main():
                V=101, B=3, F_=6, dataset="Youtube2Text", beta=(0.0, 1.0))
     train_case("tiny_nacf_ln_train", "NACF", ["-wc", "--with_layernorm", "--norm_type", "ln"], V=101, B=3, F_=6)
     train_case("tiny_nacf_pos_train", "NACF", ["-wc", "--pos_attention"], V=101, B=3, F_=6)
+    train_case("tiny_nacf_pos_ln_train", "NACF", ["-wc", "--pos_attention", "--with_layernorm"], V=101, B=3, F_=6)
     # opt['gate'] = False (models/Encoder.py:10-25,64): HighWay without its gate, out = x + tanh(w1 x)
     train_case("tiny_nab_nogate_train", "NAB", [], V=101, B=3, F_=6, dataset="Youtube2Text", beta=(0.0, 1.0), override={"gate": False})
+    # opt['parallel_mlm'] = True (models/bert.py:253-254): the self-attention block of every layer without its residual
+    train_case("tiny_nacf_pmlm_train", "NACF", ["-wc"], V=101, B=3, F_=6, override={"parallel_mlm": True})
+    train_case("tiny_nab_pmlm_ln_train", "NAB", ["--with_layernorm"], V=101, B=3, F_=6, dataset="Youtube2Text", beta=(0.0, 1.0),
+               override={"parallel_mlm": True})
     # --watch 3 (opts.py:32): AR self-attention sees the last three tokens only (models/Decoder.py:23-39)
     train_case("tiny_arb_watch_train", "ARB", ["-wc", "--watch", "3"], V=101, B=3, F_=6)
     ar_case("tiny_arb_watch_beam", "ARB", ["-wc", "--watch", "3"], V=101, B=4, F_=6, beam_size=3, topk=1, alpha=1.0,
@@ -734,6 +766,7 @@ def main():
         "mp_md": dict(paradigm="mp", use_ct=True, iterations=4, length_beam_size=4, beam_alpha=1.35,
                       masking_decision=True),
     })
+    goldlen_case()
     ar_case("tiny_arb2_beam", "ARB2", ["-wc"], V=101, B=3, F_=6)
     ar_case("tiny_arb_beam", "ARB", ["-wc"], V=101, B=3, F_=6)
     ar_case("tiny_arb_beam_eos", "ARB", ["-wc"], V=101, B=6, F_=6, beam_size=5, topk=3, alpha=1.0, eos_boost=EOS_BOOST)

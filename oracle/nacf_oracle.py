@@ -47,7 +47,7 @@ DEFAULT_OPT = dict(  # opts.py:23-50,116-129 (defaults that shape the model)
     no_encoder_bn=False, norm_type="bn", tie_weights=False,
     fusion="temporal_concat", crit=["lang"], nv_weights=[0.8, 1.0],
     visual_word_generation=False, decoding_type="ARFormer",
-    decoder="BertDecoder", encoder="Encoder_HighWay", gate=True,
+    decoder="BertDecoder", encoder="Encoder_HighWay", gate=True, parallel_mlm=False,
 )
 
 
@@ -212,13 +212,17 @@ def mha(sd: SD, pfx: str, opt: dict, q_in: Tensor, kv_in: Tensor, mask: Optional
 
 
 def attention_block(sd: SD, pfx: str, opt: dict, q_in: Tensor, kv_in: Tensor,
-                    mask: Optional[Tensor], training: bool, v_in: Optional[Tensor] = None) -> Tuple[Tensor, Tensor]:
+                    mask: Optional[Tensor], training: bool, v_in: Optional[Tensor] = None,
+                    with_residual: bool = True) -> Tuple[Tensor, Tensor]:
     """BertAttention = BertSelfAttention + BertSelfOutput,
     models/bert.py:182-215: dense -> dropout -> + query input (-> LN if enabled).  v_in: a separate value input
-    (the position attention: queries and keys from the position embeddings, values from the hidden states)."""
+    (the position attention: queries and keys from the position embeddings, values from the hidden states).
+    with_residual=False: BertSelfOutput gets no input_tensor (bert.py:195-196,212; the parallel_mlm self-attention)."""
     o, p = mha(sd, pfx, opt, q_in, kv_in, mask, training, v_in)
     o = F.linear(o, sd[pfx + "output.dense.weight"], sd[pfx + "output.dense.bias"])
-    o = _dropout(o, opt["hidden_dropout_prob"], training) + q_in
+    o = _dropout(o, opt["hidden_dropout_prob"], training)
+    if with_residual:
+        o = o + q_in
     if opt["with_layernorm"]:
         o = F.layer_norm(o, (o.shape[-1],), sd[pfx + "output.LayerNorm.weight"],
                          sd[pfx + "output.LayerNorm.bias"], opt["layer_norm_eps"])
@@ -228,7 +232,8 @@ def attention_block(sd: SD, pfx: str, opt: dict, q_in: Tensor, kv_in: Tensor,
 def bert_layer(sd: SD, pfx: str, opt: dict, x: Tensor, non_pad: Tensor, self_mask: Tensor,
                enc_output: Tensor, training: bool, pos: Optional[Tensor] = None):
     """BertLayer.forward, models/bert.py:262-303."""
-    a, p_self = attention_block(sd, pfx + "attention.", opt, x, x, self_mask, training)
+    a, p_self = attention_block(sd, pfx + "attention.", opt, x, x, self_mask, training,
+                                with_residual=not opt.get("parallel_mlm", False))      # bert.py:253-254
     a = a * non_pad
     if pos is not None:     # bert.py:274-281: q = k = position embeddings, v = hidden; the residual is the query input
         a, _ = attention_block(sd, pfx + "pos_attention.", opt, pos, pos, self_mask, training, v_in=a)
@@ -413,9 +418,15 @@ def enlarge(x: Tensor, k: int) -> Tensor:
     return x.unsqueeze(1).repeat(1, k, *([1] * (x.dim() - 1))).view(x.shape[0] * k, *x.shape[1:])
 
 
-def predict_length_beam(pred_length: Tensor, lbs: int, length_bias: int, max_len: int) -> Tensor:
-    """decoding/na_generate.py:116-135 (no gold lengths)."""
-    beam = pred_length.topk(lbs, dim=1)[1] + length_bias
+def predict_length_beam(pred_length: Tensor, lbs: int, length_bias: int, max_len: int,
+                        gold_tokens: Optional[Tensor] = None) -> Tensor:
+    """decoding/na_generate.py:116-135.  gold_tokens (opt['load_generated_captions'], :25-26,118-122): lbs
+    consecutive lengths around the number of non-<pad> tokens of the given captions (no length_bias)."""
+    if gold_tokens is not None:
+        gold = gold_tokens.ne(PAD).sum(-1)
+        beam = (gold - (lbs - 1) // 2).unsqueeze(1) + torch.arange(lbs).unsqueeze(0)
+    else:
+        beam = pred_length.topk(lbs, dim=1)[1] + length_bias
     beam = beam.clamp(min=4, max=max_len - 1)
     return beam
 
@@ -590,7 +601,7 @@ ALGORITHMS = {"mp": mask_predict, "l2r": left2right, "ef": easy_first}
 
 
 def generate(sd: SD, opt: dict, dec_opt: dict, enc_res: Dict[str, Tensor], category: Tensor,
-             teacher=None, collect: Optional[list] = None):
+             teacher=None, collect: Optional[list] = None, gold_tokens: Optional[Tensor] = None):
     """decoding.generate, decoding/na_generate.py:14-77.  ``dec_opt`` carries
     paradigm / use_ct / iterations / length_beam_size / beam_alpha / q /
     q_iterations / length_bias.  Returns (hypotheses [B, L'], all candidates
@@ -600,12 +611,17 @@ def generate(sd: SD, opt: dict, dec_opt: dict, enc_res: Dict[str, Tensor], categ
     alpha = dec_opt.get("beam_alpha", 1.0)
     pred_length = enc_res["pred_length"]
     B = pred_length.shape[0]
-    beam = predict_length_beam(pred_length, lbs, dec_opt.get("length_bias", 0), opt["max_len"])
+    beam = predict_length_beam(pred_length, lbs, dec_opt.get("length_bias", 0), opt["max_len"],
+                               gold_tokens if dec_opt.get("load_generated_captions", False) else None)
     Lp = int(beam.max())
     pos = torch.arange(Lp).view(1, 1, Lp)
     is_pad = pos >= beam.unsqueeze(-1)                                  # na_generate.py:39-40
-    tokens = torch.where(is_pad, torch.full_like(is_pad, PAD, dtype=torch.long),
-                         torch.full_like(is_pad, MASK, dtype=torch.long)).view(B * lbs, Lp)
+    start = torch.full_like(is_pad, MASK, dtype=torch.long)
+    if gold_tokens is not None and dec_opt.get("load_generated_captions", False):
+        g = gold_tokens[:, :Lp].clone()                                 # na_generate.py:42-45: the canvas starts from the
+        g[g == PAD] = MASK                                              # given captions, <pad> -> <mask>
+        start = g.unsqueeze(1).repeat(1, lbs, 1)
+    tokens = torch.where(is_pad, torch.full_like(is_pad, PAD, dtype=torch.long), start).view(B * lbs, Lp)
     enc = enlarge(enc_res["enc_output"], lbs)
     cat = enlarge(category, lbs)
     if teacher is not None:

@@ -52,8 +52,8 @@ def test_method_overlays_match_reference_flags():
         nacf_amd.get_model(dict(o, vocab_size=10, decoder="Nope"))
 
 
-@pytest.mark.parametrize("name", ["tiny_nacf_train", "tiny_nab_train", "tiny_arb2_train", "tiny_arb_train", "tiny_arb_watch_train", "tiny_nab_nogate_train",
-                                  "tiny_nab_variants_train", "tiny_nacf_ln_train", "tiny_nacf_pos_train"])
+@pytest.mark.parametrize("name", ["tiny_nacf_train", "tiny_nab_train", "tiny_arb2_train", "tiny_arb_train", "tiny_arb_watch_train", "tiny_nab_nogate_train", "tiny_nacf_pmlm_train", "tiny_nab_pmlm_ln_train",
+                                  "tiny_nab_variants_train", "tiny_nacf_ln_train", "tiny_nacf_pos_train", "tiny_nacf_pos_ln_train"])
 def test_state_dict_contract_and_flat_layout(name):
     g = load_gold(name)
     opt = gold_opt(g)
@@ -107,7 +107,7 @@ def test_default_init_consumes_rng_like_the_reference_layout():
 
 def test_unsupported_variants_fail_loudly():
     opt = gold_opt(load_gold("tiny_nacf_train"))
-    for bad in (dict(parallel_mlm=True), dict(pos_attention=True, with_layernorm=True), dict(enhance_input=1), dict(fusion="addition"), dict(hidden_act="swish")):
+    for bad in (dict(enhance_input=1), dict(fusion="addition"), dict(hidden_act="swish")):
         with pytest.raises((NotImplementedError, ValueError)):
             nacf_amd.get_model(dict(opt, **bad))
 

@@ -30,8 +30,8 @@ def _tok_labels(opt, b):
     return tokens, labels
 
 
-TRAIN_CASES = ["tiny_nacf_train", "tiny_nab_train", "tiny_arb2_train", "tiny_arb_train", "tiny_arb_watch_train", "tiny_nab_nogate_train", "tiny_nab_variants_train",
-               "tiny_nacf_ln_train", "tiny_nacf_pos_train"]
+TRAIN_CASES = ["tiny_nacf_train", "tiny_nab_train", "tiny_arb2_train", "tiny_arb_train", "tiny_arb_watch_train", "tiny_nab_nogate_train", "tiny_nacf_pmlm_train", "tiny_nab_pmlm_ln_train", "tiny_nab_variants_train",
+               "tiny_nacf_ln_train", "tiny_nacf_pos_train", "tiny_nacf_pos_ln_train"]
 
 
 def _force_tile(monkeypatch, tile):
@@ -113,13 +113,14 @@ def _run_decode(model, dec, b, dev, teacher=None, t_enc=None, graph="off"):
     tr = Translator(model, dopt, device=dev, teacher_model=teacher)
     with torch.no_grad():
         enc = model.encode(feats=b["feats"])
-    hyp, extra = tr.translate_batch(enc, b["category"], None, None, teacher_encoder_outputs=t_enc)
+    gold = b["gold_tokens"].clone() if dec.get("load_generated_captions") else None      # the captions whose lengths seed the beam
+    hyp, extra = tr.translate_batch(enc, b["category"], gold, None, teacher_encoder_outputs=t_enc)
     return enc, hyp, extra
 
 
 @pytest.mark.parametrize("tile", [None, "64", "128"])
 @pytest.mark.parametrize("graph", ["off", "on"])
-@pytest.mark.parametrize("name", ["tiny_nacf_decode", "tiny_nab_decode"])
+@pytest.mark.parametrize("name", ["tiny_nacf_decode", "tiny_nab_decode", "tiny_nacf_goldlen_decode"])
 def test_na_decode_tokens_bit_exact_vs_reference_golden(dev, name, graph, tile, monkeypatch):
     """graph='on': mask-predict variants replay from one hipGraph on a max_len-1 wide canvas and must still return the
     reference's tokens, per-iteration tokens / probabilities and shapes"""
@@ -138,6 +139,8 @@ def test_na_decode_tokens_bit_exact_vs_reference_golden(dev, name, graph, tile, 
             # a second batch through the SAME captured graph: permuted videos give permuted captions
             perm = torch.arange(hyp.shape[0] - 1, -1, -1, device=dev)
             b2 = dict(b, feats=[f[perm] for f in b["feats"]], category=b["category"][perm])
+            if "gold_tokens" in b:
+                b2["gold_tokens"] = b["gold_tokens"][perm]
             _, hyp2, _ = _run_decode(model, dec, b2, dev, graph=graph)
             w = min(hyp.shape[1], hyp2.shape[1])
             assert torch.equal(hyp2[:, :w], hyp[perm][:, :w])

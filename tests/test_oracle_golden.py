@@ -15,8 +15,8 @@ def _tok_labels(opt, b):
     return tokens, labels
 
 
-@pytest.mark.parametrize("name", ["tiny_nacf_train", "tiny_nab_train", "tiny_arb2_train", "tiny_arb_train", "tiny_arb_watch_train", "tiny_nab_nogate_train",
-                                  "tiny_nab_variants_train", "tiny_nacf_ln_train", "tiny_nacf_pos_train"])
+@pytest.mark.parametrize("name", ["tiny_nacf_train", "tiny_nab_train", "tiny_arb2_train", "tiny_arb_train", "tiny_arb_watch_train", "tiny_nab_nogate_train", "tiny_nacf_pmlm_train", "tiny_nab_pmlm_ln_train",
+                                  "tiny_nab_variants_train", "tiny_nacf_ln_train", "tiny_nacf_pos_train", "tiny_nacf_pos_ln_train"])
 def test_train_step_matches_reference(name):
     g = load_gold(name)
     opt = gold_opt(g)
@@ -45,7 +45,7 @@ def test_train_step_matches_reference(name):
             assert int(sd[k]) == int(v)
 
 
-@pytest.mark.parametrize("name,seed", [("tiny_nacf_decode", 3), ("tiny_nab_decode", 3)])
+@pytest.mark.parametrize("name,seed", [("tiny_nacf_decode", 3), ("tiny_nab_decode", 3), ("tiny_nacf_goldlen_decode", 3)])
 def test_decode_matches_reference(name, seed):
     g = load_gold(name)
     opt = gold_opt(g)
@@ -59,7 +59,7 @@ def test_decode_matches_reference(name, seed):
     for v in variants:
         dec = gold_json(g, v + ".dec_json")
         col = []
-        hyp, _, lp, beam = O.generate(sd, opt, dec, enc, b["category"], None, col)
+        hyp, _, lp, beam = O.generate(sd, opt, dec, enc, b["category"], None, col, gold_tokens=b.get("gold_tokens"))
         assert torch.equal(hyp, t(g[v + ".hyp"])), v
         toks = torch.stack([c[0] for c in col], 1)
         assert torch.equal(toks, t(g[v + ".iter_tokens"]).long()), v
