@@ -1,0 +1,226 @@
+// What a bf16-RESIDENT GEMM reaches on this model's shapes ("producer epilogues emit the bf16 copy the
+// next GEMM consumes"; north_star: >= 40 % bf16 matrix-core utilisation on the attention + FFN GEMMs).  Standalone: no
+// library, no torch.  Both operands are bf16 in HBM, k-contiguous -- what the throughput mode's activations and weights would
+// be if every producer wrote a bf16 copy -- so staging is a pure copy: global -> LDS by DMA (global_load_lds_dwordx4), no
+// vector work, no LDS stores.
+//
+//   C[M][N] (fp32) = A[M][K] (bf16) * B[N][K]^T (bf16)
+//
+//   256 threads = 4 waves (2 x 2), workgroup tile 128 x 128, BK = 64, wave tile 64 x 64 = 2 x 2 blocks of
+//   v_mfma_f32_32x32x16_bf16 (issued a = B fragment, b = A fragment: four consecutive n per accumulator quad -> float4 stores),
+//   two LDS images of 32 KB (two workgroups per CU), 128-byte LDS rows with the 16-byte chunks XOR-swizzled by (row >> 1) & 7
+//   on the DMA's SOURCE address (the LDS image of a DMA is lane-linear), one wait + two barriers per k-tile.
+//   -DWT128: wave tile 64 x 128 (workgroup tile 128 x 256, one workgroup per CU... two still fit: 96 KB) -- fewer LDS bytes per
+//   matrix instruction (the lesson of csrc/gemm_bf16_wide.hpp).
+//
+//   build: hipcc --offload-arch=gfx950 -O3 -std=c++17 bf16_resident_gemm.hip -o bf16_resident_gemm
+//   run:   ./bf16_resident_gemm            (the model's shapes + two calibration cubes; checks a small case against fp64 first)
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <cstdint>
+#include <vector>
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); exit(1); } } while (0)
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#ifdef WT128
+constexpr int BN = 256, NTW = 4;      // wave tile 64 x 128
+#else
+constexpr int BN = 128, NTW = 2;      // wave tile 64 x 64
+#endif
+constexpr int BM = 128, BK = 64, MTW = 2;
+constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2, STAGE = A_BYTES + B_BYTES;
+constexpr int A_REQ = A_BYTES / (256 * 16), B_REQ = B_BYTES / (256 * 16);      // DMA requests per thread per k-tile
+
+__device__ __forceinline__ int sw(int row) { return (row >> 1) & 7; }
+
+__global__ __launch_bounds__(256, 2) void gemm_bf16_resident(const uint16_t* __restrict__ A, const uint16_t* __restrict__ B,
+                                                              float* __restrict__ C, int M, int N, int K) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int l31 = lane & 31, lh = lane >> 5;
+  const int tiles_n = (N + BN - 1) / BN, tiles_m = (M + BM - 1) / BM;
+  // XCD-aware, bijective: consecutive logical tiles (same row panel of A) share an XCD's L2
+  const int nwg = tiles_m * tiles_n, bid = blockIdx.x;
+  const int xq = nwg >> 3, xr = nwg & 7, xcd = bid & 7;
+  const int logical = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (bid >> 3);
+  const int m0 = (logical / tiles_n) * BM, n0 = (logical % tiles_n) * BN;
+  const int nk = K / BK;
+
+  // DMA sources: request j of this thread covers LDS rows j*32 + wave*8 + (lane >> 3), position lane & 7
+  const uint16_t* asrc[A_REQ];
+  const uint16_t* bsrc[B_REQ];
+#pragma unroll
+  for (int j = 0; j < A_REQ; ++j) {
+    const int R = j * 32 + wave * 8 + (lane >> 3);
+    asrc[j] = A + (size_t)min(m0 + R, M - 1) * K + 8 * ((lane & 7) ^ sw(R));
+  }
+#pragma unroll
+  for (int j = 0; j < B_REQ; ++j) {
+    const int R = j * 32 + wave * 8 + (lane >> 3);
+    bsrc[j] = B + (size_t)min(n0 + R, N - 1) * K + 8 * ((lane & 7) ^ sw(R));
+  }
+  auto issue = [&](int kt, int stage) __attribute__((always_inline)) {
+    unsigned char* base = smem + stage * STAGE;
+#pragma unroll
+    for (int j = 0; j < A_REQ; ++j)
+      __builtin_amdgcn_global_load_lds(asrc[j] + (size_t)kt * BK, (__attribute__((address_space(3))) void*)(base + (j * 32 + wave * 8) * 128), 16, 0, 0);
+#pragma unroll
+    for (int j = 0; j < B_REQ; ++j)
+      __builtin_amdgcn_global_load_lds(bsrc[j] + (size_t)kt * BK, (__attribute__((address_space(3))) void*)(base + A_BYTES + (j * 32 + wave * 8) * 128), 16, 0, 0);
+  };
+
+  f32x16 acc[MTW][NTW];
+#pragma unroll
+  for (int a = 0; a < MTW; ++a)
+#pragma unroll
+    for (int b = 0; b < NTW; ++b)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
+
+  issue(0, 0);
+  for (int kt = 0; kt < nk; ++kt) {
+    const int st = kt & 1;
+    if (kt + 1 < nk) {
+      issue(kt + 1, st ^ 1);
+      if constexpr (A_REQ + B_REQ == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    const unsigned char* sa = smem + st * STAGE;
+    const unsigned char* sb = sa + A_BYTES;
+#pragma unroll
+    for (int s = 0; s < BK / 16; ++s) {
+      bf16x8 fa[MTW], fb[NTW];
+#pragma unroll
+      for (int a = 0; a < MTW; ++a) {
+        const int row = wm * 64 + a * 32 + l31;
+        fa[a] = *reinterpret_cast<const bf16x8*>(sa + row * 128 + 16 * ((2 * s + lh) ^ sw(row)));
+      }
+#pragma unroll
+      for (int b = 0; b < NTW; ++b) {
+        const int row = wn * (32 * NTW) + b * 32 + l31;
+        fb[b] = *reinterpret_cast<const bf16x8*>(sb + row * 128 + 16 * ((2 * s + lh) ^ sw(row)));
+      }
+#pragma unroll
+      for (int a = 0; a < MTW; ++a)
+#pragma unroll
+        for (int b = 0; b < NTW; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[b], fa[a], acc[a][b], 0, 0, 0);
+    }
+    __builtin_amdgcn_s_barrier();      // everybody is done reading this image: the next trip's DMA may overwrite it
+    asm volatile("" ::: "memory");
+  }
+  // register r of acc[a][b] at lane l: row (m) a*32 + l31, column (n) b*32 + 8*(r >> 2) + 4*lh + (r & 3)
+#pragma unroll
+  for (int a = 0; a < MTW; ++a) {
+    const int m = m0 + wm * 64 + a * 32 + l31;
+    if (m >= M) continue;
+#pragma unroll
+    for (int b = 0; b < NTW; ++b)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int n = n0 + wn * (32 * NTW) + b * 32 + 8 * j + 4 * lh;
+        float* c = C + (size_t)m * N + n;
+        if (n + 3 < N && (N & 3) == 0) *reinterpret_cast<f32x4*>(c) = f32x4{acc[a][b][4 * j], acc[a][b][4 * j + 1], acc[a][b][4 * j + 2], acc[a][b][4 * j + 3]};
+        else
+          for (int e = 0; e < 4; ++e)
+            if (n + e < N) c[e] = acc[a][b][4 * j + e];
+      }
+  }
+}
+
+static uint16_t f2bf(float x) {      // round to nearest even
+  uint32_t u; memcpy(&u, &x, 4);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (uint16_t)(u >> 16);
+}
+static float bf2f(uint16_t h) { uint32_t u = (uint32_t)h << 16; float f; memcpy(&f, &u, 4); return f; }
+static float frand(uint64_t& s) { s = s * 6364136223846793005ull + 1442695040888963407ull; return ((s >> 40) / 8388608.0f) - 1.0f; }
+
+struct Buffers { uint16_t *A, *B; float* C; };
+
+static void launch(const Buffers& d, int M, int N, int K, hipStream_t s) {
+  const int tiles = ((M + BM - 1) / BM) * ((N + BN - 1) / BN);
+  hipLaunchKernelGGL(gemm_bf16_resident, dim3(tiles), dim3(256), 2 * STAGE, s, d.A, d.B, d.C, M, N, K);
+}
+
+int main(int argc, char** argv) {
+  CK(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_resident), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE));
+  const size_t maxA = (size_t)15360 * 2048 > (size_t)8192 * 8192 ? (size_t)15360 * 2048 : (size_t)8192 * 8192;
+  const size_t maxB = std::max((size_t)10547 * 512, (size_t)8192 * 8192), maxC = std::max((size_t)5120 * 10547, (size_t)8192 * 8192);
+  Buffers d;
+  CK(hipMalloc(&d.A, maxA * 2)); CK(hipMalloc(&d.B, maxB * 2)); CK(hipMalloc(&d.C, maxC * 4));
+  // ---- correctness: a ragged case (M, N not multiples of the tile, N odd) against fp64 on the same bf16 inputs
+  {
+    const int M = 333, N = 261, K = 192;
+    std::vector<uint16_t> ha((size_t)M * K), hb((size_t)N * K);
+    uint64_t s = 777;
+    for (auto& v : ha) v = f2bf(frand(s));
+    for (auto& v : hb) v = f2bf(frand(s) * 0.5f);
+    CK(hipMemcpy(d.A, ha.data(), ha.size() * 2, hipMemcpyHostToDevice));
+    CK(hipMemcpy(d.B, hb.data(), hb.size() * 2, hipMemcpyHostToDevice));
+    CK(hipMemset(d.C, 0xff, (size_t)M * N * 4));
+    launch(d, M, N, K, 0);
+    CK(hipDeviceSynchronize());
+    std::vector<float> hc((size_t)M * N);
+    CK(hipMemcpy(hc.data(), d.C, hc.size() * 4, hipMemcpyDeviceToHost));
+    double worst = 0;
+    for (int m = 0; m < M; ++m)
+      for (int n = 0; n < N; ++n) {
+        double r = 0;
+        for (int k = 0; k < K; ++k) r += (double)bf2f(ha[(size_t)m * K + k]) * bf2f(hb[(size_t)n * K + k]);
+        worst = std::max(worst, std::fabs(r - hc[(size_t)m * N + n]));
+      }
+    printf("check %d x %d x %d vs fp64 on the same bf16 inputs: max abs err %.3e %s\n", M, N, K, worst, worst < 1e-4 ? "ok" : "WRONG");
+    if (!(worst < 1e-4)) return 1;
+  }
+  // ---- timing: per-launch HIP events, median of `reps`
+  const int reps = argc > 1 ? atoi(argv[1]) : 30;
+  {
+    std::vector<uint16_t> h(std::max(maxA, maxB));
+    uint64_t s = 99;
+    for (auto& v : h) v = f2bf(frand(s));
+    CK(hipMemcpy(d.A, h.data(), maxA * 2, hipMemcpyHostToDevice));
+    CK(hipMemcpy(d.B, h.data(), maxB * 2, hipMemcpyHostToDevice));
+  }
+  struct Shape { const char* name; int M, N, K; };
+  const Shape shapes[] = {
+    {"proj  (NACF B=128)", 5120, 512, 512}, {"qkv   (NACF B=128)", 5120, 1536, 512}, {"ffn1  (NACF B=128)", 5120, 2048, 512},
+    {"ffn2  (NACF B=128)", 5120, 512, 2048}, {"enc_lin", 7680, 512, 2048}, {"enc_hw", 7680, 1024, 512}, {"kvmem", 15360, 1024, 512},
+    {"vocab (NACF B=128)", 5120, 10547, 512},
+    {"proj  (NAB B=64)", 1280, 512, 512}, {"ffn1  (NAB B=64)", 1280, 2048, 512}, {"ffn2  (NAB B=64)", 1280, 512, 2048},
+    {"cube 4096", 4096, 4096, 4096}, {"cube 8192", 8192, 8192, 8192},
+  };
+  std::vector<hipEvent_t> ev(2 * reps);
+  for (auto& e : ev) CK(hipEventCreate(&e));
+  printf("%-22s %-18s %10s %10s %8s   (workgroup tile %d x %d, %d workgroups)\n", "gemm", "M,N,K", "median us", "min us", "TF", BM, BN, 0);
+  for (const Shape& sh : shapes) {
+    for (int i = 0; i < 3; ++i) launch(d, sh.M, sh.N, sh.K, 0);
+    CK(hipDeviceSynchronize());
+    for (int i = 0; i < reps; ++i) {
+      CK(hipEventRecord(ev[2 * i], 0));
+      launch(d, sh.M, sh.N, sh.K, 0);
+      CK(hipEventRecord(ev[2 * i + 1], 0));
+    }
+    CK(hipDeviceSynchronize());
+    std::vector<float> ms(reps);
+    for (int i = 0; i < reps; ++i) CK(hipEventElapsedTime(&ms[i], ev[2 * i], ev[2 * i + 1]));
+    std::sort(ms.begin(), ms.end());
+    const double med = ms[reps / 2], flops = 2.0 * sh.M * sh.N * sh.K;
+    const int wgs = ((sh.M + BM - 1) / BM) * ((sh.N + BN - 1) / BN);
+    printf("%-22s %5d,%5d,%5d  %10.1f %10.1f %8.1f   %d workgroups, %.3f of 2500 TF\n", sh.name, sh.M, sh.N, sh.K, med * 1e3, ms[0] * 1e3,
+           flops / (med * 1e-3) / 1e12, wgs, flops / (med * 1e-3) / 2.5e15);
+  }
+  return 0;
+}
