@@ -21,6 +21,10 @@ bool launch_wide_linear(const GemmShape& g, const EpiLinear& epi, bool has_rows,
 bool launch_wide_dx(const GemmShape& g, const EpiStore& epi, int splits, bool has_rows, hipStream_t s);
 int wide_pick(const GemmShape& g, int splits, bool has_rows, int ns, bool heavy_epilogue);
 void bf16_note_wide(const char* name);
+// DMA-staged throughput-mode kernel (gemm_bf16_dma.hpp, nacf_gemm_bf16_dma.hip): false = not eligible / not worthwhile
+bool launch_dma_linear(const GemmShape& g, const EpiLinear& epi, bool has_rows, bool heavy_epilogue, hipStream_t s);
+bool launch_dma_dx(const GemmShape& g, const EpiStore& epi, int splits, bool has_rows, hipStream_t s);
+bool dma_pick(const GemmShape& g, int splits, bool has_rows, int ns, bool heavy_epilogue);
 void launch_wimage_refresh(const WImageDesc* descs, int n_desc, int n_tiles, int ns, hipStream_t s);
 // "gemm_bf16_kernel<BM, BN, QSRC, PSRC, NS, STAGES, Epi>" of the launch the calling thread made last (profiling aid)
 const char* bf16_last_kernel_name();

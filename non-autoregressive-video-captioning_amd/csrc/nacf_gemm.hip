@@ -407,7 +407,8 @@ int nacf_linear_fwd(const float* X, int64_t ldx, const float* W, int64_t ldw, fl
   if (mode != NACF_GEMM_F32 && vec) {          // bf16 matrix cores (16-byte addressable operands only)
     find_image(W, ldw, N, K, mode, g);
     const bool heavy_w = heavy || epi.ep.p_drop1 > 0.f || epi.ep.p_drop2 > 0.f;      // nothing overlaps the wide kernel's epilogue
-    if (!(mode == NACF_GEMM_BF16X3 && launch_wide_linear(g, epi, rs != nullptr, heavy_w, as_hip(stream))))
+    if (!(mode == NACF_GEMM_BF16X3 && launch_wide_linear(g, epi, rs != nullptr, heavy_w, as_hip(stream))) &&
+        !(mode == NACF_GEMM_BF16 && launch_dma_linear(g, epi, rs != nullptr, heavy_w, as_hip(stream))))
       launch_bf16_linear(g, epi, pick_tile_bf16(0, M, N, 1, rs != nullptr, mode, heavy), mode, as_hip(stream));
     g_last_was_bf16 = true;
   } else {
@@ -475,7 +476,8 @@ int nacf_linear_bwd_data(const float* dZ, int64_t lddz, const float* W, int64_t 
   }
   if (bf16) {
     find_image_t(W, ldw, N, K, mode, g);       // P = W^T image [K, N] when registered, else the fp32 W read transposed
-    if (!(mode == NACF_GEMM_BF16X3 && launch_wide_dx(g, epi, real_splits, rs != nullptr, s)))
+    if (!(mode == NACF_GEMM_BF16X3 && launch_wide_dx(g, epi, real_splits, rs != nullptr, s)) &&
+        !(mode == NACF_GEMM_BF16 && launch_dma_dx(g, epi, real_splits, rs != nullptr, s)))
       launch_bf16_dx(g, epi, real_splits, pick_tile_bf16(1, M, K, real_splits, rs != nullptr, mode), mode, s);
     g_last_was_bf16 = true;
   } else {
