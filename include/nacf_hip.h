@@ -74,6 +74,7 @@ int nacf_abi_count(void);
  * nacf_sample_frames: out[b, i, :] = src[video[b], frame(b, i), :]           (video == NULL: b; src_len == NULL: T)
  *   mode 0 'equally_sampling': middle of segment i of n_frames equal segments of the clip (dataloader.py:24-37);
  *   mode 1 'segment_random'  : one uniform draw per segment (Philox, device {seed, step} + salt);
+ *   mode 2 'all_random'      : n_frames distinct frames of the clip, ascending (selection sampling on the same stream);
  *   a clip shorter than n_frames is stretched: round-half-even(i * (S-1) / (n_frames-1))      (dataloader.py:20-21,305)
  *   frame_ids (optional) receives the chosen indices [B, n_frames]. */
 int nacf_sample_frames(const float* src, const int32_t* video, const int32_t* src_len, int B, int T, int D,

@@ -20,11 +20,30 @@ __device__ __forceinline__ uint32_t rand_below(uint32_t r, uint32_t range) {   /
 }
 
 // out[b, i, :] = src[video[b], frame(b, i), :]
-//   mode 0 'equally_sampling': middle of segment i;  mode 1 'segment_random': uniform in segment i
+//   mode 0 'equally_sampling': middle of segment i;  mode 1 'segment_random': uniform in segment i;  mode 2 'all_random'
 //   (dataloader.py:24-37);  a clip shorter than n_frames is stretched: round-half-even(i * (S-1) / (n-1)) (:20-21,305)
 __device__ __forceinline__ int pick_frame(int b, int i, int S, int n_frames, int mode, uint32_t salt,
                                           const uint64_t* __restrict__ rng_state) {
   if (S < n_frames) return (n_frames > 1) ? (int)rint((double)(i * (S - 1)) / (double)(n_frames - 1)) : 0;
+  if (mode == 2) {
+    // 'all_random' (dataloader.py:25-26,37): n_frames distinct frames of the clip, ascending.  Selection sampling: frame t is
+    // taken with probability (still needed) / (still left), which draws every n-subset with equal probability and yields it
+    // in ascending order -- so the i-th frame taken is sorted(random.sample(range(S), n))[i] in distribution; one Philox
+    // word per frame, the same words in every (b, i) block of a clip
+    DropRng rng;
+    rng.init(rng_state);
+    int taken = 0;
+    uint4 r = make_uint4(0u, 0u, 0u, 0u);
+    for (int t = 0; t < S; ++t) {
+      if ((t & 3) == 0) r = philox4x32_10(make_uint4((uint32_t)b, salt, rng.step_lo ^ (uint32_t)(t >> 2), rng.step_hi ^ 0xA11C0FFEu), rng.key);
+      const uint32_t w = (t & 3) == 0 ? r.x : (t & 3) == 1 ? r.y : (t & 3) == 2 ? r.z : r.w;
+      if ((int)rand_below(w, (uint32_t)(S - t)) < n_frames - taken) {
+        if (taken == i) return t;
+        ++taken;
+      }
+    }
+    return S - 1;      // not reached: the last frames are taken with probability 1 once as many are needed as are left
+  }
   const int lo = seg_bound(i, S, n_frames), hi = seg_bound(i + 1, S, n_frames);
   if (mode != 1) return (lo + hi) / 2;
   if (hi <= lo + 1) return lo;

@@ -47,12 +47,21 @@ class ShardLoader:
         self.train = mode == "train"
         self.shuffle = self.train if shuffle is None else bool(shuffle)
         self.drop_last = drop_last or self.world > 1
-        if opt.get("load_feats_type", 1) not in (1, 2):
-            raise NotImplementedError("nacf_amd: load_feats_type 0 (one shared frame-id draw per sample) is not built")
+        lft = opt.get("load_feats_type", 1)
+        if lft not in (0, 1, 2):
+            raise ValueError("nacf_amd: load_feats_type must be 0, 1 or 2 (dataloader.py:297-311)")
+        # load_feats_type 0 (dataloader.py:225-229,297-298): ONE frame-id draw per sample out of opt['n_total_frames'],
+        # shared by every modality and not adapted to the clip's own length
+        self.shared_frames = lft == 0
+        if self.shared_frames:
+            nt = opt.get("n_total_frames", 60)
+            if any(s.T != nt for s in shards):
+                raise ValueError("nacf_amd: load_feats_type 0 draws frame ids out of n_total_frames = %d; the shards hold %s "
+                                 "frames per clip" % (nt, [s.T for s in shards]))
         random_type = opt.get("random_type", "segment_random") if self.train else "equally_sampling"
-        if random_type not in ("segment_random", "equally_sampling"):
-            raise NotImplementedError("nacf_amd: random_type %s is not built" % random_type)
-        self.frame_mode = 1 if random_type == "segment_random" else 0
+        if random_type not in ("segment_random", "all_random", "equally_sampling"):
+            raise ValueError("nacf_amd: random_type %s (dataloader.py:52)" % random_type)
+        self.frame_mode = {"equally_sampling": 0, "segment_random": 1, "all_random": 2}[random_type]
         self.n_frames = [s.T if opt.get("load_feats_type", 1) == 2 else opt["n_frames"] for s in self.shards]
         self.rows = [s.row_of(video_index) for s in self.shards]          # table video row -> shard row
         total = sum(s.nbytes for s in self.shards)
@@ -157,9 +166,10 @@ class ShardLoader:
                 if self.placement == "host":               # zero-copy gather: the kernel reads the pinned shard itself
                     self.pref_rows[slot][m][:n] = torch.from_numpy(np.ascontiguousarray(rows, dtype=np.int32))
                     self.pref_rows_dev[slot][m][:n].copy_(self.pref_rows[slot][m][:n], non_blocking=True)
-                    ops.sample_frames(self.host_feats[m], self.pref_rows_dev[slot][m][:n], self.d_srclen[m],
+                    ops.sample_frames(self.host_feats[m], self.pref_rows_dev[slot][m][:n],
+                                      None if self.shared_frames else self.d_srclen[m],
                                       self.n_frames[m], self.frame_mode, self.sampled[slot][m][:n],
-                                      salt=0x5EED0000 + m, rng=self.pref_rng[slot])
+                                      salt=self._frame_salt(m), rng=self.pref_rng[slot])
                     continue
                 buf = self.pinned[slot][m].numpy()
                 # one memcpy per clip (T*D*4 bytes, contiguous in the shard) straight into pinned memory, spread over a
@@ -172,6 +182,11 @@ class ShardLoader:
             ev.record(self.copy_stream)
         self._slot_event[slot] = ev
         return ev
+
+    def _frame_salt(self, m):
+        """the Philox salt of modality m's frame draw: one per modality, or one for all of them under load_feats_type 0
+        (the same {seed, step, salt, sample} gives the same frame ids: dataloader.py:225-229)"""
+        return 0x5EED0000 if self.shared_frames else 0x5EED0000 + m
 
     def bind_outputs(self, buffers):
         """Build every following batch straight INTO these tensors (a dict shaped like a batch, e.g. the step engine's
@@ -196,7 +211,8 @@ class ShardLoader:
             if video is None and src_len is None:          # host placement: already sampled by the prefetch kernel
                 batch["feats"].append(out.copy_(src))      # (the staging slot is overwritten two batches later)
                 continue
-            ops.sample_frames(src, video, src_len, self.n_frames[m], self.frame_mode, out, salt=0x5EED0000 + m, rng=self.rng)
+            ops.sample_frames(src, video, None if self.shared_frames else src_len, self.n_frames[m], self.frame_mode, out,
+                              salt=self._frame_salt(m), rng=self.rng)
             batch["feats"].append(out)
         caps, lens = self.d_caps.index_select(0, idx_dev), self.d_len.index_select(0, idx_dev)
         tags = self.d_tags.index_select(0, idx_dev)

@@ -22,7 +22,7 @@ DEFAULTS = dict(
     visual_word_generation=False, demand=['VERB', 'NOUN'], nv_weights=[0.8, 1.0],
     beam_size=1, beam_alpha=1.0, topk=1, paradigm='mp', length_beam_size=6, iterations=5, q=1, q_iterations=1,
     use_ct=False, length_bias=0, crit=['lang'], crit_name=['Cap Loss'], crit_scale=[1.0],
-    n_frames=8, dim_a=1, dim_m=2048, dim_i=2048, dim_o=1,
+    n_frames=8, random_type='segment_random', load_feats_type=1, dim_a=1, dim_m=2048, dim_i=2048, dim_o=1,
     # evaluation / checkpointing defaults of the training driver (opts.py:75-85; read by misc/run.py and misc/logger.py)
     start_eval_epoch=0, save_checkpoint_every=1, tolerence=1000, k_best_model=1, standard=['METEOR', 'CIDEr'],
 )

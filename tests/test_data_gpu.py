@@ -134,6 +134,34 @@ def test_sample_frames(dev):
             assert bound[i] <= f < bound[i + 1]
             seen[i].add(f)
     assert all(len(s) == bound[i + 1] - bound[i] for i, s in enumerate(seen))
+    # all_random (dataloader.py:25-26,37): n distinct frames of the clip, ascending; every frame is drawn about equally
+    # often (n / S of the draws); a replay of the same {seed, step} is exact; a short clip is stretched as in the other modes
+    rng = ops.RngState(9, dev)
+    vid = torch.tensor([0, 2, 3], dtype=torch.int32, device=dev)          # clip lengths 60, 28, 9
+    count = np.zeros((2, 60))
+    trials = 600
+    for t in range(trials):
+        ids = torch.empty(3, 8, dtype=torch.int32, device=dev)
+        out = torch.empty(3, 8, Dm, device=dev)
+        ops.sample_frames(src, vid, lens, 8, 2, out, salt=3, rng=rng, frame_ids=ids)
+        if t == 0:
+            again = torch.empty_like(ids)
+            ops.sample_frames(src, vid, lens, 8, 2, torch.empty_like(out), salt=3, rng=rng, frame_ids=again)
+            assert torch.equal(ids, again)
+        rng.advance()
+        for b, S in enumerate((60, 28, 9)):
+            f = ids[b].tolist()
+            assert f == sorted(set(f)) and len(f) == 8 and 0 <= f[0] and f[-1] < S, (b, f)
+            assert torch.equal(out[b], src[int(vid[b]), torch.tensor(f, device=dev)])
+            if b < 2:
+                count[b, f] += 1
+    for b, S in enumerate((60, 28)):
+        expect = trials * 8 / S
+        assert count[b, S:].sum() == 0 and np.abs(count[b, :S] - expect).max() < 5 * np.sqrt(expect), (S, count[b, :S])
+    ids = torch.empty(1, 8, dtype=torch.int32, device=dev)
+    ops.sample_frames(src, torch.tensor([4], dtype=torch.int32, device=dev), lens, 8, 2, torch.empty(1, 8, Dm, device=dev), salt=3,
+                      rng=rng, frame_ids=ids)
+    assert ids[0].tolist() == D.select_frames(5, 8, 8, 1, "equally_sampling")      # 5 frames < 8: resampling (:20-21,305)
 
 
 def _make_dataset(tmp, n_videos=12, T=60, Dm=32, seed=0):
@@ -215,3 +243,42 @@ def test_shard_loader_resident_equals_streaming_and_feeds_a_train_step(dev, tmp_
     assert len(tv) == 2 and "tokens_1" not in ev
     lens = torch.from_numpy(tv.cap_len.astype(np.int64) - 2).to(dev)
     assert torch.equal((ev["tokens"] == D.MASK).sum(1), lens.clamp(max=10))
+
+
+@pytest.mark.parametrize("random_type", ["all_random", "segment_random"])
+def test_shard_loader_shared_frame_ids_load_feats_type_0(dev, tmp_path, random_type):
+    """load_feats_type 0 (dataloader.py:225-229,297-298): ONE frame-id draw per sample, shared by the modalities; with
+    'all_random' the ids are distinct and ascending; every placement delivers the same batch"""
+    import nacf_amd
+    from nacf_amd.data import ShardLoader
+    shards, caps, tags, info, CaptionTable = _make_dataset(str(tmp_path))
+    opt = nacf_amd.opts.make_opt("NACF", "MSRVTT", with_category=True, dim_hidden=64, num_attention_heads=4,
+                                 intermediate_size=128, dim_i=32, dim_m=32, max_len=10, vocab_size=101, n_frames=8,
+                                 load_feats_type=0, random_type=random_type, n_total_frames=60)
+    table, vids = CaptionTable.from_corpus(caps, tags, info, list(range(12)), opt, "train")
+    got = {}
+    for placement in ("hbm", "host"):
+        got[placement] = list(ShardLoader(shards, table, vids, opt, batch_size=8, device=dev, mode="train", seed=5, placement=placement))[0]
+    for a, b in zip(got["hbm"]["feats"], got["host"]["feats"]):
+        assert torch.equal(a, b)
+    first = got["hbm"]
+    idx = first["sample_index"].cpu().numpy()
+    differ = 0
+    for b in range(first["tokens"].shape[0]):
+        corpus_vid = int(vids[table.video[idx[b]]])
+        clips = [torch.from_numpy(np.array(s.array[s.row_of(np.array([corpus_vid]))[0]])).to(dev) for s in shards]
+        ids = []
+        for i in range(8):
+            hit = (clips[0] == first["feats"][0][b, i]).all(1).nonzero().flatten().tolist()
+            assert len(hit) == 1
+            ids.append(hit[0])
+            assert torch.equal(first["feats"][1][b, i], clips[1][hit[0]])          # the other modality took the SAME frame
+        if random_type == "all_random":
+            assert ids == sorted(set(ids))
+        else:
+            bound = D.frame_bounds(60, 8)
+            assert all(bound[i] <= f < bound[i + 1] for i, f in enumerate(ids))
+        differ += ids != D.select_frames(60, 8, 8, 1, "equally_sampling")
+    assert differ > 0
+    with pytest.raises(ValueError):
+        ShardLoader(shards, table, vids, dict(opt, n_total_frames=40), batch_size=8, device=dev, mode="train")
