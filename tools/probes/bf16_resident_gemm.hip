@@ -10,6 +10,7 @@
 //   v_mfma_f32_32x32x16_bf16 (issued a = B fragment, b = A fragment: four consecutive n per accumulator quad -> float4 stores),
 //   two LDS images of 32 KB (two workgroups per CU), 128-byte LDS rows with the 16-byte chunks XOR-swizzled by (row >> 1) & 7
 //   on the DMA's SOURCE address (the LDS image of a DMA is lane-linear), one wait + two barriers per k-tile.
+//   -DNSTG=3: three LDS images (96 KB, one workgroup per CU), tile t + 2 in flight, one barrier per k-tile.
 //   -DWT128: wave tile 64 x 128 (workgroup tile 128 x 256, one workgroup per CU... two still fit: 96 KB) -- fewer LDS bytes per
 //   matrix instruction (the lesson of csrc/gemm_bf16_wide.hpp).
 //
@@ -34,6 +35,9 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 constexpr int BN = 256, NTW = 4;      // wave tile 64 x 128
 #else
 constexpr int BN = 128, NTW = 2;      // wave tile 64 x 64
+#endif
+#ifndef NSTG
+#define NSTG 2                        // LDS images: 2 (two barriers per k-tile, two workgroups per CU) | 3 (one barrier, tile t + 2 in flight)
 #endif
 constexpr int BM = 128, BK = 64, MTW = 2;
 constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2, STAGE = A_BYTES + B_BYTES;
@@ -86,6 +90,43 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_resident(const uint16_t* __r
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
 
+#if NSTG == 3
+  // three images, tile kt + 2 requested while tile kt is multiplied, ONE barrier per k-tile (the image a request overwrites
+  // was read two barriers ago): a short reduce loop pays the memory latency once
+  issue(0, 0);
+  if (nk > 1) issue(1, 1);
+  for (int kt = 0, st = 0; kt < nk; ++kt, st = st == 2 ? 0 : st + 1) {
+    if (kt + 1 < nk) {
+      if constexpr (A_REQ + B_REQ == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    if (kt + 2 < nk) issue(kt + 2, st == 0 ? 2 : st - 1);
+    const unsigned char* sa = smem + st * STAGE;
+    const unsigned char* sb = sa + A_BYTES;
+#pragma unroll
+    for (int s = 0; s < BK / 16; ++s) {
+      bf16x8 fa[MTW], fb[NTW];
+#pragma unroll
+      for (int a = 0; a < MTW; ++a) {
+        const int row = wm * 64 + a * 32 + l31;
+        fa[a] = *reinterpret_cast<const bf16x8*>(sa + row * 128 + 16 * ((2 * s + lh) ^ sw(row)));
+      }
+#pragma unroll
+      for (int b = 0; b < NTW; ++b) {
+        const int row = wn * (32 * NTW) + b * 32 + l31;
+        fb[b] = *reinterpret_cast<const bf16x8*>(sb + row * 128 + 16 * ((2 * s + lh) ^ sw(row)));
+      }
+#pragma unroll
+      for (int a = 0; a < MTW; ++a)
+#pragma unroll
+        for (int b = 0; b < NTW; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[b], fa[a], acc[a][b], 0, 0, 0);
+    }
+  }
+#else
   issue(0, 0);
   for (int kt = 0; kt < nk; ++kt) {
     const int st = kt & 1;
@@ -121,6 +162,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_resident(const uint16_t* __r
     __builtin_amdgcn_s_barrier();      // everybody is done reading this image: the next trip's DMA may overwrite it
     asm volatile("" ::: "memory");
   }
+#endif
   // register r of acc[a][b] at lane l: row (m) a*32 + l31, column (n) b*32 + 8*(r >> 2) + 4*lh + (r & 3)
 #pragma unroll
   for (int a = 0; a < MTW; ++a) {
@@ -152,11 +194,11 @@ struct Buffers { uint16_t *A, *B; float* C; };
 
 static void launch(const Buffers& d, int M, int N, int K, hipStream_t s) {
   const int tiles = ((M + BM - 1) / BM) * ((N + BN - 1) / BN);
-  hipLaunchKernelGGL(gemm_bf16_resident, dim3(tiles), dim3(256), 2 * STAGE, s, d.A, d.B, d.C, M, N, K);
+  hipLaunchKernelGGL(gemm_bf16_resident, dim3(tiles), dim3(256), NSTG * STAGE, s, d.A, d.B, d.C, M, N, K);
 }
 
 int main(int argc, char** argv) {
-  CK(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_resident), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE));
+  CK(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_resident), hipFuncAttributeMaxDynamicSharedMemorySize, NSTG * STAGE));
   const size_t maxA = (size_t)15360 * 2048 > (size_t)8192 * 8192 ? (size_t)15360 * 2048 : (size_t)8192 * 8192;
   const size_t maxB = std::max((size_t)10547 * 512, (size_t)8192 * 8192), maxC = std::max((size_t)5120 * 10547, (size_t)8192 * 8192);
   Buffers d;
