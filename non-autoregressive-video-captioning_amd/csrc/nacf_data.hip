@@ -211,7 +211,8 @@ int nacf_sample_frames(const float* src, const int32_t* video, const int32_t* sr
                        int mode, uint32_t salt, const uint64_t* rng_state, float* out, int32_t* frame_ids,
                        nacf_stream_t stream) {
   NACF_CHECK(src && out && B > 0 && T > 0 && D > 0 && n_frames > 0, NACF_EINVAL, "nacf_sample_frames: bad argument");
-  NACF_CHECK(mode == 0 || mode == 1, NACF_EINVAL, "nacf_sample_frames: mode must be 0 (equally_sampling) or 1 (segment_random)");
+  NACF_CHECK(mode >= 0 && mode <= 2, NACF_EINVAL,
+             "nacf_sample_frames: mode must be 0 (equally_sampling), 1 (segment_random) or 2 (all_random)");
   NACF_CHECK(!(mode == 1 && !rng_state), NACF_EINVAL, "nacf_sample_frames: segment_random needs rng_state");
   hipPointerAttribute_t attr;
   const bool host_src = hipPointerGetAttributes(&attr, src) == hipSuccess && attr.type == hipMemoryTypeHost;

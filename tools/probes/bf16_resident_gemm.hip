@@ -259,10 +259,20 @@ int main(int argc, char** argv) {
     std::vector<float> ms(reps);
     for (int i = 0; i < reps; ++i) CK(hipEventElapsedTime(&ms[i], ev[2 * i], ev[2 * i + 1]));
     std::sort(ms.begin(), ms.end());
+    // the same launches back to back between ONE pair of events: what a launch costs inside a stream of dependent kernels
+    // (a per-launch event pair adds the dispatch gap to every sample)
+    CK(hipEventRecord(ev[0], 0));
+    for (int i = 0; i < reps; ++i) launch(d, sh.M, sh.N, sh.K, 0);
+    CK(hipEventRecord(ev[1], 0));
+    CK(hipDeviceSynchronize());
+    float chain_ms = 0.f;
+    CK(hipEventElapsedTime(&chain_ms, ev[0], ev[1]));
+    const double chain_us = chain_ms * 1e3 / reps;
     const double med = ms[reps / 2], flops = 2.0 * sh.M * sh.N * sh.K;
     const int wgs = ((sh.M + BM - 1) / BM) * ((sh.N + BN - 1) / BN);
-    printf("%-22s %5d,%5d,%5d  %10.1f %10.1f %8.1f   %d workgroups, %.3f of 2500 TF\n", sh.name, sh.M, sh.N, sh.K, med * 1e3, ms[0] * 1e3,
-           flops / (med * 1e-3) / 1e12, wgs, flops / (med * 1e-3) / 2.5e15);
+    printf("%-22s %5d,%5d,%5d  %10.1f %10.1f %8.1f   %d workgroups, %.3f of 2500 TF | back to back %6.1f us = %6.1f TF (%.3f)\n", sh.name, sh.M, sh.N,
+           sh.K, med * 1e3, ms[0] * 1e3, flops / (med * 1e-3) / 1e12, wgs, flops / (med * 1e-3) / 2.5e15, chain_us,
+           flops / (chain_us * 1e-6) / 1e12, flops / (chain_us * 1e-6) / 2.5e15);
   }
   return 0;
 }
