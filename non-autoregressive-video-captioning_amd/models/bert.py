@@ -23,8 +23,8 @@ import torch.nn as nn
 from ..config import Constants
 from ..runtime import lib as L
 from ..runtime import ops
-from ..runtime.functional import (CrossAttentionFn, EmbedLNFn, LayerNormFn, LinearFn, Pack, QKVAttentionFn,
-                                  SelfAttentionFn)
+from ..runtime.functional import (CrossAttentionFn, EmbedLNFn, EmbedLNTableFn, LayerNormFn, LinearFn, Pack,
+                                  QKVAttentionFn, SelfAttentionFn)
 
 
 class BertEmbeddings(nn.Module):
@@ -32,9 +32,13 @@ class BertEmbeddings(nn.Module):
 
     def __init__(self, config):
         super().__init__()
-        if getattr(config, 'load_word_embeddings', False):
-            raise NotImplementedError('nacf_amd: load_word_embeddings (768-d projected embeddings) is not built')
-        self.word_embeddings = nn.Embedding(config.vocab_size, config.dim_hidden, padding_idx=Constants.PAD)
+        # load_word_embeddings (bert.py:51-53): a 768-wide table (e.g. pretrained word vectors) and its projection
+        self.projected = bool(getattr(config, 'load_word_embeddings', False))
+        if self.projected:
+            self.word_embeddings = nn.Embedding(config.vocab_size, 768, padding_idx=Constants.PAD)
+            self.word_embeddings_prj = nn.Linear(768, config.dim_hidden)
+        else:
+            self.word_embeddings = nn.Embedding(config.vocab_size, config.dim_hidden, padding_idx=Constants.PAD)
         self.position_embeddings = nn.Embedding(config.max_len, config.dim_hidden)
         self.category_embeddings = nn.Embedding(config.num_category, config.dim_hidden) if config.with_category else None
         self.LayerNorm = nn.LayerNorm(config.dim_hidden, eps=config.layer_norm_eps)
@@ -44,7 +48,10 @@ class BertEmbeddings(nn.Module):
         self.eps = config.layer_norm_eps
 
     def nacf_groups(self):
-        g = [[self.word_embeddings.weight], [self.position_embeddings.weight]]
+        g = [[self.word_embeddings.weight]]
+        if self.projected:
+            g += [[self.word_embeddings_prj.weight], [self.word_embeddings_prj.bias]]
+        g.append([self.position_embeddings.weight])
         if self.category_embeddings is not None:
             g.append([self.category_embeddings.weight])
         g += [[self.LayerNorm.weight], [self.LayerNorm.bias]]
@@ -62,6 +69,8 @@ class BertEmbeddings(nn.Module):
         if self.pos_LN is not None:
             self._ln_pos = flat.pack([self.pos_LN.weight], [self.pos_LN.bias])
             self._salt_pos = rt.next_salt()
+        if self.projected:
+            self._prj = flat.pack([self.word_embeddings_prj.weight], [self.word_embeddings_prj.bias], image='both')
         self._params = [p for p in self.parameters()]
 
     def run_pos(self, R, Lq, training, device):
@@ -75,6 +84,10 @@ class BertEmbeddings(nn.Module):
         if self.category_embeddings is not None:
             assert category is not None, 'with_category models need `category`'
             category = category.reshape(-1).contiguous()
+        if self.projected:
+            # rows of the PROJECTED table are looked up: one [V, 768] x [768, D] GEMM per call instead of one over every token
+            table = LinearFn.apply(self.word_embeddings.weight, None, dict(pack=self._prj), *self._params)
+            return EmbedLNTableFn.apply(additional, table, cfg, tokens, category, *self._params)
         return EmbedLNFn.apply(additional, cfg, tokens, category, *self._params)
 
 

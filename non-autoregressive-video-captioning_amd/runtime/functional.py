@@ -345,44 +345,74 @@ class LengthHeadFn(Function):
 
 
 # ---------------------------------------------------------------- decoder
+def _embed_ln_forward(ctx, additional, cfg, tokens, category, word_w):
+    R, Lq = tokens.shape
+    pos, cat = cfg["pos"], cfg["cat"]
+    D = word_w.shape[1]
+    training = cfg["training"]
+    out = _new((R, Lq, D), word_w)
+    xhat = _new((R * Lq, D), word_w) if training else None
+    rstd = _new((R * Lq,), word_w) if training else None
+    p = cfg["p"] if training else 0.0
+    add = additional.contiguous() if additional is not None else None
+    ops.embed_ln_fwd(tokens, category if cat is not None else None, add, word_w, pos.w,
+                     cat.w if cat is not None else None, cfg["ln"].w, cfg["ln"].b, out, xhat, rstd,
+                     cfg["vdiv"], cfg["vmod"], cfg["eps"], p, cfg["salt"], cfg["rng"])
+    ctx.cfg, ctx.p = cfg, p
+    ctx.tokens, ctx.category, ctx.xhat, ctx.rstd = tokens, category, xhat, rstd
+    ctx.n_video = additional.shape[0] if additional is not None else 0
+    return out
+
+
+def _embed_ln_backward(ctx, dout, V, D, word_gw, want_dadd):
+    cfg = ctx.cfg
+    pos, cat, ln = cfg["pos"], cfg["cat"], cfg["ln"]
+    R, Lq = ctx.tokens.shape
+    dE = _new((R * Lq, D), dout)
+    ops.embed_ln_bwd(dout.contiguous(), ctx.xhat, ctx.rstd, ln.w, dE, ln.gw, ln.gb, R, Lq, D, ctx.p,
+                     cfg["salt"], cfg["rng"], beta=1.0)
+    dadd = _new((ctx.n_video, D), dout) if (ctx.n_video and want_dadd) else None
+    ops.embed_scatter_bwd(dE, ctx.tokens, ctx.category if cat is not None else None, word_gw, pos.gw,
+                          cat.gw if cat is not None else None, dadd, R, Lq, D, V,
+                          cat.w.shape[0] if cat is not None else 0, cfg["vmod"], cfg["vdiv"], cfg["vmod"])
+    ctx.xhat = ctx.rstd = None
+    return dadd
+
+
 class EmbedLNFn(Function):
     """BertEmbeddings, models/bert.py:70-96."""
 
     @staticmethod
     def forward(ctx, additional, cfg, tokens, category, *params):
-        R, Lq = tokens.shape
-        word, pos, cat = cfg["word"], cfg["pos"], cfg["cat"]
-        D = word.w.shape[1]
-        training = cfg["training"]
-        out = _new((R, Lq, D), word.w)
-        xhat = _new((R * Lq, D), word.w) if training else None
-        rstd = _new((R * Lq,), word.w) if training else None
-        p = cfg["p"] if training else 0.0
-        add = additional.contiguous() if additional is not None else None
-        ops.embed_ln_fwd(tokens, category if cat is not None else None, add, word.w, pos.w,
-                         cat.w if cat is not None else None, cfg["ln"].w, cfg["ln"].b, out, xhat, rstd,
-                         cfg["vdiv"], cfg["vmod"], cfg["eps"], p, cfg["salt"], cfg["rng"])
-        ctx.cfg, ctx.p = cfg, p
-        ctx.tokens, ctx.category, ctx.xhat, ctx.rstd = tokens, category, xhat, rstd
-        ctx.n_video = additional.shape[0] if additional is not None else 0
-        return out
+        return _embed_ln_forward(ctx, additional, cfg, tokens, category, cfg["word"].w)
 
     @staticmethod
     def backward(ctx, dout):
-        cfg = ctx.cfg
-        word, pos, cat, ln = cfg["word"], cfg["pos"], cfg["cat"], cfg["ln"]
-        R, Lq = ctx.tokens.shape
-        D = word.w.shape[1]
-        dE = _new((R * Lq, D), dout)
-        ops.embed_ln_bwd(dout.contiguous(), ctx.xhat, ctx.rstd, ln.w, dE, ln.gw, ln.gb, R, Lq, D, ctx.p,
-                         cfg["salt"], cfg["rng"], beta=1.0)
-        dadd = _new((ctx.n_video, D), dout) if (ctx.n_video and ctx.needs_input_grad[0]) else None
-        ops.embed_scatter_bwd(dE, ctx.tokens, ctx.category if cat is not None else None,
-                              word.gw if cfg.get("train_word", True) else None, pos.gw,
-                              cat.gw if cat is not None else None, dadd, R, Lq, D, word.w.shape[0],
-                              cat.w.shape[0] if cat is not None else 0, cfg["vmod"], cfg["vdiv"], cfg["vmod"])
-        ctx.xhat = ctx.rstd = None
+        word = ctx.cfg["word"]
+        dadd = _embed_ln_backward(ctx, dout, word.w.shape[0], word.w.shape[1],
+                                  word.gw if ctx.cfg.get("train_word", True) else None, ctx.needs_input_grad[0])
         return (dadd, None, None, None) + (None,) * (len(ctx.needs_input_grad) - 4)
+
+
+class EmbedLNTableFn(Function):
+    """BertEmbeddings over a word table that is itself a computed tensor: opt['load_word_embeddings'] (models/bert.py:51-53,
+    77-79) looks 768-wide rows up and projects them to dim_hidden, i.e. it looks up rows of
+    `table = word_embeddings.weight @ prj.weight^T + prj.bias` ([V, D], one GEMM over the vocabulary instead of one over
+    every token; the <pad> row of the 768-wide table is zero, so table[<pad>] = prj.bias as upstream).  The gradient of the
+    table ([V, D]: the deterministic scatter of models' dE, <pad> row untouched = 0, as nn.Embedding's padding_idx leaves
+    it) goes back through autograd to the projection's LinearFn."""
+
+    @staticmethod
+    def forward(ctx, additional, table, cfg, tokens, category, *params):
+        ctx.table_shape = tuple(table.shape)
+        return _embed_ln_forward(ctx, additional, cfg, tokens, category, table.contiguous())
+
+    @staticmethod
+    def backward(ctx, dout):
+        V, D = ctx.table_shape
+        dtable = torch.zeros(V, D, dtype=dout.dtype, device=dout.device) if ctx.needs_input_grad[1] else None
+        dadd = _embed_ln_backward(ctx, dout, V, D, dtable, ctx.needs_input_grad[0])
+        return (dadd, dtable, None, None, None) + (None,) * (len(ctx.needs_input_grad) - 5)
 
 
 class LinearFn(Function):

@@ -49,7 +49,11 @@ def param_shapes(opt: dict) -> Dict[str, Tuple[int, ...]]:
         sh[n + "0.weight"] = (d, d); sh[n + "0.bias"] = (d,)
         sh[n + "3.weight"] = (ml, d); sh[n + "3.bias"] = (ml,)
     p = decoder_prefix(opt)
-    sh[p + "embedding.word_embeddings.weight"] = (V, d)
+    if opt.get("load_word_embeddings", False):       # models/bert.py:51-53: a 768-wide table and its projection
+        sh[p + "embedding.word_embeddings.weight"] = (V, 768)
+        sh[p + "embedding.word_embeddings_prj.weight"] = (d, 768); sh[p + "embedding.word_embeddings_prj.bias"] = (d,)
+    else:
+        sh[p + "embedding.word_embeddings.weight"] = (V, d)
     sh[p + "embedding.position_embeddings.weight"] = (ml, d)
     if opt["with_category"]:
         sh[p + "embedding.category_embeddings.weight"] = (opt["num_category"], d)

@@ -711,6 +711,9 @@ def main():
     if os.environ.get("ONLY_GOLDLEN"):
         goldlen_case()
         return
+    if os.environ.get("ONLY_LWE"):
+        train_case("tiny_nacf_lwe_train", "NACF", ["-wc"], V=101, B=3, F_=6, override={"load_word_embeddings": True})
+        return
     if os.environ.get("ONLY_WATCH"):
         train_case("tiny_arb_watch_train", "ARB", ["-wc", "--watch", "3"], V=101, B=3, F_=6)
         ar_case("tiny_arb_watch_beam", "ARB", ["-wc", "--watch", "3"], V=101, B=4, F_=6, beam_size=3, topk=1, alpha=1.0,
@@ -740,6 +743,8 @@ def main():
     train_case("tiny_nacf_pmlm_train", "NACF", ["-wc"], V=101, B=3, F_=6, override={"parallel_mlm": True})
     train_case("tiny_nab_pmlm_ln_train", "NAB", ["--with_layernorm"], V=101, B=3, F_=6, dataset="Youtube2Text", beta=(0.0, 1.0),
                override={"parallel_mlm": True})
+    # opt['load_word_embeddings'] = True (models/bert.py:51-53,77-79): a 768-wide word table and its projection to dim_hidden
+    train_case("tiny_nacf_lwe_train", "NACF", ["-wc"], V=101, B=3, F_=6, override={"load_word_embeddings": True})
     # --watch 3 (opts.py:32): AR self-attention sees the last three tokens only (models/Decoder.py:23-39)
     train_case("tiny_arb_watch_train", "ARB", ["-wc", "--watch", "3"], V=101, B=3, F_=6)
     ar_case("tiny_arb_watch_beam", "ARB", ["-wc", "--watch", "3"], V=101, B=4, F_=6, beam_size=3, topk=1, alpha=1.0,

@@ -47,7 +47,7 @@ DEFAULT_OPT = dict(  # opts.py:23-50,116-129 (defaults that shape the model)
     no_encoder_bn=False, norm_type="bn", tie_weights=False,
     fusion="temporal_concat", crit=["lang"], nv_weights=[0.8, 1.0],
     visual_word_generation=False, decoding_type="ARFormer",
-    decoder="BertDecoder", encoder="Encoder_HighWay", gate=True, parallel_mlm=False,
+    decoder="BertDecoder", encoder="Encoder_HighWay", gate=True, parallel_mlm=False, load_word_embeddings=False,
 )
 
 
@@ -172,8 +172,10 @@ def embeddings(sd: SD, pfx: str, opt: dict, ids: Tensor, category: Optional[Tens
     """BertEmbeddings.forward, models/bert.py:70-108 (return_pos: also the normalised position embeddings, :97-108)."""
     L = ids.shape[1]
     # nn.Embedding(padding_idx=PAD): the PAD row never receives gradient from the lookup (bert.py:53-56)
-    e = F.embedding(ids, sd[pfx + "embedding.word_embeddings.weight"], padding_idx=PAD) \
-        + sd[pfx + "embedding.position_embeddings.weight"][:L].unsqueeze(0)
+    e = F.embedding(ids, sd[pfx + "embedding.word_embeddings.weight"], padding_idx=PAD)
+    if opt.get("load_word_embeddings", False):                          # bert.py:51-53,77-79: 768-wide rows, projected
+        e = F.linear(e, sd[pfx + "embedding.word_embeddings_prj.weight"], sd[pfx + "embedding.word_embeddings_prj.bias"])
+    e = e + sd[pfx + "embedding.position_embeddings.weight"][:L].unsqueeze(0)
     if opt["with_category"]:
         e = e + sd[pfx + "embedding.category_embeddings.weight"][category.reshape(-1)].unsqueeze(1)
     if additional is not None:

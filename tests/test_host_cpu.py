@@ -52,7 +52,7 @@ def test_method_overlays_match_reference_flags():
         nacf_amd.get_model(dict(o, vocab_size=10, decoder="Nope"))
 
 
-@pytest.mark.parametrize("name", ["tiny_nacf_train", "tiny_nab_train", "tiny_arb2_train", "tiny_arb_train", "tiny_arb_watch_train", "tiny_nab_nogate_train", "tiny_nacf_pmlm_train", "tiny_nab_pmlm_ln_train",
+@pytest.mark.parametrize("name", ["tiny_nacf_train", "tiny_nab_train", "tiny_arb2_train", "tiny_arb_train", "tiny_arb_watch_train", "tiny_nab_nogate_train", "tiny_nacf_pmlm_train", "tiny_nab_pmlm_ln_train", "tiny_nacf_lwe_train",
                                   "tiny_nab_variants_train", "tiny_nacf_ln_train", "tiny_nacf_pos_train", "tiny_nacf_pos_ln_train"])
 def test_state_dict_contract_and_flat_layout(name):
     g = load_gold(name)
