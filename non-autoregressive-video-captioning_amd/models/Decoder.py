@@ -112,7 +112,7 @@ class BertDecoder(nn.Module):
         pos2 = None
         if self.pos_attention:      # Decoder.py:144-146: the embedding gets no additional features in this mode
             additional = None
-            pos2 = self.embedding.run_pos(R, Lq, training, tgt_seq.device)
+            pos2 = self.embedding.run_pos(tgt_seq, training)
         hidden = self.embedding.run(tgt_seq, category, additional, vdiv, vmod, training)
         memory_kv = kwargs.get('memory_kv')
         # live-row list of the [R, L] slot grid: by default every non-<pad> slot of tgt_seq; the NA

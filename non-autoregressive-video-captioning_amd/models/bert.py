@@ -24,7 +24,7 @@ from ..config import Constants
 from ..runtime import lib as L
 from ..runtime import ops
 from ..runtime.functional import (CrossAttentionFn, EmbedLNFn, EmbedLNTableFn, LayerNormFn, LinearFn, Pack,
-                                  QKVAttentionFn, SelfAttentionFn)
+                                  PositionRowsFn, ProjectTableFn, QKVAttentionFn, SelfAttentionFn)
 
 
 class BertEmbeddings(nn.Module):
@@ -73,10 +73,11 @@ class BertEmbeddings(nn.Module):
             self._prj = flat.pack([self.word_embeddings_prj.weight], [self.word_embeddings_prj.bias], image='both')
         self._params = [p for p in self.parameters()]
 
-    def run_pos(self, R, Lq, training, device):
+    def run_pos(self, tokens, training):
         """pos_dropout(pos_LN(position_embeddings)) for every slot: [R*Lq, D]  (bert.py:105)"""
-        rows = self.position_embeddings.weight[:Lq].repeat(R, 1)
-        cfg = dict(ln=self._ln_pos, eps=self.eps, p=self.p, salt=self._salt_pos, rng=self._rt.rng(device), training=training)
+        rows = PositionRowsFn.apply(dict(pos=self._cfg['pos']), tokens, *self._params)
+        cfg = dict(ln=self._ln_pos, eps=self.eps, p=self.p, salt=self._salt_pos, rng=self._rt.rng(tokens.device),
+                   training=training)
         return LayerNormFn.apply(rows, cfg, *self._params)
 
     def run(self, tokens, category, additional, vdiv, vmod, training):
@@ -86,7 +87,8 @@ class BertEmbeddings(nn.Module):
             category = category.reshape(-1).contiguous()
         if self.projected:
             # rows of the PROJECTED table are looked up: one [V, 768] x [768, D] GEMM per call instead of one over every token
-            table = LinearFn.apply(self.word_embeddings.weight, None, dict(pack=self._prj), *self._params)
+            table = ProjectTableFn.apply(dict(table=self._cfg['word'], pack=self._prj, train_word=self._cfg['train_word']),
+                                         *self._params)
             return EmbedLNTableFn.apply(additional, table, cfg, tokens, category, *self._params)
         return EmbedLNFn.apply(additional, cfg, tokens, category, *self._params)
 

@@ -415,6 +415,52 @@ class EmbedLNTableFn(Function):
         return (dadd, dtable, None, None, None) + (None,) * (len(ctx.needs_input_grad) - 5)
 
 
+class ProjectTableFn(Function):
+    """table = word_embeddings.weight @ prj.weight^T + prj.bias  ([V, D]; opt['load_word_embeddings'], models/bert.py:51-53,
+    77-79).  Like every other node of this runtime it writes its parameter gradients straight into the flat gradient buffer
+    (cfg['table'].gw, cfg['pack'].gw / .gb) instead of handing them to autograd's accumulation nodes, which the captured
+    training step does not go through."""
+
+    @staticmethod
+    def forward(ctx, cfg, *params):
+        table, prj = cfg["table"], cfg["pack"]
+        out = _new((table.w.shape[0], prj.w.shape[0]), table.w)
+        ops.linear_fwd(table.w, prj.w, out, ops.Epi(bias=prj.b))
+        ctx.cfg = cfg
+        return out
+
+    @staticmethod
+    def backward(ctx, dtable):
+        table, prj = ctx.cfg["table"], ctx.cfg["pack"]
+        dtable = dtable.contiguous()
+        if table.gw is not None and ctx.cfg.get("train_word", True):
+            ops.linear_bwd_data(dtable, prj.w, table.gw, beta=1.0)          # <pad> row of dtable is zero: so is its gradient row
+        if prj.gw is not None:
+            ops.linear_bwd_weight(dtable, table.w, prj.gw, prj.gb, beta=1.0)
+        return (None,) * len(ctx.needs_input_grad)
+
+
+class PositionRowsFn(Function):
+    """position_embeddings.weight[:Lq] repeated for R sequences: [R * Lq, D] (the input of pos_LN, models/bert.py:97-105).
+    Backward sums the R copies into the table's rows of the flat gradient buffer (the position part of the embedding
+    scatter: fixed summation order), not through autograd's accumulation nodes (see ProjectTableFn)."""
+
+    @staticmethod
+    def forward(ctx, cfg, tokens, *params):
+        R, Lq = tokens.shape
+        ctx.cfg, ctx.tokens = cfg, tokens
+        return cfg["pos"].w[:Lq].repeat(R, 1)
+
+    @staticmethod
+    def backward(ctx, drows):
+        pos = ctx.cfg["pos"]
+        R, Lq = ctx.tokens.shape
+        D = pos.w.shape[1]
+        if pos.gw is not None:
+            ops.embed_scatter_bwd(drows.contiguous(), ctx.tokens, None, None, pos.gw, None, None, R, Lq, D, 0, 0, 0, 1, 1)
+        return (None,) * len(ctx.needs_input_grad)
+
+
 class LinearFn(Function):
     """nn.Linear with the fused epilogue of nacf_linear_fwd.
     cfg keys: pack, act, p1, salt1, p2, salt2, row_tokens, rng, training."""

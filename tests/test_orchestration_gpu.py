@@ -106,6 +106,40 @@ def test_engine_replay_equals_launch_by_launch_with_dropout(dev):
     assert out["on"][1][0] != out["on"][1][6 + 1]        # same batch, different dropout draw: the Philox state advanced
 
 
+@pytest.mark.parametrize("extra", [dict(load_word_embeddings=True), dict(parallel_mlm=True),
+                                   dict(pos_attention=True, with_layernorm=True), dict(pos_attention=True), dict(with_layernorm=True)])
+def test_engine_replay_equals_launch_by_launch_for_the_option_variants(dev, extra):
+    """the option variants added in round 3 run under the captured step exactly as launch by launch (the projected word table's
+    gradient is a fresh zero-filled tensor inside the captured backward; its projection's dX goes through autograd)"""
+    from nacf_amd import synthetic as S
+    from nacf_amd.misc.crit import get_criterion
+    from nacf_amd.misc.optim import get_optimizer
+    from nacf_amd.misc.run import get_forword_results
+    from nacf_amd.runtime.engine import TrainStep
+    import nacf_amd
+    g = load_gold("tiny_nacf_trajectory")
+    opt = dict(gold_opt(g), hidden_dropout_prob=0.5, encoder_dropout=0.5, fused_loss=True, **extra)
+    batches = _gold_batches(g, dev)
+    out = {}
+    for graph in ("off", "on"):
+        model = nacf_amd.get_model(opt)
+        model.load_state_dict(S.init_state_dict(opt, seed=0))
+        model.to(dev).train()
+        crit, optim = get_criterion(model.opt), get_optimizer(model.opt, model)
+        engine = TrainStep(model, crit, optim, lambda b, m=model: get_forword_results(m.opt, m, b, dev), graph=graph)
+        losses = []
+        for b in batches + batches[:2]:
+            engine(b)
+            losses.append(float(engine.loss))
+        out[graph] = (model.flat.data.clone(), losses)
+        assert engine.captured == (graph == "on")
+    assert out["on"][1] == out["off"][1] and all(l == l for l in out["on"][1])
+    assert torch.equal(out["on"][0], out["off"][0])
+    start = S.init_state_dict(opt, seed=0)
+    key = [k for k in start if k.endswith("word_embeddings.weight")][0]
+    assert not torch.equal(model.state_dict()[key].cpu(), start[key])          # the word table trained
+
+
 def _write_corpus(tmp, n_videos=40, V=60, L=10, T=20, Dm=32, seed=0):
     """a corpus in the reference's on-disk layout (info_corpus pickle: prepare_corpora.py:38-60; refs pickle) whose
     captions are a deterministic function of the clip's features, so a few epochs of training learn something"""
