@@ -107,9 +107,11 @@ def test_engine_replay_equals_launch_by_launch_with_dropout(dev):
 
 
 @pytest.mark.parametrize("extra", [dict(load_word_embeddings=True), dict(parallel_mlm=True),
-                                   dict(pos_attention=True, with_layernorm=True), dict(pos_attention=True), dict(with_layernorm=True)])
+                                   dict(pos_attention=True, with_layernorm=True), dict(pos_attention=True), dict(with_layernorm=True),
+                                   dict(gate=False), dict(tie_weights=True), dict(enhance_input=0, no_encoder_bn=True),
+                                   dict(norm_type="ln", num_hidden_layers_decoder=2, hidden_act="gelu")])
 def test_engine_replay_equals_launch_by_launch_for_the_option_variants(dev, extra):
-    """the option variants added in round 3 run under the captured step exactly as launch by launch (the projected word table's
+    """the option variants (round 3's and the older ones) run under the captured step exactly as launch by launch (the projected word table's
     gradient is a fresh zero-filled tensor inside the captured backward; its projection's dX goes through autograd)"""
     from nacf_amd import synthetic as S
     from nacf_amd.misc.crit import get_criterion
