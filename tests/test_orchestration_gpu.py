@@ -142,6 +142,47 @@ def test_engine_replay_equals_launch_by_launch_for_the_option_variants(dev, extr
     assert not torch.equal(model.state_dict()[key].cpu(), start[key])          # the word table trained
 
 
+@pytest.mark.parametrize("name", ["tiny_arb_train", "tiny_arb2_train", "tiny_arb_watch_train", "tiny_nab_train",
+                                  "tiny_nab_nogate_train", "tiny_nab_variants_train"])
+def test_engine_replay_equals_launch_by_launch_for_the_other_methods(dev, name):
+    """ARB / ARB2 (causal self-attention, one pass), --watch, NAB (no category, no visual-word pass): the captured step equals the
+    launch-by-launch step, with dropout on, on the batch of the method's reference fixture"""
+    import nacf_amd
+    from nacf_amd import synthetic as S
+    from nacf_amd.misc.crit import get_criterion
+    from nacf_amd.misc.optim import get_optimizer
+    from nacf_amd.misc.run import get_forword_results
+    from nacf_amd.runtime.engine import TrainStep
+    from util import gold_batch
+    g = load_gold(name)
+    opt = dict(gold_opt(g), hidden_dropout_prob=0.5, encoder_dropout=0.5, fused_loss=True)
+    b = gold_batch(g, dev)
+    batch = {k: v for k, v in b.items() if k in ("feats", "tokens", "tokens_1", "labels", "labels_1", "category")}
+    if "tgt_length" in b:
+        batch["length_target"] = b["tgt_length"]
+    if opt["decoding_type"] == "ARFormer" and batch["labels"].shape[1] == batch["tokens"].shape[1] - 1:
+        # the fixture stores the labels the criterion sees; the training loop cuts the <bos> column itself (run.py:65-69)
+        for k in ("labels", "labels_1"):
+            if k in batch:
+                batch[k] = torch.cat([torch.zeros_like(batch[k][:, :1]), batch[k]], 1)
+    out = {}
+    for graph in ("off", "on"):
+        model = nacf_amd.get_model(opt)
+        model.load_state_dict(S.init_state_dict(opt, seed=0))
+        model.to(dev).train()
+        crit, optim = get_criterion(model.opt), get_optimizer(model.opt, model)
+        engine = TrainStep(model, crit, optim, lambda bb, m=model: get_forword_results(m.opt, m, bb, dev), graph=graph)
+        losses = []
+        for _ in range(5):
+            engine(batch)
+            losses.append(float(engine.loss))
+        out[graph] = (model.flat.data.clone(), losses)
+        assert engine.captured == (graph == "on")
+    assert out["on"][1] == out["off"][1] and all(l == l for l in out["on"][1])
+    assert torch.equal(out["on"][0], out["off"][0])
+    assert len(set(out["on"][1])) == 5          # five different dropout draws and weights
+
+
 def _write_corpus(tmp, n_videos=40, V=60, L=10, T=20, Dm=32, seed=0):
     """a corpus in the reference's on-disk layout (info_corpus pickle: prepare_corpora.py:38-60; refs pickle) whose
     captions are a deterministic function of the clip's features, so a few epochs of training learn something"""
