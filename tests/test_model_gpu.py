@@ -151,6 +151,28 @@ def test_na_decode_tokens_bit_exact_vs_reference_golden(dev, name, graph, tile, 
         assert maxerr(it_prob, t(g[v + ".iter_probs"])) < 2e-5, v
 
 
+@pytest.mark.parametrize("extra", [dict(load_word_embeddings=True), dict(parallel_mlm=True), dict(pos_attention=True),
+                                   dict(with_layernorm=True), dict(pos_attention=True, with_layernorm=True),
+                                   dict(num_hidden_layers_decoder=2, enhance_input=0)])
+def test_na_decode_graph_replay_equals_launch_by_launch_for_the_option_variants(dev, extra):
+    """mask-predict with coarse templates, easy-first and left-to-right of option-variant models: the one-graph replay returns
+    what the launch-by-launch loop returns (tokens, per-iteration tokens; probabilities bit for bit)"""
+    g = load_gold("tiny_nacf_decode")
+    opt = dict(gold_opt(g), **extra)
+    b = gold_batch(g, dev)
+    model = build(opt, O.init_state_dict(opt, seed=3), dev)
+    model.eval()
+    for v in ("mp_ct", "mp", "ef_ct", "l2r_q2"):
+        dec = gold_json(g, v + ".dec_json")
+        outs = {}
+        for graph in ("off", "on"):
+            _, hyp, (it_tok, it_prob) = _run_decode(model, dec, b, dev, graph=graph)
+            outs[graph] = (hyp, it_tok, it_prob)
+        assert torch.equal(outs["on"][0], outs["off"][0]), v
+        assert torch.equal(outs["on"][1], outs["off"][1]) and torch.equal(outs["on"][2], outs["off"][2]), v
+        assert int(outs["on"][0].ne(0).sum()) > 0
+
+
 def test_na_decode_with_ar_teacher_rescoring(dev):
     g = load_gold("tiny_nacf_teacher")
     opt, t_opt = gold_opt(g), gold_opt(g, "teacher_opt_json")
