@@ -168,19 +168,18 @@ __device__ __forceinline__ void softmax_rows(f32x4 (&s)[2][NKT], float sq, const
   }
 }
 
+// One item = (sequence, head, block of 32 queries), the work of one wave; nqb = ceil(Lq / 32) > 1 only without a causal mask.
+// Shared by fwd_kernel (one item per wave of the grid) and by the chain kernel (gemm_bf16_chain.hpp: a persistent workgroup's
+// waves walk the items of an attention stage).
 template <int NKT, int DK16>
-__global__ __launch_bounds__(256) void fwd_kernel(const float* __restrict__ Q, int64_t ldq, const float* __restrict__ K,
-                                                   int64_t ldk, const float* __restrict__ V, int64_t ldv,
-                                                   float* __restrict__ O, int64_t ldo,
-                                                   const int64_t* __restrict__ key_tokens, int causal,
-                                                   float* __restrict__ probs, int R, int H, int Lq, int Lk, int kv_div,
-                                                   int kv_mod, int nqb) {
-  // item = (sequence, head, block of 32 queries); nqb = ceil(Lq / 32) > 1 only without a causal mask.  The blocks of
-  // one (sequence, head) are consecutive items, i.e. waves of ONE workgroup: they walk the same K / V rows together.
+__device__ __forceinline__ void fwd_item(const int item, const float* __restrict__ Q, int64_t ldq, const float* __restrict__ K,
+                                         int64_t ldk, const float* __restrict__ V, int64_t ldv,
+                                         float* __restrict__ O, int64_t ldo,
+                                         const int64_t* __restrict__ key_tokens, int causal,
+                                         float* __restrict__ probs, int R, int H, int Lq, int Lk, int kv_div,
+                                         int kv_mod, int nqb) {
   constexpr int DK = 16 * DK16;
   const int lane = threadIdx.x & 63;
-  const int item = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (item >= R * H * nqb) return;
   const int qb = item % nqb, rh = item / nqb;
   const int r = rh / H, h = rh % H;
   const int q0 = qb * 32;
@@ -222,6 +221,19 @@ __global__ __launch_bounds__(256) void fwd_kernel(const float* __restrict__ Q, i
     for (int td = 0; td < DK16; ++td) o[tm][td] = f32x4{0.f, 0.f, 0.f, 0.f};
   contract_key<NKT, DK16>(o, s, Vb, ldv, Lk, i, g);
   store_rows<DK16>(o, O + ((int64_t)r * Lq + q0) * ldo + h * DK, ldo, nq, i, g);
+}
+
+template <int NKT, int DK16>
+__global__ __launch_bounds__(256) void fwd_kernel(const float* __restrict__ Q, int64_t ldq, const float* __restrict__ K,
+                                                   int64_t ldk, const float* __restrict__ V, int64_t ldv,
+                                                   float* __restrict__ O, int64_t ldo,
+                                                   const int64_t* __restrict__ key_tokens, int causal,
+                                                   float* __restrict__ probs, int R, int H, int Lq, int Lk, int kv_div,
+                                                   int kv_mod, int nqb) {
+  // The blocks of one (sequence, head) are consecutive items, i.e. waves of ONE workgroup: they walk the same K / V rows together.
+  const int item = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (item >= R * H * nqb) return;
+  fwd_item<NKT, DK16>(item, Q, ldq, K, ldk, V, ldv, O, ldo, key_tokens, causal, probs, R, H, Lq, Lk, kv_div, kv_mod, nqb);
 }
 
 // dst[key][d] (+)= sum_q T[q][key] * A[q][d]  for key tiles [tk0, tk0+TKC), T = wave-private LDS tile [32][PITCH]
@@ -610,18 +622,18 @@ __global__ __launch_bounds__(256, KB_WGS) void bwd_kb_kernel(const float* __rest
 // of a video -- taking every MFMA operand from LDS.  Same contractions, same softmax, same accumulation order per
 // query row as fwd_kernel: the results are bit-identical.
 constexpr int FL_PITCH = 68;
+// the work of one workgroup for one (memory row set kvr, head h); smem: 2 x 128 x FL_PITCH floats.  Shared by fwd_lds_kernel
+// and the chain kernel (gemm_bf16_chain.hpp), whose persistent workgroups walk several items (barrier before the next copy).
 template <int DK16>
-__global__ __launch_bounds__(256, 2) void fwd_lds_kernel(const float* __restrict__ Q, int64_t ldq, const float* __restrict__ K,
-                                                          int64_t ldk, const float* __restrict__ V, int64_t ldv,
-                                                          float* __restrict__ O, int64_t ldo, int R, int n_kv, int H, int Lq,
-                                                          int Lk, int kv_div, int kv_mod, int rounds) {
+__device__ __forceinline__ void fwd_lds_item(const int item, float* const smem, const float* __restrict__ Q, int64_t ldq,
+                                             const float* __restrict__ K, int64_t ldk, const float* __restrict__ V, int64_t ldv,
+                                             float* __restrict__ O, int64_t ldo, int R, int H, int Lq, int Lk, int kv_div,
+                                             int kv_mod, int rounds) {
   constexpr int DK = 16 * DK16;
   constexpr int NKT = 8;
-  extern __shared__ __attribute__((aligned(16))) float smem[];
   float* Ks = smem;                               // [128][FL_PITCH], rows >= Lk are never read as live keys
   float* Vs = smem + 128 * FL_PITCH;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int item = blockIdx.x;
   const int kvr = item / H, h = item % H;
   const int i = lane & 15, g = lane >> 4;
   {
@@ -676,6 +688,15 @@ __global__ __launch_bounds__(256, 2) void fwd_lds_kernel(const float* __restrict
     contract_key<NKT, DK16>(o, sc, Vs, FL_PITCH, Lk, i, g);
     store_rows<DK16>(o, O + ((int64_t)r * Lq + q0) * ldo + h * DK, ldo, nq, i, g);
   }
+}
+
+template <int DK16>
+__global__ __launch_bounds__(256, 2) void fwd_lds_kernel(const float* __restrict__ Q, int64_t ldq, const float* __restrict__ K,
+                                                          int64_t ldk, const float* __restrict__ V, int64_t ldv,
+                                                          float* __restrict__ O, int64_t ldo, int R, int n_kv, int H, int Lq,
+                                                          int Lk, int kv_div, int kv_mod, int rounds) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  fwd_lds_item<DK16>((int)blockIdx.x, smem, Q, ldq, K, ldk, V, ldv, O, ldo, R, H, Lq, Lk, kv_div, kv_mod, rounds);
 }
 
 }  // namespace attn

@@ -65,7 +65,7 @@ template <int MT, int NT, int NS> struct Geo {
 __device__ unsigned long long* g_panel_trace = nullptr;
 #define PANEL_MARK(t, i) do { if (g_panel_trace && tid == 0) { g_panel_trace[(size_t)(t) * 8 + (i)] = __builtin_readcyclecounter(); \
   if ((i) == 0) { g_panel_trace[(size_t)(t) * 8 + 4] = __builtin_amdgcn_s_memrealtime(); g_panel_trace[(size_t)(t) * 8 + 6] = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (3 << 11)); \
-                  g_panel_trace[(size_t)(t) * 8 + 7] = blockIdx.x; } \
+                  g_panel_trace[(size_t)(t) * 8 + 7] = bx; } \
   if ((i) == 3) g_panel_trace[(size_t)(t) * 8 + 5] = __builtin_amdgcn_s_memrealtime(); } } while (0)
 #if PANEL_TRACE >= 2
 #define PANEL_STEP_T(var) const unsigned long long var = __builtin_readcyclecounter()
@@ -108,19 +108,22 @@ template <int I> using IC = std::integral_constant<int, I>;
 template <class F, int... I>
 __device__ __forceinline__ void for_each_ic(F&& f, std::integer_sequence<int, I...>) { (f(IC<I>{}), ...); }
 
-// gridDim.x workgroups (one per CU; a multiple of 8 so that blockIdx & 7 is the XCD), gridDim.z reduce splits.
+// The kernel body, for workgroup `bx` of `Gx` (one per CU; Gx a multiple of 8 so that bx & 7 is the XCD) and reduce split z:
+// shared by the one-GEMM kernel below and by the chain kernel (gemm_bf16_chain.hpp), which walks a LIST of such problems.
 // g.tiles_n = N / BN column blocks; the reduce range of a split is a multiple of 256, >= 512.
+// Every fixed register the body names (a0..a223) is dead on entry and on return: the `panel_state_dead` markers tell
+// tools/check_wide_hazards.py so (a caller may run compiler-allocated code -- the chain kernel's attention stages -- between two calls).
 template <int MT, int NT, int NS, class Epi>
-__global__ __launch_bounds__(256, 1) void gemm_panel_kernel(GemmShape g, Epi epi) {
+__device__ __forceinline__ void panel_body(const GemmShape& g, const Epi& epi, const int bx, const int Gx, const int z,
+                                           unsigned char* const smem_raw) {
   static_assert(NS == 3, "exact mode only (so far)");
   using G = Geo<MT, NT, NS>;
   constexpr int BM = G::BM, BN = G::BN, SLOT = G::SLOT, WAVE_LDS = G::WAVE_LDS, DREQ = G::DREQ, NTERM = G::NTERM;
   constexpr int NSLOT = G::NSLOT, NB = G::NB;
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l31 = lane & 31, lh = lane >> 5;
-  const int z = blockIdx.z;
+  asm volatile("s_nop 0 ; panel_state_dead" ::: "memory");
 
   int Meff = g.M;
   if (g.count) Meff = min(Meff, *g.count);
@@ -128,8 +131,7 @@ __global__ __launch_bounds__(256, 1) void gemm_panel_kernel(GemmShape g, Epi epi
   const int T = tiles_m_live * g.tiles_n;                  // live tiles, row panel fastest: t = tile_n * tiles_m_live + tile_m
   // workgroup b owns the tiles [T b' / G, T (b' + 1) / G) with b' = the XCD-major index of b: an XCD's workgroups walk a
   // contiguous eighth of the list, i.e. share a few column blocks of the weights (which every panel re-reads) in their L2
-  const int Gx = gridDim.x;
-  const int bq = ((Gx & 7) == 0) ? ((int)blockIdx.x & 7) * (Gx >> 3) + ((int)blockIdx.x >> 3) : (int)blockIdx.x;
+  const int bq = ((Gx & 7) == 0) ? (bx & 7) * (Gx >> 3) + (bx >> 3) : bx;
   const int t_beg = (int)((int64_t)bq * T / Gx), t_end = (int)((int64_t)(bq + 1) * T / Gx);
   const int kbeg = z * g.k_per_split;
   const int kend = min(g.K, kbeg + g.k_per_split);
@@ -144,7 +146,7 @@ __global__ __launch_bounds__(256, 1) void gemm_panel_kernel(GemmShape g, Epi epi
   auto zero_dead_rows = [&]() {
     if (g.zero_dead && g.rows && z == 0) {
       const int n_dead = g.M - Meff, n4 = (g.N + 3) / 4;
-      const int nw = (int)gridDim.x * 4, w0 = (int)blockIdx.x * 4 + wave;
+      const int nw = Gx * 4, w0 = bx * 4 + wave;
       for (int j = w0; j < n_dead; j += 4 * nw) {
         int ph[4];
 #pragma unroll
@@ -438,7 +440,7 @@ __global__ __launch_bounds__(256, 1) void gemm_panel_kernel(GemmShape g, Epi epi
       }
       PANEL_MARK(t_cur, 3);
 #if defined(PANEL_TRACE) && PANEL_TRACE >= 2
-      if (g_panel_trace && tid == 0 && t_cur + 1 >= t_end) for (int i = 0; i < 4; ++i) g_panel_trace[(size_t)(8192 + blockIdx.x) * 8 + i] = step_cyc[i];
+      if (g_panel_trace && tid == 0 && t_cur + 1 >= t_end) for (int i = 0; i < 4; ++i) g_panel_trace[(size_t)(8192 + bx) * 8 + i] = step_cyc[i];
 #endif
       if (t_cur + 1 >= t_end) break;
       // ---- the next tile becomes the current one
@@ -450,6 +452,13 @@ __global__ __launch_bounds__(256, 1) void gemm_panel_kernel(GemmShape g, Epi epi
     }
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");      // the repeats requested behind the last tile have landed
   }
+  asm volatile("s_nop 0 ; panel_state_dead" ::: "memory");
+}
 
+// one GEMM per launch: gridDim.x workgroups (one per CU), gridDim.z reduce splits
+template <int MT, int NT, int NS, class Epi>
+__global__ __launch_bounds__(256, 1) void gemm_panel_kernel(GemmShape g, Epi epi) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  panel_body<MT, NT, NS, Epi>(g, epi, (int)blockIdx.x, (int)gridDim.x, (int)blockIdx.z, smem_raw);
 }
 }  // namespace panel

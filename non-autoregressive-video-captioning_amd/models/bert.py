@@ -219,17 +219,19 @@ class BertLayer(nn.Module):
         # dX GEMM accumulates onto it (LinearFn: res_sink / dx_acc) -- only wired when both gradients will exist.
         link = torch.is_grad_enabled() and x2.requires_grad
         h1, h2, h3 = ({}, {}, {}) if link else (None, None, None)
-        qkv = LinearFn.apply(x2, None, dict(pack=pk['qkv'], rows=rows, dx_acc=h1), *P)
-        att, p_self = SelfAttentionFn.apply(qkv, tokens, int(causal), self.H, want_probs)
-        a = LinearFn.apply(att, x2 if self.self_residual else None, dict(pack=pk['so'], p1=self.p, salt1=s[0], row_tokens=tok_flat, rng=rng,
-                                         training=training, rows=rows, res_sink=h1), *P)
-        q = LinearFn.apply(a, None, dict(pack=pk['cq'], rows=rows, dx_acc=h2), *P)
-        catt, p_cross = CrossAttentionFn.apply(q, memory_kv, self.H, Lq, M, vdiv, vmod, want_probs)
-        c = LinearFn.apply(catt, a, dict(pack=pk['co'], p1=self.p, salt1=s[1], row_tokens=tok_flat, rng=rng,
-                                         training=training, rows=rows, res_sink=h2), *P)
-        u = LinearFn.apply(c, None, dict(pack=pk['f1'], act=self.act, rows=rows, dx_acc=h3), *P)
-        y = LinearFn.apply(u, c, dict(pack=pk['f2'], p1=self.p, salt1=s[2], p2=self.p, salt2=s[3], row_tokens=tok_flat,
-                                      rng=rng, training=training, rows=rows, res_sink=h3), *P)
+        # ONE persistent launch for the whole layer (ops.chain: the eight launches below are queued and run as its stages)
+        with ops.chain():
+            qkv = LinearFn.apply(x2, None, dict(pack=pk['qkv'], rows=rows, dx_acc=h1), *P)
+            att, p_self = SelfAttentionFn.apply(qkv, tokens, int(causal), self.H, want_probs)
+            a = LinearFn.apply(att, x2 if self.self_residual else None, dict(pack=pk['so'], p1=self.p, salt1=s[0], row_tokens=tok_flat, rng=rng,
+                                             training=training, rows=rows, res_sink=h1), *P)
+            q = LinearFn.apply(a, None, dict(pack=pk['cq'], rows=rows, dx_acc=h2), *P)
+            catt, p_cross = CrossAttentionFn.apply(q, memory_kv, self.H, Lq, M, vdiv, vmod, want_probs)
+            c = LinearFn.apply(catt, a, dict(pack=pk['co'], p1=self.p, salt1=s[1], row_tokens=tok_flat, rng=rng,
+                                             training=training, rows=rows, res_sink=h2), *P)
+            u = LinearFn.apply(c, None, dict(pack=pk['f1'], act=self.act, rows=rows, dx_acc=h3), *P)
+            y = LinearFn.apply(u, c, dict(pack=pk['f2'], p1=self.p, salt1=s[2], p2=self.p, salt2=s[3], row_tokens=tok_flat,
+                                          rng=rng, training=training, rows=rows, res_sink=h3), *P)
         return y, (p_self, p_cross)
 
     def _run_subset(self, x2, tokens, causal, memory_kv, M, vdiv, vmod, want_probs, rows, out_rows):
@@ -248,17 +250,18 @@ class BertLayer(nn.Module):
             pk['q_only'] = Pack(full.w[:D], full.b[:D], None, None)
             pk['kv_only'] = Pack(full.w[D:], full.b[D:], None, None)
         sub = dict(row_tokens=tok_flat, training=False, rows=out_rows)
-        q = LinearFn.apply(x2, None, dict(pack=pk['q_only'], rows=out_rows), *P)
-        kv = LinearFn.apply(x2, None, dict(pack=pk['kv_only'], rows=rows), *P)
         att = torch.empty(R * Lq, D, dtype=x2.dtype, device=x2.device)
         p_self = torch.empty(self.H, R, Lq, Lq, dtype=x2.dtype, device=x2.device) if want_probs else None
-        ops.attention_fwd(q, kv[:, :D], kv[:, D:], att, tokens, int(causal), p_self, R, self.H, Lq, Lq, D // self.H, 1, R)
-        a = LinearFn.apply(att, x2 if self.self_residual else None, dict(pack=pk['so'], **sub), *P)
-        cq = LinearFn.apply(a, None, dict(pack=pk['cq'], rows=out_rows), *P)
-        catt, p_cross = CrossAttentionFn.apply(cq, memory_kv, self.H, Lq, M, vdiv, vmod, want_probs)
-        c = LinearFn.apply(catt, a, dict(pack=pk['co'], **sub), *P)
-        u = LinearFn.apply(c, None, dict(pack=pk['f1'], act=self.act, rows=out_rows), *P)
-        y = LinearFn.apply(u, c, dict(pack=pk['f2'], **sub), *P)
+        with ops.chain():
+            q = LinearFn.apply(x2, None, dict(pack=pk['q_only'], rows=out_rows), *P)
+            kv = LinearFn.apply(x2, None, dict(pack=pk['kv_only'], rows=rows), *P)
+            ops.attention_fwd(q, kv[:, :D], kv[:, D:], att, tokens, int(causal), p_self, R, self.H, Lq, Lq, D // self.H, 1, R)
+            a = LinearFn.apply(att, x2 if self.self_residual else None, dict(pack=pk['so'], **sub), *P)
+            cq = LinearFn.apply(a, None, dict(pack=pk['cq'], rows=out_rows), *P)
+            catt, p_cross = CrossAttentionFn.apply(cq, memory_kv, self.H, Lq, M, vdiv, vmod, want_probs)
+            c = LinearFn.apply(catt, a, dict(pack=pk['co'], **sub), *P)
+            u = LinearFn.apply(c, None, dict(pack=pk['f1'], act=self.act, rows=out_rows), *P)
+            y = LinearFn.apply(u, c, dict(pack=pk['f2'], **sub), *P)
         return y, (p_self, p_cross)
 
     def _run_layernorm(self, x2, tokens, causal, memory_kv, M, vdiv, vmod, training, want_probs, rows, pos2=None):

@@ -33,6 +33,9 @@ def shard_range(global_batch: int, rank: int, world: int):
     return rank * per, (rank + 1) * per
 
 
+_host_broadcast_seq = [0]
+
+
 def host_broadcast_int(value, tag, src=0, timeout_s=6 * 3600):
     """`value` of rank `src` on every rank, through the rendezvous store -- a HOST-side wait.  For the long one-sided phases
     of training (rank 0 decodes and scores the validation split, misc/run.py): a device collective posted by the idle
@@ -41,7 +44,13 @@ def host_broadcast_int(value, tag, src=0, timeout_s=6 * 3600):
         return int(value)
     from datetime import timedelta
     store = dist.distributed_c10d._get_default_store()
-    key = 'nacf_amd/host_broadcast/%s' % tag
+    # every rank calls this the same number of times in the same order, so a per-process call counter makes the key unique
+    # per CALL: a second train_network_all on the same process group (teacher then student, a resume, a test calling it
+    # twice) must not find the previous run's verdict under the same tag.  Keys are never deleted (a slow rank may not have
+    # read one yet; they are a few bytes per evaluated epoch)
+    seq = _host_broadcast_seq[0]
+    _host_broadcast_seq[0] += 1
+    key = 'nacf_amd/host_broadcast/%d/%s' % (seq, tag)
     if dist.get_rank() == src:
         store.set(key, str(int(value)))
         return int(value)

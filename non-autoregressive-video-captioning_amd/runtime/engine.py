@@ -290,6 +290,11 @@ class TrainStep(object):
             if upd is not None:
                 run(upd)
         self.crit._loss_cnt = [c + d for c, d in zip(self.crit._loss_cnt, self.count_delta)]
+        # the replayed Adam walk wrote the fp32 master weights on the device; the graph refreshed the weight images BEFORE
+        # it, so they are one step behind: a direct decoder / vocabulary / Translator call must rebuild them (FlatParams.ensure_images)
+        flat = getattr(self.model, 'flat', None)
+        if flat is not None:
+            flat.touch()
 
     def _graph_ready(self):
         """the criterion must keep ALL its running sums in the in-place device meter vector (fused form)"""

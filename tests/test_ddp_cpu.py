@@ -100,6 +100,8 @@ def _worker(rank, world, port, out):
     assert all(float(gathered[r].min()) == float(gathered[r].max()) == float(r) for r in range(world))
     # the evaluation verdict of misc/run.py: rank 0's value reaches everybody through the store (no collective posted)
     assert host_broadcast_int(7 if rank == 0 else -1, 'test_a') == 7 and host_broadcast_int(0 if rank == 0 else 5, 'test_b') == 0
+    # the SAME tag again (a second train_network_all on this process group): the new value, not the stored one
+    assert host_broadcast_int(3 if rank == 0 else -1, 'test_a') == 3
     dist.barrier()
     dist.destroy_process_group()
 

@@ -362,3 +362,43 @@ def test_direct_decoder_calls_see_updated_weights(dev):
         hyp2, _ = Translator(model, dopt, device=dev).translate_batch(enc, cat, None, None)
     assert not torch.equal(h0, h1)
     assert torch.equal(h1, h2) and torch.equal(lp1, lp2) and torch.equal(hyp1, hyp2)
+
+
+def test_direct_decoder_call_after_replayed_steps_sees_the_replayed_weights(dev):
+    """a captured step refreshes the weight images BEFORE its Adam walk and updates the fp32 master weights
+    on the device without running FusedAdam.step's host code, so after a replay the images are one step behind.  A direct
+    model.decoder(...) on cached encoder outputs must notice (TrainStep._replay bumps the weight version) and rebuild
+    them: the hidden states equal those after an explicit rebuild."""
+    from nacf_amd.misc.crit import get_criterion
+    from nacf_amd.misc.optim import get_optimizer
+    from nacf_amd.misc.run import get_forword_results
+    from nacf_amd.runtime.engine import TrainStep
+    from nacf_amd.runtime import ops
+    ops.set_gemm_mode("bf16x3")
+    g = load_gold("tiny_nacf_trajectory")
+    opt = gold_opt(g)
+    batches = _gold_batches(g, dev)
+    model = _model(opt, dev, fused_loss=True)
+    model.train()
+    crit, optim = get_criterion(model.opt), get_optimizer(model.opt, model)
+    engine = TrainStep(model, crit, optim, lambda b, m=model: get_forword_results(m.opt, m, b, dev), graph="on")
+    b = batches[0]
+    model.eval()
+    with torch.no_grad():
+        enc_out = model.encode(feats=b["feats"])["enc_output"].clone()      # the cached encoder outputs
+    model.train()
+    for i in range(6):
+        engine(batches[i % len(batches)])
+    assert engine.captured
+    model.eval()
+    with torch.no_grad():
+        images = model.flat.images
+        stale_version = model.flat.images_version
+        assert stale_version != model.flat.version                      # the replay announced the device-side update
+        tok, cat = b["tokens"], b["category"]
+        h1 = model.decoder(tok, enc_output=enc_out, category=cat)[0].clone()       # ensure_images rebuilds
+        assert model.flat.images_version == model.flat.version
+        model.flat.sync_images()
+        h2 = model.decoder(tok, enc_output=enc_out, category=cat)[0].clone()
+    assert images is model.flat.images
+    assert torch.equal(h1, h2)
