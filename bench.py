@@ -213,7 +213,9 @@ def roofline_from(summ, n_prof, mode, prefer_single=True, groups=None, dec_rows=
           "all_gemm_tflops": round(all_tf, 2), "all_gemm_frac_of_mode_peak": round(all_tf / MODE_PEAK[mode], 4),
           # rocprofv3 --pmc on this kernel family (profiles/r02_gemm_pmc_counters.txt) and the per-phase cycle stamps of
           # tools/bf16_trace.py (profiles/r02_bf16_phase_trace.txt): the matrix pipe is NOT what limits K = 512 launches
-          "limiter": LIMITER_WIDE if name.startswith("gemm_wide") else LIMITER_128}
+          # (the text is ONE top-level entry of the line, `limiters`: repeated per leg it pushed the decode / bf16 legs out of
+          #  the tail the driver keeps)
+          "limiter": "limiters.wide" if name.startswith("gemm_wide") else "limiters.tile128"}
     tab = newest_traffic_table()
     if tab is not None:
         path, age_h, data = tab
@@ -436,7 +438,10 @@ def bench_cpu(opt, sd, O, B, F_, budget_s=18.0):
     ncpu = os.cpu_count()
     all_threads = torch.get_num_threads()
     v_all, n_all, spread_all = train_leg(B, all_threads, budget_s, 2)
-    v_one, n_one, spread_one = train_leg(8, 1, budget_s * 0.6, 2)
+    # one thread, the SAME 128-video batch: a step takes ~5 s there, so 1 warm-up + 3 timed
+    N_WARM, N_TIMED = 1, 3
+    v_one, n_one, spread_one = train_leg(B, 1, budget_s * 0.6, 2)
+    N_WARM, N_TIMED = 3, 10
     torch.set_num_threads(all_threads)
     # NA decode (mask-predict + coarse templates, T = 5, lbs = 6), batch 32
     db = O.synth_batch(opt, 32, F_, seed=2)
@@ -460,8 +465,8 @@ def bench_cpu(opt, sd, O, B, F_, budget_s=18.0):
             "cpu_model": cpu_model_name(), "logical_cpus": ncpu,
             "one_thread": {"value": round(v_one, 3), "unit": "videos/s", "cores": 1,
                            "spread_min_max": spread_one,
-                           "sample": "same step on an 8-video batch (a 128-video step takes ~5 s on one thread: 13 of them would "
-                                     "not fit the default run), %d warm-ups + %d timed steps, median" % (N_WARM, n_one)},
+                           "sample": "the same %d-video step on ONE thread: 1 warm-up + %d timed steps, median (a step takes seconds "
+                                     "there; 3 + 10 of them would not fit the default run)" % (B, n_one)},
             "decode": {"value": round(32 / statistics.median(ts), 2), "unit": "captions/s", "cores": all_threads,
                        "spread_min_max": [round(32 / max(ts), 2), round(32 / min(ts), 2)],
                        "sample": "oracle encode + generate (mp + coarse templates, T=5, lbs=6) of 32 videos: %d warm-ups + %d timed, "
@@ -667,9 +672,11 @@ def main():
                           "graph_collectives": bool(getattr(engine, "graph_collectives", False)),
                           "gradient_buckets": (3 if engine.three else 2) if staged else 1},
                "timing": extra_timing, "rank_losses": rank_losses,
-               "roofline": roofline, "cpu_baseline": cpu, "decode": decode, "train_L30": l30,
-               "nacf_bf16": nacf_bf16, "config1_nab_bf16": nab, "config5_ar_vs_na": compare,
-               "loader_fed": loader_leg, "final_loss": round(final_loss, 4), "gemm_kernels": gemm_table}
+               # (bulky / referenced entries first: what reads only the END of this line keeps the legs below)
+               "gemm_kernels": gemm_table, "limiters": {"tile128": LIMITER_128, "wide": LIMITER_WIDE},
+               "loader_fed": loader_leg, "train_L30": l30, "config5_ar_vs_na": compare,
+               "nacf_bf16": nacf_bf16, "config1_nab_bf16": nab, "decode": decode,
+               "roofline": roofline, "cpu_baseline": cpu, "final_loss": round(final_loss, 4)}
     if multi:
         dist.barrier()
         dist.destroy_process_group()

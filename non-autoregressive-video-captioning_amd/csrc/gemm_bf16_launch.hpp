@@ -15,7 +15,6 @@ void launch_bf16_argmax(GemmShape g, const EpiArgmax& epi, int tile, int ns, hip
 void launch_bf16_dx(GemmShape g, const EpiStore& epi, int splits, int tile, int ns, hipStream_t s);       // dX = dZ W
 void launch_bf16_dw(GemmShape g, const EpiStore& epi, int splits, int tile, int ns, hipStream_t s);       // dW = dZ^T X
 void launch_bf16_dw_group(const GemmGroup<EpiStore>& t, int ns, hipStream_t s);
-void launch_widet_dw_group(const GemmGroup<EpiStore>& t, hipStream_t s);                                       // grouped dW, 128x256 tiles, one workgroup per CU (exact mode)                            // grouped dW (128x128 tiles)
 // wide-wave-tile kernels (gemm_bf16_wide.hpp, nacf_gemm_bf16_wide.hip): false = not eligible / not worthwhile, use the others
 bool launch_wide_linear(const GemmShape& g, const EpiLinear& epi, bool has_rows, bool heavy_epilogue, hipStream_t s);
 bool launch_wide_dx(const GemmShape& g, const EpiStore& epi, int splits, bool has_rows, hipStream_t s);
@@ -35,10 +34,6 @@ bool chain_queue_attention(const float* Q, int64_t ldq, const float* K, int64_t 
                            const int64_t* key_tokens, int causal, float* probs, int R, int H, int Lq, int Lk, int dk, int kv_div,
                            int kv_mod, bool aligned, hipStream_t s);
 int chain_flush(hipStream_t s);
-// DMA-staged throughput-mode kernel (gemm_bf16_dma.hpp, nacf_gemm_bf16_dma.hip): false = not eligible / not worthwhile
-bool launch_dma_linear(const GemmShape& g, const EpiLinear& epi, bool has_rows, bool heavy_epilogue, hipStream_t s);
-bool launch_dma_dx(const GemmShape& g, const EpiStore& epi, int splits, bool has_rows, hipStream_t s);
-bool dma_pick(const GemmShape& g, int splits, bool has_rows, int ns, bool heavy_epilogue);
 void launch_wimage_refresh(const WImageDesc* descs, int n_desc, int n_tiles, int ns, hipStream_t s);
 // "gemm_bf16_kernel<BM, BN, QSRC, PSRC, NS, STAGES, Epi>" of the launch the calling thread made last (profiling aid)
 const char* bf16_last_kernel_name();

@@ -443,8 +443,7 @@ int nacf_linear_fwd(const float* X, int64_t ldx, const float* W, int64_t ldw, fl
     if (mode == NACF_GEMM_BF16X3) find_frag(W, ldw, N, K, mode, g);
     const bool heavy_w = heavy || epi.ep.p_drop1 > 0.f || epi.ep.p_drop2 > 0.f;      // nothing overlaps the wide kernel's epilogue
     if (!(mode == NACF_GEMM_BF16X3 && launch_panel_linear(g, epi, rs != nullptr, as_hip(stream))) &&
-        !(mode == NACF_GEMM_BF16X3 && launch_wide_linear(g, epi, rs != nullptr, heavy_w, as_hip(stream))) &&
-        !(mode == NACF_GEMM_BF16 && launch_dma_linear(g, epi, rs != nullptr, heavy_w, as_hip(stream))))
+        !(mode == NACF_GEMM_BF16X3 && launch_wide_linear(g, epi, rs != nullptr, heavy_w, as_hip(stream))))
       launch_bf16_linear(g, epi, pick_tile_bf16(0, M, N, 1, rs != nullptr, mode, heavy), mode, as_hip(stream));
     g_last_was_bf16 = true;
   } else {
@@ -526,8 +525,7 @@ int nacf_linear_bwd_data(const float* dZ, int64_t lddz, const float* W, int64_t 
   }
   if (bf16) {
     find_image_t(W, ldw, N, K, mode, g);       // P = W^T image [K, N] when registered, else the fp32 W read transposed
-    if (!(mode == NACF_GEMM_BF16X3 && launch_wide_dx(g, epi, real_splits, rs != nullptr, s)) &&
-        !(mode == NACF_GEMM_BF16 && launch_dma_dx(g, epi, real_splits, rs != nullptr, s)))
+    if (!(mode == NACF_GEMM_BF16X3 && launch_wide_dx(g, epi, real_splits, rs != nullptr, s)))
       launch_bf16_dx(g, epi, real_splits, pick_tile_bf16(1, M, K, real_splits, rs != nullptr, mode), mode, s);
     g_last_was_bf16 = true;
   } else {
@@ -619,35 +617,31 @@ static int dw_group_flush_locked(hipStream_t s);
 // group, a workgroup should walk about W / target k-tiles (target = NACF_DW_GROUP_WGS, default 1024 = two rounds of the
 // 512 resident 128x128 workgroups), never fewer than 24; a problem gets ceil(its k-tiles / that) splits.  Longest walks
 // first in the grid, so that the short ones fill the tail.
-static int dw_subset_launch_locked(const std::vector<int>& subset, bool widet, hipStream_t s);
+static int dw_subset_launch_locked(const std::vector<int>& subset, hipStream_t s);
 static int dw_items_launch_locked(hipStream_t s) {
   const int n_all = (int)g_dw_items.size();
   g_dw_last_group_launches = 0;
   g_dw_last_group_wgs = 0;
   if (n_all == 0) return NACF_OK;
-  // NACF_DW_WIDE (exact mode): 1 = every problem on the one-workgroup-per-CU kernel (gemm_bf16_widet.hpp: 128 x 256 output
-  // tiles, a workgroup of it does twice the work of a 128 x 128 one, 256 of them are resident); 2 = the problems WITHOUT a
-  // row list on it (its row-list loop spills), the others on the 128 x 128 group kernel, as two grouped launches
-  const int wide_mode = gemm_mode() == NACF_GEMM_BF16X3 ? [] { const char* e = getenv("NACF_DW_WIDE"); return e ? atoi(e) : 0; }() : 0;
-  std::vector<int> a, b;
-  for (int i = 0; i < n_all; ++i) ((wide_mode == 1 || (wide_mode == 2 && !g_dw_items[i].has_rs)) ? a : b).push_back(i);
-  int rc = NACF_OK;
-  if (!a.empty()) rc = dw_subset_launch_locked(a, true, s);
-  if (rc == NACF_OK && !b.empty()) rc = dw_subset_launch_locked(b, false, s);
+  // (round 3 also had a one-workgroup-per-CU member for this launch, 128 x 256 tiles on the wide kernel's geometry with both
+  //  operands through the transposing stager: +23 % on one long problem, +-0 on the step's mix -- DESIGN.md section 4; removed)
+  std::vector<int> all(n_all);
+  for (int i = 0; i < n_all; ++i) all[i] = i;
+  const int rc = dw_subset_launch_locked(all, s);
   g_dw_items.clear();
   return rc;
 }
-static int dw_subset_launch_locked(const std::vector<int>& subset, const bool widet, hipStream_t s) {
+static int dw_subset_launch_locked(const std::vector<int>& subset, hipStream_t s) {
   const int n = (int)subset.size();
   static const int target_env = [] { const char* e = getenv("NACF_DW_GROUP_WGS"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 0; }();
   const int mode = gemm_mode();
   // measured on the NACF step (bench.py, B = 128): exact mode 1024: 2.91 ms, 1280: 2.89, 1536: 2.90, 3072: 2.93;
   // throughput mode (its k-tiles are 3x shorter, the fixed cost of a split weighs less) 1024: 2.30, 1536: 2.12, 4096: 2.08
-  const int tile_cols = widet ? 256 : 128;
-  const int target = target_env > 0 ? target_env : (mode == NACF_GEMM_BF16 ? 4096 : (widet ? 768 : 1280));
+  const int tile_cols = 128;
+  const int target = target_env > 0 ? target_env : (mode == NACF_GEMM_BF16 ? 4096 : 1280);
   // NACF_DW_GROUP_ORDER=0: every split spreads its tiles over the 8 XCDs (round 2); default 1: see GemmGroup
   static const bool split_major_env = [] { const char* e = getenv("NACF_DW_GROUP_ORDER"); return !(e && atoi(e) == 0); }();
-  const bool split_major = split_major_env || widet;
+  const bool split_major = split_major_env;
   std::vector<int> kt(n), tiles(n), sp(n), order(n);
   long W = 0;
   for (int i = 0; i < n; ++i) {
@@ -697,7 +691,7 @@ static int dw_subset_launch_locked(const std::vector<int>& subset, const bool wi
       g.tiles_m = cdiv(g.M, 128);
       g.tiles_n = cdiv(g.N, tile_cols);
       const int real = cdiv(it.M, g.k_per_split);
-      if (split_major && !widet) {
+      if (split_major) {
         // an XCD's run of `run` consecutive tiles inside one split: as square as the tile grid allows (GemmShape::group_n)
         const long run = ((long)tiles[i] * real + 7) / 8;
         if (run < tiles[i]) {
@@ -729,8 +723,7 @@ static int dw_subset_launch_locked(const std::vector<int>& subset, const bool wi
       }
     }
     t.wg0[t.n] = wg;
-    if (widet) launch_widet_dw_group(t, s);
-    else launch_bf16_dw_group(t, mode, s);
+    launch_bf16_dw_group(t, mode, s);
     g_last_was_bf16 = true;
     NACF_LAUNCH_CHECK("nacf_dw_group_flush(grouped gemm)");
     ++g_dw_last_group_launches;

@@ -132,7 +132,7 @@ class Seq2Seq(nn.Module):
             self.flat.attach_grads(zero=True)
 
     # ------------------------------------------------------------- reference surface
-    def encode(self, feats, defer_join=False, **kwargs):
+    def encode(self, feats, **kwargs):
         results = LazyResults()
         if self.opt.get('automatic_mask', False):
             raise NotImplementedError('nacf_amd: automatic_mask is not built')
@@ -161,42 +161,13 @@ class Seq2Seq(nn.Module):
         else:
             pooled = pooled_dec = MeanTimeFn.apply(enc_output)
         if self.auxiliary_task_predictor is not None:
-            # The length head (two 128-row GEMMs, a row soft-max; ~55 us forward, ~75 us backward of launch-latency-sized
-            # kernels) depends on the pooled memory only: in training it runs on a SIDE stream next to the decoder -- a
-            # parallel branch of the captured step graph.  autograd runs a node's backward on its forward's stream and
-            # orders producers / consumers across streams, so the backward overlaps the decoder's too.
-            # opt['aux_side_stream'], default OFF: no difference in an A/B inside one box (2.765 vs 2.766 ms; the "slower" of a
-            # first measurement was box-to-box variance) -- the decoder's launches leave no idle time a parallel branch of
-            # ~130 us of small kernels could fill.
-            side = self._aux_stream(enc_output) if (self.training and defer_join is not None) else None
-            if side is not None:
-                main = torch.cuda.current_stream(enc_output.device)
-                side.wait_stream(main)
-                with torch.cuda.stream(side):
-                    aux = self.auxiliary_task_predictor(enc_output=enc_output, pooled=pooled)
-                for v in aux.values():
-                    if torch.is_tensor(v):
-                        v.record_stream(main)            # consumed by the criterion on the main stream
-                results.update(aux)
-                if defer_join:
-                    results['_aux_stream'] = side        # Seq2Seq._run joins after the decoder's forward
-                else:
-                    main.wait_stream(side)
-            else:
-                results.update(self.auxiliary_task_predictor(enc_output=enc_output, pooled=pooled))
+            # (The length head -- ~130 us of launch-latency-sized kernels that depend on the pooled memory only -- was tried as a
+            #  parallel branch of the step graph on a side stream: no difference, 2.765 vs 2.766 ms in one box; removed.)
+            results.update(self.auxiliary_task_predictor(enc_output=enc_output, pooled=pooled))
         results['enc_output'] = enc_output
         results.lazy('enc_hidden', enc_hidden_fn)
         results['_pooled_memory'] = pooled_dec
         return results
-
-    def _aux_stream(self, ref):
-        if not ref.is_cuda or not self.opt.get('aux_side_stream', False):
-            return None
-        st = self.__dict__.get('_aux_side')
-        if st is None or st.device != ref.device:
-            st = torch.cuda.Stream(device=ref.device)
-            self.__dict__['_aux_side'] = st
-        return st
 
     def prepare_inputs_for_decoder(self, encoder_outputs, category):
         inputs_for_decoder = {'category': category, 'enc_output': encoder_outputs['enc_output']}
@@ -230,7 +201,7 @@ class Seq2Seq(nn.Module):
             self._ensure_grads()
             self.rt.rng(feats[0].device)
             self.rt.advance()
-        results = self.encode(feats, defer_join=True)
+        results = self.encode(feats)
         if self.training:
             # the encoder/decoder boundary, for the staged backward of runtime/ddp.py: every path from the loss to an
             # encoder / fusion parameter goes through enc_output (the pooled memory and the length head hang off it),
@@ -242,9 +213,6 @@ class Seq2Seq(nn.Module):
                                                pooled_memory=results['_pooled_memory'], **inputs_for_decoder)
         if not isinstance(hidden_states, list):
             hidden_states = [hidden_states]
-        side = results.pop('_aux_stream', None)
-        if side is not None:
-            torch.cuda.current_stream(hidden_states[0].device).wait_stream(side)
         if self.opt.get('fused_loss', False):
             results['_nacf_hidden'] = hidden_states
             results['_nacf_vocab'] = (self._vocab_pack, [p for p in self.tgt_word_prj.parameters()])

@@ -92,6 +92,24 @@ class DataParallel(object):
         else:                       # gloo (CPU tests)
             dist.all_gather(list(out.unbind(0)), t, group=self.group)
 
+    def assert_equal_rows(self, n_rows, what='SyncBN'):
+        """SyncBN forms the global statistics as if every rank held `n_rows` rows (runtime/functional.py:BNConcatFn: n_tot =
+        rows x world; the reference's single process has one batch).  Checked on every launch-by-launch step (a host read,
+        so not inside a stream capture: a captured step has the shapes of the eager steps before it; and never skipped from
+        a per-rank cache -- ranks that disagree must all reach the collective): a ragged global batch must fail loudly,
+        not normalise with the wrong count."""
+        if self.world == 1 or not dist.is_initialized():
+            return
+        if torch.cuda.is_available() and torch.cuda.is_current_stream_capturing():
+            return
+        dev = self.model.flat.data.device if hasattr(self.model, 'flat') else torch.device('cpu')
+        t = torch.tensor([n_rows, -n_rows], dtype=torch.int64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
+        hi, lo = int(t[0]), -int(t[1])
+        if hi != lo:
+            raise RuntimeError('nacf_amd: %s needs the same number of rows on every rank (this rank %d, ranks hold %d..%d): '
+                               'shard the global batch evenly (runtime/ddp.py:shard_range)' % (what, n_rows, lo, hi))
+
     @property
     def grad_scale(self):
         return 1.0 / self.world

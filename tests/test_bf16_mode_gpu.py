@@ -112,42 +112,3 @@ def test_bf16_mode_trains_under_the_graph_engine(dev, restore_mode):
         model.flat.images.img.zero_()                        # corrupt the cache ...
         e2 = model.encode(feats=batch["feats"])["enc_output"]   # ... the forward entry rebuilds it
     assert torch.equal(e1, e2)
-
-
-def test_bf16_mode_with_the_dma_staged_kernel_inside_the_model(dev, restore_mode, monkeypatch):
-    """NACF_GEMM_DMA=1 puts the eligible forward / dX GEMMs of a full-shape NACF step (row lists, fused nn.Linear epilogues,
-    dropout) on csrc/gemm_bf16_dma.hpp: the kernel multiplies the same bf16 values as the register-staged kernels, so loss
-    and gradients agree to fp32 summation-order noise and the dropout masks are the same"""
-    import nacf_amd
-    from nacf_amd import synthetic as S
-    from nacf_amd.misc.crit import get_criterion
-    from nacf_amd.runtime import lib as L
-    opt = nacf_amd.opts.make_opt("NACF", "MSRVTT", with_category=True, max_len=20, vocab_size=10547, n_frames=60,
-                                 fused_loss=True, hidden_dropout_prob=0.5, encoder_dropout=0.5)
-    b = S.synth_batch(opt, 32, 60, seed=5)
-    out = {}
-    for dma in ("0", "1"):
-        monkeypatch.setenv("NACF_GEMM_DMA", dma)
-        model = _model(opt, dev, "bf16")
-        model.train()
-        crit = get_criterion(model.opt)
-        with torch.no_grad():
-            model.encode(feats=[f.to(dev) for f in b["feats"]])["enc_output"]
-        seen = L.load().nacf_gemm_last_kernel().decode()              # the encoder's last GEMM
-        assert seen.startswith("gemm_dma_kernel") == (dma == "1"), (dma, seen)
-        model.zero_grad()
-        res = model(feats=[f.to(dev) for f in b["feats"]], tgt_tokens=[b["tokens_1"].to(dev), b["tokens"].to(dev)],
-                    category=b["category"].to(dev))
-        res["tgt_word_labels"] = [b["labels_1"].to(dev), b["labels"].to(dev)]
-        res["tgt_length"] = b["tgt_length"].to(dev)
-        loss = crit.get_loss(res)
-        loss.backward()
-        out[dma] = (float(loss.detach()), model.flat.grad.clone(), res["enc_output"].detach().clone(), seen)
-    (l0, g0, e0, _), (l1, g1, e1, _) = out["0"], out["1"]
-    assert torch.isfinite(g1).all()
-    assert abs(l1 - l0) < 1e-5 * abs(l0), (l0, l1)
-    assert float((e1 - e0).abs().max()) < 1e-4 * float(e0.abs().max())
-    assert torch.equal(e1.eq(0), e0.eq(0))                                           # encoder dropout: identical masks
-    cos = float(torch.nn.functional.cosine_similarity(g1, g0, dim=0))
-    assert cos > 0.99999, cos
-    assert float((g1 - g0).abs().max()) < 1e-3 * float(g0.abs().max())

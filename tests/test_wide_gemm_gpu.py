@@ -259,52 +259,3 @@ def test_joint_encoder_streams_equal_the_per_stream_nodes(dev, monkeypatch):
         assert torch.equal(a, b)
     for n in res[True][1]:
         assert torch.equal(res[True][1][n], res[False][1][n]), n
-
-
-# ------------------------------------------------------------------ the weight-gradient member (csrc/gemm_bf16_widet.hpp)
-DW_SHAPES = [(1000, 512, 256, False, True), (777, 300, 130, False, True), (2048, 128, 512, False, False),
-             (1500, 1030, 256, True, True), (96, 256, 128, False, True), (5120, 640, 512, True, True),
-             (31, 128, 128, True, True), (4096, 512, 2048, False, True)]
-
-
-@pytest.mark.parametrize("M,N,K,with_rows,with_bias", DW_SHAPES)
-def test_widet_weight_gradient_group(dev, monkeypatch, M, N, K, with_rows, with_bias):
-    """NACF_DW_WIDE=1: the grouped weight-gradient launch on the one-workgroup-per-CU kernel (128 x 256 output tiles,
-    register-staged transposed split planes): dW (+)= dZ^T X and db (+)= column sums of dZ over the live rows, against fp64
-    at the fp32 kernels' bar and against the 128 x 128 group kernel (rounding only); ragged tiles, reduce splits, tiny M"""
-    ops, L = _ops()
-    ops.set_gemm_mode("bf16x3")
-    dz = rnd(M, N, seed=1).to(dev)
-    x = rnd(M, K, seed=2).to(dev)
-    rows = None
-    live = torch.arange(M)
-    if with_rows:
-        tok = (torch.rand(M, generator=torch.Generator().manual_seed(3)) < 0.6).long().to(dev)      # 0 = <pad>
-        rows = ops.rowset_build(tokens=tok)
-        live = tok.cpu().nonzero().squeeze(1)
-    base_w, base_b = rnd(N, K, seed=4).to(dev), rnd(N, seed=5).to(dev)
-    ref_w = base_w.double().cpu() + dz.double().cpu()[live].t() @ x.double().cpu()[live]
-    ref_b = base_b.double().cpu() + dz.double().cpu()[live].sum(0)
-    # a second, unrelated problem in the same group: the table walk and the XCD order see more than one entry
-    dz2, x2 = rnd(640, 256, seed=6).to(dev), rnd(640, 384, seed=7).to(dev)
-    out = {}
-    for wide in ("0", "1"):
-        monkeypatch.setenv("NACF_DW_WIDE", wide)
-        dw, db = base_w.clone(), (base_b.clone() if with_bias else None)
-        dw2 = torch.zeros(256, 384, device=dev)
-        with ops.dw_group():
-            ops.linear_bwd_weight(dz, x, dw, db, beta=1.0, rows=rows)
-            ops.linear_bwd_weight(dz2, x2, dw2, None, beta=0.0)
-        torch.cuda.synchronize()
-        out[wide] = (dw, db, dw2)
-        if N >= 128 and K >= 128:
-            name = last_kernel(L)
-            assert ("widet" in name) == (wide == "1"), name
-    for wide in ("0", "1"):
-        dw, db, dw2 = out[wide]
-        scale = max(1.0, float(ref_w.abs().max()))
-        assert err(dw, ref_w) < tol(len(live), scale), (wide, err(dw, ref_w))
-        assert err(dw2, dz2.double().cpu().t() @ x2.double().cpu()) < tol(640, 8.0)
-        if with_bias:
-            assert err(db, ref_b) < tol(len(live), max(1.0, float(ref_b.abs().max())))
-    assert err(out["0"][0], out["1"][0]) < tol(len(live), 1.0)

@@ -26,14 +26,11 @@ python $ROOT/tools/gemm_bench.py --iters 20 --modes f32,bf16x3,bf16 --images > /
 python $ROOT/tools/gemm_bench.py --iters 20 --modes bf16x3 --tiles 128,wide1,wide2,auto --images --only fwd >> /tmp/mb.txt 2>> /tmp/mb.err
 python $ROOT/tools/gemm_bench.py --iters 20 --modes bf16x3 --tiles 128,wide1,wide2,auto --images --only dX >> /tmp/mb.txt 2>> /tmp/mb.err
 { echo "# per-launch HIP events, MEDIAN of 20 launches (tools/gemm_bench.py)"; grep "^#" /tmp/mb.err; cat /tmp/mb.txt; } > $OUT/${R}_gemm_microbench.txt
-# 4b. the grouped weight-gradient launch: 128x128 group kernel vs the one-workgroup-per-CU kernel (NACF_DW_WIDE=1), per problem and as the step's mix
+# 4b. the grouped weight-gradient launch per problem and as the step's mix
 python $ROOT/tools/dw_group_bench.py 10 > $OUT/${R}_dw_group_bench.txt 2> /dev/null
-# 4c. throughput mode: the register-staged kernels vs the DMA-staged one (NACF_GEMM_DMA=1, csrc/gemm_bf16_dma.hpp), and what a
-# bf16-RESIDENT kernel reaches on the same shapes (standalone probe, built by hand: see its header)
-{ python $ROOT/tools/gemm_bench.py --iters 20 --modes bf16 --tiles 64,128,dma --images --only fwd; python $ROOT/tools/gemm_bench.py --iters 20 --modes bf16 --tiles 64,128,dma --images --only dX; } > $OUT/${R}_dma_gemm_bench.txt 2> /dev/null
-for b in bf16_resident_gemm bf16_resident_gemm_wt128; do
-  if [ -x $ROOT/tools/probes/$b ]; then $ROOT/tools/probes/$b 30 >> $OUT/${R}_bf16_resident_probe.txt 2>&1; fi
-done
+# 4c. the fused decoder layer (round 4, both opt-in): the layer chain against the call-by-call layer, stage by stage
+python $ROOT/tools/chain_probe.py 20 2> /dev/null | grep -v amdgpu.ids > $OUT/${R}_chain_probe.txt
+python $ROOT/tools/chain_probe2.py 20 2> /dev/null | grep -v amdgpu.ids > $OUT/${R}_chain_stage_probe.txt
 $ROOT/tools/mfma_peak 20000 > $OUT/${R}_mfma_peak.txt 2>&1
 # 5. SQ / GRBM counters of the vocabulary GEMM at K = 512 (the model's shape) and K = 8192, exact and throughput mode
 { for m in bf16x3 bf16; do echo "== mode $m"; $ROOT/tools/pmc_gemm.sh 0:5120:10547:512,0:5120:10547:8192 128 $m --images 2>/dev/null | grep "^pass"; done;

@@ -1,5 +1,5 @@
-"""Times the grouped weight-gradient launch (nacf_dw_group_launch_gemms alone, HIP events) for the 128x128 group kernel and
-the one-workgroup-per-CU kernel (NACF_DW_WIDE=1): one long problem (the k-loop's rate) and the NACF step's set of problems.
+"""Times the grouped weight-gradient launch (nacf_dw_group_launch_gemms alone, HIP events): one long problem (the k-loop's
+rate), the step's problems one at a time, and the NACF step's set of problems.
 usage (GPU box): python tools/dw_group_bench.py [reps]"""
 import os, sys
 import torch
@@ -25,8 +25,7 @@ SETS = {
 for title, probs in SETS.items():
     ts = [(torch.randn(M, N, device=dev), torch.randn(M, K, device=dev), torch.zeros(N, K, device=dev)) for M, N, K in probs]
     flops = sum(2.0 * M * N * K for M, N, K in probs)
-    for wide, wgs in (("0", None), ("1", None)):
-        os.environ["NACF_DW_WIDE"] = wide
+    for wide, wgs in (("-", None),):
         if wgs: os.environ["NACF_DW_GROUP_WGS"] = wgs
         else: os.environ.pop("NACF_DW_GROUP_WGS", None)
         best = []
