@@ -305,10 +305,13 @@ int nacf_wimage_refresh(const nacf_wimage_desc* table, int n_desc, int n_tiles, 
 /* Backward of the fused epilogue: from dY produce dZ (grad of the pre-bias
  * GEMM output) and, when ep->residual != NULL, dR (+= when accumulate_dR).
  * `ep` must be the struct used in forward (preact required when act != NONE).
- * dZ may alias dY. */
+ * dZ may alias dY.
+ * rs (optional live-row list, the one the forward GEMM took): only the live rows are walked -- the dead rows of dZ are
+ * left UNTOUCHED (the dX / dW GEMMs that read dZ take the same list), the dead rows of dR receive zeros (what the row mask
+ * gives; nothing is read for them) unless accumulate_dR.  NULL = every row. */
 int nacf_epilogue_bwd(const float* dY, int64_t lddy, float* dZ, int64_t lddz,
                       float* dR, int64_t lddr, int accumulate_dR,
-                      int M, int N, const nacf_epilogue* ep, nacf_stream_t stream);
+                      int M, int N, const nacf_epilogue* ep, const nacf_rowset* rs, nacf_stream_t stream);
 
 /* ------------------------------------------------------------------------
  * Visual encoder tail + feature fusion  

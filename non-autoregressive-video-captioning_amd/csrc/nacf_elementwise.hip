@@ -608,17 +608,28 @@ __global__ void epilogue_bwd_kernel(const float* __restrict__ dY, int64_t lddy, 
   }
 }
 
-// float4 variant (N % 4 == 0, 16-byte aligned rows): one Philox call covers the 4 elements it was drawn for
+// float4 variant (N % 4 == 0, 16-byte aligned rows): one Philox call covers the 4 elements it was drawn for.
+// With a live-row list (rows / count: nacf_rowset) only the listed live rows are walked -- the GEMMs that consume dZ take the
+// same list, so its dead rows are never read -- and the dead rows of dR (which flows on to consumers that read every row:
+// the embedding backward) get the zeros the row mask would have produced, without reading anything.  The dropout masks are
+// functions of the PHYSICAL element index, as in the forward epilogue.
 __global__ void epilogue_bwd_v4_kernel(const float* __restrict__ dY, int64_t lddy, float* __restrict__ dZ, int64_t lddz,
                                        float* __restrict__ dR, int64_t lddr, int accumulate_dR, int M, int N,
-                                       nacf_epilogue ep) {
+                                       nacf_epilogue ep, const int* __restrict__ rows, const int* __restrict__ count) {
   const int N4 = N >> 2;
   const int64_t total = (int64_t)M * N4;
   const bool any_drop = ep.p_drop1 > 0.f || ep.p_drop2 > 0.f;
+  const int n_live = rows ? min(M, *count) : M;
   DropRng rng;
   if (any_drop) rng.init(ep.rng_state);
-  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
-    const int m = (int)(e / N4), n = (int)(e % N4) * 4;
+  for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < total; q += (int64_t)gridDim.x * blockDim.x) {
+    const int pos = (int)(q / N4), n = (int)(q % N4) * 4;
+    const int m = rows ? rows[pos] : pos;
+    if (pos >= n_live) {                     // a dead row: its gradient is zero by the row mask
+      if (dR && !accumulate_dR) *reinterpret_cast<f32x4*>(dR + (int64_t)m * lddr + n) = f32x4{0.f, 0.f, 0.f, 0.f};
+      continue;
+    }
+    const int64_t e = (int64_t)m * N4 + (n >> 2);
     f32x4 g = *reinterpret_cast<const f32x4*>(dY + (int64_t)m * lddy + n);
     if (ep.row_tokens && ep.row_tokens[m] == NACF_PAD) g = f32x4{0.f, 0.f, 0.f, 0.f};
     if (ep.p_drop2 > 0.f) g *= rng.keep4((uint64_t)e, ep.salt2, ep.p_drop2);
@@ -1386,8 +1397,9 @@ int nacf_loss_combine_bwd(const float* gtotal, const float* coef, int n_terms, i
 }
 
 int nacf_epilogue_bwd(const float* dY, int64_t lddy, float* dZ, int64_t lddz, float* dR, int64_t lddr,
-                      int accumulate_dR, int M, int N, const nacf_epilogue* ep, nacf_stream_t stream) {
+                      int accumulate_dR, int M, int N, const nacf_epilogue* ep, const nacf_rowset* rs, nacf_stream_t stream) {
   NACF_CHECK(dY && dZ && ep && M > 0 && N > 0, NACF_EINVAL, "nacf_epilogue_bwd: bad argument");
+  NACF_CHECK(!rs || (rs->rows && rs->count), NACF_EINVAL, "nacf_epilogue_bwd: incomplete row set");
   NACF_CHECK(!(ep->act != NACF_ACT_NONE && !ep->preact), NACF_EINVAL, "nacf_epilogue_bwd: activation backward needs preact");
   NACF_CHECK(!((ep->p_drop1 > 0.f || ep->p_drop2 > 0.f) && !ep->rng_state), NACF_EINVAL,
              "nacf_epilogue_bwd: dropout needs rng_state");
@@ -1395,8 +1407,8 @@ int nacf_epilogue_bwd(const float* dY, int64_t lddy, float* dZ, int64_t lddz, fl
                   (!ep->preact || ep->ld_preact % 4 == 0) && bn_aligned16(dY, dZ, dR, ep->preact);
   if (v4)
     hipLaunchKernelGGL(epilogue_bwd_v4_kernel, dim3(grid_for((int64_t)M * (N / 4))), dim3(256), 0, as_hip(stream), dY, lddy,
-                       dZ, lddz, dR, lddr, accumulate_dR, M, N, *ep);
-  else
+                       dZ, lddz, dR, lddr, accumulate_dR, M, N, *ep, rs ? rs->rows : nullptr, rs ? rs->count : nullptr);
+  else      // (unaligned operands: every row, as without a list -- dead rows then carry whatever the row mask makes of dY)
     hipLaunchKernelGGL(epilogue_bwd_kernel, dim3(grid_for((int64_t)M * N)), dim3(256), 0, as_hip(stream), dY, lddy, dZ, lddz,
                        dR, lddr, accumulate_dR, M, N, *ep);
   NACF_LAUNCH_CHECK("nacf_epilogue_bwd");

@@ -463,6 +463,11 @@ class PositionRowsFn(Function):
         return (None,) * len(ctx.needs_input_grad)
 
 
+# NACF_DEAD_ROWS=fill (tuning / A-B): round 3's policy -- every row-list GEMM zero-fills its dead rows, the epilogue backward
+# walks every row.  Default: only where something reads every row (models/bert.py:BertLayer.run).
+_FILL_ALL = os.environ.get("NACF_DEAD_ROWS", "") == "fill"
+
+
 class LinearFn(Function):
     """nn.Linear with the fused epilogue of nacf_linear_fwd.
     cfg keys: pack, act, p1, salt1, p2, salt2, row_tokens, rng, training."""
@@ -485,7 +490,9 @@ class LinearFn(Function):
                       residual=res, p2=cfg.get("p2", 0.0) if training else 0.0, salt2=cfg.get("salt2", 0),
                       row_tokens=cfg.get("row_tokens"), rng=cfg.get("rng"))
         out = mk((M, N), x)
-        ops.linear_fwd(x, pk.w, out, epi, rows, zero_dead=True)
+        # cfg['fill'] = False: every consumer of `out` (and of the pre-activation) walks the same row list, so the dead rows
+        # need no zeros (a 2048-wide FFN1 output of 5120 slots: 36 MB of zero stores per step with its pre-activation)
+        ops.linear_fwd(x, pk.w, out, epi, rows, zero_dead=bool(cfg.get("fill", True)) or _FILL_ALL)
         ctx.cfg, ctx.epi, ctx.x, ctx.rows = cfg, epi, x, rows
         ctx.has_res = residual is not None
         return out
@@ -506,7 +513,8 @@ class LinearFn(Function):
             dz = _new((M, N), dy)
             dr = _new((M, N), dy) if ctx.has_res else None
             epi.residual = dr  # only its presence matters to the kernel
-            ops.epilogue_bwd(dy, dz, dr, epi)
+            # (live rows only; dead rows of dr: zeros, of dz: untouched)
+            ops.epilogue_bwd(dy, dz, dr, epi, rows=None if _FILL_ALL else ctx.rows)
             epi.residual = None
         dx = None
         rows = ctx.rows
@@ -525,7 +533,8 @@ class LinearFn(Function):
                 ops.linear_bwd_data(dz, pk.w, dx, beta=1.0, rows=rows)
             else:
                 dx = _new((M, K), dy)
-                ops.linear_bwd_data(dz, pk.w, dx, rows=rows, zero_dead=True)
+                # cfg['dx_fill'] = False: the producer of x backpropagates through a row-list epilogue (LinearFn of the same list)
+                ops.linear_bwd_data(dz, pk.w, dx, rows=rows, zero_dead=bool(cfg.get("dx_fill", True)) or _FILL_ALL)
         if pk.gw is not None:
             ops.linear_bwd_weight(dz, ctx.x, pk.gw, pk.gb, beta=1.0, rows=rows)
         ctx.x = None

@@ -603,13 +603,16 @@ def loss_combine_bwd(gtotal: Tensor, coef: Tensor, n_terms: int, stride: int, gs
             "nacf_loss_combine_bwd")
 
 
-def epilogue_bwd(dy: Tensor, dz: Tensor, dr: Optional[Tensor], epi: Epi, accumulate_dr: bool = False) -> None:
+def epilogue_bwd(dy: Tensor, dz: Tensor, dr: Optional[Tensor], epi: Epi, accumulate_dr: bool = False,
+                 rows: Optional[RowSet] = None) -> None:
+    """rows: the forward GEMM's live-row list -- only those rows of dz are written (its consumers take the same list); the
+    dead rows of dr get zeros"""
     _chk_f32(dy, dz, dr)
     M, N, lddy = _rows2d(dy)
     ep = epi.cstruct()
     L.check(L.load().nacf_epilogue_bwd(_ptr(dy), lddy, _ptr(dz), dz.stride(0), _ptr(dr),
                                        dr.stride(0) if dr is not None else 0, int(accumulate_dr), M, N,
-                                       ctypes.byref(ep), _stream()), "nacf_epilogue_bwd")
+                                       ctypes.byref(ep), _rs(rows, False), _stream()), "nacf_epilogue_bwd")
 
 
 # ---------------------------------------------------------------- encoder tail

@@ -257,6 +257,37 @@ def test_epilogue_bwd_matches_autograd(dev):
     assert err(dz, z.grad) < 1e-5 and err(dr, r.grad) < 1e-6
 
 
+def test_epilogue_bwd_with_a_live_row_list(dev):
+    """the forward GEMM's row list: live rows are bit-identical to the all-rows launch (same dropout masks: functions of the
+    physical element index), dead rows of dZ are left untouched, dead rows of dR get zeros without anything being read
+    (dY / the pre-activation hold NaNs there), and with accumulate_dR they are left alone"""
+    ops, L = _ops()
+    M, N = 300, 256
+    tok = torch.randint(0, 3, (M,), generator=torch.Generator().manual_seed(3))
+    live = tok.ne(0)
+    rows = ops.rowset_build(tokens=tok.to(dev))
+    rng = ops.RngState(99, dev)
+    z = rnd(M, N, seed=1)
+    dy = rnd(M, N, seed=4)
+    mk = lambda pre: ops.Epi(act=L.ACT_GELU_NEW, preact=pre.to(dev), p1=0.3, salt1=7, residual=torch.empty(M, N, device=dev),
+                             p2=0.2, salt2=8, row_tokens=tok.to(dev), rng=rng)
+    dz0, dr0 = torch.empty(M, N, device=dev), torch.empty(M, N, device=dev)
+    ops.epilogue_bwd(dy.to(dev), dz0, dr0, mk(z))
+    # poison what must not be read
+    z_p, dy_p = z.clone(), dy.clone()
+    z_p[~live] = float("nan")
+    dy_p[~live] = float("nan")
+    dz1, dr1 = torch.full((M, N), 7.0, device=dev), torch.full((M, N), 7.0, device=dev)
+    ops.epilogue_bwd(dy_p.to(dev), dz1, dr1, mk(z_p), rows=rows)
+    lv = live.to(dev)
+    assert torch.equal(dz1[lv], dz0[lv]) and torch.equal(dr1[lv], dr0[lv]) and bool(dz1[lv].ne(0).any())
+    assert float((dz1[~lv] - 7.0).abs().max()) == 0.0                  # untouched
+    assert float(dr1[~lv].abs().max()) == 0.0 and float(dr0[~lv].abs().max()) == 0.0
+    acc = torch.full((M, N), 2.0, device=dev)
+    ops.epilogue_bwd(dy_p.to(dev), dz1, acc, mk(z_p), accumulate_dr=True, rows=rows)
+    assert torch.equal(acc[lv], dr0[lv] + 2.0) and float((acc[~lv] - 2.0).abs().max()) == 0.0
+
+
 @pytest.mark.parametrize("rows,V,K", [(57, 101, 64), (300, 1000, 64), (128, 10547, 512)])
 def test_vocab_argmax_fused(dev, rows, V, K):
     ops, _ = _ops()
