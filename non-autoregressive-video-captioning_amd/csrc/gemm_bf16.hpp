@@ -809,9 +809,7 @@ __device__ __forceinline__ void gemm_bf16_body(const GemmShape& g, const Epi& ep
         const int m = m0 + tid;
         if (m < g.M) {
           const float t = red[tid];
-          // (a split launch that combines in the kernel carries BOTH: the partials here, the result from the last arriver below)
-          if (g.colsum_part && nz > 1) g.colsum_part[(int64_t)z * g.M + m] = t;
-          else if (g.colsum_out) g.colsum_out[m] = (g.colsum_beta != 0.f) ? t + g.colsum_beta * g.colsum_out[m] : t;
+          if (g.colsum_out) g.colsum_out[m] = (g.colsum_beta != 0.f) ? t + g.colsum_beta * g.colsum_out[m] : t;
           else g.colsum_part[(int64_t)z * g.M + m] = t;
         }
       }
@@ -832,63 +830,6 @@ __device__ __forceinline__ void gemm_bf16_body(const GemmShape& g, const Epi& ep
     else epilogue_all<0, TM, TN, true, Epi>(epi, acc, mlog, mphys, ncol, Meff, g.N, z);
   } else {
     argmax_epilogue<BM, BN, WM, WN, TM, TN>(reinterpret_cast<float*>(smem), g, epi, acc, m0, n0, Meff, tile_n, wm, wn, li, lg, tid);
-  }
-  // ---- in-kernel combine of the reduce splits (EpiStore::cnt): the last workgroup of this tile's nz splits adds the slabs
-  if constexpr (std::is_same<Epi, EpiStore>::value) {
-    if (epi.cnt && nz > 1) {
-      __shared__ int s_last;
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // this wave's slab (and bias-partial) stores have left it
-      __syncthreads();
-      if (tid == 0) {
-        // release: this XCD's L2 is written back before the arrival is visible (the other splits ran on other XCDs, whose
-        // L2s are not coherent with this one for plain stores); the last arriver acquires before it reads their slabs
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        int* const c = epi.cnt + (tile_m * g.tiles_n + tile_n);
-        const int old = __hip_atomic_fetch_add(c, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const int last = (old == nz - 1) ? 1 : 0;
-        if (last) {
-          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-          __hip_atomic_store(c, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // zero again for the next launch
-        }
-        s_last = last;
-      }
-      __syncthreads();
-      if (s_last) {
-        const int n_rows = min(BM, (ROWS_ARE_K ? g.M : Meff) - m0), n_cols = min(BN, g.N - n0);
-        const int* const rmap = (g.rows && !ROWS_ARE_K) ? g.rows : nullptr;
-        if (epi.vec_dst && epi.vec_out && (n_cols & 3) == 0) {
-          const int c4n = n_cols >> 2;
-          for (int q = tid; q < n_rows * c4n; q += 256) {
-            const int r = q / c4n, c = (q - r * c4n) * 4;
-            const int mp = rmap ? rmap[m0 + r] : m0 + r;
-            const float* sp = epi.C + (int64_t)mp * epi.ldc + n0 + c;
-            f32x4 acc = *reinterpret_cast<const f32x4*>(sp);
-            for (int zz = 1; zz < nz; ++zz) acc += *reinterpret_cast<const f32x4*>(sp + (int64_t)zz * epi.slab_stride);
-            f32x4* d = reinterpret_cast<f32x4*>(epi.dst + (int64_t)mp * epi.ldd + n0 + c);
-            *d = (epi.dbeta != 0.f) ? acc + epi.dbeta * (*d) : acc;
-          }
-        } else {
-          for (int q = tid; q < n_rows * n_cols; q += 256) {
-            const int r = q / n_cols, c = q - r * n_cols;
-            const int mp = rmap ? rmap[m0 + r] : m0 + r;
-            const float* sp = epi.C + (int64_t)mp * epi.ldc + n0 + c;
-            float acc = 0.f;
-            for (int zz = 0; zz < nz; ++zz) acc += sp[(int64_t)zz * epi.slab_stride];
-            float* d = epi.dst + (int64_t)mp * epi.ldd + n0 + c;
-            *d = (epi.dbeta != 0.f) ? acc + epi.dbeta * (*d) : acc;
-          }
-        }
-        if constexpr (ROWS_ARE_K) {
-          // the bias gradient of this row tile: the partials of column tile 0's workgroups, in split order
-          if (tile_n == 0 && g.colsum_part && g.colsum_out && tid < BM && m0 + tid < g.M) {
-            const int m = m0 + tid;
-            float acc = 0.f;
-            for (int zz = 0; zz < nz; ++zz) acc += g.colsum_part[(int64_t)zz * g.M + m];
-            g.colsum_out[m] = (g.colsum_beta != 0.f) ? acc + g.colsum_beta * g.colsum_out[m] : acc;
-          }
-        }
-      }
-    }
   }
 #ifdef NACF_BF16_TRACE
   if (g_bf16_trace && tid == 0) {

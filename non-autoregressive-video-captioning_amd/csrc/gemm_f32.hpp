@@ -206,16 +206,6 @@ struct EpiStore {
   float beta;
   int64_t slab_stride;  // elements between blockIdx.z slabs (0: none)
   int vec_out;
-  // In-kernel combine of the reduce splits (gemm_bf16_body only; cnt == nullptr: off, a combine kernel follows the GEMM).
-  // Every split stores its slab as above; the workgroup that is the LAST of a tile's splits to arrive (cnt[tile], an agent-scope
-  // counter that is zero before the launch and zero again after it) adds the slabs of that tile in split order -- the sums are
-  // those of the combine kernels (splitk_reduce_*), whoever arrives last -- and writes dst = dbeta * dst + sum.  With a
-  // live-row list the dead rows of dst are zero-filled by the dead row tiles' workgroups of split 0 (dbeta == 0).
-  int* cnt = nullptr;
-  float* dst = nullptr;
-  int64_t ldd = 0;
-  float dbeta = 0.f;
-  int vec_dst = 0;
   static constexpr bool kArgmax = false;
   __device__ __forceinline__ void operator()(int m, int mp, int n, f32x4 v, int M, int N, int z) const {
     if (m >= M || n >= N) return;
@@ -235,15 +225,6 @@ struct EpiStore {
   }
   // dead-row fill (see nacf_rowset.zero_dead): columns [n, n + 4) of physical row mp
   __device__ __forceinline__ void zero4(int mp, int n, int N) const {
-    if (cnt) {                                      // slabs combined in the kernel: the zeros go to the final rows
-      if (dbeta != 0.f) return;
-      float* p = dst + (int64_t)mp * ldd + n;
-      if (vec_dst && n + 4 <= N) *reinterpret_cast<f32x4*>(p) = f32x4{0.f, 0.f, 0.f, 0.f};
-      else
-        for (int e = 0; e < 4; ++e)
-          if (n + e < N) p[e] = 0.f;
-      return;
-    }
     if (beta != 0.f || slab_stride != 0) return;   // accumulate: dead rows contribute nothing
     float* p = C + (int64_t)mp * ldc + n;
     if (vec_out && n + 4 <= N) *reinterpret_cast<f32x4*>(p) = f32x4{0.f, 0.f, 0.f, 0.f};

@@ -153,26 +153,6 @@ void launch_gemm(const GemmShape& g0, const Epi& epi, int splits, int tile, bool
   }
 }
 
-// ---- in-kernel split combine (EpiStore::cnt, gemm_bf16.hpp): one agent-scope arrival counter per output tile.  The array is
-// zero at module load and every launch leaves its counters zero again (the last arriver of a tile resets it), so a launch
-// only needs a range no launch still in flight uses: ranges are handed out cyclically (one stream: launches are ordered; a
-// captured launch keeps its range, which later launch-by-launch calls may reuse -- never at the same time).
-// NACF_SPLITK_COMBINE=kernel (tuning / tests): the round-3 path, a combine kernel behind the GEMM.
-constexpr int TILE_CNT_N = 1 << 16;
-__device__ int g_tile_cnt[TILE_CNT_N];
-static int* tile_counters(int n_tiles) {
-  { const char* e = getenv("NACF_SPLITK_COMBINE"); if (e && !strcmp(e, "kernel")) return nullptr; }
-  static int* base = [] { void* p = nullptr; return hipGetSymbolAddress(&p, HIP_SYMBOL(g_tile_cnt)) == hipSuccess ? static_cast<int*>(p) : nullptr; }();
-  static std::mutex mu;
-  static int next = 0;
-  if (!base || n_tiles <= 0 || n_tiles > TILE_CNT_N) return nullptr;
-  std::lock_guard<std::mutex> lk(mu);
-  if (next + n_tiles > TILE_CNT_N) next = 0;
-  int* r = base + next;
-  next += n_tiles;
-  return r;
-}
-
 inline void set_rows(GemmShape& g, const nacf_rowset* rs) {
   g.rows = rs ? rs->rows : nullptr;
   g.count = rs ? rs->count : nullptr;
@@ -543,28 +523,16 @@ int nacf_linear_bwd_data(const float* dZ, int64_t lddz, const float* W, int64_t 
     epi.C = dX; epi.ldc = lddx; epi.beta = beta; epi.slab_stride = 0;
     epi.vec_out = ((lddx % 4 == 0) && aligned16(dX)) ? 1 : 0;
   }
-  bool combined = false;       // the slabs are added inside the GEMM (last arriver per tile): no combine launch
   if (bf16) {
     find_image_t(W, ldw, N, K, mode, g);       // P = W^T image [K, N] when registered, else the fp32 W read transposed
-    if (!(mode == NACF_GEMM_BF16X3 && launch_wide_dx(g, epi, real_splits, rs != nullptr, s))) {
-      const int tile = pick_tile_bf16(1, M, K, real_splits, rs != nullptr, mode);
-      const int t = tile == 0 ? 128 : 64;
-      if (real_splits > 1) {
-        if (int* cnt = tile_counters(cdiv(M, t) * cdiv(K, t))) {
-          epi.cnt = cnt; epi.dst = dX; epi.ldd = lddx; epi.dbeta = beta;
-          epi.vec_dst = ((lddx % 4 == 0) && aligned16(dX)) ? 1 : 0;
-          set_rows(g, rs);                      // (zero_dead back on: the dead row tiles of split 0 fill dX directly)
-          combined = true;
-        }
-      }
-      launch_bf16_dx(g, epi, real_splits, tile, mode, s);
-    }
+    if (!(mode == NACF_GEMM_BF16X3 && launch_wide_dx(g, epi, real_splits, rs != nullptr, s)))
+      launch_bf16_dx(g, epi, real_splits, pick_tile_bf16(1, M, K, real_splits, rs != nullptr, mode), mode, s);
     g_last_was_bf16 = true;
   } else {
     launch_gemm<true, false, EpiStore>(g, epi, real_splits, pick_tile(M, K, real_splits, rs != nullptr), vec, s);
   }
   NACF_LAUNCH_CHECK("nacf_linear_bwd_data");
-  if (real_splits > 1 && !combined) {
+  if (real_splits > 1) {
     const int64_t total = (int64_t)M * K;
     const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
     hipLaunchKernelGGL(splitk_reduce_rows_kernel, dim3(blocks), dim3(256), 0, s, epi.C, (int64_t)M * K, real_splits, dX,
@@ -735,27 +703,21 @@ static int dw_subset_launch_locked(const std::vector<int>& subset, hipStream_t s
       float* slabs = it.ws;
       float* part = slabs + (real > 1 ? (size_t)real * it.N * it.K : 0);
       EpiStore epi;
-      bool combined = false;
       if (real > 1) {
         epi.C = slabs; epi.ldc = it.K; epi.beta = 0.f; epi.slab_stride = (int64_t)it.N * it.K; epi.vec_out = (it.K % 4 == 0) ? 1 : 0;
-        if (int* cnt = tile_counters(tiles[i])) {      // the slabs are added inside the GEMM (last arriver per tile)
-          epi.cnt = cnt; epi.dst = it.dW; epi.ldd = it.lddw; epi.dbeta = it.beta;
-          epi.vec_dst = ((it.K % 4 == 0) && (it.lddw % 4 == 0) && aligned16(it.dW) && aligned16(slabs)) ? 1 : 0;
-          combined = true;
-        }
       } else {
         epi.C = it.dW; epi.ldc = it.lddw; epi.beta = it.beta; epi.slab_stride = 0;
         epi.vec_out = ((it.lddw % 4 == 0) && aligned16(it.dW)) ? 1 : 0;
       }
       if (it.db) {
         if (real > 1) g.colsum_part = part;
-        if (real == 1 || combined) { g.colsum_out = it.db; g.colsum_beta = it.beta; }
+        else { g.colsum_out = it.db; g.colsum_beta = it.beta; }
       }
       const int gx = split_major ? tiles[i] : (tiles[i] + 7) / 8 * 8;
       t.g[t.n] = g; t.e[t.n] = epi; t.gx[t.n] = gx; t.nz[t.n] = real; t.wg0[t.n] = wg;
       wg += split_major ? (gx * real + 7) / 8 * 8 : gx * real;
       ++t.n;
-      if (real > 1 && !combined) {
+      if (real > 1) {
         const int rc = dw_combine_push_locked(slabs, it.dW, it.lddw, it.db ? part : nullptr, it.db, it.N, it.K, real, it.beta, s);
         if (rc != NACF_OK) return rc;
       }
