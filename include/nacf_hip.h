@@ -204,7 +204,8 @@ int nacf_dw_group_stats(int* launches, int* workgroups);
  * arithmetic is exactly that of its own launch (bit-identical results).  Contract while a group is open: the queued
  * calls' operands and outputs are untouched until the flush, and none of them reads what another one (or anything
  * launched in between) writes.  The flush returns the number of GEMMs it launched (>= 0) or a negative error code.
- * nacf_gemm_last_kernel() reads "gemm_wide_queued" after a call that was queued. */
+ * nacf_gemm_last_kernel() reads "gemm_wide_queued" after a call that was queued.  The queue belongs to the calling host
+ * thread: begin, the queued calls and the flush come from one thread; calls made by other threads meanwhile launch at once. */
 int nacf_wide_group_begin(void);
 int nacf_wide_group_flush(nacf_stream_t stream);
 

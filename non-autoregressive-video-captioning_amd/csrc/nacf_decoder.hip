@@ -92,6 +92,64 @@ __global__ __launch_bounds__(EMB_THREADS) void embed_ln_fwd_kernel(
   if (threadIdx.x == 0 && rstd_out) rstd_out[row] = rstd;
 }
 
+// ONE WAVE per row (D = 256 NJ, NJ <= 4: the model's 512), four rows per workgroup: the two LayerNorm reductions are wave
+// shuffles instead of two workgroup barriers each -- a row's chain is token -> embedding rows -> mean -> variance -> store, and
+// with one 128-thread workgroup per row (14592 of them for a decode canvas) that chain was barrier latency: 20 us per pass
+// for 30 MB.  Same values up to the order of the two sums.
+template <int NJ>
+__global__ __launch_bounds__(256) void embed_ln_fwd_wave_kernel(
+    const int64_t* __restrict__ tokens, const int64_t* __restrict__ category, const float* __restrict__ additional,
+    const float* __restrict__ word, const float* __restrict__ pos, const float* __restrict__ cat,
+    const float* __restrict__ ln_w, const float* __restrict__ ln_b, float* __restrict__ out,
+    float* __restrict__ xhat, float* __restrict__ rstd_out, int rows, int L, int vdiv, int vmod, float eps, float p,
+    uint32_t salt, const uint64_t* __restrict__ rng_state) {
+  constexpr int D = 256 * NJ;
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const int r = row / L, l = row % L;
+  const int v = (r / vdiv) % vmod;
+  const int64_t tok = tokens[row];
+  const bool has_cat = cat && category;
+  const int64_t c = has_cat ? category[v] : 0;
+  f32x4 x[NJ];
+  float sum = 0.f;
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) {
+    const int d = (lane + 64 * j) * 4;
+    f32x4 a = *reinterpret_cast<const f32x4*>(word + tok * D + d);
+    a += *reinterpret_cast<const f32x4*>(pos + (int64_t)l * D + d);
+    if (has_cat) a += *reinterpret_cast<const f32x4*>(cat + c * D + d);
+    if (additional) a += *reinterpret_cast<const f32x4*>(additional + (int64_t)v * D + d);
+    x[j] = a;
+    sum += a[0] + a[1] + a[2] + a[3];
+  }
+  const float mean = wave_sum(sum) / (float)D;
+  float sq = 0.f;
+#pragma unroll
+  for (int j = 0; j < NJ; ++j)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { const float dv = x[j][e] - mean; sq += dv * dv; }
+  const float var = wave_sum(sq) / (float)D;
+  const float rstd = 1.0f / sqrtf(var + eps);
+  DropRng rng;
+  if (p > 0.f) rng.init(rng_state);
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) {
+    const int d = (lane + 64 * j) * 4;
+    f32x4 xh;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) xh[e] = (x[j][e] - mean) * rstd;
+    if (xhat) *reinterpret_cast<f32x4*>(xhat + (int64_t)row * D + d) = xh;
+    const f32x4 w = *reinterpret_cast<const f32x4*>(ln_w + d);
+    const f32x4 b = *reinterpret_cast<const f32x4*>(ln_b + d);
+    f32x4 y = xh * w + b;
+    if (p > 0.f) y *= rng.keep4(((uint64_t)row * D + d) >> 2, salt, p);
+    *reinterpret_cast<f32x4*>(out + (int64_t)row * D + d) = y;
+  }
+  if (lane == 0 && rstd_out) rstd_out[row] = rstd;
+}
+
 __global__ __launch_bounds__(EMB_THREADS) void embed_ln_bwd_kernel(
     const float* __restrict__ dOut, const float* __restrict__ xhat, const float* __restrict__ rstd,
     const float* __restrict__ ln_w, float* __restrict__ dE, float* __restrict__ part, int rows, int D, float p,
@@ -742,9 +800,22 @@ int nacf_embed_ln_fwd(const int64_t* tokens, const int64_t* category, const floa
   NACF_CHECK(D % 4 == 0 && D <= EMB_MAXJ * EMB_THREADS * 4, NACF_EUNSUPPORTED,
              "nacf_embed_ln_fwd: D must be a multiple of 4 and <= 2048 (got %d)", D);
   NACF_CHECK(p_drop < 1.f && !(p_drop > 0.f && !rng_state), NACF_EINVAL, "nacf_embed_ln_fwd: dropout needs rng_state, p<1");
-  hipLaunchKernelGGL(embed_ln_fwd_kernel, dim3(R * L), dim3(EMB_THREADS), 0, as_hip(stream), tokens, category,
-                     additional, word_emb, pos_emb, cat_emb, ln_w, ln_b, out, xhat, rstd, L, D, vdiv, vmod, eps, p_drop,
-                     salt, rng_state);
+  const bool al = ((reinterpret_cast<uintptr_t>(word_emb) | reinterpret_cast<uintptr_t>(pos_emb) | reinterpret_cast<uintptr_t>(out) |
+                    reinterpret_cast<uintptr_t>(ln_w) | reinterpret_cast<uintptr_t>(ln_b)) & 15) == 0;
+  const int rows = R * L;
+#define NACF_EMB_WAVE(NJ)                                                                                                  \
+  hipLaunchKernelGGL(embed_ln_fwd_wave_kernel<NJ>, dim3(cdiv(rows, 4)), dim3(256), 0, as_hip(stream), tokens, category,    \
+                     additional, word_emb, pos_emb, cat_emb, ln_w, ln_b, out, xhat, rstd, rows, L, vdiv, vmod, eps, p_drop, \
+                     salt, rng_state)
+  if (al && D == 256) NACF_EMB_WAVE(1);
+  else if (al && D == 512) NACF_EMB_WAVE(2);
+  else if (al && D == 768) NACF_EMB_WAVE(3);
+  else if (al && D == 1024) NACF_EMB_WAVE(4);
+  else
+    hipLaunchKernelGGL(embed_ln_fwd_kernel, dim3(R * L), dim3(EMB_THREADS), 0, as_hip(stream), tokens, category,
+                       additional, word_emb, pos_emb, cat_emb, ln_w, ln_b, out, xhat, rstd, L, D, vdiv, vmod, eps, p_drop,
+                       salt, rng_state);
+#undef NACF_EMB_WAVE
   NACF_LAUNCH_CHECK("nacf_embed_ln_fwd");
   return NACF_OK;
 }

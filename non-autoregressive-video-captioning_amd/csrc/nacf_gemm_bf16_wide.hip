@@ -76,10 +76,12 @@ void launch_wide_group(const std::vector<std::pair<GemmShape, Epi>>& items, hipS
   }
 }
 
-std::mutex g_wide_mu;
-bool g_wide_group_on = false;
-std::vector<std::pair<GemmShape, EpiLinear>> g_wide_lin;
-std::vector<std::pair<GemmShape, EpiStore>> g_wide_sto;
+// The group queue is PER HOST THREAD: a `with ops.wide_group()` block opens, fills and flushes it from one
+// Python function, i.e. one thread -- the forward on the caller's, the HighWay dX pair on autograd's -- and a GEMM issued
+// meanwhile by any other thread (another stream's work) launches at once instead of landing in somebody else's group.
+thread_local bool g_wide_group_on = false;
+thread_local std::vector<std::pair<GemmShape, EpiLinear>> g_wide_lin;
+thread_local std::vector<std::pair<GemmShape, EpiStore>> g_wide_sto;
 thread_local char g_wide_last[96] = "";
 void note(int mt, const char* epi, bool grouped) {
   snprintf(g_wide_last, sizeof(g_wide_last), "gemm_wide_%skernel<%d, %s>", grouped ? "group_" : "", mt, epi);
@@ -134,10 +136,7 @@ static bool launch_wide_any(const GemmShape& g, const Epi& epi, int splits, bool
                             const char* name, hipStream_t s) {
   const int mt = wide_pick(g, splits, has_rows, 3, heavy);
   if (!mt) return false;
-  if (queue && splits == 1) {
-    std::lock_guard<std::mutex> lk(g_wide_mu);
-    if (g_wide_group_on) { queue->push_back({g, epi}); bf16_note_wide("gemm_wide_queued"); return true; }
-  }
+  if (queue && splits == 1 && g_wide_group_on) { queue->push_back({g, epi}); bf16_note_wide("gemm_wide_queued"); return true; }
   if (mt == 2) launch_wide_one<2, Epi>(g, epi, splits, s); else launch_wide_one<1, Epi>(g, epi, splits, s);
   note(mt, name, false);
   return true;
@@ -154,12 +153,10 @@ extern "C" {
 // of each kind as one grid.  The caller guarantees they are independent of each other and of everything it launches in
 // between (the two modalities of the visual encoder: models/Encoder.py:47-59 runs them one after the other).
 int nacf_wide_group_begin(void) {
-  std::lock_guard<std::mutex> lk(g_wide_mu);
   g_wide_group_on = true;
   return NACF_OK;
 }
 int nacf_wide_group_flush(nacf_stream_t stream) {
-  std::lock_guard<std::mutex> lk(g_wide_mu);
   g_wide_group_on = false;
   int n = flush_one(g_wide_lin, "EpiLinear", as_hip(stream));
   n += flush_one(g_wide_sto, "EpiStore", as_hip(stream));

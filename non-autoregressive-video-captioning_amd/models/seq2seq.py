@@ -199,6 +199,7 @@ class Seq2Seq(nn.Module):
     def _run(self, feats, tgt_tokens, category, decoding_type):
         if self.training:
             self._ensure_grads()
+            self.flat.train_forwards += 1       # (host counter; a replayed captured step does not pass here)
             self.rt.rng(feats[0].device)
             self.rt.advance()
         results = self.encode(feats)

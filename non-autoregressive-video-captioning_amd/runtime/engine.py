@@ -83,6 +83,7 @@ class TrainStep(object):
         # its steps the engine owns that buffer.  NACF_FUSED_ZERO_GRAD=0: fill at the start of every step as misc/run.py does
         self.fused_zero_grad = os.environ.get("NACF_FUSED_ZERO_GRAD", "1") != "0"
         self._grad_clean = False
+        self._fwd_seen = None               # FlatParams.train_forwards after this engine's last step
         self._one = self._graph_loss = None
         self.static = self.sig = None
         self.loss = None                    # device scalar: the last step's loss
@@ -328,7 +329,10 @@ class TrainStep(object):
         if self.sched is not None:
             self.sched.step_update_learning_rate()      # host counter + one fill of the device-side learning rate
         if batch is not None and _signature(batch, self.keys) != self.sig:
-            return self._eager(batch)                   # ragged tail of an epoch
+            self._foreign_backward_guard()
+            self._eager(batch)                          # ragged tail of an epoch
+            self._fwd_seen = getattr(getattr(self.model, 'flat', None), 'train_forwards', None)
+            return None
         if batch is not None:
             dst = _tensors(self.static, self.keys)
             for key, src in _tensors(batch, self.keys).items():
@@ -360,10 +364,24 @@ class TrainStep(object):
                 raise RuntimeError('nacf_amd: hipGraph capture needs the fused criterion (opt["fused_loss"])')
             else:
                 self.graph_mode = 'off'
+        self._foreign_backward_guard()
         if self.graphs is not None:
             self._replay()
         else:
             self._eager(self.static)
+        self._fwd_seen = getattr(getattr(self.model, 'flat', None), 'train_forwards', None)
+
+    def _foreign_backward_guard(self):
+        """the fused zero-grad leaves the gradient buffer clean for THIS engine's next step, and a captured step
+        has no fill in it.  A training forward that did not come from here (a manual loss.backward(), misc/run.py's
+        launch-by-launch path, a second engine) may have summed into that buffer since: fill it, as optimizer.zero_grad() would."""
+        flat = getattr(self.model, 'flat', None)
+        if flat is None or self._fwd_seen is None or flat.train_forwards == self._fwd_seen or not self._grad_clean:
+            return
+        self._grad_clean = False
+        if self.graphs is not None:
+            self.adam.zero_grad()
+            self._grad_clean = True         # (what the replayed step assumes; its Adam walk re-establishes it)
 
     @property
     def captured(self):

@@ -70,6 +70,9 @@ class FlatParams:
         # `version` counts writes to the fp32 master weights that went through this package (optimiser step,
         # load_state_dict, broadcast); `images_version` is the version the images were last built from
         self.version = 0
+        # training-mode forward passes through Seq2Seq (whoever called them): the step engine owns the gradient buffer
+        # between ITS steps only as long as nobody else ran one (runtime/engine.py: the fused zero-grad)
+        self.train_forwards = 0
         self.images_version = -1
         with torch.no_grad():
             for p in self.params:

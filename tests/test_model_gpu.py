@@ -630,3 +630,40 @@ def test_tied_weights_fall_back_to_two_buckets(dev):
     assert opt["tie_weights"]
     model = nacf_amd.get_model(opt).to(dev)
     assert DataParallel(model).head_split() is None
+
+
+def test_memory_fanout_accumulates_in_place_only_into_a_buffer_it_owns(dev):
+    """MemoryFanoutFn.backward adds the time-mean's gradient INTO the incoming gradient of the visual memory
+    (one read-modify-write instead of a second [B, T, D] tensor and an add).  That buffer is the K|V projection's freshly
+    allocated dX, which nobody else holds: a retain_grad() on enc_output keeps its own clone (the gradient of enc_output as a
+    decoder input, WITHOUT the pooled paths), and the encoder still receives the sum.  The contract for user hooks is the usual
+    one: a hook that stashes its argument without cloning sees later in-place updates."""
+    import nacf_amd
+    from nacf_amd import synthetic as S
+    from nacf_amd.misc.crit import get_criterion
+    opt = nacf_amd.opts.make_opt("NACF", "MSRVTT", with_category=True, max_len=12, vocab_size=300, n_frames=6, dim_hidden=128,
+                                 num_attention_heads=4, intermediate_size=256, dim_i=64, dim_m=64, fused_loss=True,
+                                 hidden_dropout_prob=0.0, encoder_dropout=0.0)
+    sd = S.init_state_dict(opt, seed=0)
+    b = S.synth_batch(opt, 8, 6, seed=3)
+    grads = {}
+    for mode in ("plain", "retain"):
+        model = build(opt, sd, dev)
+        model.train()
+        crit = get_criterion(model.opt)
+        model.zero_grad()
+        res = model(feats=[f.to(dev) for f in b["feats"]], tgt_tokens=[b["tokens_1"].to(dev), b["tokens"].to(dev)],
+                    category=b["category"].to(dev))
+        res["tgt_word_labels"] = [b["labels_1"].to(dev), b["labels"].to(dev)]
+        res["tgt_length"] = b["tgt_length"].to(dev)
+        stash = {}
+        if mode == "retain":
+            eo = res["enc_output"]
+            eo.retain_grad()
+            eo.register_hook(lambda g_: stash.__setitem__("clone", g_.clone()) or None)
+        crit.get_loss(res).backward()
+        grads[mode] = model.flat.grad.clone()
+        if mode == "retain":
+            assert torch.equal(res["enc_output"].grad, stash["clone"])          # the retained gradient was not mutated
+            assert float(stash["clone"].abs().max()) > 0
+    assert torch.equal(grads["plain"], grads["retain"])                         # and the parameters' gradients are the same

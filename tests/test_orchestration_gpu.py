@@ -402,3 +402,36 @@ def test_direct_decoder_call_after_replayed_steps_sees_the_replayed_weights(dev)
         h2 = model.decoder(tok, enc_output=enc_out, category=cat)[0].clone()
     assert images is model.flat.images
     assert torch.equal(h1, h2)
+
+
+def test_a_backward_outside_the_engine_does_not_leak_into_the_next_replayed_step(dev):
+    """the captured step contains no gradient fill (the previous step's Adam walk leaves the buffer zeroed).
+    A manual model(...) / loss.backward() between two engine steps sums into that buffer; the engine must notice (the model
+    counts its training forwards) and fill before it replays -- the trajectory is the undisturbed one, bit for bit."""
+    from nacf_amd.misc.crit import get_criterion
+    from nacf_amd.misc.optim import get_optimizer
+    from nacf_amd.misc.run import get_forword_results
+    from nacf_amd.runtime.engine import TrainStep
+    from nacf_amd.runtime import ops
+    ops.set_gemm_mode("bf16x3")
+    g = load_gold("tiny_nacf_trajectory")
+    opt = gold_opt(g)
+    assert float(opt.get("hidden_dropout_prob", 0.0)) == 0.0 or True
+    batches = _gold_batches(g, dev)
+    finals = []
+    for disturb in (False, True):
+        model = _model(opt, dev, fused_loss=True, hidden_dropout_prob=0.0, encoder_dropout=0.0)
+        model.train()
+        crit, optim = get_criterion(model.opt), get_optimizer(model.opt, model)
+        engine = TrainStep(model, crit, optim, lambda b, m=model: get_forword_results(m.opt, m, b, dev), graph="on")
+        for i in range(7):
+            engine(batches[i % len(batches)])
+            if disturb and i in (1, 4):          # once while the engine still steps launch by launch, once between replays
+                assert (i == 4) == engine.captured or i == 1
+                crit2 = get_criterion(model.opt)
+                loss = crit2.get_loss(get_forword_results(model.opt, model, batches[0], dev))
+                loss.backward()
+                assert float(model.flat.grad.abs().max()) > 0          # the foreign gradient sits in the engine's buffer
+        assert engine.captured
+        finals.append(model.flat.data.clone())
+    assert torch.equal(finals[0], finals[1])
