@@ -120,8 +120,9 @@ int wide_pick(const GemmShape& g, int splits, bool has_rows, int ns, bool heavy_
   if (g.K % 64 != 0 || kps % 64 != 0 || kps < 128 || (splits > 1 && g.K % kps != 0)) return 0;
   if (!al16(g.Q) || g.ldq % 4 != 0 || (int64_t)g.M * g.ldq * 4 >= (1LL << 32) || (int64_t)g.N * 64 >= (1LL << 32)) return 0;
   if (forced == 1 || forced == 2) return forced;
-  { static const int heavy_min = [] { const char* e = getenv("NACF_WIDE_HEAVY_MIN_K"); return e ? atoi(e) : 2048; }();
-    if (heavy_epilogue && kps < heavy_min) return 0; }
+  // (round 4 A/B, one box: heavy epilogues on this kernel from K = 512 on -- HighWay forward, the decoder's dropout
+  //  epilogues -- 2.78 -> 2.86 ms per step)
+  if (heavy_epilogue && kps < 2048) return 0;
   const long t2 = tiles_of(g, 128, splits, has_rows), t1 = tiles_of(g, 64, splits, has_rows);
   // With a live-row list the host does not know how many row tiles survive, and one workgroup per CU makes a partly
   // filled last round expensive (decode, 8921 live of 14592 rows x 1024: 280 workgroups = 1.1 rounds, 0.111 vs 0.081 ms
