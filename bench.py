@@ -264,12 +264,20 @@ def bench_decode(model, dev, feats, category, n_batches, with_roofline=True, mod
     for _ in range(4):       # launch by launch, hipGraph capture (decoding/na_generate.py), first replays
         hyp = dec_once()
     torch.cuda.synchronize()
+    evs = [torch.cuda.Event(enable_timing=True) for _ in range(n_batches + 1)]
     t1 = time.perf_counter()
-    for _ in range(n_batches):
+    evs[0].record()
+    for i in range(n_batches):
         hyp = dec_once()
+        evs[i + 1].record()
     torch.cuda.synchronize()
     ddt = (time.perf_counter() - t1) / n_batches
-    out = {"captions_per_s": round(B / ddt, 1), "ms_per_batch": round(ddt * 1e3, 2), "batch": B, "weights": "seeded init (seed 0)",
+    per = sorted(evs[i].elapsed_time(evs[i + 1]) for i in range(n_batches))
+    out = {"captions_per_s": round(B / ddt, 1), "ms_per_batch": round(ddt * 1e3, 2),
+           # per-batch HIP-event times: a one-off host stall (allocator growth, a graph re-instantiation) moves the mean of a
+           # short loop by 10-50 %; the median says what a batch costs
+           "median_ms_per_batch": round(per[len(per) // 2], 3), "max_ms_per_batch": round(per[-1], 3),
+           "batch": B, "weights": "seeded init (seed 0)",
            "paradigm": "mp+ct" if model.opt.get("use_ct") else "mp", "iterations": 5, "length_beam_size": 6,
            "width": int(hyp.shape[1]), "hipgraph": any(k[0] != "seen" for k in getattr(model, "_nacf_decode_graphs", {}))}
     if with_roofline:

@@ -388,6 +388,32 @@ __global__ __launch_bounds__(1024) void rowset_build_kernel(const int64_t* __res
   if (threadIdx.x == 0) count[0] = base_s;
 }
 
+// A weight gradient too small for the matrix-core kernels: N < 128 output rows cannot join the grouped launch, and the 64x64
+// kernel spent 17 us on the length head's second Linear (dW [20, 512] over 128 rows: 8 workgroups on its checked-load path,
+// 2.3 TF -- VERDICT round 3).  One thread per output element, an fp32 fmaf chain over the (live) rows in order: exact fp32
+// products, deterministic; the thread of column 0 also sums its row's bias gradient.
+__global__ __launch_bounds__(256) void dw_small_kernel(const float* __restrict__ dZ, int64_t lddz, const float* __restrict__ X,
+                                                       int64_t ldx, float* __restrict__ dW, int64_t lddw, float* __restrict__ db,
+                                                       int M, int N, int K, float beta, const int* __restrict__ rows,
+                                                       const int* __restrict__ count) {
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx >= N * K) return;
+  const int n = idx / K, k = idx - n * K;
+  const int Mlive = rows ? min(M, *count) : M;
+  float acc = 0.f, bsum = 0.f;
+  const bool do_b = db && k == 0;
+#pragma unroll 8
+  for (int i = 0; i < Mlive; ++i) {
+    const int m = rows ? rows[i] : i;
+    const float z = dZ[(int64_t)m * lddz + n];
+    acc = fmaf(z, X[(int64_t)m * ldx + k], acc);
+    bsum += z;
+  }
+  float* d = dW + (int64_t)n * lddw + k;
+  *d = (beta != 0.f) ? acc + beta * (*d) : acc;
+  if (do_b) db[n] = (beta != 0.f) ? bsum + beta * db[n] : bsum;
+}
+
 }  // namespace
 
 extern "C" {
@@ -827,6 +853,14 @@ int nacf_linear_bwd_weight(const float* dZ, int64_t lddz, const float* X, int64_
   const bool vec = (lddz % 4 == 0) && (ldx % 4 == 0) && aligned16(dZ) && aligned16(X);
   const int mode = gemm_mode();
   const bool bf16 = mode != NACF_GEMM_F32 && vec;
+  if (N < 64 && M <= 1024 && (int64_t)N * K <= (1 << 16) && forced_tile() < 0) {      // (the length head: models/Predictor.py:15-20)
+    hipLaunchKernelGGL(dw_small_kernel, dim3(cdiv(N * K, 256)), dim3(256), 0, as_hip(stream), dZ, lddz, X, ldx, dW, lddw, db, M, N, K,
+                       beta, rs ? rs->rows : nullptr, rs ? rs->count : nullptr);
+    g_last_was_bf16 = false;
+    snprintf(g_last_f32_kernel, sizeof(g_last_f32_kernel), "dw_small_kernel");
+    NACF_LAUNCH_CHECK("nacf_linear_bwd_weight(small)");
+    return NACF_OK;
+  }
   const int splits = bf16 ? bwd_weight_splits_bf16(M, N, K, rs != nullptr, &tile) : bwd_weight_splits(M, N, K, rs != nullptr, &tile);
   hipStream_t s = as_hip(stream);
   if (bf16 && N >= 128 && K >= 128 && forced_tile() != 1) {

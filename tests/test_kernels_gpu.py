@@ -1288,3 +1288,34 @@ def test_grouped_dw_gemms(dev):
     ref[0] = 2 * ref[0]
     for a, b in zip(ref, dws):
         assert float((a - b.double()).abs().max()) <= 2e-6 * float(a.abs().max())
+
+
+@pytest.mark.parametrize("mode", ["bf16x3", "f32"])
+def test_small_weight_gradient_kernel(dev, monkeypatch, mode):
+    """the length head's second Linear (models/Predictor.py:15-20): dW [20, 512] over 128 rows takes the one-thread-per-element
+    kernel (fp32 fmaf chain in row order): fp64 reference, bias gradient, beta = 1, a live-row list, run-to-run identical"""
+    ops, L = _ops()
+    monkeypatch.setenv("NACF_GEMM_MODE", mode)
+    M, N, K = 128, 20, 512
+    dz, x = rnd(M, N, seed=1).to(dev), rnd(M, K, seed=2).to(dev)
+    w0, b0 = rnd(N, K, seed=3).to(dev), rnd(N, seed=4).to(dev)
+    for with_rows in (False, True):
+        rows = live = None
+        if with_rows:
+            tok = (torch.rand(M, generator=torch.Generator().manual_seed(5)) < 0.6).long().to(dev)
+            rows, live = ops.rowset_build(tokens=tok), tok.ne(0)
+        outs = []
+        for _ in range(2):
+            dw, db = w0.clone(), b0.clone()
+            ops.linear_bwd_weight(dz, x, dw, db, beta=1.0, rows=rows)
+            assert L.load().nacf_gemm_last_kernel().decode() == "dw_small_kernel"
+            outs.append((dw, db))
+        assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+        dz64, x64 = dz.double(), x.double()
+        if live is not None:
+            dz64, x64 = dz64[live], x64[live]
+        assert err(outs[0][0], w0.double() + dz64.t() @ x64) < 2e-5
+        assert err(outs[0][1], b0.double() + dz64.sum(0)) < 2e-5
+    dw = torch.full((N, K), 5.0, device=dev)
+    ops.linear_bwd_weight(dz, x, dw, None, beta=0.0)
+    assert err(dw, dz.double().t() @ x.double()) < 2e-5
