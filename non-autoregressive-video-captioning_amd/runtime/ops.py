@@ -202,6 +202,62 @@ def set_gemm_mode(mode) -> None:
     L.check(L.load().nacf_gemm_set_mode(int(mode)), "nacf_gemm_set_mode")
 
 
+_FIXED_REG_SELFTEST = {"done": False}
+
+
+def selftest_fixed_register_kernels(device) -> None:
+    """ADVICE round 3: the wide (and panel) GEMM kernels keep their accumulators in registers the compiler is not told about;
+    the build checks their disassembly (csrc/Makefile: wide-check), but a library built elsewhere, with another hipcc or
+    other flags, would corrupt results silently.  Once per process, before the first exact-mode weight images of a model are
+    built: one 512 x 512 x 256 product on the wide kernel (both wave-tile heights) against the 128 x 128 kernel, which keeps
+    its accumulators in compiler-visible registers.  A mismatch beyond summation-order noise raises."""
+    if _FIXED_REG_SELFTEST["done"] or os.environ.get("NACF_SELFTEST", "1") == "0":
+        return
+    if torch.cuda.is_current_stream_capturing() or PROFILER.enabled or wide_group.current is not None:
+        return                                             # (not now: the next set of images tries again)
+    _FIXED_REG_SELFTEST["done"] = True
+    saved = {k: os.environ.get(k) for k in ("NACF_GEMM_TILE", "NACF_GEMM_WIDE", "NACF_GEMM_MODE", "NACF_GEMM_PANEL")}
+    for k in saved:
+        os.environ.pop(k, None)
+    mode = gemm_mode()                                     # the PROCESS mode (the environment override is out of the way)
+    try:
+        g = torch.Generator().manual_seed(1234)
+        M, N, K = 512, 512, 256
+        x = (torch.rand(M, K, generator=g) - 0.5).to(device)
+        flat = ((torch.rand(N * K, generator=g) - 0.5) * 0.2).to(device)
+        w = flat.view(N, K)
+        set_gemm_mode("bf16x3")
+        imgs = WeightImages(flat, [(0, N, K, False)], 3, _selftest=True)
+        imgs.refresh()
+        outs = {}
+        for tag, env in (("tile128", {"NACF_GEMM_TILE": "128"}), ("wide1", {"NACF_GEMM_WIDE": "1"}), ("wide2", {"NACF_GEMM_WIDE": "2"})):
+            for k in ("NACF_GEMM_TILE", "NACF_GEMM_WIDE"):
+                os.environ.pop(k, None)
+            os.environ.update(env)
+            y = torch.empty(M, N, device=device)
+            linear_fwd(x, w, y, None)
+            outs[tag] = (y, (L.load().nacf_gemm_last_kernel() or b"").decode())
+        imgs.close()
+        ref = outs["tile128"][0]
+        scale = float(ref.abs().max())
+        for tag in ("wide1", "wide2"):
+            y, name = outs[tag]
+            if not name.startswith("gemm_wide"):
+                continue                                   # (the kernel was not eligible here: nothing to check)
+            err = float((y - ref).abs().max())
+            if not (err <= 1e-5 * max(scale, 1.0)):
+                raise RuntimeError("nacf_amd: the %s kernel disagrees with the 128x128 kernel (max |diff| %.3e of %.3e): this "
+                                   "libnacf_hip.so was not built by csrc/Makefile's checked recipe -- rebuild it "
+                                   "(python __graft_entry__.py)" % (name, err, scale))
+    finally:
+        set_gemm_mode(mode)
+        for k, v in saved.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
 class WeightImages:
     """bf16 image planes of the GEMM weight matrices that live in ONE flat fp32 buffer (see nacf_wimage_* in
     nacf_hip.h).  mats: [(offset, N, K, want_transposed)], each matrix contiguous ([N, K], row pitch K) at
@@ -210,9 +266,11 @@ class WeightImages:
     kernel takes (csrc/gemm_bf16_panel.hpp: rows a multiple of 128, reduce dimension a multiple of 256 from 512 on) also get
     fragment-major images (nacf_wimage_register_frag).  `refresh()` is one launch."""
 
-    def __init__(self, flat: Tensor, mats, ns: int):
+    def __init__(self, flat: Tensor, mats, ns: int, _selftest: bool = False):
         assert flat.is_cuda and flat.dtype == torch.float32 and flat.is_contiguous() and flat.data_ptr() % 16 == 0
         assert ns in (1, 3)
+        if ns == 3 and not _selftest:
+            selftest_fixed_register_kernels(flat.device)
         self.flat, self.ns, self.mats = flat, int(ns), list(mats)
         up32 = lambda v: (v + 31) // 32 * 32
         f_off, t_off, f_total, t_total = [], [], 0, 0

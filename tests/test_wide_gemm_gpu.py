@@ -259,3 +259,19 @@ def test_joint_encoder_streams_equal_the_per_stream_nodes(dev, monkeypatch):
         assert torch.equal(a, b)
     for n in res[True][1]:
         assert torch.equal(res[True][1][n], res[False][1][n]), n
+
+
+def test_fixed_register_kernels_selftest_runs_and_leaves_no_trace(dev, monkeypatch):
+    """ops.selftest_fixed_register_kernels (once per process before the first exact-mode weight images): wide kernel, both
+    wave-tile heights, against the 128x128 kernel; the GEMM mode and the tuning environment are as before afterwards"""
+    import os
+    from nacf_amd.runtime import ops
+    monkeypatch.setenv("NACF_GEMM_MODE", "bf16")          # an override in force while the self-test runs
+    before_env = {k: os.environ.get(k) for k in ("NACF_GEMM_TILE", "NACF_GEMM_WIDE", "NACF_GEMM_MODE", "NACF_GEMM_PANEL")}
+    ops._FIXED_REG_SELFTEST["done"] = False
+    ops.selftest_fixed_register_kernels(dev)
+    assert ops._FIXED_REG_SELFTEST["done"]
+    assert {k: os.environ.get(k) for k in before_env} == before_env
+    assert ops.gemm_mode() == 1                            # the override is back in force
+    monkeypatch.delenv("NACF_GEMM_MODE")
+    assert ops.gemm_mode() in (0, 1, 3)
