@@ -226,50 +226,59 @@ __global__ void easy_first_update_kernel(int64_t* __restrict__ tokens, float* __
 // ---------------------------------------------------------------- AR beam search step
 constexpr int BEAM_MAX = 8;
 
-// One workgroup per instance: Beam.advance (models/Beam.py:68-117) for step t.
-__global__ __launch_bounds__(256) void beam_step_kernel(const float* __restrict__ logp, int64_t ldl, int n_bm, int V,
+// One workgroup per instance: Beam.advance (models/Beam.py:68-117) for step t.  NB = beam size (compile time): every thread
+// keeps the NB best of its candidates in a sorted register list, BRANCH-FREE -- a candidate bubbles through the list with
+// compare + select pairs, wanted or not.  (With the beam size a run-time bound and the insertion behind a "better than my
+// worst" test, hipcc built ~330 branches and 1350 register moves out of it; in a wave some lane always wants the insertion,
+// so every candidate paid for all of it: 173 us per step at B = 256 with 256 threads, 74 with 1024; the 54 MB read are worth ~15.)
+constexpr int BEAM_THREADS = 1024;
+template <int NB>
+__global__ __launch_bounds__(BEAM_THREADS) void beam_step_kernel(const float* __restrict__ logp, int64_t ldl, int V,
                                                          int t, int max_len, int want, int64_t* __restrict__ seqs,
                                                          float* __restrict__ scores, float* __restrict__ fin_scores,
                                                          int32_t* __restrict__ fin_len, int64_t* __restrict__ fin_tokens,
                                                          int32_t* __restrict__ fin_count, int32_t* __restrict__ done) {
-  __shared__ float s_val[256];
-  __shared__ int s_idx[256];
+  constexpr int n_bm = NB;
   __shared__ float w_val[BEAM_MAX];
   __shared__ int w_idx[BEAM_MAX];
   __shared__ int64_t s_seq[BEAM_MAX * 64];
-  __shared__ float red_v[4];
-  __shared__ int red_i[4];
-  __shared__ int red_t[4];
+  __shared__ float red_v[BEAM_THREADS / 64];
+  __shared__ int red_i[BEAM_THREADS / 64];
+  __shared__ int red_t[BEAM_THREADS / 64];
   const int b = blockIdx.x;
   if (done[b]) return;
   const int tid = threadIdx.x;
   const int n_rows = (t == 1) ? 1 : n_bm;           // first step: only beam 0 holds <bos> (Beam.py:79-80)
   const float NEG = -3.0e38f;
-  float lv[BEAM_MAX];
-  int li[BEAM_MAX];
+  float lv[NB];
+  int li[NB];
 #pragma unroll
-  for (int k = 0; k < BEAM_MAX; ++k) { lv[k] = NEG; li[k] = 0x7fffffff; }
-  float tail_v = NEG;
-  int tail_i = 0x7fffffff;
-  for (int r = 0; r < n_rows; ++r) {
-    const bool ended = (t > 1) && seqs[((int64_t)b * n_bm + r) * max_len + (t - 1)] == NACF_EOS;
-    const float base = (t > 1) ? scores[b * n_bm + r] : 0.f;
-    const float* row = logp + ((int64_t)b * n_bm + r) * ldl;
-    for (int v = tid; v < V; v += 256) {
-      const float val = ended ? -1e20f : row[v] + base;      // beam_lk[i] = -1e20 (Beam.py:76-77)
-      const int idx = r * V + v;
-      if (val > tail_v || (val == tail_v && idx < tail_i)) {
-        // insert into the thread-local sorted list (descending value, ascending index on ties)
-        float cv = val;
-        int ci = idx;
+  for (int k = 0; k < NB; ++k) { lv[k] = NEG; li[k] = 0x7fffffff; }
+  // per-row state first (one round trip for all beams), then one trip of loads for EVERY beam at a time
+  bool ended[NB];
+  float base[NB];
 #pragma unroll
-        for (int k = 0; k < BEAM_MAX; ++k) {
-          if (k < n_bm && (cv > lv[k] || (cv == lv[k] && ci < li[k]))) {
-            const float tv = lv[k]; const int ti = li[k];
-            lv[k] = cv; li[k] = ci; cv = tv; ci = ti;
-          }
-          if (k == n_bm - 1) { tail_v = lv[k]; tail_i = li[k]; }   // static register indexing only
-        }
+  for (int r = 0; r < NB; ++r) {
+    ended[r] = (r < n_rows) && (t > 1) && seqs[((int64_t)b * n_bm + r) * max_len + (t - 1)] == NACF_EOS;
+    base[r] = (t > 1) ? scores[b * n_bm + r] : 0.f;
+  }
+  for (int v = tid; v < V; v += BEAM_THREADS) {
+    float raw[NB];
+#pragma unroll
+    for (int r = 0; r < NB; ++r) raw[r] = (r < n_rows && !ended[r]) ? logp[((int64_t)b * n_bm + r) * ldl + v] : 0.f;
+#pragma unroll
+    for (int r = 0; r < NB; ++r) {
+      // rows beyond n_rows (step 1) never win: NEG with the largest index loses every comparison against a real candidate
+      float cv = (r < n_rows) ? (ended[r] ? -1e20f : raw[r] + base[r]) : NEG;      // beam_lk[i] = -1e20 (Beam.py:76-77)
+      int ci = (r < n_rows) ? r * V + v : 0x7fffffff;
+#pragma unroll
+      for (int k = 0; k < NB; ++k) {         // descending value, ascending index on ties
+        const bool better = cv > lv[k] || (cv == lv[k] && ci < li[k]);
+        const float nv = better ? cv : lv[k];
+        const int ni = better ? ci : li[k];
+        cv = better ? lv[k] : cv;
+        ci = better ? li[k] : ci;
+        lv[k] = nv; li[k] = ni;
       }
     }
   }
@@ -279,7 +288,7 @@ __global__ __launch_bounds__(256) void beam_step_kernel(const float* __restrict_
     float hv = NEG;
     int hi = 0x7fffffff;
 #pragma unroll
-    for (int j = 0; j < BEAM_MAX; ++j)
+    for (int j = 0; j < NB; ++j)
       if (j == head) { hv = lv[j]; hi = li[j]; }
     if (head >= n_bm) { hv = NEG; hi = 0x7fffffff; }
     float bv = hv;
@@ -294,21 +303,20 @@ __global__ __launch_bounds__(256) void beam_step_kernel(const float* __restrict_
     if ((tid & 63) == 0) { red_v[tid >> 6] = bv; red_i[tid >> 6] = bi; red_t[tid >> 6] = bt; }
     __syncthreads();
     bv = red_v[0]; bi = red_i[0]; bt = red_t[0];
-    for (int w = 1; w < 4; ++w)
+    for (int w = 1; w < BEAM_THREADS / 64; ++w)
       if (red_v[w] > bv || (red_v[w] == bv && red_i[w] < bi)) { bv = red_v[w]; bi = red_i[w]; bt = red_t[w]; }
     if (tid == bt) head++;
     if (tid == 0) { w_val[k] = bv; w_idx[k] = bi; }
     __syncthreads();
   }
-  (void)s_val; (void)s_idx;
   // reorder the hypotheses by back-pointer and append the new word (prev_ks / next_ys, Beam.py:91-97)
-  for (int e = tid; e < n_bm * max_len; e += 256) {
+  for (int e = tid; e < n_bm * max_len; e += BEAM_THREADS) {
     const int k = e / max_len, l = e % max_len;
     const int pk = w_idx[k] / V;
     s_seq[e] = (l == t) ? (int64_t)(w_idx[k] - pk * V) : seqs[((int64_t)b * n_bm + pk) * max_len + l];
   }
   __syncthreads();
-  for (int e = tid; e < n_bm * max_len; e += 256) seqs[(int64_t)b * n_bm * max_len + e] = s_seq[e];
+  for (int e = tid; e < n_bm * max_len; e += BEAM_THREADS) seqs[(int64_t)b * n_bm * max_len + e] = s_seq[e];
   if (tid < n_bm) scores[b * n_bm + tid] = w_val[tid];
   __syncthreads();
   if (tid == 0) {
@@ -376,8 +384,20 @@ int nacf_beam_step(const float* logp, int64_t ldl, int B, int n_bm, int V, int t
   NACF_CHECK(max_len >= 2 && max_len <= 64 && t >= 1 && t < max_len, NACF_EINVAL, "nacf_beam_step: bad step/max_len");
   NACF_CHECK((long)n_bm * V < 0x7fffffffL, NACF_EUNSUPPORTED, "nacf_beam_step: beam x vocab too large");
   hipStream_t s = as_hip(stream);
-  hipLaunchKernelGGL(beam_step_kernel, dim3(B), dim3(256), 0, s, logp, ldl, n_bm, V, t, max_len, want, seqs, scores,
-                     fin_scores, fin_len, fin_tokens, fin_count, done);
+#define NACF_BEAM(NB)                                                                                                    \
+  hipLaunchKernelGGL(beam_step_kernel<NB>, dim3(B), dim3(BEAM_THREADS), 0, s, logp, ldl, V, t, max_len, want, seqs, scores, \
+                     fin_scores, fin_len, fin_tokens, fin_count, done)
+  switch (n_bm) {
+    case 1: NACF_BEAM(1); break;
+    case 2: NACF_BEAM(2); break;
+    case 3: NACF_BEAM(3); break;
+    case 4: NACF_BEAM(4); break;
+    case 5: NACF_BEAM(5); break;
+    case 6: NACF_BEAM(6); break;
+    case 7: NACF_BEAM(7); break;
+    default: NACF_BEAM(8); break;
+  }
+#undef NACF_BEAM
   if (n_active) hipLaunchKernelGGL(count_active_kernel, dim3(1), dim3(256), 0, s, done, B, n_active);
   NACF_LAUNCH_CHECK("nacf_beam_step");
   return NACF_OK;

@@ -8,7 +8,12 @@ one `nacf_beam_step` launch per step: flat top-k over beam x vocab with the
 <eos> masking rule, back-pointer re-ordering, finished-list bookkeeping and the
 done flags all stay on the device; the host reads one int32 (instances still
 active) per step.  Like the reference, every step re-runs the decoder on the
-whole prefix (no KV cache) and takes the last position.
+whole prefix (no KV cache) and takes the last position -- but only THAT
+position's hidden state is ever read (Translator.py:111: `dec_output[:, -1, :]`),
+so the last decoder layer projects keys / values for the whole prefix and runs
+everything else -- query projection, one-query attention cores, both output
+projections, the FFN -- densely on the last slot of every hypothesis
+(BertLayer._run_last; opt['ar_last_slot_only'] = False restores the full pass).
 
 Returns what the reference returns: (list[B] of list[n_best] of token lists,
 list[B] of list[n_best] of length-normalised scores).
@@ -47,10 +52,18 @@ def beam_search(model, opt, encoder_outputs, category):
     buf = torch.empty(R, ops.vocab_ld(V), dtype=torch.float32, device=dev)
     logits = buf[:, :V]
 
+    subset = opt.get('ar_last_slot_only', True)
+    host = model.__dict__.get('_nacf_beam_host')          # two pinned counters + events, kept with the model
+    if host is None:
+        host = ([torch.ones(1, dtype=torch.int32).pin_memory() for _ in range(2)], [torch.cuda.Event() for _ in range(2)])
+        model.__dict__['_nacf_beam_host'] = host
+    host_cnt, ev = host
+    for c_ in host_cnt:
+        c_.fill_(1)
     for t in range(1, max_len):
         tokens = seqs[:, :, :t].reshape(R, t).contiguous()
         out = model.decoder(tokens, enc_output=enc_output, category=category, decoding_type='ARFormer',
-                            row_map=('div', n_bm), memory_kv=memory_kv)
+                            row_map=('div', n_bm), memory_kv=memory_kv, last_slot_only=subset)
         h = out[0]
         if isinstance(h, list):
             h = h[-1]
@@ -59,8 +72,16 @@ def beam_search(model, opt, encoder_outputs, category):
         ops.vocab_logsoftmax_fwd(logits, V, None, None, None, None)
         ops.beam_step(logits, V, t, max_len, want, seqs, scores, fin_scores, fin_len, fin_tokens, fin_count, done,
                       n_active)
-        if int(n_active.item()) == 0:                                       # all instances reached <eos> (Translator.py:153-154)
-            break
+        # all instances reached <eos> (Translator.py:153-154).  The count travels to the host asynchronously and is looked at
+        # ONE step late: the device never waits for the host's read (a blocking .item() per step idled it for a host round
+        # trip, 19 times per batch), and the one step that may run after everything has finished changes nothing -- finished
+        # instances are skipped by nacf_beam_step and their results are already final.
+        host_cnt[t % 2].copy_(n_active, non_blocking=True)
+        ev[t % 2].record()
+        if t > 1:
+            ev[(t - 1) % 2].synchronize()
+            if int(host_cnt[(t - 1) % 2]) == 0:
+                break
 
     # sort_finished (Beam.py:123-130): score / len^alpha, stable descending sort, n_best hypotheses
     f_sc, f_len, f_tok, f_cnt = fin_scores.tolist(), fin_len.tolist(), fin_tokens.tolist(), fin_count.tolist()

@@ -126,9 +126,16 @@ class BertDecoder(nn.Module):
         out_rows = kwargs.get('out_row_set') if not (training or torch.is_grad_enabled()) else None
         x2 = hidden.reshape(R * Lq, D)
         all_attentions = ()
+        causal = (1 + self.watch) if decoding_type == 'ARFormer' else 0
+        # autoregressive step of the beam search (models/Beam.py): only the last slot's hidden state is read
+        last_only = bool(kwargs.get('last_slot_only')) and not (training or torch.is_grad_enabled()) and not output_attentions \
+            and self.layer[-1].can_run_last(causal)
         for i, layer in enumerate(self.layer):
             kv = memory_kv[i] if memory_kv is not None else layer.project_memory(enc_output)
             last = i == len(self.layer) - 1
+            if last and last_only:
+                y = layer._run_last(x2, tgt_seq, kv, M, vdiv, vmod, rows)
+                return ([y.view(R, 1, D)], None,)
             x2, att = layer.run(x2, tgt_seq, (1 + self.watch) if decoding_type == 'ARFormer' else 0, kv, M, vdiv, vmod, training,
                                 output_attentions, rows, pos2, out_rows if last else None)
             if output_attentions:

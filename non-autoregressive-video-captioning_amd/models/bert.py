@@ -272,6 +272,38 @@ class BertLayer(nn.Module):
             y = LinearFn.apply(u, c, dict(pack=pk['f2'], **sub), *P)
         return y, (p_self, p_cross)
 
+    def can_run_last(self, causal):
+        """_run_last serves the plain layer under the plain triangular mask (no LayerNorm / position-attention variants, no
+        --watch window: models/Decoder.py:23-39)"""
+        return (not self.with_layernorm) and self.pos_attention is None and int(causal) == 1
+
+    def _run_last(self, x2, tokens, memory_kv, M, vdiv, vmod, rows):
+        """Inference, last layer, autoregressive step (models/Translator.py:105-111 reads `dec_output[:, -1, :]` and nothing
+        else): the hidden state of the LAST slot of every sequence, [R, D].  Keys and values are projected for the whole
+        prefix; the query projection, the two attention cores (one query per sequence: under the triangular mask the last query
+        sees every key, so no causal mask is needed), both output projections and the FFN run densely on R rows -- the
+        same sums per kept row as `run`, in the order the dense GEMMs' tiles give."""
+        R, Lq = tokens.shape
+        D = x2.shape[1]
+        P, pk = self._params, self._pk
+        if 'q_only' not in pk:
+            full = pk['qkv']
+            pk['q_only'] = Pack(full.w[:D], full.b[:D], None, None)
+            pk['kv_only'] = Pack(full.w[D:], full.b[D:], None, None)
+        x_last = x2.view(R, Lq, D)[:, Lq - 1, :].contiguous()
+        tok_last = tokens[:, Lq - 1].contiguous()
+        sub = dict(row_tokens=tok_last, training=False)
+        kv = LinearFn.apply(x2, None, dict(pack=pk['kv_only'], rows=rows), *P)
+        q = LinearFn.apply(x_last, None, dict(pack=pk['q_only']), *P)
+        att = torch.empty(R, D, dtype=x2.dtype, device=x2.device)
+        ops.attention_fwd(q, kv[:, :D], kv[:, D:], att, tokens, 0, None, R, self.H, 1, Lq, D // self.H, 1, R)
+        a = LinearFn.apply(att, x_last if self.self_residual else None, dict(pack=pk['so'], **sub), *P)
+        cq = LinearFn.apply(a, None, dict(pack=pk['cq']), *P)
+        catt, _ = CrossAttentionFn.apply(cq, memory_kv, self.H, 1, M, vdiv, vmod, False)
+        c = LinearFn.apply(catt, a, dict(pack=pk['co'], **sub), *P)
+        u = LinearFn.apply(c, None, dict(pack=pk['f1'], act=self.act), *P)
+        return LinearFn.apply(u, c, dict(pack=pk['f2'], **sub), *P)
+
     def _run_layernorm(self, x2, tokens, causal, memory_kv, M, vdiv, vmod, training, want_probs, rows, pos2=None):
         """with_layernorm=True (opts.py:36): LayerNorm sits between the residual add and the <pad> mask,
         so the GEMM epilogue stops at the residual and a LayerNorm kernel finishes the block:

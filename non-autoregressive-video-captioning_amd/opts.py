@@ -29,7 +29,7 @@ DEFAULTS = dict(
 
 # keys that configure THIS runtime, not the model: never written into a checkpoint's `settings` (the reference's
 # loaders would carry them along, and a reloaded model must return the reference's forward contract by default)
-RUNTIME_KEYS = ('fused_loss', 'hipgraph', 'decode_graph', 'gemm_mode', 'sync_bn', 'encoder_joint_streams')
+RUNTIME_KEYS = ('fused_loss', 'hipgraph', 'decode_graph', 'gemm_mode', 'sync_bn', 'encoder_joint_streams', 'ar_last_slot_only')
 
 
 def persistable(opt):

@@ -240,3 +240,29 @@ def test_config0_nab_youtube2text_shape_train_step_vs_oracle(dev):
         worst = max(worst, (e64, k))
     print("configs[0] NAB/Youtube2Text-shape B=16: loss %.6f, worst gradient error vs the double oracle %.2e of max (%s)"
           % (float(loss), worst[0], worst[1]))
+
+
+def test_ar_beam_last_slot_subset_equals_the_full_prefix_pass(dev):
+    """models/Beam.py reads only the last position's hidden state of every step (Translator.py:111), so the last layer's
+    query-side work runs on that slot alone (opt['ar_last_slot_only'], default on).  Against the full-prefix pass: the same
+    hypotheses, scores to fp32 round-off (the GEMMs of the two forms see different row counts, i.e. tile choices)."""
+    import nacf_amd
+    from nacf_amd import synthetic as S
+    from nacf_amd.models.Translator import Translator
+    opt = nacf_amd.opts.make_opt("ARB2", "MSRVTT", with_category=True, max_len=20, vocab_size=10547, n_frames=60)
+    sd = S.init_state_dict(opt, seed=11)
+    sd["tgt_word_prj.weight"][O.EOS] *= 3.0
+    b = S.synth_batch(opt, 32, 60, seed=22)
+    model = build(opt, sd, dev)
+    model.eval()
+    out = {}
+    for sub in (True, False):
+        dopt = dict(model.opt, beam_size=5, beam_alpha=1.0, topk=1, ar_last_slot_only=sub)
+        with torch.no_grad():
+            enc = model.encode(feats=[f.to(dev) for f in b["feats"]])
+            out[sub] = Translator(model, dopt, device=dev).translate_batch(enc, b["category"].to(dev), None, None)
+    (h1, s1), (h0, s0) = out[True], out[False]
+    same = sum(1 for i in range(32) if h1[i][0] == h0[i][0])
+    assert same >= 31, same
+    for i in range(32):
+        assert abs(s1[i][0] - s0[i][0]) < (5e-4 if h1[i][0] == h0[i][0] else 2e-3), (i, s1[i][0], s0[i][0])
