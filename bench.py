@@ -640,7 +640,8 @@ def main():
                 compare = {"batch": CB, "nacf_mp_ct_captions_per_s": round(CB / t_na, 1),
                            "arb2_beam5_captions_per_s": round(CB / t_ar, 1), "nacf_over_arb2": round(t_ar / t_na, 2),
                            "gemm_mode": mode,
-                           "note": "random-init weights: AR hypotheses rarely emit <eos>, so beam search runs all max_len-1 steps"}
+                           "note": "random-init weights: AR hypotheses rarely emit <eos>, so beam search runs all max_len-1 steps (each on the last "
+                                   "slot of every hypothesis only, DESIGN.md 4f); the NA side decodes 6 length candidates in 6 passes"}
                 del amodel
                 model.train()
 
