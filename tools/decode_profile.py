@@ -11,7 +11,8 @@ m = nacf_amd.get_model(opt); m.load_state_dict(S.init_state_dict(opt, 0)); m.to(
 B = int(os.environ.get('DECODE_BATCH', '128'))
 b = S.synth_batch(opt, B, 60, seed=1)
 feats = [f.to(dev) for f in b["feats"]]; cat = b["category"].to(dev)
-dopt = dict(m.opt); dopt.update(paradigm="mp", use_ct=True, iterations=5, length_beam_size=6, beam_alpha=1.35)
+dopt = dict(m.opt); dopt.update(paradigm=os.environ.get("DECODE_PARADIGM", "mp"), use_ct=True, iterations=5, length_beam_size=6, beam_alpha=1.35,
+                                q=int(os.environ.get("DECODE_Q", "1")))
 tr = Translator(m, dopt, device=dev)
 def once():
     with torch.no_grad():
