@@ -1,0 +1,4 @@
+cd /tmp && export TMPDIR=/tmp
+rm -rf /tmp/prof_step
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_step -o b -- python $GRAFT_REPO_ROOT/tools/step_profile.py 300 > $GRAFT_REPO_ROOT/gpurun_out/s4/prof_step.txt 2>/dev/null
+cp /tmp/prof_step/b_kernel_stats.csv $GRAFT_REPO_ROOT/gpurun_out/s4/prof_step.csv
