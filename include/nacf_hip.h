@@ -64,7 +64,7 @@ int nacf_version(void);
  * included).  nacf_abi_count() returns the value the LIBRARY was built with; the ctypes loader
  * (runtime/lib.py:load) refuses a library whose count differs from its own signature table, so a stale
  * libnacf_hip.so next to a newer Python package fails at import time, not at the first missing symbol. */
-#define NACF_ABI_COUNT 91
+#define NACF_ABI_COUNT 86
 int nacf_abi_count(void);
 
 /* ---- batch construction (reference: dataloader.py) ----------------------------------------
@@ -209,32 +209,6 @@ int nacf_dw_group_stats(int* launches, int* workgroups);
 int nacf_wide_group_begin(void);
 int nacf_wide_group_flush(nacf_stream_t stream);
 
-/* Layer chain: a DEPENDENT sequence of forward launches as ONE persistent launch (csrc/gemm_bf16_chain.hpp).  The
- * reference's decoder layer is one Python function (models/bert.py:262-303: BertSelfAttention :139-179 -> BertSelfOutput
- * :182-215 -> the same pair on the visual memory -> BertIntermediate / BertOutput :218-247); launched call by call it is
- * 8-10 kernels of 15-35 us each.  Between nacf_chain_begin() and nacf_chain_flush(stream), on the calling host thread,
- *   nacf_linear_fwd calls the panel GEMM body can run (bf16x3 mode, fragment-major weight image: N % 128 == 0, K % 256 == 0,
- *     K >= 512, 16-byte addressable activations), and
- *   nacf_attention_fwd calls with 64-wide heads on the matrix-core path (Lk <= 128)
- * are QUEUED in call order -- up to 8 + 4 of them -- and the flush runs them as the stages of one launch of one workgroup
- * per CU, separated by device-wide barriers: stage i + 1 may read whatever stages <= i wrote.  Any other nacf_linear_fwd /
- * nacf_attention_fwd call first launches what is queued and then runs on its own behind it (stream order), so the block
- * computes the same values whatever is eligible; each stage's arithmetic is that of its stand-alone kernel (bit-identical
- * to the panel kernel / nacf_attention_fwd).  Contract: no OTHER entry point of this library, and nothing else on `stream`,
- * touches the queued calls' operands or outputs before the flush; chains on different streams must not run concurrently
- * (the barrier counters are per device, and the grid must have the device to itself to be co-resident).
- * nacf_chain_flush returns the number of stages of its last launch (>= 0) or a negative error code;
- * nacf_gemm_last_kernel() reads "chain_queued" after a queued nacf_linear_fwd.
- * nacf_chain_status synchronises `stream` and returns 1 if, since the previous call, a workgroup of a chain launch gave up
- * waiting at a barrier (0.25 s: the grid was not co-resident -- results of that launch are undefined), else 0. */
-int nacf_chain_begin(void);
-int nacf_chain_flush(nacf_stream_t stream);
-int nacf_chain_status(nacf_stream_t stream);
-/* tuning: with NACF_CHAIN_TRACE=1 in the environment a chain launch stamps the 100 MHz wall clock per stage s -- out[3 s]:
- * workgroup 0 starts the stage, out[3 s + 1]: workgroup 0 has done its share, out[3 s + 2]: the last workgroup has; out[3 n]:
- * workgroup 0 is past the last stage.  Synchronises `stream`; n <= 37 values of the LAST launch. */
-int nacf_chain_stamps(uint64_t* out, int n, nacf_stream_t stream);
-
 /* Which GEMM kernel a call will launch (for profiling / roofline bookkeeping):
  * kind 0 = linear_fwd (also vocab_argmax), 1 = linear_bwd_data, 2 = linear_bwd_weight,
  * with the SAME (M, N, K) the entry point takes.  tile[0] = 128 or 64 (square
@@ -286,20 +260,9 @@ typedef struct nacf_wimage_desc {
   int32_t N, K;
   int32_t tile0;         /* index of this matrix' first 32x32 tile in the launch */
   int32_t tiles_k;       /* ceil(K / 32) */
-  uint16_t* fimg;        /* FRAGMENT-MAJOR forward image or NULL (see nacf_wimage_register_frag) */
-  uint16_t* fimgT;       /* fragment-major transposed image or NULL */
 } nacf_wimage_desc;
 int nacf_wimage_register(const float* w, int N, int K, int64_t ldw, const uint16_t* img, int64_t plane_elems,
                          const uint16_t* imgT, int64_t planeT_elems, int ns);
-/* Fragment-major images of a matrix registered before (same w, ns), for the panel GEMM kernel (csrc/gemm_bf16_panel.hpp:
- * the skinny launches of the decoder layer, models/bert.py:139-247).  Per (16-deep reduce step, 32-row block, term) the
- * 1 KB one wave loads as the matrix instruction's operand, the ns terms of a block next to each other:
- *   fimg [((k / 16) * ceil(N/32) + n / 32) * ns + s][((k % 16) / 8) * 32 + n % 32][k % 8] = term s of W[n][k]
- *   fimgT[((n / 16) * ceil(K/32) + k / 32) * ns + s][((n % 16) / 8) * 32 + k % 32][n % 8] = term s of W[n][k]
- * i.e. ceil(K/16) * ceil(N/32) * ns * 512 (fimg) / ceil(N/16) * ceil(K/32) * ns * 512 (fimgT) elements, zero-filled by the
- * caller once (the refresh writes only real elements).  Either may be NULL.  nacf_wimage_refresh fills them from the
- * descriptor's fimg / fimgT. */
-int nacf_wimage_register_frag(const float* w, int ns, const uint16_t* fimg, const uint16_t* fimgT);
 int nacf_wimage_unregister(const float* w_base, int64_t n_elems);
 int nacf_wimage_refresh(const nacf_wimage_desc* table, int n_desc, int n_tiles, int ns, nacf_stream_t stream);
 

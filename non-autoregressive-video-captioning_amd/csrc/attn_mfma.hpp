@@ -169,7 +169,7 @@ __device__ __forceinline__ void softmax_rows(f32x4 (&s)[2][NKT], float sq, const
 }
 
 // One item = (sequence, head, block of 32 queries), the work of one wave; nqb = ceil(Lq / 32) > 1 only without a causal mask.
-// Shared by fwd_kernel (one item per wave of the grid) and by the chain kernel (gemm_bf16_chain.hpp: a persistent workgroup's
+// Shared by fwd_kernel (one item per wave of the grid) and by persistent callers (a workgroup's
 // waves walk the items of an attention stage).
 template <int NKT, int DK16>
 __device__ __forceinline__ void fwd_item(const int item, const float* __restrict__ Q, int64_t ldq, const float* __restrict__ K,
@@ -622,8 +622,8 @@ __global__ __launch_bounds__(256, KB_WGS) void bwd_kb_kernel(const float* __rest
 // of a video -- taking every MFMA operand from LDS.  Same contractions, same softmax, same accumulation order per
 // query row as fwd_kernel: the results are bit-identical.
 constexpr int FL_PITCH = 68;
-// the work of one workgroup for one (memory row set kvr, head h); smem: 2 x 128 x FL_PITCH floats.  Shared by fwd_lds_kernel
-// and the chain kernel (gemm_bf16_chain.hpp), whose persistent workgroups walk several items (barrier before the next copy).
+// the work of one workgroup for one (memory row set kvr, head h); smem: 2 x 128 x FL_PITCH floats (a caller that walks
+// several items puts a barrier before the next copy).
 template <int DK16>
 __device__ __forceinline__ void fwd_lds_item(const int item, float* const smem, const float* __restrict__ Q, int64_t ldq,
                                              const float* __restrict__ K, int64_t ldk, const float* __restrict__ V, int64_t ldv,

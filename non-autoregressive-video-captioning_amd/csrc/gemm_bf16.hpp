@@ -893,7 +893,6 @@ __global__ __launch_bounds__(256, (BM == 64 ? 3 : 2)) void gemm_bf16_group_kerne
 // One launch rebuilds every registered image from the fp32 master weights: for matrix i (N x K, row pitch ld),
 //   img [s][(k / 32) * N + n][k % 32] = bf16 term s of W[n][k]     (forward: P = W,   reduce over k, zero-padded to 32)
 //   imgT[s][(n / 32) * K + k][n % 32] = bf16 term s of W[n][k]     (dX:      P = W^T, reduce over n, zero-padded to 32)
-// and, where the descriptor asks for them, the fragment-major images of the panel kernel (nacf_hip.h, nacf_wimage_register_frag)
 // A workgroup converts one 32 x 32 tile; the transposed copies go through LDS so that every store is at least 8 bytes.
 typedef nacf_wimage_desc WImageDesc;   // include/nacf_hip.h
 
@@ -931,26 +930,17 @@ __global__ __launch_bounds__(256) void wimage_refresh_kernel(const WImageDesc* _
     // img[k / 32][n][k % 32]: the 64 bytes of row n in k-tile k0 / 32; columns k >= K receive zeros (x = 0 there)
     if (d.img && n < d.N)
       *reinterpret_cast<u32x2*>(d.img + p * d.plane + ((int64_t)(k0 >> 5) * d.N + n) * 32 + c4) = u32x2{w0[p], w1[p]};
-    // fimg: (row n, k .. k + 3) of term p: step k / 16, block n / 32, lane ((k % 16) / 8) * 32 + n % 32, elements k % 8 ..
-    if (d.fimg && n < d.N && k < d.K)
-      *reinterpret_cast<u32x2*>(d.fimg + ((((int64_t)(k >> 4) * ((d.N + 31) >> 5) + (n >> 5)) * NS + p) * 64 + ((k & 15) >> 3) * 32 + (n & 31)) * 8 + (k & 7)) =
-          u32x2{w0[p], w1[p]};
     *reinterpret_cast<u32x2*>(&tile[p][r][c4]) = u32x2{w0[p], w1[p]};
   }
-  if (d.imgT || d.fimgT) {
+  if (d.imgT) {
     __syncthreads();
     const int kk = k0 + r;    // imgT[n / 32][k][n % 32]: thread (r, c4) writes row k0 + r, columns n0 + c4 .. + 3 (zeros for n >= N)
     if (kk < d.K) {
-      const int nn = n0 + c4;
 #pragma unroll
       for (int p = 0; p < NS; ++p) {
         const uint32_t lo = (uint32_t)tile[p][c4][r] | ((uint32_t)tile[p][c4 + 1][r] << 16);
         const uint32_t hi = (uint32_t)tile[p][c4 + 2][r] | ((uint32_t)tile[p][c4 + 3][r] << 16);
         if (d.imgT) *reinterpret_cast<u32x2*>(d.imgT + p * d.planeT + ((int64_t)(n0 >> 5) * d.K + kk) * 32 + c4) = u32x2{lo, hi};
-        // fimgT: the image of W^T: (row kk, reduce index nn .. nn + 3)
-        if (d.fimgT && nn < d.N)
-          *reinterpret_cast<u32x2*>(d.fimgT + ((((int64_t)(nn >> 4) * ((d.K + 31) >> 5) + (kk >> 5)) * NS + p) * 64 + ((nn & 15) >> 3) * 32 + (kk & 31)) * 8 + (nn & 7)) =
-              u32x2{lo, hi};
       }
     }
   }

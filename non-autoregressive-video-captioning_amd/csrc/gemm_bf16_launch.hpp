@@ -20,20 +20,6 @@ bool launch_wide_linear(const GemmShape& g, const EpiLinear& epi, bool has_rows,
 bool launch_wide_dx(const GemmShape& g, const EpiStore& epi, int splits, bool has_rows, hipStream_t s);
 int wide_pick(const GemmShape& g, int splits, bool has_rows, int ns, bool heavy_epilogue);
 void bf16_note_wide(const char* name);
-// panel kernel (gemm_bf16_panel.hpp, nacf_gemm_bf16_panel.hip): skinny exact-mode launches; false = not eligible / not worthwhile
-bool launch_panel_linear(const GemmShape& g, const EpiLinear& epi, bool has_rows, hipStream_t s);
-bool launch_panel_dx(const GemmShape& g, const EpiStore& epi, bool has_rows, hipStream_t s);
-bool panel_eligible(const GemmShape& g);      // what the panel body can run at all (image, shape, alignment)
-// layer chain (gemm_bf16_chain.hpp, nacf_gemm_bf16_chain.hip): between nacf_chain_begin and nacf_chain_flush the forward
-// nn.Linear GEMMs the panel body can run and the attention cores are QUEUED and leave as one persistent launch.
-// chain_queue_*: true = queued (the caller returns); false = not chainable -- the caller then calls chain_flush (what was
-// queued so far must run first) and launches on its own.
-bool chain_active();
-bool chain_queue_linear(const GemmShape& g, const EpiLinear& epi, hipStream_t s);
-bool chain_queue_attention(const float* Q, int64_t ldq, const float* K, int64_t ldk, const float* V, int64_t ldv, float* O, int64_t ldo,
-                           const int64_t* key_tokens, int causal, float* probs, int R, int H, int Lq, int Lk, int dk, int kv_div,
-                           int kv_mod, bool aligned, hipStream_t s);
-int chain_flush(hipStream_t s);
 void launch_wimage_refresh(const WImageDesc* descs, int n_desc, int n_tiles, int ns, hipStream_t s);
 // "gemm_bf16_kernel<BM, BN, QSRC, PSRC, NS, STAGES, Epi>" of the launch the calling thread made last (profiling aid)
 const char* bf16_last_kernel_name();

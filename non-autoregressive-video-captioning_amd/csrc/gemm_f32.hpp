@@ -84,11 +84,6 @@ struct GemmShape {
   // a group's slice of P (g * BN rows) stays in the XCD's 4 MB L2 while X streams past once per group: for a wide P
   // (the vocabulary: 83 column tiles) that is tiles_n / g passes over X instead of tiles_m / 8 passes over P.
   int group_n = 0;
-  // panel kernel (gemm_bf16_panel.hpp): the P operand as a FRAGMENT-MAJOR pre-split image -- per (16-deep k-step k16, 32-row
-  // block nt, term s) the 1 KB a wave loads as the matrix instruction's operand: element (row, k) of term s at
-  // Pfrag[k16 * ldpf + ((nt * NS + s) * 64 + ((k & 15) >> 3) * 32 + (row & 31)) * 8 + (k & 7)], k16 = k / 16, nt = row / 32
-  const unsigned short* Pfrag = nullptr;
-  int64_t ldpf = 0;
 };
 
 __device__ __forceinline__ int lds_sw(int row) { return (-(row >> 2)) & 3; }

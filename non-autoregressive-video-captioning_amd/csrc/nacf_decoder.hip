@@ -9,13 +9,6 @@
 #include "attn_mfma.hpp"
 #include <stdlib.h>
 
-// layer chain (gemm_bf16_launch.hpp / nacf_gemm_bf16_chain.hip)
-bool chain_active();
-bool chain_queue_attention(const float* Q, int64_t ldq, const float* K, int64_t ldk, const float* V, int64_t ldv, float* O, int64_t ldo,
-                           const int64_t* key_tokens, int causal, float* probs, int R, int H, int Lq, int Lk, int dk, int kv_div,
-                           int kv_mod, bool aligned, hipStream_t s);
-int chain_flush(hipStream_t s);
-
 namespace {
 
 // shapes the register-resident MFMA attention covers; anything else (or NACF_ATTN_VALU=1)
@@ -950,14 +943,6 @@ int nacf_attention_fwd(const float* Q, int64_t ldq, const float* K, int64_t ldk,
   NACF_CHECK(R > 0 && H > 0 && Lq > 0 && Lk > 0 && dk > 0 && kv_div > 0 && kv_mod > 0, NACF_EINVAL,
              "nacf_attention_fwd: bad shape");
   NACF_CHECK(!(causal && Lq != Lk), NACF_EINVAL, "nacf_attention_fwd: causal mask needs Lq == Lk");
-  if (chain_active()) {      // inside a layer chain (gemm_bf16_chain.hpp): a stage of the one persistent launch, or behind what is queued
-    const bool al = attn_aligned(Q, ldq) && attn_aligned(K, ldk) && attn_aligned(V, ldv) && attn_aligned(O, ldo);
-    const char* ev = getenv("NACF_ATTN_VALU");
-    if (!(ev && atoi(ev) != 0) &&
-        chain_queue_attention(Q, ldq, K, ldk, V, ldv, O, ldo, key_tokens, causal, probs, R, H, Lq, Lk, dk, kv_div, kv_mod, al, as_hip(stream)))
-      return NACF_OK;
-    chain_flush(as_hip(stream));
-  }
   // more than 32 queries per sequence run as blocks of 32 (one wave each) when no causal mask ties a query to its index
   if (attn_mfma_ok(causal ? Lq : min(Lq, 32), Lk, dk) && attn_aligned(Q, ldq) && attn_aligned(K, ldk) &&
       attn_aligned(V, ldv) && attn_aligned(O, ldo)) {

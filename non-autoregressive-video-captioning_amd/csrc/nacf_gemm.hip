@@ -30,8 +30,7 @@ thread_local bool g_last_was_bf16 = false;
 
 // ---- registry of pre-split bf16 weight images (nacf_wimage_register): one entry per weight matrix
 struct ImgMat { const float* w; int N, K; int64_t ld; const unsigned short* img; int64_t plane;
-                const unsigned short* imgT; int64_t planeT; int ns;
-                const unsigned short* fimg = nullptr; const unsigned short* fimgT = nullptr; };
+                const unsigned short* imgT; int64_t planeT; int ns; };
 std::vector<ImgMat> g_imgs;
 
 // forward image of W [N, K] (row pitch ldw): W is a registered matrix or a run of whole rows of one (packed q|k|v
@@ -53,30 +52,6 @@ bool find_image_t(const float* W, int64_t ldw, int N, int K, int ns, GemmShape& 
   for (const ImgMat& m : g_imgs) {
     if (m.w == W && m.N == N && m.K == K && m.ld == ldw && m.ns == ns && m.imgT) {
       g.Pimg = m.imgT; g.ldpi = (int64_t)m.K * 32; g.pimg_plane = m.planeT;
-      return true;
-    }
-  }
-  return false;
-}
-
-// fragment-major forward image (panel kernel) of W [N, K] or of a run of whole 32-row blocks of a registered matrix
-bool find_frag(const float* W, int64_t ldw, int N, int K, int ns, GemmShape& g) {
-  for (const ImgMat& m : g_imgs) {
-    if (m.ns != ns || !m.fimg || m.ld != ldw || m.K != K || W < m.w) continue;
-    const int64_t off = W - m.w;
-    if (off % m.ld != 0) continue;
-    const int64_t n0 = off / m.ld;
-    if (n0 + N > m.N || (n0 & 31) != 0) continue;
-    g.Pfrag = m.fimg + (n0 >> 5) * ns * 512; g.ldpf = (int64_t)cdiv(m.N, 32) * ns * 512;
-    return true;
-  }
-  return false;
-}
-// ... and of W^T (dX = dZ W: P rows = the K output columns, reduce over N): exactly this matrix
-bool find_frag_t(const float* W, int64_t ldw, int N, int K, int ns, GemmShape& g) {
-  for (const ImgMat& m : g_imgs) {
-    if (m.w == W && m.N == N && m.K == K && m.ld == ldw && m.ns == ns && m.fimgT) {
-      g.Pfrag = m.fimgT; g.ldpf = (int64_t)cdiv(m.K, 32) * ns * 512;
       return true;
     }
   }
@@ -455,21 +430,10 @@ int nacf_linear_fwd(const float* X, int64_t ldx, const float* W, int64_t ldw, fl
   const bool heavy = epi.ep.act == NACF_ACT_GELU_NEW || epi.ep.act == NACF_ACT_GELU_ERF || epi.ep.act == NACF_ACT_TANH ||
                      epi.ep.act == NACF_ACT_SIGMOID || epi.ep.act == NACF_ACT_TANH_SIGMOID;
   const int mode = gemm_mode();
-  if (chain_active()) {
-    // inside nacf_chain_begin / nacf_chain_flush: what the panel body can run is queued for the one persistent launch of the
-    // layer (gemm_bf16_chain.hpp); anything else runs now, BEHIND what is queued already
-    if (mode == NACF_GEMM_BF16X3 && vec && find_frag(W, ldw, N, K, mode, g) && chain_queue_linear(g, epi, as_hip(stream))) {
-      g_last_was_bf16 = true;
-      return NACF_OK;
-    }
-    chain_flush(as_hip(stream));
-  }
   if (mode != NACF_GEMM_F32 && vec) {          // bf16 matrix cores (16-byte addressable operands only)
     find_image(W, ldw, N, K, mode, g);
-    if (mode == NACF_GEMM_BF16X3) find_frag(W, ldw, N, K, mode, g);
     const bool heavy_w = heavy || epi.ep.p_drop1 > 0.f || epi.ep.p_drop2 > 0.f;      // nothing overlaps the wide kernel's epilogue
-    if (!(mode == NACF_GEMM_BF16X3 && launch_panel_linear(g, epi, rs != nullptr, as_hip(stream))) &&
-        !(mode == NACF_GEMM_BF16X3 && launch_wide_linear(g, epi, rs != nullptr, heavy_w, as_hip(stream))))
+    if (!(mode == NACF_GEMM_BF16X3 && launch_wide_linear(g, epi, rs != nullptr, heavy_w, as_hip(stream))))
       launch_bf16_linear(g, epi, pick_tile_bf16(0, M, N, 1, rs != nullptr, mode, heavy), mode, as_hip(stream));
     g_last_was_bf16 = true;
   } else {
@@ -522,20 +486,6 @@ int nacf_linear_bwd_data(const float* dZ, int64_t lddz, const float* W, int64_t 
   const bool vec = (lddz % 4 == 0) && (ldw % 4 == 0) && aligned16(dZ) && aligned16(W);
   const int mode = gemm_mode();
   const bool bf16 = mode != NACF_GEMM_F32 && vec;
-  if (mode == NACF_GEMM_BF16X3 && vec) {
-    // the panel kernel (skinny launches with a long reduce dimension) never splits the reduce dimension over workgroups
-    GemmShape gp = g;
-    gp.k_per_split = N;
-    set_rows(gp, rs);
-    EpiStore e1;
-    e1.C = dX; e1.ldc = lddx; e1.beta = beta; e1.slab_stride = 0;
-    e1.vec_out = ((lddx % 4 == 0) && aligned16(dX)) ? 1 : 0;
-    if (find_frag_t(W, ldw, N, K, mode, gp) && launch_panel_dx(gp, e1, rs != nullptr, s)) {
-      g_last_was_bf16 = true;
-      NACF_LAUNCH_CHECK("nacf_linear_bwd_data(panel)");
-      return NACF_OK;
-    }
-  }
   const int ka = bf16 ? 32 : 16;
   g.k_per_split = cdiv(cdiv(N, splits), ka) * ka;
   set_rows(g, rs);
@@ -949,19 +899,11 @@ int nacf_wimage_register(const float* w, int N, int K, int64_t ldw, const uint16
   NACF_CHECK((!img || (aligned16(img) && plane_elems % 8 == 0 && plane_elems >= (int64_t)cdiv(K, 32) * 32 * N)) &&
              (!imgT || (aligned16(imgT) && planeT_elems % 8 == 0 && planeT_elems >= (int64_t)cdiv(N, 32) * 32 * K)),
              NACF_EINVAL, "nacf_wimage_register: images must be 16-byte aligned and hold whole 32-wide k-tiles");
-  const ImgMat e{w, N, K, ldw, img, plane_elems, imgT, planeT_elems, ns, nullptr, nullptr};
+  const ImgMat e{w, N, K, ldw, img, plane_elems, imgT, planeT_elems, ns};
   for (ImgMat& m : g_imgs)
     if (m.w == w && m.ns == ns) { m = e; return NACF_OK; }
   g_imgs.push_back(e);
   return NACF_OK;
-}
-int nacf_wimage_register_frag(const float* w, int ns, const uint16_t* fimg, const uint16_t* fimgT) {
-  NACF_CHECK(w && (ns == 1 || ns == 3) && (fimg || fimgT), NACF_EINVAL, "nacf_wimage_register_frag: bad argument");
-  NACF_CHECK((!fimg || aligned16(fimg)) && (!fimgT || aligned16(fimgT)), NACF_EINVAL, "nacf_wimage_register_frag: images must be 16-byte aligned");
-  for (ImgMat& m : g_imgs)
-    if (m.w == w && m.ns == ns) { m.fimg = fimg; m.fimgT = fimgT; return NACF_OK; }
-  nacf_set_error("nacf_wimage_register_frag: the matrix has no registration (nacf_wimage_register first)");
-  return NACF_EINVAL;
 }
 int nacf_wimage_unregister(const float* w_base, int64_t n_elems) {
   NACF_CHECK(w_base && n_elems > 0, NACF_EINVAL, "nacf_wimage_unregister: bad argument");

@@ -219,24 +219,22 @@ class BertLayer(nn.Module):
         # dX GEMM accumulates onto it (LinearFn: res_sink / dx_acc) -- only wired when both gradients will exist.
         link = torch.is_grad_enabled() and x2.requires_grad
         h1, h2, h3 = ({}, {}, {}) if link else (None, None, None)
-        # ONE persistent launch for the whole layer (ops.chain: the eight launches below are queued and run as its stages)
         # dead (<pad>) rows: zero-filled where something reads EVERY row -- q|k|v and the cross-attention query (the attention
         # cores and their backward), the layer's output; the three buffers in between (a, c, u) are only ever read through
         # the same row list (the next nn.Linear, the residual of the one after, the weight-gradient GEMMs), so they are not
         # filled (fill=False), and FFN2's dX feeds FFN1's row-list epilogue backward (dx_fill=False)
         nf = dict(fill=False) if rows is not None else {}
-        with ops.chain():
-            qkv = LinearFn.apply(x2, None, dict(pack=pk['qkv'], rows=rows, dx_acc=h1), *P)
-            att, p_self = SelfAttentionFn.apply(qkv, tokens, int(causal), self.H, want_probs)
-            a = LinearFn.apply(att, x2 if self.self_residual else None, dict(pack=pk['so'], p1=self.p, salt1=s[0], row_tokens=tok_flat, rng=rng,
-                                             training=training, rows=rows, res_sink=h1, **nf), *P)
-            q = LinearFn.apply(a, None, dict(pack=pk['cq'], rows=rows, dx_acc=h2), *P)
-            catt, p_cross = CrossAttentionFn.apply(q, memory_kv, self.H, Lq, M, vdiv, vmod, want_probs)
-            c = LinearFn.apply(catt, a, dict(pack=pk['co'], p1=self.p, salt1=s[1], row_tokens=tok_flat, rng=rng,
-                                             training=training, rows=rows, res_sink=h2, **nf), *P)
-            u = LinearFn.apply(c, None, dict(pack=pk['f1'], act=self.act, rows=rows, dx_acc=h3, **nf), *P)
-            y = LinearFn.apply(u, c, dict(pack=pk['f2'], p1=self.p, salt1=s[2], p2=self.p, salt2=s[3], row_tokens=tok_flat,
-                                          rng=rng, training=training, rows=rows, res_sink=h3, dx_fill=rows is None), *P)
+        qkv = LinearFn.apply(x2, None, dict(pack=pk['qkv'], rows=rows, dx_acc=h1), *P)
+        att, p_self = SelfAttentionFn.apply(qkv, tokens, int(causal), self.H, want_probs)
+        a = LinearFn.apply(att, x2 if self.self_residual else None, dict(pack=pk['so'], p1=self.p, salt1=s[0], row_tokens=tok_flat, rng=rng,
+                                         training=training, rows=rows, res_sink=h1, **nf), *P)
+        q = LinearFn.apply(a, None, dict(pack=pk['cq'], rows=rows, dx_acc=h2), *P)
+        catt, p_cross = CrossAttentionFn.apply(q, memory_kv, self.H, Lq, M, vdiv, vmod, want_probs)
+        c = LinearFn.apply(catt, a, dict(pack=pk['co'], p1=self.p, salt1=s[1], row_tokens=tok_flat, rng=rng,
+                                         training=training, rows=rows, res_sink=h2, **nf), *P)
+        u = LinearFn.apply(c, None, dict(pack=pk['f1'], act=self.act, rows=rows, dx_acc=h3, **nf), *P)
+        y = LinearFn.apply(u, c, dict(pack=pk['f2'], p1=self.p, salt1=s[2], p2=self.p, salt2=s[3], row_tokens=tok_flat,
+                                      rng=rng, training=training, rows=rows, res_sink=h3, dx_fill=rows is None), *P)
         return y, (p_self, p_cross)
 
     def _run_subset(self, x2, tokens, causal, memory_kv, M, vdiv, vmod, want_probs, rows, out_rows):
@@ -260,16 +258,15 @@ class BertLayer(nn.Module):
         # inference: nothing walks the dead rows of q, a, cq, c, u backwards, and forward they are read through `out_rows` only
         # (the attention cores compute garbage for the unlisted queries, which nobody gathers): no zero fill -- 150 MB of zero
         # stores per pass at B = 128 with 6 length candidates; k|v (masked keys multiply V by an exact 0) and y are filled
-        with ops.chain():
-            q = LinearFn.apply(x2, None, dict(pack=pk['q_only'], rows=out_rows, fill=False), *P)
-            kv = LinearFn.apply(x2, None, dict(pack=pk['kv_only'], rows=rows), *P)
-            ops.attention_fwd(q, kv[:, :D], kv[:, D:], att, tokens, int(causal), p_self, R, self.H, Lq, Lq, D // self.H, 1, R)
-            a = LinearFn.apply(att, x2 if self.self_residual else None, dict(pack=pk['so'], fill=False, **sub), *P)
-            cq = LinearFn.apply(a, None, dict(pack=pk['cq'], rows=out_rows, fill=False), *P)
-            catt, p_cross = CrossAttentionFn.apply(cq, memory_kv, self.H, Lq, M, vdiv, vmod, want_probs)
-            c = LinearFn.apply(catt, a, dict(pack=pk['co'], fill=False, **sub), *P)
-            u = LinearFn.apply(c, None, dict(pack=pk['f1'], act=self.act, rows=out_rows, fill=False), *P)
-            y = LinearFn.apply(u, c, dict(pack=pk['f2'], **sub), *P)
+        q = LinearFn.apply(x2, None, dict(pack=pk['q_only'], rows=out_rows, fill=False), *P)
+        kv = LinearFn.apply(x2, None, dict(pack=pk['kv_only'], rows=rows), *P)
+        ops.attention_fwd(q, kv[:, :D], kv[:, D:], att, tokens, int(causal), p_self, R, self.H, Lq, Lq, D // self.H, 1, R)
+        a = LinearFn.apply(att, x2 if self.self_residual else None, dict(pack=pk['so'], fill=False, **sub), *P)
+        cq = LinearFn.apply(a, None, dict(pack=pk['cq'], rows=out_rows, fill=False), *P)
+        catt, p_cross = CrossAttentionFn.apply(cq, memory_kv, self.H, Lq, M, vdiv, vmod, want_probs)
+        c = LinearFn.apply(catt, a, dict(pack=pk['co'], fill=False, **sub), *P)
+        u = LinearFn.apply(c, None, dict(pack=pk['f1'], act=self.act, rows=out_rows, fill=False), *P)
+        y = LinearFn.apply(u, c, dict(pack=pk['f2'], **sub), *P)
         return y, (p_self, p_cross)
 
     def can_run_last(self, causal):

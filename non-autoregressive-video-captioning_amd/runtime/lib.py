@@ -38,8 +38,7 @@ class WImageDesc(ctypes.Structure):
     """struct nacf_wimage_desc: one weight matrix of the bf16 image table (nacf_wimage_refresh)."""
     _fields_ = [("w", c_void_p), ("img", c_void_p), ("imgT", c_void_p),
                 ("ld", c_int64), ("plane", c_int64), ("planeT", c_int64),
-                ("N", c_int32), ("K", c_int32), ("tile0", c_int32), ("tiles_k", c_int32),
-                ("fimg", c_void_p), ("fimgT", c_void_p)]
+                ("N", c_int32), ("K", c_int32), ("tile0", c_int32), ("tiles_k", c_int32)]
 
 
 # GEMM arithmetic modes (nacf_hip.h NACF_GEMM_*)
@@ -67,11 +66,6 @@ SIGNATURES = {
     "nacf_gemm_get_mode": (c_int, []),
     "nacf_gemm_last_kernel": (c_char_p, []),
     "nacf_wimage_register": (c_int, [_P, _I, _I, _L, _P, _L, _P, _L, _I]),
-    "nacf_wimage_register_frag": (c_int, [_P, _I, _P, _P]),
-    "nacf_chain_begin": (c_int, []),
-    "nacf_chain_flush": (c_int, [_P]),
-    "nacf_chain_status": (c_int, [_P]),
-    "nacf_chain_stamps": (c_int, [_P, _I, _P]),
     "nacf_wimage_unregister": (c_int, [_P, _L]),
     "nacf_wimage_refresh": (c_int, [_P, _I, _I, _I, _P]),
     "nacf_linear_bwd_weight": (c_int, [_P, _L, _P, _L, _P, _L, _P, _I, _I, _I, _F, _P, _S, _RS, _P]),

@@ -206,7 +206,7 @@ _FIXED_REG_SELFTEST = {"done": False}
 
 
 def selftest_fixed_register_kernels(device) -> None:
-    """ADVICE round 3: the wide (and panel) GEMM kernels keep their accumulators in registers the compiler is not told about;
+    """ADVICE round 3: the wide GEMM kernels keep their accumulators in registers the compiler is not told about;
     the build checks their disassembly (csrc/Makefile: wide-check), but a library built elsewhere, with another hipcc or
     other flags, would corrupt results silently.  Once per process, before the first exact-mode weight images of a model are
     built: one 512 x 512 x 256 product on the wide kernel (both wave-tile heights) against the 128 x 128 kernel, which keeps
@@ -216,7 +216,7 @@ def selftest_fixed_register_kernels(device) -> None:
     if torch.cuda.is_current_stream_capturing() or PROFILER.enabled or wide_group.current is not None:
         return                                             # (not now: the next set of images tries again)
     _FIXED_REG_SELFTEST["done"] = True
-    saved = {k: os.environ.get(k) for k in ("NACF_GEMM_TILE", "NACF_GEMM_WIDE", "NACF_GEMM_MODE", "NACF_GEMM_PANEL")}
+    saved = {k: os.environ.get(k) for k in ("NACF_GEMM_TILE", "NACF_GEMM_WIDE", "NACF_GEMM_MODE")}
     for k in saved:
         os.environ.pop(k, None)
     mode = gemm_mode()                                     # the PROCESS mode (the environment override is out of the way)
@@ -262,9 +262,7 @@ class WeightImages:
     """bf16 image planes of the GEMM weight matrices that live in ONE flat fp32 buffer (see nacf_wimage_* in
     nacf_hip.h).  mats: [(offset, N, K, want_transposed)], each matrix contiguous ([N, K], row pitch K) at
     flat[offset:].  Forward images (k-tile-major, zero-padded to whole k-tiles) serve y = x W^T -- also for a run of
-    whole rows of a registered matrix -- transposed ones the dX GEMMs.  In the exact mode the matrices whose shape the panel
-    kernel takes (csrc/gemm_bf16_panel.hpp: rows a multiple of 128, reduce dimension a multiple of 256 from 512 on) also get
-    fragment-major images (nacf_wimage_register_frag).  `refresh()` is one launch."""
+    whole rows of a registered matrix -- transposed ones the dX GEMMs.  `refresh()` is one launch."""
 
     def __init__(self, flat: Tensor, mats, ns: int, _selftest: bool = False):
         assert flat.is_cuda and flat.dtype == torch.float32 and flat.is_contiguous() and flat.data_ptr() % 16 == 0
@@ -283,27 +281,10 @@ class WeightImages:
                 t_total += up32(N) * K
         self.img = torch.zeros(ns, max(f_total, 8), dtype=torch.int16, device=flat.device)
         self.imgT = torch.zeros(ns, max(t_total, 8), dtype=torch.int16, device=flat.device)
-        # fragment-major images: [k / 16][n / 32][term][64 lanes][8] (forward), the same of W^T (dX): only when the panel kernel
-        # or the layer chain is switched on (both are off by default: DESIGN.md section 4d) -- NACF_GEMM_PANEL=2: the reduce
-        # dimensions its shape rule takes (>= 1536); NACF_GEMM_PANEL=1 / NACF_CHAIN=1: every matrix the body can run
-        up = lambda v, m: (v + m - 1) // m
-        pe, ce = os.environ.get("NACF_GEMM_PANEL", "0"), os.environ.get("NACF_CHAIN", "0")
-        min_red = 512 if (pe == "1" or ce == "1") else (1536 if pe == "2" else 1 << 30)
-        frag_ok = lambda rows, red: ns == 3 and rows % 128 == 0 and red % 256 == 0 and red >= min_red
-        ff_off, ft_off, ff_total, ft_total = [], [], 0, 0
-        for off, N, K, want_t in self.mats:
-            ff_off.append(ff_total if frag_ok(N, K) else None)
-            if frag_ok(N, K):
-                ff_total += up(K, 16) * up(N, 32) * ns * 512
-            ft_off.append(ft_total if (want_t and frag_ok(K, N)) else None)
-            if want_t and frag_ok(K, N):
-                ft_total += up(N, 16) * up(K, 32) * ns * 512
-        self.fimg = torch.zeros(max(ff_total, 8), dtype=torch.int16, device=flat.device)
-        self.fimgT = torch.zeros(max(ft_total, 8), dtype=torch.int16, device=flat.device)
         descs = (L.WImageDesc * max(len(self.mats), 1))()
         tile0 = 0
         lib = L.load()
-        for d, (off, N, K, want_t), fo, to, ffo, fto in zip(descs, self.mats, f_off, t_off, ff_off, ft_off):
+        for d, (off, N, K, want_t), fo, to in zip(descs, self.mats, f_off, t_off):
             d.w = flat.data_ptr() + 4 * off
             d.img = self.img.data_ptr() + 2 * fo
             d.imgT = self.imgT.data_ptr() + 2 * to if want_t else None
@@ -313,11 +294,6 @@ class WeightImages:
             L.check(lib.nacf_wimage_register(ctypes.c_void_p(d.w), N, K, K, ctypes.c_void_p(d.img), d.plane,
                                              ctypes.c_void_p(d.imgT) if want_t else None, d.planeT, self.ns),
                     "nacf_wimage_register")
-            d.fimg = self.fimg.data_ptr() + 2 * ffo if ffo is not None else None
-            d.fimgT = self.fimgT.data_ptr() + 2 * fto if fto is not None else None
-            if d.fimg or d.fimgT:
-                L.check(lib.nacf_wimage_register_frag(ctypes.c_void_p(d.w), self.ns, ctypes.c_void_p(d.fimg) if d.fimg else None,
-                                                      ctypes.c_void_p(d.fimgT) if d.fimgT else None), "nacf_wimage_register_frag")
         self.n_tiles = tile0
         self.n_desc = len(self.mats)
         self.table = torch.frombuffer(bytearray(bytes(descs)), dtype=torch.uint8).to(flat.device)
@@ -585,42 +561,6 @@ class wide_group:
         g = wide_group.current
         if g is not None and (L.load().nacf_gemm_last_kernel() or b"") == b"gemm_wide_queued":
             g.queued.append((M, N, K, rows))
-
-
-class chain:
-    """with ops.chain(): <the forward launches of ONE decoder layer, in dependence order>  -- the nn.Linear GEMMs the panel
-    body can run and the attention cores are queued and leave as ONE persistent launch with device-wide barriers between
-    its stages when the block exits (nacf_chain_*, include/nacf_hip.h; csrc/gemm_bf16_chain.hpp).  Inside the block only
-    ops.linear_fwd / ops.attention_fwd may touch the queued calls' buffers.  OFF unless NACF_CHAIN=1 (set before the model's
-    weight images are built): measured, one chain launch of the NACF layer takes 468 us against 279 us call by call
-    (profiles/r04_chain_probe.txt); the per-call GEMM profiler turns the chain off as well."""
-
-    current = None
-
-    @staticmethod
-    def enabled() -> bool:
-        return os.environ.get("NACF_CHAIN", "0") == "1" and not PROFILER.enabled and gemm_mode() == L.GEMM_BF16X3
-
-    def __enter__(self):
-        self.on = chain.current is None and chain.enabled()
-        if self.on:
-            L.check(L.load().nacf_chain_begin(), "nacf_chain_begin")
-            chain.current = self
-        return self
-
-    def __exit__(self, exc_type, exc, tb):
-        if not self.on:
-            return False
-        chain.current = None
-        rc = L.load().nacf_chain_flush(_stream())
-        if exc_type is None and rc < 0:
-            L.check(rc, "nacf_chain_flush")
-        return False
-
-
-def chain_status() -> int:
-    """synchronises the stream; 1 = a chain launch gave up at a barrier since the last call (its results are undefined)"""
-    return int(L.load().nacf_chain_status(_stream()))
 
 
 def dw_group_begin(defer_gemm: bool = True) -> None:

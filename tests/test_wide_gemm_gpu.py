@@ -267,7 +267,7 @@ def test_fixed_register_kernels_selftest_runs_and_leaves_no_trace(dev, monkeypat
     import os
     from nacf_amd.runtime import ops
     monkeypatch.setenv("NACF_GEMM_MODE", "bf16")          # an override in force while the self-test runs
-    before_env = {k: os.environ.get(k) for k in ("NACF_GEMM_TILE", "NACF_GEMM_WIDE", "NACF_GEMM_MODE", "NACF_GEMM_PANEL")}
+    before_env = {k: os.environ.get(k) for k in ("NACF_GEMM_TILE", "NACF_GEMM_WIDE", "NACF_GEMM_MODE")}
     ops._FIXED_REG_SELFTEST["done"] = False
     ops.selftest_fixed_register_kernels(dev)
     assert ops._FIXED_REG_SELFTEST["done"]

@@ -28,9 +28,6 @@ python $ROOT/tools/gemm_bench.py --iters 20 --modes bf16x3 --tiles 128,wide1,wid
 { echo "# per-launch HIP events, MEDIAN of 20 launches (tools/gemm_bench.py)"; grep "^#" /tmp/mb.err; cat /tmp/mb.txt; } > $OUT/${R}_gemm_microbench.txt
 # 4b. the grouped weight-gradient launch per problem and as the step's mix
 python $ROOT/tools/dw_group_bench.py 10 > $OUT/${R}_dw_group_bench.txt 2> /dev/null
-# 4c. the fused decoder layer (round 4, both opt-in): the layer chain against the call-by-call layer, stage by stage
-python $ROOT/tools/chain_probe.py 20 2> /dev/null | grep -v amdgpu.ids > $OUT/${R}_chain_probe.txt
-python $ROOT/tools/chain_probe2.py 20 2> /dev/null | grep -v amdgpu.ids > $OUT/${R}_chain_stage_probe.txt
 $ROOT/tools/mfma_peak 20000 > $OUT/${R}_mfma_peak.txt 2>&1
 # 5. SQ / GRBM counters of the vocabulary GEMM at K = 512 (the model's shape) and K = 8192, exact and throughput mode
 { for m in bf16x3 bf16; do echo "== mode $m"; $ROOT/tools/pmc_gemm.sh 0:5120:10547:512,0:5120:10547:8192 128 $m --images 2>/dev/null | grep "^pass"; done;

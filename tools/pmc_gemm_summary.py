@@ -18,7 +18,7 @@ def main():
         for r in csv.DictReader(open(os.path.join(base, "trace_%s.csv" % i))):
             dur[r["Dispatch_Id"]] = int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
         for r in csv.DictReader(open(path)):
-            if not any(k in r["Kernel_Name"] for k in ("gemm_f32_kernel", "gemm_bf16_kernel", "gemm_wide_kernel", "gemm_panel_kernel")):
+            if not any(k in r["Kernel_Name"] for k in ("gemm_f32_kernel", "gemm_bf16_kernel", "gemm_wide_kernel")):
                 continue
             d = per[(i, r["Dispatch_Id"])]
             d["kernel"] = r["Kernel_Name"].split("(")[0][5:64]
