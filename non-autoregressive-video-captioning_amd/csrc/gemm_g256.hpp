@@ -43,6 +43,15 @@ constexpr int HALF = 128 * 128;            // bytes of a half-tile
 constexpr int BUF = 4 * HALF;              // one k-tile: A0 A1 B0 B1
 constexpr int LDS_BYTES = 2 * BUF;
 
+// a pointer the compiler cannot prove wave-uniform (it is): through readfirstlane, or every buffer operation built on it is
+// wrapped in a waterfall loop (cdna_hip_programming.md, T20)
+template <class T>
+__device__ __forceinline__ T* uniform_ptr(T* q) {
+  const uint64_t v = reinterpret_cast<uint64_t>(q);
+  const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+  return reinterpret_cast<T*>(((uint64_t)hi << 32) | lo);
+}
+
 // one DMA-staged operand as a workgroup sees it: byte offset of (half h, request j, k-tile kt) = base + h*half_step + j*j_step + kt*kt_step
 struct Stage {
   __amdgpu_buffer_rsrc_t rsrc;
@@ -54,7 +63,8 @@ struct Stage {
 __device__ __forceinline__ Stage stage_f(const uint16_t* p, int64_t ld, int row0, int rows_total, int kt0, int lane, int wave) {
   Stage s;
   const size_t bytes = (size_t)(rows_total > row0 ? rows_total - row0 : 0) * (size_t)ld * 2;
-  s.rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(p + (size_t)row0 * ld), 0, (unsigned)(bytes < 0xfffffff0u ? bytes : 0xfffffff0u), 0x00020000);
+  s.rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)uniform_ptr(p + (size_t)row0 * ld), 0,
+                                             (unsigned)__builtin_amdgcn_readfirstlane((unsigned)(bytes < 0xfffffff0u ? bytes : 0xfffffff0u)), 0x00020000);
   const unsigned rowstep = (unsigned)ld * 2u;
   s.voff = (unsigned)(lane >> 3) * rowstep + (unsigned)(((lane & 7) ^ (lane >> 3)) << 4);
   s.base = (unsigned)(wave * 16) * rowstep + (unsigned)kt0 * 128u;
@@ -68,7 +78,8 @@ __device__ __forceinline__ Stage stage_w(const uint16_t* p, int64_t ld, int col0
   Stage s;
   const size_t all = (size_t)rows_total * (size_t)ld * 2, off = (size_t)col0 * 2;
   const size_t bytes = all > off ? all - off : 0;
-  s.rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(p + col0), 0, (unsigned)(bytes < 0xfffffff0u ? bytes : 0xfffffff0u), 0x00020000);
+  s.rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)uniform_ptr(p + col0), 0,
+                                             (unsigned)__builtin_amdgcn_readfirstlane((unsigned)(bytes < 0xfffffff0u ? bytes : 0xfffffff0u)), 0x00020000);
   const unsigned rowstep = (unsigned)ld * 2u;
   const int r4 = lane >> 4, c16 = lane & 15;
   s.voff = (unsigned)r4 * rowstep + (unsigned)((((c16 >> 1) ^ (r4 | ((wave & 1) << 2))) << 5) + ((c16 & 1) << 4));

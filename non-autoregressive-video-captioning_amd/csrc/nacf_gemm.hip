@@ -2,6 +2,7 @@
 // the fused vocabulary projection + softmax-max used by NA decoding.
 #include "gemm_f32.hpp"
 #include "gemm_bf16_launch.hpp"
+#include "gemm_g256_launch.hpp"
 #include <stdlib.h>
 #include <mutex>
 #include <algorithm>
@@ -161,8 +162,11 @@ template <bool VEC>
 __device__ __forceinline__ void splitk_reduce_body(const float* __restrict__ slabs, int64_t slab_stride, int splits,
                                                    float* __restrict__ dst, int64_t ldd, int rows, int cols, float beta,
                                                    const float* __restrict__ part, float* __restrict__ db, int64_t gid,
-                                                   int64_t gstride) {
-  if constexpr (VEC) {
+                                                   int64_t gstride, int part_rows = -1) {
+  if (part_rows < 0) part_rows = splits;      // the bias-gradient partials: one row per split unless told otherwise
+  if (splits <= 0) {
+    // (nothing to combine: the GEMM wrote dW itself; only the bias gradient is left)
+  } else if constexpr (VEC) {
     const int c4n = cols >> 2;
     const int64_t total = (int64_t)rows * c4n;
     for (int64_t idx = gid; idx < total; idx += gstride) {
@@ -186,7 +190,7 @@ __device__ __forceinline__ void splitk_reduce_body(const float* __restrict__ sla
   if (db) {
     for (int64_t n = gid; n < rows; n += gstride) {
       float acc = 0.f;
-      for (int zz = 0; zz < splits; ++zz) acc += part[(int64_t)zz * rows + n];
+      for (int zz = 0; zz < part_rows; ++zz) acc += part[(int64_t)zz * rows + n];
       db[n] = (beta != 0.f) ? acc + beta * db[n] : acc;
     }
   }
@@ -214,6 +218,7 @@ struct DwReduceDesc {
   int splits, rows, cols, vec;
   float beta;
   int block0;        // first block of this combine in the grouped launch
+  int part_rows;     // rows of `part` (-1: one per split)
 };
 struct DwReduceTable {
   int n;
@@ -228,8 +233,8 @@ __global__ void dw_group_reduce_kernel(DwReduceTable t) {
   const int nblk = (e + 1 < t.n ? t.d[e + 1].block0 : t.block_end) - d.block0;
   const int64_t gid = (int64_t)((int)blockIdx.x - d.block0) * blockDim.x + threadIdx.x;
   const int64_t gstride = (int64_t)nblk * blockDim.x;
-  if (d.vec) splitk_reduce_body<true>(d.slabs, d.slab_stride, d.splits, d.dst, d.ldd, d.rows, d.cols, d.beta, d.part, d.db, gid, gstride);
-  else splitk_reduce_body<false>(d.slabs, d.slab_stride, d.splits, d.dst, d.ldd, d.rows, d.cols, d.beta, d.part, d.db, gid, gstride);
+  if (d.vec) splitk_reduce_body<true>(d.slabs, d.slab_stride, d.splits, d.dst, d.ldd, d.rows, d.cols, d.beta, d.part, d.db, gid, gstride, d.part_rows);
+  else splitk_reduce_body<false>(d.slabs, d.slab_stride, d.splits, d.dst, d.ldd, d.rows, d.cols, d.beta, d.part, d.db, gid, gstride, d.part_rows);
 }
 
 // merge the per-tile (max, idx, sumexp) partials and apply the decode bookkeeping
@@ -586,7 +591,7 @@ static int g_dw_defer_gemm = 0;
 static int g_dw_last_group_launches = 0, g_dw_last_group_wgs = 0;
 
 static int dw_combine_push_locked(float* slabs, float* dW, int64_t lddw, const float* part, float* db, int N, int K, int real_splits,
-                                  float beta, hipStream_t s);
+                                  float beta, hipStream_t s, int part_rows = -1);
 static int dw_group_flush_locked(hipStream_t s);
 
 // Launch every queued weight-gradient GEMM in grouped grids.  Splits: with W = sum of (output tiles x k-tiles) over the
@@ -601,6 +606,31 @@ static int dw_items_launch_locked(hipStream_t s) {
   if (n_all == 0) return NACF_OK;
   // (round 3 also had a one-workgroup-per-CU member for this launch, 128 x 256 tiles on the wide kernel's geometry with both
   //  operands through the transposing stager: +23 % on one long problem, +-0 on the step's mix -- DESIGN.md section 4; removed)
+  if (g256_dw_enabled(gemm_mode())) {
+    // bf16 matrix cores: the 256 x 256 eight-phase body on the fp32 operands, live-row gather in its DMA (nacf_gemm_g256.hip)
+    std::vector<G256DwItem> gi(n_all);
+    for (int i = 0; i < n_all; ++i) {
+      const DwGemmItem& it = g_dw_items[i];
+      G256DwItem& x = gi[i];
+      x.dZ = it.dZ; x.X = it.X; x.dW = it.dW; x.db = it.db; x.ws = it.ws; x.ws_bytes = it.ws_bytes; x.lddz = it.lddz; x.ldx = it.ldx;
+      x.lddw = it.lddw; x.M = it.M; x.N = it.N; x.K = it.K; x.rows = it.has_rs ? it.rs.rows : nullptr; x.count = it.has_rs ? it.rs.count : nullptr;
+      x.beta = it.beta;
+    }
+    std::vector<G256Reduce> red;
+    int wgs = 0;
+    int rc = g256_dw_group_launch(gi.data(), n_all, gemm_mode() == NACF_GEMM_BF16X3 ? 3 : 1, red, &wgs, s);
+    g_dw_items.clear();
+    if (rc != NACF_OK) return rc;
+    g_last_was_bf16 = true;
+    bf16_note_wide("g256_dw_group_kernel");
+    g_dw_last_group_launches = 1;
+    g_dw_last_group_wgs = wgs;
+    for (const G256Reduce& r : red) {
+      rc = dw_combine_push_locked(r.slabs, r.dW, r.lddw, r.part, r.db, r.N, r.K, r.splits, r.beta, s, r.part_rows);
+      if (rc != NACF_OK) return rc;
+    }
+    return NACF_OK;
+  }
   std::vector<int> all(n_all);
   for (int i = 0; i < n_all; ++i) all[i] = i;
   const int rc = dw_subset_launch_locked(all, s);
@@ -709,7 +739,7 @@ static int dw_subset_launch_locked(const std::vector<int>& subset, hipStream_t s
 }
 
 static int dw_combine_push_locked(float* slabs, float* dW, int64_t lddw, const float* part, float* db, int N, int K, int real_splits,
-                                  float beta, hipStream_t s) {
+                                  float beta, hipStream_t s, int part_rows) {
   const bool v4 = (K % 4 == 0) && (lddw % 4 == 0) && aligned16(dW) && aligned16(slabs);
   const int64_t total = (int64_t)N * (v4 ? K / 4 : K);
   if (g_dw_group.n == DW_GROUP_MAX) {
@@ -725,7 +755,8 @@ static int dw_combine_push_locked(float* slabs, float* dW, int64_t lddw, const f
   DwReduceDesc& d = g_dw_group.d[g_dw_group.n++];
   d.slabs = slabs; d.dst = dW; d.part = part; d.db = db; d.slab_stride = (int64_t)N * K; d.ldd = lddw;
   d.splits = real_splits; d.rows = N; d.cols = K; d.vec = v4 ? 1 : 0; d.beta = beta; d.block0 = g_dw_group.block_end;
-  const int64_t want = (total + 1023) / 1024;          // ~4 elements (float4s) per thread
+  d.part_rows = part_rows;
+  const int64_t want = real_splits > 0 ? (total + 1023) / 1024 : (N + 255) / 256;          // ~4 elements (float4s) per thread
   g_dw_group.block_end += (int)(want < 1 ? 1 : (want > 2048 ? 2048 : want));
   return NACF_OK;
 }
@@ -785,7 +816,8 @@ size_t nacf_linear_bwd_weight_workspace(int M, int N, int K) {
   if (d > s) s = d;
   const size_t slabs = s > 1 ? (size_t)s * N * K * sizeof(float) : 0;
   const size_t col = (size_t)64 * N * sizeof(float);
-  return slabs + col + 256;
+  const size_t g2 = g256_dw_enabled(gemm_mode()) ? g256_dw_workspace(M, N, K) : 0;      // (nacf_gemm_g256.hip)
+  return slabs + col + 256 > g2 ? slabs + col + 256 : g2;
 }
 
 int nacf_linear_bwd_weight(const float* dZ, int64_t lddz, const float* X, int64_t ldx, float* dW, int64_t lddw,

@@ -779,5 +779,59 @@ def main():
     full_shape_case()
 
 
+def check_fixtures():
+    """python oracle/make_golden.py --check: regenerate every fixture into a scratch directory and compare it with the committed
+    one array by array (npz), value by value (json) and tensor by tensor (the checkpoint); exit status 1 on ANY difference.  This is
+    the one-command pin of the oracle's fixtures against the reference (needs /root/reference: this container only)."""
+    global GOLD
+    import tempfile
+    committed = GOLD
+    with tempfile.TemporaryDirectory() as tmp:
+        GOLD = tmp
+        main()
+        GOLD = committed
+        bad, n_arrays = [], 0
+        names = sorted(set(os.listdir(tmp)) | {f for f in os.listdir(committed) if f.endswith((".npz", ".json", ".pth.tar"))})
+        for name in names:
+            a, b = os.path.join(tmp, name), os.path.join(committed, name)
+            if not (os.path.exists(a) and os.path.exists(b)):
+                bad.append("%s: %s" % (name, "not committed" if os.path.exists(a) else "not regenerated"))
+                continue
+            if name.endswith(".npz"):
+                x, y = np.load(a, allow_pickle=False), np.load(b, allow_pickle=False)
+                for k in sorted(set(x.files) | set(y.files)):
+                    n_arrays += 1
+                    if k not in x.files or k not in y.files:
+                        bad.append("%s[%s]: only in the %s file" % (name, k, "regenerated" if k in x.files else "committed"))
+                    elif x[k].dtype != y[k].dtype or x[k].shape != y[k].shape or x[k].tobytes() != y[k].tobytes():
+                        bad.append("%s[%s]: differs" % (name, k))
+            elif name.endswith(".json"):
+                n_arrays += 1
+                if json.load(open(a)) != json.load(open(b)):
+                    bad.append("%s: differs" % name)
+            else:
+                x, y = torch.load(a, map_location="cpu", weights_only=True), torch.load(b, map_location="cpu", weights_only=True)
+
+                def same(u, v):
+                    if isinstance(u, dict):
+                        return isinstance(v, dict) and u.keys() == v.keys() and all(same(u[k], v[k]) for k in u)
+                    if torch.is_tensor(u):
+                        return torch.is_tensor(v) and u.dtype == v.dtype and torch.equal(u, v)
+                    return u == v
+                n_arrays += 1
+                if not same(x, y):
+                    bad.append("%s: differs" % name)
+    print("make_golden --check: %d files, %d arrays compared, %d differ" % (len(names), n_arrays, len(bad)))
+    for b in bad:
+        print("  DIFF", b)
+    sys.exit(1 if bad else 0)
+
+
 if __name__ == "__main__":
-    main()
+    if "--check" in sys.argv[1:]:
+        sys.argv = [sys.argv[0]]
+        check_fixtures()
+    elif len(sys.argv) > 1:
+        sys.exit("usage: python oracle/make_golden.py [--check]      (ONLY_* environment variables select a single case)")
+    else:
+        main()
