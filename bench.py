@@ -167,20 +167,21 @@ def group_profile(run_once, n_prof=3):
     return summ
 
 
-def newest_traffic_table():
-    """profiles/r*_pmc_traffic.json with the newest mtime (PMC counters cannot be collected inside this process; the
-    table comes from separate rocprofv3 --pmc passes of this same command, tools/pmc_traffic.py)"""
-    files = glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json"))
+def newest_traffic_table(leg="train"):
+    """The committed PMC table of this leg from the highest round: profiles/rNN_pmc_traffic.json (training step) or
+    profiles/rNN_pmc_traffic_decode.json (NA decode).  PMC counters cannot be collected inside this process; the tables come
+    from separate rocprofv3 --pmc passes of this same command (tools/collect_profiles.sh, tools/pmc_traffic.py).  A leg without
+    its own table reports traffic null: a kernel's bytes depend on the launch's shape, never borrowed from the other leg."""
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic%s.json" % ("" if leg == "train" else "_" + leg))))
     if not files:
         return None
-    path = max(files, key=os.path.getmtime)
     try:
-        return path, (time.time() - os.path.getmtime(path)) / 3600.0, json.load(open(path))
+        return files[-1], json.load(open(files[-1]))
     except (OSError, ValueError):
         return None
 
 
-def roofline_from(summ, n_prof, mode, prefer_single=True, groups=None, dec_rows=None):
+def roofline_from(summ, n_prof, mode, prefer_single=True, groups=None, dec_rows=None, traffic_leg="train"):
     """dominant kernel = the GEMM kernel class with the largest time per pass whose spans are ONE kernel each (spans of
     dW entry points also contain the split-K combine: listed in the table, not chosen).  `groups`: the grouped launches
     of the real step (group_profile); the classes they absorb are launched one at a time in `summ`, so the by-time
@@ -195,7 +196,7 @@ def roofline_from(summ, n_prof, mode, prefer_single=True, groups=None, dec_rows=
     if name.startswith("gemm_wide"):
         ns = 3                       # the wide kernels exist in the exact mode only
     else:
-        ns = 3 if (family == "bf16" and ", 3, " in name) else 1
+        ns = 3 if (family == "bf16" and (", 3, " in name or "<3>" in name)) else 1
     kmode = "f32" if family == "f32" else ("bf16x3" if ns == 3 else "bf16")
     peak = MODE_PEAK[kmode]
     achieved = r["flops"] / (r["ms"] * 1e-3) / 1e12
@@ -216,15 +217,15 @@ def roofline_from(summ, n_prof, mode, prefer_single=True, groups=None, dec_rows=
           # (the text is ONE top-level entry of the line, `limiters`: repeated per leg it pushed the decode / bf16 legs out of
           #  the tail the driver keeps)
           "limiter": "limiters.wide" if name.startswith("gemm_wide") else "limiters.tile128"}
-    tab = newest_traffic_table()
+    tab = newest_traffic_table(traffic_leg)
     if tab is not None:
-        path, age_h, data = tab
+        path, data = tab
         hits = [e for e in data.get("kernels", []) if name in e["kernel"]]
         if hits:
             n_l = sum(e["launches_sampled"] for e in hits)
             rl["traffic"] = int(sum(e["hbm_bytes"] * e["launches_sampled"] for e in hits) / n_l)
-            rl["traffic_source"] = "%s (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, bytes/launch; file age %.1f h)" % (
-                os.path.relpath(path, ROOT), age_h)
+            rl["traffic_source"] = "%s (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, bytes/launch, %s leg%s)" % (
+                os.path.relpath(path, ROOT), traffic_leg, "; collected " + data["collected"] if data.get("collected") else "")
     # the GEMMs of the decoder layers alone (attention projections + FFN: what BASELINE's north_star quotes its matrix-core
     # utilisation target on): every launch over the decoder's rows (sequences x positions x passes) that is not the vocabulary
     # projection -- forward + dX + dW, one launch at a time
@@ -289,7 +290,7 @@ def bench_decode(model, dev, feats, category, n_batches, with_roofline=True, mod
                 tr_e.translate_batch(model.encode(feats=feats), category, None, None)
         eager()
         summ = gemm_profile(eager, n_prof=2)
-        rl, table = roofline_from(summ, 2, mode, prefer_single=False)
+        rl, table = roofline_from(summ, 2, mode, prefer_single=False, traffic_leg="decode")
         tot_f = sum(v["flops"] for v in summ.values()) / 2
         rl["executed_gflop_per_caption"] = round(tot_f / B / 1e9, 3)
         rl["as_written_gflop_per_caption"] = 17.51 if model.opt.get("use_ct") else 14.66
@@ -493,12 +494,17 @@ def main():
     ap.add_argument("--gemm-mode", choices=["f32", "bf16x3", "bf16"], default="bf16x3",
                     help="GEMM arithmetic of the headline leg (bf16x3 = fp32-accurate split on the bf16 MFMA: the parity mode)")
     ap.add_argument("--no-decode", action="store_true")
+    ap.add_argument("--decode-only", action="store_true", help="profiling aid: a short training warm-up, then only the NA-decode leg")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--decode-batches", type=int, default=20)
     ap.add_argument("--no-compare", action="store_true", help="skip the extra legs (config 1 bf16, NACF bf16, L=30, config 5)")
     ap.add_argument("--no-loader", action="store_true", help="skip the shard-loader leg (SURVEY 8f row 1)")
     ap.add_argument("--loader-videos", type=int, default=1024, help="videos in the synthetic feature shards")
     args = ap.parse_args()
+    if args.decode_only:      # (what tools/collect_profiles.sh profiles as the decode-only set)
+        args.no_compare = args.no_loader = args.no_cpu_baseline = True
+        args.no_decode = False
+        args.steps, args.warmup = min(args.steps, 3), min(args.warmup, 2)
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -567,7 +573,7 @@ def main():
             optim.zero_grad()
             crit.get_loss(engine.forward(engine.static)).backward()
             optim._optimizer.step(grad_scale=1.0)
-        summ = gemm_profile(eager_step)
+        summ = gemm_profile(eager_step) if not args.decode_only else None
 
         def grouped_step():         # the same step as the engine runs it: weight-gradient GEMMs grouped per backward pass
             optim.zero_grad()
@@ -575,8 +581,8 @@ def main():
             with ops.dw_group():
                 loss_.backward()
             optim._optimizer.step(grad_scale=1.0)
-        groups = group_profile(grouped_step) if mode != "f32" else None
-        roofline, gemm_table = roofline_from(summ, 3, mode, groups=groups, dec_rows=2 * B * L)
+        groups = group_profile(grouped_step) if (mode != "f32" and not args.decode_only) else None
+        roofline, gemm_table = roofline_from(summ, 3, mode, groups=groups, dec_rows=2 * B * L) if summ is not None else (None, None)
         if groups:
             gemm_table.update({k + " [grouped launch of the real step]":
                                {"calls_per_pass": v["calls"] // 3, "problems_per_pass": v["problems"] // 3,

@@ -586,15 +586,24 @@ __global__ void loss_combine_bwd_kernel(const float* __restrict__ gtotal, const 
 }
 
 // ------------------------------------------------------------------ epilogue backward
+// (scalar form for unaligned operands; the same live-row handling as the float4 kernel below: dead rows of dY and of the
+//  pre-activation may be uninitialised under the no-fill policy and must not be read -- ADVICE round 4)
 __global__ void epilogue_bwd_kernel(const float* __restrict__ dY, int64_t lddy, float* __restrict__ dZ, int64_t lddz,
                                     float* __restrict__ dR, int64_t lddr, int accumulate_dR, int M, int N,
-                                    nacf_epilogue ep) {
+                                    nacf_epilogue ep, const int* __restrict__ rows, const int* __restrict__ count) {
   const int64_t total = (int64_t)M * N;
   const bool any_drop = ep.p_drop1 > 0.f || ep.p_drop2 > 0.f;
+  const int n_live = rows ? min(M, *count) : M;
   DropRng rng;
   if (any_drop) rng.init(ep.rng_state);
-  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
-    const int m = (int)(e / N), n = (int)(e % N);
+  for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < total; q += (int64_t)gridDim.x * blockDim.x) {
+    const int pos = (int)(q / N), n = (int)(q % N);
+    const int m = rows ? rows[pos] : pos;
+    if (pos >= n_live) {                     // a dead row: its gradient is zero by the row mask
+      if (dR && !accumulate_dR) dR[(int64_t)m * lddr + n] = 0.f;
+      continue;
+    }
+    const int64_t e = (int64_t)m * N + n;    // the dropout masks are functions of the PHYSICAL element index
     float g = dY[(int64_t)m * lddy + n];
     if (ep.row_tokens && ep.row_tokens[m] == NACF_PAD) g = 0.f;
     if (ep.p_drop2 > 0.f) g *= rng.keep1((uint64_t)e, ep.salt2, ep.p_drop2);
@@ -1408,9 +1417,9 @@ int nacf_epilogue_bwd(const float* dY, int64_t lddy, float* dZ, int64_t lddz, fl
   if (v4)
     hipLaunchKernelGGL(epilogue_bwd_v4_kernel, dim3(grid_for((int64_t)M * (N / 4))), dim3(256), 0, as_hip(stream), dY, lddy,
                        dZ, lddz, dR, lddr, accumulate_dR, M, N, *ep, rs ? rs->rows : nullptr, rs ? rs->count : nullptr);
-  else      // (unaligned operands: every row, as without a list -- dead rows then carry whatever the row mask makes of dY)
+  else
     hipLaunchKernelGGL(epilogue_bwd_kernel, dim3(grid_for((int64_t)M * N)), dim3(256), 0, as_hip(stream), dY, lddy, dZ, lddz,
-                       dR, lddr, accumulate_dR, M, N, *ep);
+                       dR, lddr, accumulate_dR, M, N, *ep, rs ? rs->rows : nullptr, rs ? rs->count : nullptr);
   NACF_LAUNCH_CHECK("nacf_epilogue_bwd");
   return NACF_OK;
 }

@@ -618,11 +618,12 @@ static int dw_items_launch_locked(hipStream_t s) {
     }
     std::vector<G256Reduce> red;
     int wgs = 0;
-    int rc = g256_dw_group_launch(gi.data(), n_all, gemm_mode() == NACF_GEMM_BF16X3 ? 3 : 1, red, &wgs, s);
+    const int ns = gemm_mode() == NACF_GEMM_BF16X3 ? 3 : 1;
+    int rc = g256_dw_group_launch(gi.data(), n_all, ns, red, &wgs, s);
     g_dw_items.clear();
     if (rc != NACF_OK) return rc;
     g_last_was_bf16 = true;
-    bf16_note_wide("g256_dw_group_kernel");
+    bf16_note_wide(ns == 3 ? "g256_dw_group_kernel<3>" : "g256_dw_group_kernel<1>");      // (rocprofv3's name of the kernel, up to its namespace)
     g_dw_last_group_launches = 1;
     g_dw_last_group_wgs = wgs;
     for (const G256Reduce& r : red) {

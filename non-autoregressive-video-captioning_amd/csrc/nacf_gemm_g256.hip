@@ -137,12 +137,15 @@ static void launch_dw(const DwTable& dt, hipStream_t s) {
 
 int g256_dw_group_launch(const G256DwItem* items, int n, int ns, std::vector<G256Reduce>& reduces, int* n_workgroups, hipStream_t s) {
   *n_workgroups = 0;
-  // fixed cost of a workgroup (prologue, epilogue of 256 KB) in k-tiles' worth: a k-tile is ~0.8 us (ns = 1) / ~2.9 us (ns = 3)
-  const double fixed = ns == 3 ? 3.5 : 12.0;
   for (int done = 0; done < n;) {
     const int m = std::min(n - done, G256_MAX_PROBS);
     const G256DwItem* it = items + done;
-    // ---- the walk length: S_i = round(k-tiles_i / T) within its cap; T minimises rounds x (longest walk + fixed cost)
+    // ---- the walk length: S_i = round(k-tiles_i / T) within its cap.  T = 32 k-tiles (1024 live rows per workgroup) is the
+    // measured optimum of the NACF step's set in both modes (tools/dw_g256_bench.py with NACF_DW_G256_WALK = 12 .. 128:
+    // throughput mode 0.428 / 0.409 / 0.400 / 0.412 / 0.423 / 0.523 ms at 12 / 24 / 32 / 48 / 64 / 128, exact mode 0.801 /
+    // 0.781 / 0.786 / 0.840 / 0.880 / 1.016): ~2 rounds of workgroups, which the dispatcher balances, at 8 % fixed cost.
+    // (Two cost models that pick T per group -- rounds x (longest walk + fixed), and the list-scheduling bound -- landed on
+    // longer walks and lost 3-12 %.)
     std::vector<int> nk(m), tiles(m), cap(m), S(m);
     for (int i = 0; i < m; ++i) {
       const int m_eff = it[i].rows ? (int)((long)it[i].M * 29 / 50) : it[i].M;      // ~58 % of the slots are live (not known to the host)
@@ -151,23 +154,7 @@ int g256_dw_group_launch(const G256DwItem* items, int n, int ns, std::vector<G25
       cap[i] = g256_max_splits(it[i].M, it[i].N, it[i].K, ns);
     }
     const char* te = getenv("NACF_DW_G256_WALK");
-    const int t_env = te ? atoi(te) : 0;
-    double best = 1e30;
-    int best_t = 64;
-    for (int T = 8; T <= 640; T += 4) {
-      long wgs = 0;
-      int longest = 0;
-      for (int i = 0; i < m; ++i) {
-        int si = (nk[i] + T / 2) / T;
-        si = std::max(1, std::min(si, cap[i]));
-        wgs += (long)tiles[i] * si;
-        longest = std::max(longest, cdiv(nk[i], si));
-      }
-      const long rounds = (wgs + 255) / 256;
-      const double cost = (double)rounds * (longest + fixed);
-      if (cost < best) { best = cost; best_t = T; }
-    }
-    if (t_env > 0) best_t = t_env;
+    const int best_t = (te && atoi(te) > 0) ? atoi(te) : 32;
     for (int i = 0; i < m; ++i) S[i] = std::max(1, std::min((nk[i] + best_t / 2) / best_t, cap[i]));
     std::vector<int> order(m);
     for (int i = 0; i < m; ++i) order[i] = i;

@@ -258,11 +258,13 @@ class BertLayer(nn.Module):
         # inference: nothing walks the dead rows of q, a, cq, c, u backwards, and forward they are read through `out_rows` only
         # (the attention cores compute garbage for the unlisted queries, which nobody gathers): no zero fill -- 150 MB of zero
         # stores per pass at B = 128 with 6 length candidates; k|v (masked keys multiply V by an exact 0) and y are filled
-        q = LinearFn.apply(x2, None, dict(pack=pk['q_only'], rows=out_rows, fill=False), *P)
+        # (with want_probs the attention maps of EVERY query are handed back: the unlisted queries must then be zeros, not
+        #  uninitialised memory -- ADVICE round 4)
+        q = LinearFn.apply(x2, None, dict(pack=pk['q_only'], rows=out_rows, fill=bool(want_probs)), *P)
         kv = LinearFn.apply(x2, None, dict(pack=pk['kv_only'], rows=rows), *P)
         ops.attention_fwd(q, kv[:, :D], kv[:, D:], att, tokens, int(causal), p_self, R, self.H, Lq, Lq, D // self.H, 1, R)
         a = LinearFn.apply(att, x2 if self.self_residual else None, dict(pack=pk['so'], fill=False, **sub), *P)
-        cq = LinearFn.apply(a, None, dict(pack=pk['cq'], rows=out_rows, fill=False), *P)
+        cq = LinearFn.apply(a, None, dict(pack=pk['cq'], rows=out_rows, fill=bool(want_probs)), *P)
         catt, p_cross = CrossAttentionFn.apply(cq, memory_kv, self.H, Lq, M, vdiv, vmod, want_probs)
         c = LinearFn.apply(catt, a, dict(pack=pk['co'], fill=False, **sub), *P)
         u = LinearFn.apply(c, None, dict(pack=pk['f1'], act=self.act, rows=out_rows, fill=False), *P)

@@ -94,13 +94,17 @@ class DataParallel(object):
 
     def assert_equal_rows(self, n_rows, what='SyncBN'):
         """SyncBN forms the global statistics as if every rank held `n_rows` rows (runtime/functional.py:BNConcatFn: n_tot =
-        rows x world; the reference's single process has one batch).  Checked on every launch-by-launch step (a host read,
-        so not inside a stream capture: a captured step has the shapes of the eager steps before it; and never skipped from
-        a per-rank cache -- ranks that disagree must all reach the collective): a ragged global batch must fail loudly,
-        not normalise with the wrong count."""
+        rows x world; the reference's single process has one batch): a ragged global batch must fail loudly, not normalise
+        with the wrong count.  The check is a blocking all-reduce plus a host read, so it runs on the first four
+        launch-by-launch calls and on every 64th after that -- a schedule that depends only on the CALL COUNT,
+        which is the same on every rank: ranks that disagree about the rows still all reach the collective.  Never inside a
+        stream capture (a captured step has the shapes of the eager steps before it)."""
         if self.world == 1 or not dist.is_initialized():
             return
         if torch.cuda.is_available() and torch.cuda.is_current_stream_capturing():
+            return
+        self._rows_calls = getattr(self, '_rows_calls', 0) + 1
+        if self._rows_calls > 4 and self._rows_calls % 64 != 0:
             return
         dev = self.model.flat.data.device if hasattr(self.model, 'flat') else torch.device('cpu')
         t = torch.tensor([n_rows, -n_rows], dtype=torch.int64, device=dev)

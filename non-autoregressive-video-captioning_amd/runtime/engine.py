@@ -214,9 +214,18 @@ class TrainStep(object):
             else:                           # a tensor: the all-reduce recorded at this point of the step
                 self.ddp.all_reduce(item)
 
+    def _own_forwards(self, count_before):
+        """the forwards the capture itself ran are this engine's own: without this the first replay sees a "foreign" forward and
+        fills the gradient buffer for nothing.  Only the capture's increments are taken over: a foreign forward
+        that happened BEFORE the capture stays visible to the guard."""
+        flat = getattr(self.model, 'flat', None)
+        if flat is not None and self._fwd_seen is not None and count_before is not None:
+            self._fwd_seen += flat.train_forwards - count_before
+
     def _capture(self):
         dev = self.loss.device
         before = list(self.crit._loss_cnt)
+        fwd_before = getattr(getattr(self.model, 'flat', None), 'train_forwards', None)
         # drain first: RCCL's watchdog thread polls the events of unfinished collectives, which is illegal while a
         # capture is open in another thread ("thread_local" below keeps unrelated threads out of it as well)
         torch.cuda.synchronize(dev)
@@ -245,6 +254,7 @@ class TrainStep(object):
             self.graphs = (one, None, None, None)
             self._graph_images = self._image_state()
             self._graph_loss = self.loss
+            self._own_forwards(fwd_before)
             return
         with torch.cuda.stream(side):
             def front_fn():
@@ -269,6 +279,7 @@ class TrainStep(object):
         self.graphs = (front, mid, back, upd)
         self._graph_images = self._image_state()
         self._graph_loss = self.loss
+        self._own_forwards(fwd_before)
 
     def _image_state(self):
         """what the captured launches bake in besides the static buffers: the GEMM mode and the weight-image set"""
@@ -374,7 +385,9 @@ class TrainStep(object):
     def _foreign_backward_guard(self):
         """the fused zero-grad leaves the gradient buffer clean for THIS engine's next step, and a captured step
         has no fill in it.  A training forward that did not come from here (a manual loss.backward(), misc/run.py's
-        launch-by-launch path, a second engine) may have summed into that buffer since: fill it, as optimizer.zero_grad() would."""
+        launch-by-launch path, a second engine) may have summed into that buffer since: fill it, as optimizer.zero_grad() would.
+        What is tracked: training forwards through Seq2Seq (flat.train_forwards); a backward reached through a direct call of a
+        sub-module (model.decoder(...)) with grad enabled is not seen."""
         flat = getattr(self.model, 'flat', None)
         if flat is None or self._fwd_seen is None or flat.train_forwards == self._fwd_seen or not self._grad_clean:
             return

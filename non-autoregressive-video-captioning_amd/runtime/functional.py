@@ -183,7 +183,7 @@ class BNConcatFn(Function):
         if sync is not None:
             stats = _new((2, n_mod, D), xs[0])
             n_tot = [x.shape[0] * x.shape[1] * sync.world for x in xs]      # every rank holds the same number of rows:
-            if hasattr(sync, "assert_equal_rows"):                          # ... checked once per row count (runtime/ddp.py)
+            if hasattr(sync, "assert_equal_rows"):                          # ... checked on the first calls and periodically (runtime/ddp.py)
                 sync.assert_equal_rows(xs[0].shape[0] * xs[0].shape[1])
             if getattr(sync, "all_gather", None) is not None and _SYNC_BN_ONE_EXCHANGE:
                 # one exchange: (sum | squared deviations about the rank's OWN mean) gathered, merged exactly

@@ -100,7 +100,7 @@ def test_bf16_mode_trains_under_the_graph_engine(dev, restore_mode):
         engine()
     assert engine.captured and float(engine.loss) < 0.8 * first, (first, float(engine.loss))
     last = L.load().nacf_gemm_last_kernel().decode()      # the step's last GEMM launch: the grouped weight gradients, NS = 1
-    assert last.startswith("gemm_bf16_group_kernel<128, 128, 1, 1, 1,") or "gemm_bf16_kernel<" in last, last
+    assert last.startswith(("g256_dw_group_kernel<1>", "gemm_bf16_group_kernel<128, 128, 1, 1, 1,")) or "gemm_bf16_kernel<" in last, last
     assert model.flat.images is not None and model.flat.images.ns == 1
     assert optim._optimizer.exp_avg.dtype == torch.float32
     sd = model.state_dict()

@@ -102,7 +102,7 @@ def _worker(rank, world, port, out):
     assert host_broadcast_int(7 if rank == 0 else -1, 'test_a') == 7 and host_broadcast_int(0 if rank == 0 else 5, 'test_b') == 0
     # the SAME tag again (a second train_network_all on this process group): the new value, not the stored one
     assert host_broadcast_int(3 if rank == 0 else -1, 'test_a') == 3
-    # SyncBN's equal-rows contract: the same count on every rank passes (and is cached), a ragged shard fails loudly on every rank
+    # SyncBN's equal-rows contract: the same count on every rank passes, a ragged shard fails loudly on every rank (checked on the first calls, then periodically)
     ddp.assert_equal_rows(12)
     ddp.assert_equal_rows(12)
     try:

@@ -123,11 +123,15 @@ def test_full_size_na_decode_vs_oracle(dev, B, graph):
     score = o_lp.sum(-1) / (o_beam.float() ** dec["beam_alpha"])
     top2 = score.topk(2, dim=1).values
     safe_vid = safe_rows.view(B, lbs).all(1) & ((top2[:, 0] - top2[:, 1]) > 1e-5)
-    assert float(safe_vid.float().mean()) >= 0.93, float(safe_vid.float().mean())      # (one video of 32 is 3 %)
+    # (one video of 32 is 3 %; at 128 videos the ORACLE's own decisions are free of numerical ties for 124 of 128 videos = 0.969 --
+    #  a property of the seeded inputs, printed below: a regression of the best-candidate scorer must not hide inside the small
+    #  batch's slack)
+    assert float(safe_vid.float().mean()) >= (0.96 if B >= 128 else 0.93), float(safe_vid.float().mean())
     assert hyp.shape == o_hyp.shape
     assert torch.equal(hyp.cpu()[safe_vid], o_hyp[safe_vid])
-    print("full-size NA decode B=%d graph=%s: %d/%d candidate sequences and %d/%d videos free of numerical ties, all bit-exact"
-          % (B, graph, int(safe_rows.sum()), safe_rows.numel(), int(safe_vid.sum()), B))
+    print("full-size NA decode B=%d graph=%s: %d/%d candidate sequences (%.4f) and %d/%d videos (%.4f) free of numerical ties, all bit-exact"
+          % (B, graph, int(safe_rows.sum()), safe_rows.numel(), float(safe_rows.float().mean()), int(safe_vid.sum()), B,
+             float(safe_vid.float().mean())))
 
 
 def test_full_size_ar_beam_vs_oracle(dev):
@@ -193,6 +197,43 @@ def test_ar_beam_at_the_bench_batch_is_the_small_batch_result(dev):
     for i in range(32):
         assert abs(s256[i][0] - s32[i][0]) < (5e-4 if h256[i][0] == h32[i][0] else 2e-3), (i, s256[i][0], s32[i][0])
     assert len({len(h[0]) for h in h256}) > 3          # ends at mixed steps
+
+
+@pytest.mark.parametrize("graph", ["off", "on"])
+def test_na_decode_at_the_bench_batch_is_the_small_batch_result(dev, graph):
+    """BASELINE configs[4], the NA side: bench.py decodes 256 videos per batch; the oracle comparison above runs at 32 and 128.
+    Mask-predict treats videos independently (decoding/na_generate.py:19-131), so the first 128 videos of a 256-video batch must
+    come out as in the 128-video batch -- which extends the oracle parity of the B = 128 test to the bench's batch size.  (The GEMM
+    tile choice depends on the row count, so logits differ by summation order: a numerically tied argmax may flip a token; the
+    share of identical captions is asserted and printed, the per-iteration tokens agree on >= 99.5 % of the slots.)"""
+    import nacf_amd
+    from nacf_amd import synthetic as S
+    from nacf_amd.models.Translator import Translator
+    opt = nacf_amd.opts.make_opt("NACF", "MSRVTT", with_category=True, max_len=20, vocab_size=10547, n_frames=60, fused_loss=True)
+    sd = S.init_state_dict(opt, seed=0)
+    b = S.synth_batch(opt, 256, 60, seed=21)
+    model = build(opt, sd, dev)
+    model.eval()
+    dopt = dict(model.opt)
+    dopt.update(paradigm="mp", use_ct=True, iterations=5, length_beam_size=6, beam_alpha=1.35,
+                collect_best_candidate_iterative_results=True, not_only_best_candidate=True, decode_graph=graph)
+    out = {}
+    for n in (256, 128):
+        with torch.no_grad():
+            enc = model.encode(feats=[f[:n].to(dev) for f in b["feats"]])
+            tr = Translator(model, dopt, device=dev)
+            hyp, (it_tok, _) = tr.translate_batch(enc, b["category"][:n].to(dev), None, None)
+            if graph == "on":
+                hyp, (it_tok, _) = tr.translate_batch(enc, b["category"][:n].to(dev), None, None)      # the replayed graph
+        out[n] = (hyp.cpu(), it_tok.cpu())
+    (h256, t256), (h128, t128) = out[256], out[128]
+    assert h256.shape[0] == 256 and h128.shape[0] == 128
+    lbs = 6
+    same_vid = float((h256[:128] == h128).all(1).float().mean())
+    same_tok = float((t256[:128 * lbs] == t128).float().mean())
+    print("NA decode, graph %s: first 128 of 256 videos vs the 128-video batch: %.4f of the captions identical, %.5f of the per-iteration tokens"
+          % (graph, same_vid, same_tok))
+    assert same_vid >= 0.97 and same_tok >= 0.995, (same_vid, same_tok)
 
 
 def test_config0_nab_youtube2text_shape_train_step_vs_oracle(dev):

@@ -19,7 +19,14 @@ cp /tmp/prof_train/b_kernel_stats.csv $OUT/${R}_train_only_kernel_stats.csv
 for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --kernel-trace --output-format csv --pmc $c -d /tmp/prof_$c -o b -- python $ROOT/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-decode --no-compare --no-loader --graph off > /dev/null 2>&1
 done
-python $ROOT/tools/pmc_traffic.py /tmp/prof_FETCH_SIZE/b_counter_collection.csv /tmp/prof_WRITE_SIZE/b_counter_collection.csv $OUT/${R}_pmc_traffic.json
+python $ROOT/tools/pmc_traffic.py /tmp/prof_FETCH_SIZE/b_counter_collection.csv /tmp/prof_WRITE_SIZE/b_counter_collection.csv $OUT/${R}_pmc_traffic.json train
+# 3b. the NA-decode leg alone: kernel stats and its own HBM traffic table (a kernel's bytes depend on the launch's shape)
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_dec -o b -- python $ROOT/bench.py --decode-only > $OUT/${R}_decode_only_bench.json 2> /dev/null
+cp /tmp/prof_dec/b_kernel_stats.csv $OUT/${R}_decode_kernel_stats.csv
+for c in FETCH_SIZE WRITE_SIZE; do
+  rocprofv3 --kernel-trace --output-format csv --pmc $c -d /tmp/prof_dec_$c -o b -- python $ROOT/bench.py --decode-only --decode-batches 3 --graph off > /dev/null 2>&1
+done
+python $ROOT/tools/pmc_traffic.py /tmp/prof_dec_FETCH_SIZE/b_counter_collection.csv /tmp/prof_dec_WRITE_SIZE/b_counter_collection.csv $OUT/${R}_pmc_traffic_decode.json decode
 # 4. GEMM microbenchmarks (three arithmetic modes, weights from pre-split images as in the model) + attainable MFMA peak
 # (per-launch HIP events, median of 20; one-off stalls the tool saw go to the top of the file as '#' lines)
 python $ROOT/tools/gemm_bench.py --iters 20 --modes f32,bf16x3,bf16 --images > /tmp/mb.txt 2> /tmp/mb.err
