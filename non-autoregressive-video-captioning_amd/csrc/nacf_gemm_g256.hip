@@ -155,7 +155,14 @@ int g256_dw_group_launch(const G256DwItem* items, int n, int ns, std::vector<G25
     }
     const char* te = getenv("NACF_DW_G256_WALK");
     const int best_t = (te && atoi(te) > 0) ? atoi(te) : 32;
-    for (int i = 0; i < m; ++i) S[i] = std::max(1, std::min((nk[i] + best_t / 2) / best_t, cap[i]));
+    // ... and no more slabs than `slab_mb` MB per problem: a split of a big output (the vocabulary projection: 21.6 MB) costs more
+    // HBM traffic (slab write + combine read) than its shorter walk buys -- its long walks go first in the grid instead
+    const char* se = getenv("NACF_DW_G256_SLAB_MB");
+    const double slab_mb = (se && atof(se) > 0) ? atof(se) : 16.0;
+    for (int i = 0; i < m; ++i) {
+      const int by_bytes = std::max(1, (int)(slab_mb * 1048576.0 / ((double)it[i].N * it[i].K * 4.0)));
+      S[i] = std::max(1, std::min(std::min((nk[i] + best_t / 2) / best_t, cap[i]), by_bytes));
+    }
     std::vector<int> order(m);
     for (int i = 0; i < m; ++i) order[i] = i;
     std::sort(order.begin(), order.end(), [&](int a, int b) {
