@@ -62,3 +62,42 @@ def test_multi_rank_launch_sequence_with_one_rank_group(dev):
     one = run({"NACF_BENCH_FORCE_DIST": "1", "NACF_DDP_GRAPH_COLLECTIVES": "1", "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": "29580"})
     assert one["config"]["hipgraph"] is True and one["final_loss"] == multi["final_loss"]
     assert one["config"].get("graph_collectives") is True and not multi["config"].get("graph_collectives")
+
+
+def test_forced_collective_sequences_yield_the_single_process_weights(dev, tmp_path):
+    """What a final loss printed to four decimals would not notice (a bucket that skipped its Adam walk, a stage whose gradients
+    were reduced twice): the POST-STEP WEIGHTS of the N > 1 launch sequences -- two and three gradient buckets with SyncBN, and
+    the RCCL calls captured inside one step graph -- against the single-process step.  1-rank RCCL group, dropout 0, 3 steps
+    (one launch by launch, two replayed); SyncBN folds its statistics in another order and the staged backward groups the
+    weight-gradient GEMMs differently, so the bar is round-off: max |dw| <= 1e-5 on weights of O(0.1)."""
+    import torch
+    helper = os.path.join(ROOT, "tests", "ddp_step_helper.py")
+
+    def run(tag, kind, port, **env_extra):
+        path = str(tmp_path / (tag + ".pt"))
+        env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), **env_extra)
+        out = subprocess.run([sys.executable, helper, path, kind, "3"], capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
+        assert out.returncode == 0, out.stderr[-2000:]
+        return torch.load(path, weights_only=True)
+    single = run("single", "single", 29590)
+    assert single["captured"] and single["buckets"] == 1
+    w0 = single["weights"]
+    for tag, env, buckets, in_graph in (("two", {}, 2, False), ("three", {"NACF_DDP_STAGES": "3"}, 3, False),
+                                        ("ingraph", {"NACF_DDP_GRAPH_COLLECTIVES": "1"}, None, True)):
+        r = run(tag, "dist", 29591 + len(tag), **env)
+        assert r["captured"], tag
+        if buckets is not None:
+            assert r["staged"] and r["buckets"] == buckets, (tag, r["buckets"])
+        assert r["graph_collectives"] == in_graph, tag
+        err = float((r["weights"] - w0).abs().max())
+        assert err <= 1e-5, (tag, err)
+        assert abs(r["loss"] - single["loss"]) <= 1e-4 * abs(single["loss"]), (tag, r["loss"], single["loss"])
+    # ... and the steps did move the weights (three Adam steps at the schedule's learning rate)
+    import nacf_amd
+    from nacf_amd import synthetic as S
+    opt = nacf_amd.opts.make_opt("NACF", "MSRVTT", with_category=True, max_len=20, vocab_size=1001, n_frames=12, fused_loss=True,
+                                 hidden_dropout_prob=0.0, encoder_dropout=0.0, use_ct=True)
+    m = nacf_amd.get_model(opt)
+    m.load_state_dict(S.init_state_dict(opt, 0))
+    m.to(dev)
+    assert float((m.flat.data.cpu() - w0).abs().max()) > 1e-4
