@@ -64,7 +64,7 @@ int nacf_version(void);
  * included).  nacf_abi_count() returns the value the LIBRARY was built with; the ctypes loader
  * (runtime/lib.py:load) refuses a library whose count differs from its own signature table, so a stale
  * libnacf_hip.so next to a newer Python package fails at import time, not at the first missing symbol. */
-#define NACF_ABI_COUNT 86
+#define NACF_ABI_COUNT 87
 int nacf_abi_count(void);
 
 /* ---- batch construction (reference: dataloader.py) ----------------------------------------
@@ -86,6 +86,12 @@ int nacf_sample_frames(const float* src, const int32_t* video, const int32_t* sr
  *   the copies to overlap with kernels. */
 int nacf_gather_clips_h2d(void* dst, const void* src_host, const int32_t* rows, int n, size_t clip_bytes,
                           nacf_stream_t stream);
+/* nacf_gather_clips_zc: the same gather by kernel-issued PCIe reads: src_host is PINNED host memory (device-mapped, 16-byte
+ * aligned), rows_dev a DEVICE array; `workgroups` of 256 threads keep 16 x 16 bytes per thread in flight (<= 0: 24).
+ * clip_bytes % 16 == 0.  Replaces the per-clip DMAs of dataloader.py:132-144,263-315's batch assembly when whole clips are
+ * needed and the shards live in pinned host memory. */
+int nacf_gather_clips_zc(void* dst, const void* src_host, const int32_t* rows_dev, int n, size_t clip_bytes, int workgroups,
+                         nacf_stream_t stream);
 /* nacf_build_targets: the decoder inputs / labels of B captions, dataloader.py:317-425.
  *   caps[b, 0..cap_len[b]) = <bos> w1 .. wn <eos> (int32, row pitch ld_caps), pos_tags alike.
  *   narformer != 0: masked-LM pair (:346-380).  train: a uniformly random subset of the n word slots (size uniform

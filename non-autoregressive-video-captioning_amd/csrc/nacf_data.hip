@@ -203,6 +203,34 @@ __global__ void build_targets_kernel(const int* __restrict__ caps, int ld, const
   }
 }
 
+// Whole clips out of PINNED HOST memory by kernel-issued PCIe reads (the pinned allocation is mapped into the device's address
+// space): dst[j] = src[rows[j]].  A few workgroups keep ZC_UNROLL x 16 bytes per thread in flight (24 workgroups: 1.5 MB of reads
+// outstanding) while the training step owns the rest of the chip.  One DMA per clip
+// (nacf_gather_clips_h2d) tops out at ~26 GB/s for the 491 KB clips of a 60 x 2048 batch; this form is what the pinned-host
+// placement of the loader uses when the whole clip is needed (data/loader.py).
+typedef uint32_t zc_u32x4 __attribute__((ext_vector_type(4)));
+#ifndef ZC_UNROLL
+#define ZC_UNROLL 16
+#endif
+__global__ __launch_bounds__(256) void gather_clips_zc_kernel(zc_u32x4* __restrict__ dst, const zc_u32x4* __restrict__ src,
+                                                              const int32_t* __restrict__ rows, int n, int64_t chunks) {
+  constexpr int U = ZC_UNROLL;
+  const int64_t per_clip = (chunks + 256 * U - 1) / (256 * U);
+  for (int64_t w = blockIdx.x; w < (int64_t)n * per_clip; w += gridDim.x) {
+    const int j = (int)(w / per_clip);
+    const int64_t c0 = (w - (int64_t)j * per_clip) * (256 * U) + threadIdx.x;
+    const zc_u32x4* s = src + (int64_t)rows[j] * chunks;
+    zc_u32x4* d = dst + (int64_t)j * chunks;
+    zc_u32x4 v[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+      if (c0 + u * 256 < chunks) v[u] = __builtin_nontemporal_load(s + c0 + u * 256);
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+      if (c0 + u * 256 < chunks) d[c0 + u * 256] = v[u];
+  }
+}
+
 }  // namespace
 
 extern "C" {
@@ -243,6 +271,19 @@ int nacf_gather_clips_h2d(void* dst, const void* src_host, const int32_t* rows, 
                                         hipMemcpyHostToDevice, s);
     NACF_CHECK(e == hipSuccess, NACF_ELAUNCH, "nacf_gather_clips_h2d: %s", hipGetErrorString(e));
   }
+  return NACF_OK;
+}
+
+int nacf_gather_clips_zc(void* dst, const void* src_host, const int32_t* rows_dev, int n, size_t clip_bytes, int workgroups,
+                         nacf_stream_t stream) {
+  NACF_CHECK(dst && src_host && rows_dev && n >= 0 && clip_bytes > 0 && clip_bytes % 16 == 0, NACF_EINVAL, "nacf_gather_clips_zc: bad argument");
+  NACF_CHECK((reinterpret_cast<uintptr_t>(dst) & 15) == 0 && (reinterpret_cast<uintptr_t>(src_host) & 15) == 0, NACF_EINVAL,
+             "nacf_gather_clips_zc: 16-byte aligned buffers");
+  if (n == 0) return NACF_OK;
+  if (workgroups <= 0) workgroups = 24;
+  hipLaunchKernelGGL(gather_clips_zc_kernel, dim3(workgroups), dim3(256), 0, as_hip(stream), static_cast<zc_u32x4*>(dst),
+                     static_cast<const zc_u32x4*>(src_host), rows_dev, n, (int64_t)(clip_bytes / 16));
+  NACF_LAUNCH_CHECK("nacf_gather_clips_zc");
   return NACF_OK;
 }
 

@@ -11,9 +11,12 @@ tokens_1 / labels_1 (visual-word pass), length_target, category -- built ON THE 
       - few frames per clip (n_frames <= T/3, e.g. the reference's 8 of 60): pinned memory is mapped into the device's
         address space and the frame-sampling kernel itself pulls exactly the sampled rows over PCIe (zero-copy gather:
         7.5x fewer bytes than copying clips, no host loop per clip; measured ~18 GB/s of kernel-issued PCIe reads);
-      - most frames needed: one asynchronous DMA per clip (T*D*4 contiguous bytes, ~56 GB/s; issued by a C loop,
-        `nacf_gather_clips_h2d`) into a device staging buffer, frame sampling then runs on the staged clips.  (The
-        copy engines do not compete with the training kernels for compute units; the gather kernel does.)
+      - most frames needed: the whole clips (T*D*4 contiguous bytes each) go to a device staging buffer, frame sampling then
+        runs on the staged clips.  Default: a copy KERNEL reading the pinned shard over PCIe (`nacf_gather_clips_zc`, 24
+        workgroups with 16 x 16 bytes per thread in flight): 34.0 k videos/s on the NACF step at 128 videos against 24.3 k
+        for one asynchronous DMA per clip (`nacf_gather_clips_h2d`, opt['loader_clip_copy'] = 'dma': 256 copies of 491 KB
+        per batch top out at ~26 GB/s); measured 8 / 16 / 24 / 32 / 64 / 128 workgroups: 22 / 34 / 34 / 33 / 29 / 27 k --
+        more workgroups take compute units from the training step, fewer do not cover the link's latency.
   * mmap mode (larger than host memory): the batch's clips are copied from the memory-mapped shard into one of two
     pinned staging buffers by a few host threads and uploaded on the side stream (double buffering).
     In both streaming modes frame sampling then runs on the staged rows.
@@ -111,6 +114,9 @@ class ShardLoader:
                 self.pref_rows_dev = [[torch.empty(self.B, dtype=torch.int32, device=self.dev) for _ in self.shards]
                                       for _ in range(2)]
                 self.n_built = 0
+                # whole clips out of pinned memory: "kernel" = kernel-issued PCIe reads, "dma" = one hipMemcpyAsync per clip
+                self.clip_copy = opt.get("loader_clip_copy", os.environ.get("NACF_LOADER_CLIP_COPY", "kernel"))
+                self.clip_copy_wgs = int(opt.get("loader_clip_copy_wgs", os.environ.get("NACF_LOADER_CLIP_COPY_WGS", "24")))
             else:
                 self.pinned = [[torch.empty(self.B, s.T, s.D, dtype=torch.float32).pin_memory() for s in self.shards]
                                for _ in range(2)]
@@ -158,8 +164,13 @@ class ShardLoader:
                 self.pref_rng[slot].state.copy_(self.pref_state[slot], non_blocking=True)
             for m, s in enumerate(self.shards):
                 rows = self.rows[m][vids_host]
-                if self.placement == "host" and not self.zero_copy:    # one DMA per clip, pinned RAM -> device staging
-                    ops.gather_clips_h2d(self.staged[slot][m], self.host_feats[m], rows)
+                if self.placement == "host" and not self.zero_copy:    # whole clips, pinned RAM -> device staging
+                    if self.clip_copy == "kernel":                      # kernel-issued PCIe reads (nacf_gather_clips_zc)
+                        self.pref_rows[slot][m][:n] = torch.from_numpy(np.ascontiguousarray(rows, dtype=np.int32))
+                        self.pref_rows_dev[slot][m][:n].copy_(self.pref_rows[slot][m][:n], non_blocking=True)
+                        ops.gather_clips_zc(self.staged[slot][m], self.host_feats[m], self.pref_rows_dev[slot][m][:n], self.clip_copy_wgs)
+                    else:                                               # one DMA per clip
+                        ops.gather_clips_h2d(self.staged[slot][m], self.host_feats[m], rows)
                     self.pinned_len[slot][m][:n] = torch.from_numpy(s.lengths[rows])
                     self.staged_len[slot][m][:n].copy_(self.pinned_len[slot][m][:n], non_blocking=True)
                     continue

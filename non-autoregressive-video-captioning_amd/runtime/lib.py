@@ -79,6 +79,7 @@ SIGNATURES = {
     "nacf_epilogue_bwd": (c_int, [_P, _L, _P, _L, _P, _L, _I, _I, _I, _EP, _RS, _P]),
     "nacf_sample_frames": (c_int, [_P, _P, _P, _I, _I, _I, _I, _I, _U, _P, _P, _P, _P]),
     "nacf_gather_clips_h2d": (c_int, [_P, _P, _P, _I, ctypes.c_size_t, _P]),
+    "nacf_gather_clips_zc": (c_int, [_P, _P, _P, _I, ctypes.c_size_t, _I, _P]),
     "nacf_build_targets": (c_int, [_P, _I, _P, _P, _P, _P, _I, _I, _I, _I, _I, ctypes.c_double, ctypes.c_double, _U, _P,
                                    _P, _P, _P, _P, _P]),
     "nacf_loss_combine": (c_int, [_P, _I, _I, _P, _P, _P, _P, _P, _I, _P, _P]),

@@ -1118,6 +1118,18 @@ def gather_clips_h2d(dst: Tensor, src_host: Tensor, rows_host) -> None:
                                            _stream()), "nacf_gather_clips_h2d")
 
 
+def gather_clips_zc(dst: Tensor, src_host: Tensor, rows_dev: Tensor, workgroups: int = 0) -> None:
+    """dst[j] = src_host[rows_dev[j]] (whole clips) by kernel-issued PCIe reads on the current stream; src_host: pinned
+    [N, T, D] tensor (device-mapped), rows_dev: int32 device tensor"""
+    n = int(rows_dev.numel())
+    assert dst.is_cuda and dst.is_contiguous() and src_host.is_pinned() and src_host.is_contiguous()
+    assert rows_dev.is_cuda and rows_dev.dtype == torch.int32 and rows_dev.is_contiguous()
+    assert dst.shape[0] >= n and dst.shape[1:] == src_host.shape[1:] and dst.dtype == src_host.dtype
+    clip = src_host[0].numel() * src_host.element_size()
+    L.check(L.load().nacf_gather_clips_zc(_ptr(dst), ctypes.c_void_p(src_host.data_ptr()), _ptr(rows_dev), n, clip, int(workgroups),
+                                          _stream()), "nacf_gather_clips_zc")
+
+
 def build_targets(caps: Tensor, cap_len: Tensor, pos_tags: Optional[Tensor], tag_demanded: Optional[Tensor],
                   word_is_be: Optional[Tensor], max_len: int, narformer: bool, visual_word: bool, train: bool,
                   beta=(0.0, 1.0), salt: int = 0, rng: Optional[RngState] = None, into=None):

@@ -198,14 +198,15 @@ def test_shard_loader_resident_equals_streaming_and_feeds_a_train_step(dev, tmp_
                                  encoder_dropout=0.0, vocab_size=101, fused_loss=True, n_frames=8)
     table, vids = CaptionTable.from_corpus(caps, tags, info, list(range(12)), opt, "train")
     batches = {}
-    for placement in ("hbm", "host", "host_dma", "mmap"):
-        o = dict(opt, loader_zero_copy=False) if placement == "host_dma" else opt
+    for placement in ("hbm", "host", "host_dma", "host_kernel", "mmap"):
+        # whole clips out of pinned memory: one DMA per clip | the copy kernel (nacf_gather_clips_zc, the default)
+        o = dict(opt, loader_zero_copy=False, loader_clip_copy="dma" if placement == "host_dma" else "kernel") if placement.startswith("host_") else opt
         ld = ShardLoader(shards, table, vids, o, batch_size=8, device=dev, mode="train", seed=3, placement=placement[:4])
         assert len(ld) == (len(table) + 7) // 8 and ld.placement == placement[:4]
         assert ld.zero_copy == (placement == "host")          # 8 of 60 frames: the kernel gathers straight from pinned RAM
         batches[placement] = list(ld)
     batches[True] = batches["hbm"]
-    for other in ("host", "host_dma", "mmap"):         # the placements deliver identical batches
+    for other in ("host", "host_dma", "host_kernel", "mmap"):         # the placements deliver identical batches
         for a, b in zip(batches["hbm"], batches[other]):
             assert set(a) == set(b)
             for k in a:
