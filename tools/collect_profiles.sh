@@ -35,6 +35,18 @@ python $ROOT/tools/gemm_bench.py --iters 20 --modes bf16x3 --tiles 128,wide1,wid
 { echo "# per-launch HIP events, MEDIAN of 20 launches (tools/gemm_bench.py)"; grep "^#" /tmp/mb.err; cat /tmp/mb.txt; } > $OUT/${R}_gemm_microbench.txt
 # 4b. the grouped weight-gradient launch per problem and as the step's mix
 python $ROOT/tools/dw_group_bench.py 10 > $OUT/${R}_dw_group_bench.txt 2> /dev/null
+# 4c. the same set on the 256 x 256 eight-phase body for fp32 operands against the 128 x 128 grouped kernel, both bf16 modes (graph replay)
+{ for m in bf16 bf16x3; do echo "== mode $m"; MODE=$m python $ROOT/tools/dw_g256_bench.py 10 2>/dev/null | grep -v amdgpu.ids; done; } > $OUT/${R}_dw_g256_bench.txt
+# 4d. the eight-phase bodies alone (standalone probes; built by hand, see their headers)
+[ -x $ROOT/tools/probes/gemm256_8phase ] && $ROOT/tools/probes/gemm256_8phase 20 > $OUT/${R}_gemm256_8phase_probe.txt 2>&1
+[ -x $ROOT/tools/probes/gemm256w_probe ] && $ROOT/tools/probes/gemm256w_probe 10 > $OUT/${R}_gemm256w_probe.txt 2>&1
+# 4e. captured training steps of the throughput mode under rocprofv3 (configs[1] NAB B = 64, and NACF B = 128)
+for cfg in "NACF 128 bf16 nacf128_bf16" "NAB 64 bf16 nab64_bf16"; do
+  set -- $cfg
+  rm -rf /tmp/prof_step
+  METHOD=$1 BATCH=$2 MODE=$3 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_step -o b -- python $ROOT/tools/step_profile.py 300 > $OUT/${R}_step_$4.txt 2>/dev/null
+  cp /tmp/prof_step/b_kernel_stats.csv $OUT/${R}_step_$4_kernel_stats.csv
+done
 $ROOT/tools/mfma_peak 20000 > $OUT/${R}_mfma_peak.txt 2>&1
 # 5. SQ / GRBM counters of the vocabulary GEMM at K = 512 (the model's shape) and K = 8192, exact and throughput mode
 { for m in bf16x3 bf16; do echo "== mode $m"; $ROOT/tools/pmc_gemm.sh 0:5120:10547:512,0:5120:10547:8192 128 $m --images 2>/dev/null | grep "^pass"; done;
