@@ -504,7 +504,6 @@ def main():
     if args.decode_only:      # (what tools/collect_profiles.sh profiles as the decode-only set)
         args.no_compare = args.no_loader = args.no_cpu_baseline = True
         args.no_decode = False
-        args.steps, args.warmup = min(args.steps, 3), min(args.warmup, 2)
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -541,6 +540,14 @@ def main():
 
     # each rank owns its shard of the global batch (seeded per rank), resident in HBM
     batch = to_batch(O.synth_batch(opt, B, F_, seed=1 + rank), dev, True)
+    if args.decode_only:
+        # profiling aid (tools/collect_profiles.sh): the NA-decode leg and nothing else on the device, so that a rocprofv3 /
+        # PMC table of this command holds decode launches only (same seeded weights as the default run's decode leg).  NOT the
+        # driver's line.
+        model.eval()
+        decode = bench_decode(model, dev, batch["feats"], batch["category"], args.decode_batches, mode=mode)
+        print(json.dumps({"metric": METRIC, "leg": "decode only (profiling aid, not the driver's line)", "decode": decode}), flush=True)
+        return
     engine, crit, optim = make_engine(model, dev, batch, ddp=ddp if multi else None, graph=args.graph,
                                       eager_steps=max(args.warmup, 2))
     use_graph = engine.captured
@@ -573,7 +580,7 @@ def main():
             optim.zero_grad()
             crit.get_loss(engine.forward(engine.static)).backward()
             optim._optimizer.step(grad_scale=1.0)
-        summ = gemm_profile(eager_step) if not args.decode_only else None
+        summ = gemm_profile(eager_step)
 
         def grouped_step():         # the same step as the engine runs it: weight-gradient GEMMs grouped per backward pass
             optim.zero_grad()
@@ -581,8 +588,8 @@ def main():
             with ops.dw_group():
                 loss_.backward()
             optim._optimizer.step(grad_scale=1.0)
-        groups = group_profile(grouped_step) if (mode != "f32" and not args.decode_only) else None
-        roofline, gemm_table = roofline_from(summ, 3, mode, groups=groups, dec_rows=2 * B * L) if summ is not None else (None, None)
+        groups = group_profile(grouped_step) if mode != "f32" else None
+        roofline, gemm_table = roofline_from(summ, 3, mode, groups=groups, dec_rows=2 * B * L)
         if groups:
             gemm_table.update({k + " [grouped launch of the real step]":
                                {"calls_per_pass": v["calls"] // 3, "problems_per_pass": v["problems"] // 3,
