@@ -129,7 +129,10 @@ __device__ __forceinline__ void read_b(const unsigned char* smem, const Frag& f,
 // (phase 2: both halves of A are in place, nothing restages them before phase 3), into ITS accumulator in LDS: the exact-mode
 // kernel has no register left to carry a sum across the k-loop
 template <int BUFI>
-__device__ __forceinline__ void colsum_rows(unsigned char* smem, int tid) {
+__device__ __forceinline__ void colsum_rows(unsigned char* smem, int wave) {
+  // (the thread index rebuilt from v_mbcnt + the wave number: kept across the loop it is spilled in the exact-mode kernel, and a
+  //  spill reload costs a vmcnt(0), i.e. the DMA pipeline)
+  const int tid = wave * 64 + (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
   const int c = tid & 255, cc = c & 127;
   const unsigned off = (unsigned)(BUFI * BUF + (c >> 7) * HALF + (tid >> 8) * (16 * 512) + (cc << 2));
   const unsigned char* p0 = smem + off;                     // rows 0..7 of the 16: (r >> 3) & 1 = 0
@@ -188,7 +191,7 @@ __device__ __forceinline__ void ktile(unsigned char* smem, const Operand& oa, co
   read_b<NS, BUFI, 1>(smem, f, b1);
   if constexpr (SUM) {
     __builtin_amdgcn_sched_barrier(0);      // (B1's raw registers are free again)
-    colsum_rows<BUFI>(smem, threadIdx.x);
+    colsum_rows<BUFI>(smem, wave);
   }
   if (next2) stage<BUFI, 1, 0>(smem, ob, lds_stage, rw);
   G256W_BARRIER_A();
@@ -209,10 +212,56 @@ __device__ __forceinline__ void ktile(unsigned char* smem, const Operand& oa, co
   G256W_BARRIER();
 }
 
+// The same k-tile in TWO phases (two quadrants = 32 x NS(NS+1)/2 matrix instructions per barrier pair): four barriers per k-tile
+// instead of eight.  Staging moves to two half-tiles per phase: phase A(t) stages {A0, A1}[t+1] into the other buffer (A0's last
+// read was phase A(t-1), A1's phase B(t-1): retired before that phase's first barrier), phase B(t) stages {B0, B1}[t+2] into its
+// own (read in phase A(t)).  Counted waits: phase A leaves {B[t+1], A[t+1]} = 8 requests in flight (A1[t] is retired: read in
+// phase B), phase B leaves {A1[t+1], B[t+2]} = 6 (B[t+1] and A0[t+1] are retired: read in phase A(t+1)).
+template <int NS, bool SUM, int BUFI>
+__device__ __forceinline__ void ktile2(unsigned char* smem, const Operand& oa, const Operand& ob, const Frag& f, unsigned lds_stage, const Walk& w, int kt,
+                                       Rows& rw, f32x4 (&acc)[8][4], u32x4_t (&a)[4][NS], u32x4_t (&b0)[2][NS], u32x4_t (&b1)[2][NS], int lane, int wave) {
+  const bool next1 = kt + 1 < w.nk, next2 = kt + 2 < w.nk;      // wave-uniform
+  // ---- phase A   (rw = the rows of tile kt + 1 on entry)
+  read_b<NS, BUFI, 0>(smem, f, b0);
+  read_b<NS, BUFI, 1>(smem, f, b1);
+  if constexpr (NS == 3) __builtin_amdgcn_sched_barrier(0);      // (the raw fp32 registers of B are dead before A0's are loaded)
+  read_a<NS, BUFI, 0>(smem, f, a);
+  if (next1) {
+    stage<BUFI ^ 1, 0, 0>(smem, oa, lds_stage, rw);
+    stage<BUFI ^ 1, 0, 1>(smem, oa, lds_stage, rw);
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+  } else {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+  if (next2) rw = rows_of_tile(w.tile0 + (kt + 2) * w.step, w.n_live, w.list, lane, wave);
+  G256W_BARRIER_A();
+  quadrant<NS, 0, 0>(acc, a, b0);
+  quadrant<NS, 0, 1>(acc, a, b1);
+  G256W_BARRIER();
+  // ---- phase B
+  read_a<NS, BUFI, 1>(smem, f, a);
+  if constexpr (SUM) {
+    __builtin_amdgcn_sched_barrier(0);
+    colsum_rows<BUFI>(smem, wave);
+  }
+  if (next2) {
+    stage<BUFI, 1, 0>(smem, ob, lds_stage, rw);
+    stage<BUFI, 1, 1>(smem, ob, lds_stage, rw);
+    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+  } else if (next1) {
+    asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+  }
+  G256W_BARRIER_A();
+  quadrant<NS, 1, 0>(acc, a, b0);
+  quadrant<NS, 1, 1>(acc, a, b1);
+  G256W_BARRIER();
+}
+
 // epi(row, col, v): the four outputs (row, col .. col + 3) of the 256 x 256 tile; episum(row, s) (SUM): the sum of A's column `row` of
 // the tile over the workgroup's reduce rows
-template <int NS, bool SUM, class Epi, class EpiSum>
+template <int NS, bool SUM, int PH, class Epi, class EpiSum>
 __device__ __forceinline__ void body(unsigned char* smem, const Operand& oa, const Operand& ob, const Walk& w, const Epi& epi, const EpiSum& episum) {
+  static_assert(PH == 4 || PH == 2, "phases per k-tile");
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int wr = wave >> 2, wc = wave & 3;
@@ -229,25 +278,45 @@ __device__ __forceinline__ void body(unsigned char* smem, const Operand& oa, con
 
   // ---- prologue: all of tile 0, then tile 1's B0, A0, B1 (its A1 is staged by tile 0's phase 1)
   Rows rw = rows_of_tile(w.tile0, w.n_live, w.list, lane, wave);
-  stage<0, 0, 0>(smem, oa, lds_stage, rw);
-  stage<0, 1, 0>(smem, ob, lds_stage, rw);
-  stage<0, 1, 1>(smem, ob, lds_stage, rw);
-  stage<0, 0, 1>(smem, oa, lds_stage, rw);
-  if (w.nk > 1) {
-    rw = rows_of_tile(w.tile0 + w.step, w.n_live, w.list, lane, wave);
-    stage<1, 1, 0>(smem, ob, lds_stage, rw);
-    stage<1, 0, 0>(smem, oa, lds_stage, rw);
-    stage<1, 1, 1>(smem, ob, lds_stage, rw);
-    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-  } else {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if constexpr (PH == 4) {
+    stage<0, 0, 0>(smem, oa, lds_stage, rw);
+    stage<0, 1, 0>(smem, ob, lds_stage, rw);
+    stage<0, 1, 1>(smem, ob, lds_stage, rw);
+    stage<0, 0, 1>(smem, oa, lds_stage, rw);
+    if (w.nk > 1) {
+      rw = rows_of_tile(w.tile0 + w.step, w.n_live, w.list, lane, wave);
+      stage<1, 1, 0>(smem, ob, lds_stage, rw);
+      stage<1, 0, 0>(smem, oa, lds_stage, rw);
+      stage<1, 1, 1>(smem, ob, lds_stage, rw);
+      asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+  } else {      // B[0], A0[0], A1[0], then B[1]: B[0] and A0[0] are retired here, A1[0] by tile 0's phase A
+    stage<0, 1, 0>(smem, ob, lds_stage, rw);
+    stage<0, 1, 1>(smem, ob, lds_stage, rw);
+    stage<0, 0, 0>(smem, oa, lds_stage, rw);
+    stage<0, 0, 1>(smem, oa, lds_stage, rw);
+    if (w.nk > 1) {
+      rw = rows_of_tile(w.tile0 + w.step, w.n_live, w.list, lane, wave);
+      stage<1, 1, 0>(smem, ob, lds_stage, rw);
+      stage<1, 1, 1>(smem, ob, lds_stage, rw);
+      asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    }
   }
   G256W_BARRIER();
   if (wr == 1) G256W_BARRIER();      // the second wave row runs one barrier behind the first
 
   for (int kt = 0; kt < w.nk; kt += 2) {
-    ktile<NS, SUM, 0>(smem, oa, ob, f, lds_stage, w, kt, rw, acc, a, b0, b1, lane, wave);
-    if (kt + 1 < w.nk) ktile<NS, SUM, 1>(smem, oa, ob, f, lds_stage, w, kt + 1, rw, acc, a, b0, b1, lane, wave);
+    if constexpr (PH == 4) {
+      ktile<NS, SUM, 0>(smem, oa, ob, f, lds_stage, w, kt, rw, acc, a, b0, b1, lane, wave);
+      if (kt + 1 < w.nk) ktile<NS, SUM, 1>(smem, oa, ob, f, lds_stage, w, kt + 1, rw, acc, a, b0, b1, lane, wave);
+    } else {
+      ktile2<NS, SUM, 0>(smem, oa, ob, f, lds_stage, w, kt, rw, acc, a, b0, b1, lane, wave);
+      if (kt + 1 < w.nk) ktile2<NS, SUM, 1>(smem, oa, ob, f, lds_stage, w, kt + 1, rw, acc, a, b0, b1, lane, wave);
+    }
   }
   if (wr == 0) G256W_BARRIER();
 

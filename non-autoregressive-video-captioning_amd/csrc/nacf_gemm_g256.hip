@@ -14,6 +14,9 @@
 
 namespace {
 
+#ifndef G256W_PHASES
+#define G256W_PHASES 2      // phases per k-tile of the body (gemm_g256w.hpp: 4 | 2; 2 measured 6-11 % faster in both modes)
+#endif
 constexpr int G256_MAX_PROBS = 24;
 constexpr int G256_MAX_SPLITS = 8;
 
@@ -95,19 +98,19 @@ __global__ __launch_bounds__(512, 2) void g256_dw_group_kernel(DwTable t) {
   epi.ldc = p.ldc; epi.rows = p.I - i0; epi.cols = p.J - j0; epi.vec = p.vec; epi.beta = p.S == 1 ? p.beta : 0.f;
   EpiBias eb;
   eb.b = p.bias ? p.bias + (p.S == 1 ? 0 : (int64_t)z * p.I) + i0 : nullptr; eb.rows = p.I - i0; eb.beta = p.S == 1 ? p.beta : 0.f;
-  if (p.bias && tj == 0) g256w::body<NS, true>(smem, oa, ob, w, epi, eb);
-  else g256w::body<NS, false>(smem, oa, ob, w, epi, eb);
+  if (p.bias && tj == 0) g256w::body<NS, true, G256W_PHASES>(smem, oa, ob, w, epi, eb);
+  else g256w::body<NS, false, G256W_PHASES>(smem, oa, ob, w, epi, eb);
 }
 
 }  // namespace
 
-// Which arithmetic modes take this path.  Measured on the NACF step (128 videos, one box, interleaved): throughput mode 1.957 ->
-// 1.786 ms per step; exact mode 2.635 -> 2.652 ms (its 128 x 128 grouped kernel is already at 0.42 of its roof) -- so the default
-// is the throughput mode only.  NACF_DW_G256 (A/B switch, read per call: a handful of calls per step, none inside a replayed
-// graph): 0 = off, 1 = throughput mode, 3 = both modes.
+// Which arithmetic modes take this path: both bf16 matrix-core modes.  Measured on the NACF step (128 videos, one box, interleaved
+// runs): throughput mode 1.937 -> 1.732 ms per step, exact mode 2.645 -> 2.58 ms (the grouped launch 0.643 -> 0.58 ms = 0.46 of
+// the mode's roof; with four phases per k-tile it tied at 2.652).  NACF_DW_G256 (A/B switch, read per call: a handful of calls per
+// step, none inside a replayed graph): 0 = the 128 x 128 grouped kernel of gemm_bf16.hpp, 1 = throughput mode only, 3 = both (default).
 bool g256_dw_enabled(int mode) {
   const char* e = getenv("NACF_DW_G256");
-  const int v = e ? atoi(e) : 1;
+  const int v = e ? atoi(e) : 3;
   return mode == NACF_GEMM_BF16 ? v != 0 : (mode == NACF_GEMM_BF16X3 && v == 3);
 }
 

@@ -1275,7 +1275,9 @@ def test_grouped_dw_gemms(dev):
         refb = b0.double() + dz64.sum(0)
         scale = float(ref.abs().max())
         e_one, e_grp = float((a.double() - ref).abs().max()) / scale, float((c.double() - ref).abs().max()) / scale
-        assert e_grp <= max(2e-6, 1.5 * e_one), (tuple(dz.shape), e_one, e_grp)
+        # (a problem that keeps ONE split -- the vocabulary projection on the 256 x 256 body -- sums all its live rows in a single fp32
+        #  accumulation chain: ~3000 products, 2.0e-6 of the largest entry measured; the split launches sum shorter chains)
+        assert e_grp <= max(3e-6, 1.5 * e_one), (tuple(dz.shape), e_one, e_grp)
         assert float((cb.double() - refb).abs().max()) <= 1e-5 * float(refb.abs().max()) + 1e-4
     # two chunks (more than 16 problems) and a repeated target
     many = [(r(2048, 128), r(2048, 256)) for _ in range(20)]

@@ -9,6 +9,9 @@
 #include "gemm_g256w.hpp"
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); exit(1); } } while (0)
 
+#ifndef PHASES
+#define PHASES 4
+#endif
 struct EpiPlain {
   float* C; int64_t ldc; int rows, cols;
   __device__ __forceinline__ void operator()(int r, int c, g256::f32x4 v) const {
@@ -32,7 +35,7 @@ __global__ __launch_bounds__(512, 2) void gemm_w32(const float* __restrict__ A, 
   const g256w::Operand oa = g256w::operand(A, I, ti * 256, R, lane, wave), ob = g256w::operand(B, J, tj * 256, R, lane, wave);
   EpiPlain epi;
   epi.C = C + (size_t)z * I * J + (size_t)ti * 256 * J + tj * 256; epi.ldc = J; epi.rows = I - ti * 256; epi.cols = J - tj * 256;
-  g256w::body<NS, false>(smem, oa, ob, w, epi, EpiNoSum());
+  g256w::body<NS, false, PHASES>(smem, oa, ob, w, epi, EpiNoSum());
 }
 
 int main(int argc, char** argv) {
@@ -69,7 +72,7 @@ int main(int argc, char** argv) {
       CK(hipDeviceSynchronize());
       float ms; CK(hipEventElapsedTime(&ms, e0, e1));
       const double us = ms * 1e3 / reps, fl = 2.0 * c.R * c.I * c.J;
-      printf("NS=%d %-40s %9.1f us  %7.1f TF useful  (%d workgroups, %d k-tiles each: %.2f us per k-tile)\n", ns, c.name, us, fl / us / 1e6, tiles * c.S,
+      printf("PH=%d NS=%d %-40s %9.1f us  %7.1f TF useful  (%d workgroups, %d k-tiles each: %.2f us per k-tile)\n", PHASES, ns, c.name, us, fl / us / 1e6, tiles * c.S,
              (c.R / 32) / c.S, us / ((double)(c.R / 32) / c.S * std::max(1, (tiles * c.S + 255) / 256)));
     }
   return 0;
