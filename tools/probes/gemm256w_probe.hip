@@ -51,7 +51,7 @@ int main(int argc, char** argv) {
   CK(hipMemcpy(A, h.data(), n * 4, hipMemcpyHostToDevice));
   CK(hipMemcpy(B, h.data(), n * 4, hipMemcpyHostToDevice));
   std::vector<int> hl(8192);
-  for (int i = 0; i < 8192; ++i) hl[i] = (i * 37) % 8192;      // a permutation
+  for (int i = 0; i < 8192; ++i) hl[i] = (i * 37) % 4096 + (i / 4096) * 4096;      // a permutation of each half (the cases with a list use 4096 rows)
   CK(hipMemcpy(L, hl.data(), 8192 * 4, hipMemcpyHostToDevice));
   struct Case { const char* name; int R, I, J, S, use_list; };
   const Case cases[] = {{"cube 4096 dense", 4096, 4096, 4096, 1, 0}, {"cube 4096 row list", 4096, 4096, 4096, 1, 1}, {"8192 x 2048 x 2048, 8 splits", 8192, 2048, 2048, 4, 0},
@@ -66,6 +66,21 @@ int main(int argc, char** argv) {
         else hipLaunchKernelGGL(gemm_w32<3>, dim3(tiles * c.S), dim3(512), g256w::LDS_BYTES, 0, A, B, C, c.use_list ? L : nullptr, c.R, c.I, c.J, c.S);
       };
       go(); CK(hipDeviceSynchronize());
+      if (c.S == 1) {      // sampled fp64 check (A and B hold the same data)
+        double worst = 0;
+        for (int t = 0; t < 64; ++t) {
+          const int i = (t * 997 + 13) % c.I, j = (t * 4051 + 7) % c.J;
+          double ref = 0, mag = 0;
+          for (int r = 0; r < c.R; ++r) {
+            const int pr = c.use_list ? hl[r] : r;
+            const double x = (double)h[(size_t)pr * c.I + i] * (double)h[(size_t)pr * c.J + j];
+            ref += x; mag += fabs(x);
+          }
+          float got; CK(hipMemcpy(&got, C + (size_t)i * c.J + j, 4, hipMemcpyDeviceToHost));
+          worst = std::max(worst, fabs(got - ref) / mag);
+        }
+        printf("   check: worst |err| / sum|terms| over 64 samples = %.2e\n", worst);
+      }
       CK(hipEventRecord(e0, 0));
       for (int i = 0; i < reps; ++i) go();
       CK(hipEventRecord(e1, 0));
