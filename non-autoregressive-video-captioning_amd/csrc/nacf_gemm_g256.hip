@@ -30,7 +30,7 @@ struct DwProb {
   int M, I, J, tiles_j, tiles, S, wg0, vec;
   float beta;
 };
-struct DwTable { int n; int wg_end; DwProb p[G256_MAX_PROBS]; };
+struct DwTable { int n; int wg_end; int xcd_run; DwProb p[G256_MAX_PROBS]; };
 
 struct EpiAcc {
   float* C; int64_t ldc; int rows, cols, vec; float beta;
@@ -71,9 +71,20 @@ __device__ __forceinline__ float uni(float v) { return __uint_as_float(__builtin
 template <int NS>
 __global__ __launch_bounds__(512, 2) void g256_dw_group_kernel(DwTable t) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  // Workgroups go to the 8 XCDs round-robin; each XCD has its own L2.  Inside windows of 8 * xcd_run workgroups the index is
+  // permuted so that one XCD takes xcd_run CONSECUTIVE entries of the schedule (tiles of one problem and one split: they share
+  // their operand panels), the windows keep the longest-first order of the schedule across the chip.
+  int bid = (int)blockIdx.x;
+  if (t.xcd_run > 1) {
+    const int win = 8 * t.xcd_run, w0 = bid / win * win;
+    if (w0 + win <= t.wg_end) {
+      const int r = bid - w0;
+      bid = w0 + (r & 7) * t.xcd_run + (r >> 3);
+    }
+  }
   int e = 0;
 #pragma unroll 1
-  while (e + 1 < t.n && (int)blockIdx.x >= t.p[e + 1].wg0) ++e;
+  while (e + 1 < t.n && bid >= t.p[e + 1].wg0) ++e;
   DwProb p;
   {
     const DwProb& q = t.p[e];
@@ -81,7 +92,7 @@ __global__ __launch_bounds__(512, 2) void g256_dw_group_kernel(DwTable t) {
     p.slab_stride = uni(q.slab_stride); p.list = uni(q.list); p.count = uni(q.count); p.M = uni(q.M); p.I = uni(q.I); p.J = uni(q.J);
     p.tiles_j = uni(q.tiles_j); p.tiles = uni(q.tiles); p.S = uni(q.S); p.wg0 = uni(q.wg0); p.vec = uni(q.vec); p.beta = uni(q.beta);
   }
-  const int local = blockIdx.x - p.wg0;
+  const int local = bid - p.wg0;
   const int z = local / p.tiles, tile = local - z * p.tiles;
   const int ti = tile / p.tiles_j, tj = tile - ti * p.tiles_j;
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -156,6 +167,10 @@ int g256_dw_group_launch(const G256DwItem* items, int n, int ns, std::vector<G25
       tiles[i] = cdiv(it[i].N, g256w::BM) * cdiv(it[i].K, g256w::BN);
       cap[i] = g256_max_splits(it[i].M, it[i].N, it[i].K, ns);
     }
+    const char* xe = getenv("NACF_DW_G256_XCD_RUN");      // consecutive schedule entries per XCD (0 / 1: plain round-robin)
+    // step set, graph replay, one box: throughput mode 0.372 / 0.348 / 0.351 / 0.362 / 0.420 ms at 0 / 4 / 8 / 16 / 32; exact mode 0.703 /
+    // 0.702 / 0.692 / 0.782 / 0.825 (long runs unbalance the XCDs: the walks differ per problem)
+    const int xcd_run = xe ? atoi(xe) : 4;
     const char* te = getenv("NACF_DW_G256_WALK");
     const int best_t = (te && atoi(te) > 0) ? atoi(te) : 32;
     // ... and no more slabs than `slab_mb` MB per problem: a split of a big output (the vocabulary projection: 21.6 MB) costs more
@@ -196,6 +211,7 @@ int g256_dw_group_launch(const G256DwItem* items, int n, int ns, std::vector<G25
       wg += tiles[i] * S[i];
     }
     dt.wg_end = wg;
+    dt.xcd_run = xcd_run;
     if (ns == 3) launch_dw<3>(dt, s);
     else launch_dw<1>(dt, s);
     NACF_LAUNCH_CHECK("nacf_dw_group_flush(g256 grouped gemm)");
