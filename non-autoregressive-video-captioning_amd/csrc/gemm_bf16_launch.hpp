@@ -5,6 +5,7 @@
 #pragma once
 #include <cstdlib>
 #include "gemm_bf16.hpp"
+#include "gemm_dma64.hpp"
 
 #ifndef NACF_BF16_EXACT128_STAGES
 #define NACF_BF16_EXACT128_STAGES 3     // LDS staging of the exact mode's 128x128 tile: 1 | 3 (gemm_bf16.hpp "STAGES")
@@ -24,6 +25,7 @@ void launch_wimage_refresh(const WImageDesc* descs, int n_desc, int n_tiles, int
 // "gemm_bf16_kernel<BM, BN, QSRC, PSRC, NS, STAGES, Epi>" of the launch the calling thread made last (profiling aid)
 const char* bf16_last_kernel_name();
 void bf16_note_kernel(int tile, int qsrc, int psrc, int ns, int stages, const char* epi);
+void bf16_note_dma64(const char* epi);
 
 template <int BM, int QSRC, int PSRC, int NS, int STAGES, class Epi>
 inline void launch_bf16_one(const GemmShape& g, const Epi& epi, dim3 grid, hipStream_t s) {
@@ -50,6 +52,22 @@ inline void launch_bf16_any(GemmShape g, const Epi& epi, int splits, int tile, i
     // groups of 4..16 all give +5-6 % (exact) / +11 % (bf16) over n-fastest; NACF_GEMM_GROUP_N overrides (0 = off)
     static const int group_n = [] { const char* e = getenv("NACF_GEMM_GROUP_N"); return e ? atoi(e) : 6; }();
     if (group_n > 0 && g.tiles_n >= 32 && splits == 1) g.group_n = group_n;
+  }
+  // throughput mode, the 64 x 64 tile with a weight image, launches of at most 3 tiles per CU: the DMA-fed kernel of
+  // gemm_dma64.hpp on 32 x 64 tiles (NACF_DMA64=0: gemm_bf16_kernel<64, 64>).  Threshold scan on the NACF / NAB steps:
+  // 768 / 1024 / 2048 tiles -> 1.694 / 1.720 / 1.725 ms (NACF B = 128), 1.019 / 1.023 / 1.024 ms (NAB B = 64).
+  if constexpr (QSRC == SRC_F32_KC && PSRC == SRC_BF16_KC) {
+    static const int max_tiles = [] { const char* e = getenv("NACF_DMA64_MAX"); return e ? atoi(e) : 768; }();
+    if (ns == 1 && tile != 0 && g.tiles_m * g.tiles_n * splits <= max_tiles && dma64::eligible(g, splits)) {
+      const char* e = getenv("NACF_DMA64");
+      if (!e || atoi(e) != 0) {
+        g.tiles_m = cdiv(g.M, 32);
+        grid.x = (g.tiles_m + (g.zero_dead ? 1 : 0)) * g.tiles_n;
+        dma64::launch<32, Epi>(g, epi, grid, s);
+        bf16_note_dma64(epi_name);
+        return;
+      }
+    }
   }
   // LDS images: two of each operand where they fit (one barrier per k-tile); the exact mode's 128x128 tile keeps one
   // image of Q and two of P (72 KB, two workgroups per CU): P is loaded during the MFMA phase, two tiles ahead

@@ -9,6 +9,7 @@ void bf16_note_kernel(int tile, int qsrc, int psrc, int ns, int stages, const ch
            stages, epi);
 }
 
+void bf16_note_dma64(const char* epi) { snprintf(g_last_kernel, sizeof(g_last_kernel), "gemm_dma64_kernel<32, %s>", epi); }
 void bf16_note_wide(const char* name) { snprintf(g_last_kernel, sizeof(g_last_kernel), "%s", name); }
 
 void launch_bf16_linear(GemmShape g, const EpiLinear& epi, int tile, int ns, hipStream_t s) {
