@@ -55,6 +55,9 @@ LIMITER_G256W = ("the operand split: a k-tile of 32 reduce rows is 192 v_mfma_f3
                  "fragment time (every wave for its own fragments) plus 4 barriers and 8 DMA requests; in-loop the matrix pipe is ~60 % busy "
                  "(204-224 TF of 416.7 on a 4096 cube, tools/probes/gemm256w_probe.hip; ablations in profiles/r05_g256w_ablation.txt); a grouped "
                  "launch adds the ragged last round of its 12 problems and the slab combine")
+LIMITER_DMA64 = ("launch latency and fp32 outputs, not the matrix pipe: a launch of <= 768 tiles of 32 x 64 is 2-12 GFLOP (1-5 us of the chip's "
+                 "bf16 rate) inside a ~4.7 us launch floor, one HBM latency of prologue and an epilogue that writes fp32 (with the pre-activation: "
+                 "8 bytes per output against 2 x 512 flops); per launch 7-18 us (profiles/r05_dma64_timeline.txt)")
 LIMITER_WIDE = ("inside the k-loop the matrix pipe is 93 % busy (3250-3310 cycles per k-tile of 96 v_mfma_f32_32x32x16_bf16 = 3072; "
                 "64-row tiles 81 %: tools/probes/wide_gemm.hip stamps); what is left is outside it: one workgroup per CU, so "
                 "nothing overlaps its prologue (~4 k cycles: DMA latency + the first operand split) and epilogue (10-14 k cycles, "
@@ -221,7 +224,8 @@ def roofline_from(summ, n_prof, mode, prefer_single=True, groups=None, dec_rows=
           # tools/bf16_trace.py (profiles/r02_bf16_phase_trace.txt): the matrix pipe is NOT what limits K = 512 launches
           # (the text is ONE top-level entry of the line, `limiters`: repeated per leg it pushed the decode / bf16 legs out of
           #  the tail the driver keeps)
-          "limiter": "limiters.wide" if name.startswith("gemm_wide") else "limiters.g256w" if name.startswith("g256_dw") else "limiters.tile128"}
+          "limiter": ("limiters.wide" if name.startswith("gemm_wide") else "limiters.g256w" if name.startswith("g256_dw")
+                      else "limiters.dma64" if name.startswith("gemm_dma64") else "limiters.tile128")}
     tab = newest_traffic_table(traffic_leg)
     if tab is not None:
         path, data = tab
@@ -700,7 +704,7 @@ def main():
                           "gradient_buckets": (3 if engine.three else 2) if staged else 1},
                "timing": extra_timing, "rank_losses": rank_losses,
                # (bulky / referenced entries first: what reads only the END of this line keeps the legs below)
-               "gemm_kernels": gemm_table, "limiters": {"tile128": LIMITER_128, "wide": LIMITER_WIDE, "g256w": LIMITER_G256W},
+               "gemm_kernels": gemm_table, "limiters": {"tile128": LIMITER_128, "wide": LIMITER_WIDE, "g256w": LIMITER_G256W, "dma64": LIMITER_DMA64},
                "loader_fed": loader_leg, "train_L30": l30, "config5_ar_vs_na": compare,
                "nacf_bf16": nacf_bf16, "config1_nab_bf16": nab, "decode": decode,
                "roofline": roofline, "cpu_baseline": cpu, "final_loss": round(final_loss, 4)}
