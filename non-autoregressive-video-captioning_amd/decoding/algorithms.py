@@ -53,6 +53,14 @@ class Algorithm_Base(object):
         self.masking_decision = opt.get('masking_decision', False)
         self.no_candidate_decision = opt.get('no_candidate_decision', False)
         self.vocab = tgt_vocab
+        # [open slots before the last pass, open slots after it] of a fixed-pass-count run (EasyFirst; see static_passes)
+        self.status = None
+
+    def static_passes(self):
+        """True while the decode is being captured into a hipGraph (or opt['decode_fixed_passes'], for tests): the
+        data-dependent pass counts of Left2Right / EasyFirst are replaced by their upper bounds -- the extra passes
+        select no slot and change nothing -- so that the launch sequence is fixed and no host read sits between passes"""
+        return bool(self.opt.get('decode_fixed_passes', False)) or torch.cuda.is_current_stream_capturing()
 
     # ------------------------------------------------------------ helpers
     def collect_data(self, tokens, probs, is_last=False):
@@ -207,7 +215,9 @@ class Left2Right(_QFill):
         rank = torch.empty(R, Lp, dtype=torch.int32, device=tokens.device)
         counts = torch.empty(2, dtype=torch.int32, device=tokens.device)
         ops.mask_rank(tokens, rank, counts)              # rank of every <mask> slot within its row
-        n_slots = int(counts[0].item())                  # one host read replaces the per-step `mask_ind.sum() == 0`
+        # one host read replaces the per-step `mask_ind.sum() == 0`; without it (graph capture) every rank up to the canvas
+        # width is visited: a pass past a row's last <mask> selects nothing in that row
+        n_slots = Lp if self.static_passes() else int(counts[0].item())
         for cur in range(0, min(n_slots, Lp), self.q):
             ops.select_rank(rank, cur, self.q, tokens, mask)
             self.na_pass(ctx, tokens, probs, pad_tokens, update_mask=mask)
@@ -226,6 +236,25 @@ class EasyFirst(_QFill):
         new_tokens = torch.empty_like(tokens)
         new_probs = torch.empty_like(probs)
         pre = 0
+        if self.static_passes():
+            # fixed launch sequence: ceil(Lp / q) passes fill every row that makes progress; further passes on a finished or
+            # stalled canvas recompute what is there.  A slot may also stay open because its prediction WAS the <mask> id
+            # (then the reference simply runs more passes): the open-slot counts before and after the last pass go to
+            # `self.status`, and the caller falls back to the host-driven loop when they show an unfinished, moving canvas
+            n_pass = (Lp + self.q - 1) // self.q
+            self.status = torch.zeros(2, dtype=torch.int32, device=tokens.device)
+            for i in range(n_pass):
+                if i == n_pass - 1:
+                    ops.mask_rank(tokens, rank, counts)
+                    self.status[0:1].copy_(counts[1:2])
+                self.na_pass(ctx, tokens, probs, pad_tokens, out_tokens=new_tokens, out_probs=new_probs)
+                ops.easy_first_update(tokens, probs, new_tokens, new_probs, self.q)
+                self.collect_data(tokens, probs)
+            ops.mask_rank(tokens, rank, counts)
+            self.status[1:2].copy_(counts[1:2])
+            self._refine(ctx, tokens, probs, pad_tokens, mask, visual_mask)
+            tp = self.scoring_by_teacher(teacher_ctx, tokens, pad_tokens, is_last=True)
+            return tokens, probs, tp, self.get_collected_data()
         while True:
             # the reference reads `mask_ind.sum()` on the host every pass as well (algorithms.py:380-385):
             # a slot whose prediction is the <mask> id itself stays open, so the pass count is data dependent

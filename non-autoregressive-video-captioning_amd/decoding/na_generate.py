@@ -6,9 +6,10 @@ best-candidate gather are device kernels, the visual memory is addressed by
 `row // lbs` instead of being repeated lbs times (misc/utils.py:205-229), and
 its cross-attention K|V projection is computed once per video.  The single host
 read per batch is the canvas width (`beam.max().item()`, na_generate.py:37),
-kept so the returned hypotheses have exactly the reference's shape; for
-mask-predict it moves behind the work, which replays from one hipGraph
-(`_generate_graphed`, opt['decode_graph'] = 'auto' | 'on' | 'off').
+kept so the returned hypotheses have exactly the reference's shape; it moves
+behind the work, which replays from one hipGraph (`_generate_graphed`,
+opt['decode_graph'] = 'auto' | 'on' | 'off'): mask-predict as is, left-to-right
+and easy-first with their pass-count upper bounds (Algorithm_Base.static_passes).
 """
 import torch
 
@@ -31,15 +32,18 @@ def generate(opt, model, teacher_model, encoder_outputs, teacher_encoder_outputs
         raise NotImplementedError('nacf_amd: attention collection / example mode of generate() is not built')
     mode = opt.get('decode_graph', 'auto')
     assert mode in ('auto', 'on', 'off')
-    # mask-predict has a fixed launch sequence once the canvas width is fixed: replay it from a hipGraph
-    # ('l2r' / 'ef' read a slot count on the host between passes; a vocabulary remap table is uploaded per call)
-    if mode != 'off' and paradigm == 'mp' and not dict_mapping:
+    # mask-predict has a fixed launch sequence once the canvas width is fixed: replay it from a hipGraph.  'l2r' / 'ef' read a
+    # slot count on the host between passes (algorithms.py:275-418); under capture they run their pass-count upper bounds
+    # instead (Algorithm_Base.static_passes) -- unless the per-pass results are collected, whose number the extra passes
+    # would change.  (A vocabulary remap table is uploaded per call: not graphed.)
+    per_pass = opt.get('collect_best_candidate_iterative_results', False) and not opt.get('collect_last', False)
+    if mode != 'off' and not dict_mapping and (paradigm == 'mp' or not per_pass):
         out = _generate_graphed(opt, model, teacher_model, encoder_outputs, teacher_encoder_outputs, category,
                                 tgt_vocab, length_bias, mode, gold)
         if out is not None:
             return out
-    hyp, lprobs, _ = _generate(opt, model, teacher_model, encoder_outputs, teacher_encoder_outputs, category, tgt_vocab,
-                               dict_mapping, length_bias, None, gold)
+    hyp, lprobs, _, _ = _generate(opt, model, teacher_model, encoder_outputs, teacher_encoder_outputs, category, tgt_vocab,
+                                  dict_mapping, length_bias, None, gold)
     return hyp, lprobs
 
 
@@ -62,7 +66,7 @@ def _generate_graphed(opt, model, teacher_model, enc, t_enc, category, tgt_vocab
     te = _enc_tensors(t_enc) if (teacher_model is not None and t_enc is not None) else None
     keys = ('paradigm', 'use_ct', 'iterations', 'length_beam_size', 'beam_alpha', 'masking_decision',
             'no_candidate_decision', 'collect_best_candidate_iterative_results', 'collect_last',
-            'not_only_best_candidate')
+            'not_only_best_candidate', 'q', 'q_iterations')
     flat = getattr(model, 'flat', None)          # the graph holds raw pointers into the parameter buffer
     key = (None if flat is None else (flat.data.data_ptr(), flat.image_epoch), ops.gemm_mode(), tuple(e.shape), tuple(pl.shape), None if category is None else tuple(category.shape), int(length_bias),
            id(teacher_model) if te is not None else None, None if te is None else tuple(te[0].shape),
@@ -100,7 +104,7 @@ def _generate_graphed(opt, model, teacher_model, enc, t_enc, category, tgt_vocab
                 outs = run()
         torch.cuda.current_stream(dev).wait_stream(side)
         entry = cache[key] = (graph, st, outs)
-    graph, st, (hyp, lprobs, beam_max) = entry
+    graph, st, (hyp, lprobs, beam_max, status) = entry
     st['e'].copy_(e)
     st['pl'].copy_(pl)
     if pooled is not None:
@@ -115,6 +119,10 @@ def _generate_graphed(opt, model, teacher_model, enc, t_enc, category, tgt_vocab
                 dst.copy_(src)
     graph.replay()
     Lp = int(beam_max.item())                   # the reference's one host read (na_generate.py:37), after the work
+    if status is not None:                      # EasyFirst under a fixed pass count: open slots before / after the last pass
+        before, after = (int(v) for v in status.tolist())
+        if after != 0 and after != before:      # still filling (a prediction was the <mask> id): the host-driven loop decides
+            return None
     out_l = None if lprobs is None else tuple(x[..., :Lp].clone() for x in lprobs)
     return hyp[:, :Lp].clone(), out_l
 
@@ -176,4 +184,4 @@ def _generate(opt, model, teacher_model, encoder_outputs, teacher_encoder_output
             sents = [s.view(B, lbs, Lp).gather(1, idx).squeeze(1) for s in sents]
             scores = [s.view(B, lbs, Lp).gather(1, idx).squeeze(1) for s in scores]
         lprobs = (torch.stack(sents, dim=1), torch.stack(scores, dim=1))
-    return hypotheses, lprobs, beam_max
+    return hypotheses, lprobs, beam_max, algorithm.status

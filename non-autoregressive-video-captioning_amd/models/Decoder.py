@@ -94,8 +94,6 @@ class BertDecoder(nn.Module):
         if isinstance(enc_output, list):
             assert len(enc_output) == 1
             enc_output = enc_output[0]
-        if signals is not None:
-            raise NotImplementedError('nacf_amd: `signals` is not built')
         if decoding_type not in ('NARFormer', 'ARFormer'):
             raise NotImplementedError('nacf_amd: decoding_type %s is not built' % decoding_type)
         tgt_seq = tgt_seq.contiguous()
@@ -109,6 +107,13 @@ class BertDecoder(nn.Module):
             additional = kwargs.get('pooled_memory')
             if additional is None:
                 additional = MeanTimeFn.apply(enc_output)
+        if signals is not None:     # Decoder.py:141-142: added to (or standing in for) the additional features of the embedding
+            # the embedding kernel broadcasts ONE additional row per video over its slots: per-video signals only
+            if signals.numel() != Bv * D or signals.shape[0] != Bv:
+                raise NotImplementedError('nacf_amd: `signals` must be one row per video ([B, D] or [B, 1, D]); got %s'
+                                          % (tuple(signals.shape),))
+            sig = signals.reshape(Bv, D).to(enc_output.dtype)
+            additional = sig if additional is None else additional.reshape(Bv, D) + sig
         pos2 = None
         if self.pos_attention:      # Decoder.py:144-146: the embedding gets no additional features in this mode
             additional = None

@@ -105,11 +105,12 @@ def test_train_step_vs_reference_golden(dev, name, fused, tile, monkeypatch):
         assert abs(mine[k] - v) < 1e-3 * max(1.0, abs(v)), (k, mine[k], v)
 
 
-def _run_decode(model, dec, b, dev, teacher=None, t_enc=None, graph="off"):
+def _run_decode(model, dec, b, dev, teacher=None, t_enc=None, graph="off", collect=True, **more):
     from nacf_amd.models.Translator import Translator
     dopt = dict(model.opt)
     dopt.update(dec)
-    dopt.update(collect_best_candidate_iterative_results=True, not_only_best_candidate=True, decode_graph=graph)
+    dopt.update(collect_best_candidate_iterative_results=collect, not_only_best_candidate=True, decode_graph=graph)
+    dopt.update(more)
     tr = Translator(model, dopt, device=dev, teacher_model=teacher)
     with torch.no_grad():
         enc = model.encode(feats=b["feats"])
@@ -171,6 +172,36 @@ def test_na_decode_graph_replay_equals_launch_by_launch_for_the_option_variants(
         assert torch.equal(outs["on"][0], outs["off"][0]), v
         assert torch.equal(outs["on"][1], outs["off"][1]) and torch.equal(outs["on"][2], outs["off"][2]), v
         assert int(outs["on"][0].ne(0).sum()) > 0
+
+
+@pytest.mark.parametrize("name", ["tiny_nacf_decode", "tiny_nacf_goldlen_decode"])
+def test_l2r_and_easy_first_replay_from_one_graph_with_the_reference_tokens(dev, name):
+    """decoding/algorithms.py:275-418 read a slot count on the host between passes; captured into a hipGraph (and under
+    opt['decode_fixed_passes']) they run their pass-count upper bounds instead -- the extra passes select nothing -- and
+    must return the reference's tokens (golden fixtures), a second batch through the same graph included"""
+    g = load_gold(name)
+    opt = gold_opt(g)
+    b = gold_batch(g, dev)
+    model = build(opt, O.init_state_dict(opt, seed=3), dev)
+    model.eval()
+    variants = [v for v in sorted({k.split(".")[0] for k in g.files if k.endswith(".hyp")})
+                if gold_json(g, v + ".dec_json").get("paradigm", "mp") in ("l2r", "ef")]
+    assert variants
+    for v in variants:
+        dec = gold_json(g, v + ".dec_json")
+        want = t(g[v + ".hyp"])
+        n_graphs = len([k for k in model.__dict__.get("_nacf_decode_graphs", {}) if k[0] != "seen"])
+        _, hyp_fixed, _ = _run_decode(model, dec, b, dev, graph="off", collect=False, decode_fixed_passes=True)
+        _, hyp_graph, _ = _run_decode(model, dec, b, dev, graph="on", collect=False)
+        assert len([k for k in model._nacf_decode_graphs if k[0] != "seen"]) == n_graphs + 1, v      # it WAS captured
+        assert torch.equal(hyp_fixed.cpu(), want) and torch.equal(hyp_graph.cpu(), want), v
+        perm = torch.arange(hyp_graph.shape[0] - 1, -1, -1, device=dev)
+        b2 = dict(b, feats=[f[perm] for f in b["feats"]], category=b["category"][perm])
+        if "gold_tokens" in b:
+            b2["gold_tokens"] = b["gold_tokens"][perm]
+        _, hyp2, _ = _run_decode(model, dec, b2, dev, graph="on", collect=False)
+        w = min(hyp_graph.shape[1], hyp2.shape[1])
+        assert torch.equal(hyp2[:, :w], hyp_graph[perm][:, :w]), v
 
 
 def test_na_decode_with_ar_teacher_rescoring(dev):
@@ -505,6 +536,32 @@ def test_decoder_query_subset_is_bit_identical_on_the_kept_slots(dev, layers):
     assert out[1] is None and int(keep.sum()) > 10
     assert torch.equal(sub[keep], full[keep])
     assert float(sub[~keep].abs().max()) == 0.0           # everything else is zero-filled, never garbage
+
+
+def test_decoder_signals_join_the_additional_features(dev):
+    """models/Decoder.py:141-142: `signals` are added to the embedding's additional features (or stand in for them);
+    one row per video here, as the embedding kernel broadcasts one additional row over a video's slots"""
+    import nacf_amd
+    from nacf_amd import synthetic as S
+    opt = nacf_amd.opts.make_opt("NACF", "MSRVTT", with_category=True, max_len=20, vocab_size=1000, n_frames=8)
+    model = nacf_amd.get_model(opt)
+    model.load_state_dict(S.init_state_dict(opt, seed=2))
+    model.to(dev).eval()
+    b = S.synth_batch(opt, 6, 8, seed=3)
+    feats, cat, tokens = [f.to(dev) for f in b["feats"]], b["category"].to(dev), b["tokens"].to(dev)
+    with torch.no_grad():
+        enc = model.encode(feats=feats)["enc_output"]
+        pooled = enc.mean(1)
+        sig = torch.randn(pooled.shape, generator=torch.Generator().manual_seed(5)).to(dev) * 0.3
+        take = lambda o: (o[0][-1] if isinstance(o[0], list) else o[0])
+        base = take(model.decoder(tokens, enc_output=enc, category=cat, pooled_memory=pooled + sig))
+        with_sig = take(model.decoder(tokens, enc_output=enc, category=cat, pooled_memory=pooled, signals=sig.unsqueeze(1)))
+        plain = take(model.decoder(tokens, enc_output=enc, category=cat, pooled_memory=pooled))
+        zero = take(model.decoder(tokens, enc_output=enc, category=cat, pooled_memory=pooled, signals=torch.zeros_like(sig)))
+    assert torch.equal(with_sig, base) and torch.equal(zero, plain)
+    assert float((with_sig - plain).abs().max()) > 1e-3
+    with pytest.raises(NotImplementedError):
+        model.decoder(tokens, enc_output=enc, category=cat, signals=torch.zeros(tokens.shape[0], tokens.shape[1], pooled.shape[1], device=dev))
 
 
 @pytest.mark.parametrize("B", [1, 64])
