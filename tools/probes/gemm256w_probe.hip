@@ -55,7 +55,9 @@ int main(int argc, char** argv) {
   CK(hipMemcpy(L, hl.data(), 8192 * 4, hipMemcpyHostToDevice));
   struct Case { const char* name; int R, I, J, S, use_list; };
   const Case cases[] = {{"cube 4096 dense", 4096, 4096, 4096, 1, 0}, {"cube 4096 row list", 4096, 4096, 4096, 1, 1}, {"8192 x 2048 x 2048, 8 splits", 8192, 2048, 2048, 4, 0},
-                        {"enc_lin 7680 x 512 x 2048, 16 splits", 7680, 512, 2048, 16, 0}};
+                        {"enc_lin 7680 x 512 x 2048, 16 splits", 7680, 512, 2048, 16, 0},
+                        {"vocabulary dX-like: reduce 10560, 2560 x 512, 12 splits", 10560, 2560, 512, 12, 0},
+                        {"vocabulary dX-like: reduce 10560, 2560 x 512, 24 splits", 10560, 2560, 512, 24, 0}};
   hipEvent_t e0, e1;
   CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
   for (int ns = 1; ns <= 3; ns += 2)
