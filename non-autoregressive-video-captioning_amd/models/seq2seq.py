@@ -136,9 +136,14 @@ class Seq2Seq(nn.Module):
         results = LazyResults()
         if self.opt.get('automatic_mask', False):
             raise NotImplementedError('nacf_amd: automatic_mask is not built')
-        # bf16 GEMM modes: the weight images follow the fp32 master weights at every forward entry (one launch; the
-        # forward's and the backward's GEMMs then read images of exactly the weights an fp32 kernel would read)
-        self.flat.sync_images()
+        # bf16 GEMM modes: the weight images follow the fp32 master weights at every training forward entry (one launch, part
+        # of a captured step; the forward's and the backward's GEMMs then read images of exactly the weights an fp32 kernel
+        # would read).  Inference rebuilds them only when the weights were written since (FlatParams.version: optimiser
+        # step, step replay, load_state_dict, broadcast) -- 37 us per decode batch otherwise
+        if self.training or torch.is_grad_enabled():
+            self.flat.sync_images()
+        else:
+            self.flat.ensure_images()
         enc_streams, _ = self.encoder([f.contiguous() for f in feats])
         def enc_hidden_fn(streams=[s_.detach() for s_ in enc_streams]):
             # mean-over-time hidden of every stream, then the mean over the modalities (models/Encoder.py:51,

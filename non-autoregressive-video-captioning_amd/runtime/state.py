@@ -135,7 +135,7 @@ class FlatParams:
         if not self.data.is_cuda or torch.cuda.is_current_stream_capturing():
             return
         stale = self.images is None or self.images.ns != ops.gemm_mode() or self.images_version != self.version
-        if ops.gemm_mode() != 0 and stale:
+        if stale if ops.gemm_mode() != 0 else self.images is not None:      # (fp32 mode: an existing image set is retired, as at a forward entry)
             self.sync_images()
 
     def pack(self, ws: Sequence[nn.Parameter], bs: Optional[Sequence[nn.Parameter]] = None,

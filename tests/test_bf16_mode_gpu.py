@@ -105,11 +105,15 @@ def test_bf16_mode_trains_under_the_graph_engine(dev, restore_mode):
     assert optim._optimizer.exp_avg.dtype == torch.float32
     sd = model.state_dict()
     assert all(v.dtype == torch.float32 for v in sd.values() if v.is_floating_point())
-    # the images follow the masters: a forward after the last update reads images of exactly the current weights
+    # the images follow the masters: a forward after the last update reads images of exactly the current weights (the replayed
+    # step bumped FlatParams.version, so the first inference entry rebuilds them; later ones do not touch an up-to-date cache)
     model.eval()
     with torch.no_grad():
+        assert model.flat.images_version != model.flat.version
         e1 = model.encode(feats=batch["feats"])["enc_output"].clone()
-        model.flat.images.img.zero_()                        # corrupt the cache ...
+        assert model.flat.images_version == model.flat.version
+        model.flat.images.img.zero_()                        # corrupt the cache and declare the weights written ...
+        model.flat.touch()
         e2 = model.encode(feats=batch["feats"])["enc_output"]   # ... the forward entry rebuilds it
     assert torch.equal(e1, e2)
 
