@@ -64,7 +64,7 @@ int nacf_version(void);
  * included).  nacf_abi_count() returns the value the LIBRARY was built with; the ctypes loader
  * (runtime/lib.py:load) refuses a library whose count differs from its own signature table, so a stale
  * libnacf_hip.so next to a newer Python package fails at import time, not at the first missing symbol. */
-#define NACF_ABI_COUNT 87
+#define NACF_ABI_COUNT 89
 int nacf_abi_count(void);
 
 /* ---- batch construction (reference: dataloader.py) ----------------------------------------
@@ -475,6 +475,22 @@ int nacf_attention_bwd(const float* Q, int64_t ldq, const float* K, int64_t ldk,
                        const int64_t* key_tokens, int causal,
                        int R, int n_kv, int H, int Lq, int Lk, int dk, int kv_div, int kv_mod,
                        nacf_stream_t stream);
+
+/* The same with attention_probs_dropout_prob (models/bert.py:135,169: P = dropout(softmax(S)) before P V; the returned
+ * `probs` are the dropped ones, as upstream).  Mask of element ((r * H + h) * Lq + q) * Lk + k from the device Philox stream
+ * {seed, step} = rng_state[0..1] and `salt`, keep-scale 1 / (1 - p); p_drop = 0 is nacf_attention_fwd / _bwd.  p_drop > 0
+ * runs the LDS-tile kernels (Lq, Lk, dk must fit 160 KB of LDS). */
+int nacf_attention_fwd_dropout(const float* Q, int64_t ldq, const float* K, int64_t ldk,
+                               const float* V, int64_t ldv, float* O, int64_t ldo,
+                               const int64_t* key_tokens, int causal, float* probs,
+                               int R, int H, int Lq, int Lk, int dk, int kv_div, int kv_mod,
+                               float p_drop, uint32_t salt, const uint64_t* rng_state, nacf_stream_t stream);
+int nacf_attention_bwd_dropout(const float* Q, int64_t ldq, const float* K, int64_t ldk,
+                               const float* V, int64_t ldv, const float* dO, int64_t lddo,
+                               float* dQ, int64_t lddq, float* dK, int64_t lddk, float* dV, int64_t lddv,
+                               const int64_t* key_tokens, int causal,
+                               int R, int n_kv, int H, int Lq, int Lk, int dk, int kv_div, int kv_mod,
+                               float p_drop, uint32_t salt, const uint64_t* rng_state, nacf_stream_t stream);
 
 /* masked row mean of the last layer (the `embs` output, models/bert.py:301):
  * out[r,:] = sum_l y[r,l,:] / count(tokens[r,:] != PAD) */

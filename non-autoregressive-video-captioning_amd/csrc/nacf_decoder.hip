@@ -619,9 +619,14 @@ __global__ __launch_bounds__(256) void attention_fwd_kernel(const float* __restr
                                                              float* __restrict__ O, int64_t ldo,
                                                              const int64_t* __restrict__ key_tokens, int causal,
                                                              float* __restrict__ probs, int R, int Lq, int Lk, int dk,
-                                                             int kv_div, int kv_mod) {
+                                                             int kv_div, int kv_mod, float p_drop, uint32_t salt,
+                                                             const uint64_t* __restrict__ rng_state) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
   const int r = blockIdx.x, h = blockIdx.y;
+  // attention_probs_dropout_prob (models/bert.py:135,169): element ((r * H + h) * Lq + q) * Lk + k of the device Philox stream
+  DropRng rng;
+  if (p_drop > 0.f) rng.init(rng_state);
+  const uint64_t e0 = ((uint64_t)r * gridDim.y + h) * (uint64_t)Lq * (uint64_t)Lk;
   const int kvr = (r / kv_div) % kv_mod;
   const int ldd = dk + 1;
   float* qs = sm;                // [Lq][dk+1]
@@ -660,7 +665,8 @@ __global__ __launch_bounds__(256) void attention_fwd_kernel(const float* __restr
     for (int k = lane; k < Lk; k += 64) { const float e = expf(row[k] - m); row[k] = e; s += e; }
     s = wave_sum(s);
     for (int k = lane; k < Lk; k += 64) {
-      const float p = row[k] / s;
+      float p = row[k] / s;
+      if (p_drop > 0.f) p *= rng.keep1(e0 + (uint64_t)q * Lk + k, salt, p_drop);      // (the returned probabilities are the dropped ones)
       row[k] = p;
       if (probs) probs[(((int64_t)h * R + r) * Lq + q) * Lk + k] = p;
     }
@@ -687,9 +693,12 @@ __global__ __launch_bounds__(256) void attention_bwd_kernel(
     const float* __restrict__ Q, int64_t ldq, const float* __restrict__ K, int64_t ldk, const float* __restrict__ V,
     int64_t ldv, const float* __restrict__ dO, int64_t lddo, float* __restrict__ dQ, int64_t lddq,
     float* __restrict__ dK, int64_t lddk, float* __restrict__ dV, int64_t lddv,
-    const int64_t* __restrict__ key_tokens, int causal, int R, int Lq, int Lk, int dk, int kv_div, int kv_mod) {
+    const int64_t* __restrict__ key_tokens, int causal, int R, int Lq, int Lk, int dk, int kv_div, int kv_mod, float p_drop,
+    uint32_t salt, const uint64_t* __restrict__ rng_state) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
   const int kvr = blockIdx.x, h = blockIdx.y;
+  DropRng rng;
+  if (p_drop > 0.f) rng.init(rng_state);
   const int ldd = dk + 1;
   float* qs = sm;                 // [Lq][dk+1]
   float* dos = qs + Lq * ldd;     // [Lq][dk+1]
@@ -742,6 +751,24 @@ __global__ __launch_bounds__(256) void attention_bwd_kernel(
       for (int k = lane; k < Lk; k += 64) { const float e = expf(row[k] - m); row[k] = e; s += e; }
       s = wave_sum(s);
       float dotp = 0.f;
+      if (p_drop > 0.f) {
+        // O = (P o M) V with M = keep / (1 - p): dP = (dO V^T) o M, the soft-max backward runs on the undropped P, dV on P o M
+        const uint64_t e0 = (((uint64_t)r * gridDim.y + h) * (uint64_t)Lq + q) * (uint64_t)Lk;
+        for (int k = lane; k < Lk; k += 64) {
+          const float p = row[k] / s, mk = rng.keep1(e0 + k, salt, p_drop);
+          const float dpk = drow[k] * mk;
+          dotp += p * dpk;
+          row[k] = p;
+          drow[k] = dpk;
+        }
+        dotp = wave_sum(dotp);
+        for (int k = lane; k < Lk; k += 64) {
+          const float p = row[k];
+          drow[k] = p * (drow[k] - dotp) / sq;
+          row[k] = p * rng.keep1(e0 + k, salt, p_drop);
+        }
+        continue;
+      }
       for (int k = lane; k < Lk; k += 64) { const float p = row[k] / s; row[k] = p; dotp += p * drow[k]; }
       dotp = wave_sum(dotp);
       for (int k = lane; k < Lk; k += 64) drow[k] = row[k] * (drow[k] - dotp) / sq;  // grad wrt Q.K^T
@@ -936,15 +963,19 @@ int nacf_masked_mean_fwd(const float* y, const int64_t* tokens, float* out, int 
   return NACF_OK;
 }
 
-int nacf_attention_fwd(const float* Q, int64_t ldq, const float* K, int64_t ldk, const float* V, int64_t ldv, float* O,
-                       int64_t ldo, const int64_t* key_tokens, int causal, float* probs, int R, int H, int Lq, int Lk,
-                       int dk, int kv_div, int kv_mod, nacf_stream_t stream) {
+int nacf_attention_fwd_dropout(const float* Q, int64_t ldq, const float* K, int64_t ldk, const float* V, int64_t ldv, float* O,
+                               int64_t ldo, const int64_t* key_tokens, int causal, float* probs, int R, int H, int Lq, int Lk,
+                               int dk, int kv_div, int kv_mod, float p_drop, uint32_t salt, const uint64_t* rng_state,
+                               nacf_stream_t stream) {
   NACF_CHECK(Q && K && V && O, NACF_EINVAL, "nacf_attention_fwd: null pointer");
+  NACF_CHECK(p_drop >= 0.f && p_drop < 1.f && !(p_drop > 0.f && !rng_state), NACF_EINVAL,
+             "nacf_attention_fwd: dropout needs 0 <= p < 1 and an rng state");
   NACF_CHECK(R > 0 && H > 0 && Lq > 0 && Lk > 0 && dk > 0 && kv_div > 0 && kv_mod > 0, NACF_EINVAL,
              "nacf_attention_fwd: bad shape");
   NACF_CHECK(!(causal && Lq != Lk), NACF_EINVAL, "nacf_attention_fwd: causal mask needs Lq == Lk");
   // more than 32 queries per sequence run as blocks of 32 (one wave each) when no causal mask ties a query to its index
-  if (attn_mfma_ok(causal ? Lq : min(Lq, 32), Lk, dk) && attn_aligned(Q, ldq) && attn_aligned(K, ldk) &&
+  // (probability dropout runs on the LDS-tile kernel below: the probabilities sit in LDS there, one mask multiply away)
+  if (p_drop == 0.f && attn_mfma_ok(causal ? Lq : min(Lq, 32), Lk, dk) && attn_aligned(Q, ldq) && attn_aligned(K, ldk) &&
       attn_aligned(V, ldv) && attn_aligned(O, ldo)) {
     {
       // cross-attention over a long memory: one workgroup per (memory row set, head) stages K / V in LDS once and its
@@ -991,23 +1022,33 @@ int nacf_attention_fwd(const float* Q, int64_t ldq, const float* K, int64_t ldk,
     attr_set = true;
   }
   hipLaunchKernelGGL(attention_fwd_kernel, dim3(R, H), dim3(256), lds, as_hip(stream), Q, ldq, K, ldk, V, ldv, O, ldo,
-                     key_tokens, causal, probs, R, Lq, Lk, dk, kv_div, kv_mod);
+                     key_tokens, causal, probs, R, Lq, Lk, dk, kv_div, kv_mod, p_drop, salt, rng_state);
   NACF_LAUNCH_CHECK("nacf_attention_fwd");
   return NACF_OK;
 }
 
-int nacf_attention_bwd(const float* Q, int64_t ldq, const float* K, int64_t ldk, const float* V, int64_t ldv,
-                       const float* dO, int64_t lddo, float* dQ, int64_t lddq, float* dK, int64_t lddk, float* dV,
-                       int64_t lddv, const int64_t* key_tokens, int causal, int R, int n_kv, int H, int Lq, int Lk,
+int nacf_attention_fwd(const float* Q, int64_t ldq, const float* K, int64_t ldk, const float* V, int64_t ldv, float* O,
+                       int64_t ldo, const int64_t* key_tokens, int causal, float* probs, int R, int H, int Lq, int Lk,
                        int dk, int kv_div, int kv_mod, nacf_stream_t stream) {
+  return nacf_attention_fwd_dropout(Q, ldq, K, ldk, V, ldv, O, ldo, key_tokens, causal, probs, R, H, Lq, Lk, dk, kv_div, kv_mod,
+                                    0.f, 0u, nullptr, stream);
+}
+
+int nacf_attention_bwd_dropout(const float* Q, int64_t ldq, const float* K, int64_t ldk, const float* V, int64_t ldv,
+                               const float* dO, int64_t lddo, float* dQ, int64_t lddq, float* dK, int64_t lddk, float* dV,
+                               int64_t lddv, const int64_t* key_tokens, int causal, int R, int n_kv, int H, int Lq, int Lk,
+                               int dk, int kv_div, int kv_mod, float p_drop, uint32_t salt, const uint64_t* rng_state,
+                               nacf_stream_t stream) {
   NACF_CHECK(Q && K && V && dO && dQ && dK && dV, NACF_EINVAL, "nacf_attention_bwd: null pointer");
+  NACF_CHECK(p_drop >= 0.f && p_drop < 1.f && !(p_drop > 0.f && !rng_state), NACF_EINVAL,
+             "nacf_attention_bwd: dropout needs 0 <= p < 1 and an rng state");
   NACF_CHECK(R > 0 && n_kv > 0 && H > 0 && Lq > 0 && Lk > 0 && dk > 0 && kv_div > 0 && kv_mod > 0, NACF_EINVAL,
              "nacf_attention_bwd: bad shape");
   NACF_CHECK(n_kv == kv_mod || (kv_div == 1 && kv_mod >= R && n_kv == R), NACF_EINVAL,
              "nacf_attention_bwd: n_kv must equal kv_mod (or R for the identity map)");
   NACF_CHECK(Lk * dk <= ATT_BWD_MAXJ * 256, NACF_EUNSUPPORTED, "nacf_attention_bwd: Lk*dk > %d", ATT_BWD_MAXJ * 256);
   NACF_CHECK(!(causal && Lq != Lk), NACF_EINVAL, "nacf_attention_bwd: causal mask needs Lq == Lk");
-  if (attn_mfma_ok(Lq, Lk, dk) && attn_aligned(Q, ldq) && attn_aligned(K, ldk) && attn_aligned(V, ldv) &&
+  if (p_drop == 0.f && attn_mfma_ok(Lq, Lk, dk) && attn_aligned(Q, ldq) && attn_aligned(K, ldk) && attn_aligned(V, ldv) &&
       attn_aligned(dO, lddo) && attn_aligned(dQ, lddq) && attn_aligned(dK, lddk) && attn_aligned(dV, lddv)) {
     // sequences per memory row set (upper bound) -> waves per item (1, 2 or 4) and rounds of the item loop
     const int groups = cdiv(R, kv_div);
@@ -1066,9 +1107,17 @@ int nacf_attention_bwd(const float* Q, int64_t ldq, const float* K, int64_t ldk,
     attr_set = true;
   }
   hipLaunchKernelGGL(attention_bwd_kernel, dim3(n_kv, H), dim3(256), lds, as_hip(stream), Q, ldq, K, ldk, V, ldv, dO, lddo,
-                     dQ, lddq, dK, lddk, dV, lddv, key_tokens, causal, R, Lq, Lk, dk, kv_div, kv_mod);
+                     dQ, lddq, dK, lddk, dV, lddv, key_tokens, causal, R, Lq, Lk, dk, kv_div, kv_mod, p_drop, salt, rng_state);
   NACF_LAUNCH_CHECK("nacf_attention_bwd");
   return NACF_OK;
+}
+
+int nacf_attention_bwd(const float* Q, int64_t ldq, const float* K, int64_t ldk, const float* V, int64_t ldv,
+                       const float* dO, int64_t lddo, float* dQ, int64_t lddq, float* dK, int64_t lddk, float* dV,
+                       int64_t lddv, const int64_t* key_tokens, int causal, int R, int n_kv, int H, int Lq, int Lk,
+                       int dk, int kv_div, int kv_mod, nacf_stream_t stream) {
+  return nacf_attention_bwd_dropout(Q, ldq, K, ldk, V, ldv, dO, lddo, dQ, lddq, dK, lddk, dV, lddv, key_tokens, causal, R, n_kv, H,
+                                    Lq, Lk, dk, kv_div, kv_mod, 0.f, 0u, nullptr, stream);
 }
 
 }  // extern "C"

@@ -131,8 +131,6 @@ class BertLayer(nn.Module):
         super().__init__()
         # parallel_mlm (bert.py:253-254): the self-attention block's BertSelfOutput gets no residual input
         self.self_residual = not getattr(config, 'parallel_mlm', False)
-        if config.attention_probs_dropout_prob != 0.0:
-            raise NotImplementedError('nacf_amd: attention_probs_dropout_prob must be 0 (reference default, opts.py:29)')
         if config.hidden_act not in L.ACT_BY_NAME:
             raise NotImplementedError('nacf_amd: hidden_act %s is not built' % config.hidden_act)
         self.attention = BertAttention(config)
@@ -145,6 +143,8 @@ class BertLayer(nn.Module):
         self.eps = config.layer_norm_eps
         self.H = config.num_attention_heads
         self.p = config.hidden_dropout_prob
+        # attention_probs_dropout_prob (bert.py:135,169; reference default 0): > 0 runs the LDS-tile attention kernels in training
+        self.p_att = float(config.attention_probs_dropout_prob)
         self.act = L.ACT_BY_NAME[config.hidden_act]
 
     def nacf_groups(self):
@@ -182,6 +182,8 @@ class BertLayer(nn.Module):
             for key, m in (('ln_so', a.output), ('ln_co', c.output), ('ln_f2', self.output)):
                 self._pk[key] = flat.pack([m.LayerNorm.weight], [m.LayerNorm.bias])
         self._salts = [rt.next_salt() for _ in range(4)]
+        # (drawn only when used: the salts of every other dropout site stay what they are with p_att = 0)
+        self._salts_att = [rt.next_salt() for _ in range(3)] if self.p_att > 0.0 else None
         pa = self.pos_attention
         if pa is not None:
             self._pk['pqk'] = flat.pack([pa.self.query.weight, pa.self.key.weight], [pa.self.query.bias, pa.self.key.bias],
@@ -192,6 +194,12 @@ class BertLayer(nn.Module):
                 self._pk['ln_po'] = flat.pack([pa.output.LayerNorm.weight], [pa.output.LayerNorm.bias])
             self._salt_pos = rt.next_salt()
         self._params = [p for p in self.parameters()]
+
+    def _att_drop(self, which, training, rng):
+        """(p, salt, rng) of the probability dropout of attention block `which` (0 self, 1 cross, 2 position), or None"""
+        if not (training and self.p_att > 0.0):
+            return None
+        return (self.p_att, self._salts_att[which], rng)
 
     def project_memory(self, enc_output):
         """K|V projection of the visual memory: [Bv, M, D] -> [Bv*M, 2D]"""
@@ -225,11 +233,11 @@ class BertLayer(nn.Module):
         # filled (fill=False), and FFN2's dX feeds FFN1's row-list epilogue backward (dx_fill=False)
         nf = dict(fill=False) if rows is not None else {}
         qkv = LinearFn.apply(x2, None, dict(pack=pk['qkv'], rows=rows, dx_acc=h1), *P)
-        att, p_self = SelfAttentionFn.apply(qkv, tokens, int(causal), self.H, want_probs)
+        att, p_self = SelfAttentionFn.apply(qkv, tokens, int(causal), self.H, want_probs, self._att_drop(0, training, rng))
         a = LinearFn.apply(att, x2 if self.self_residual else None, dict(pack=pk['so'], p1=self.p, salt1=s[0], row_tokens=tok_flat, rng=rng,
                                          training=training, rows=rows, res_sink=h1, **nf), *P)
         q = LinearFn.apply(a, None, dict(pack=pk['cq'], rows=rows, dx_acc=h2), *P)
-        catt, p_cross = CrossAttentionFn.apply(q, memory_kv, self.H, Lq, M, vdiv, vmod, want_probs)
+        catt, p_cross = CrossAttentionFn.apply(q, memory_kv, self.H, Lq, M, vdiv, vmod, want_probs, self._att_drop(1, training, rng))
         c = LinearFn.apply(catt, a, dict(pack=pk['co'], p1=self.p, salt1=s[1], row_tokens=tok_flat, rng=rng,
                                          training=training, rows=rows, res_sink=h2, **nf), *P)
         u = LinearFn.apply(c, None, dict(pack=pk['f1'], act=self.act, rows=rows, dx_acc=h3, **nf), *P)
@@ -315,19 +323,19 @@ class BertLayer(nn.Module):
         ln = lambda key, p=0.0, salt=0: dict(ln=pk[key], eps=self.eps, p=p, salt=salt, rng=rng, training=training,
                                              row_tokens=tok_flat)
         qkv = LinearFn.apply(x2, None, dict(pack=pk['qkv'], rows=rows), *P)
-        att, p_self = SelfAttentionFn.apply(qkv, tokens, int(causal), self.H, want_probs)
+        att, p_self = SelfAttentionFn.apply(qkv, tokens, int(causal), self.H, want_probs, self._att_drop(0, training, rng))
         a = LinearFn.apply(att, x2 if self.self_residual else None, dict(pack=pk['so'], p1=self.p, salt1=s[0], rng=rng, training=training, rows=rows), *P)
         a = LayerNormFn.apply(a, ln('ln_so'), *P)
         if self.pos_attention is not None:      # pos_attention with LayerNorm: the block of _run_pos, LN before the <pad> mask
             assert pos2 is not None, 'pos_attention layers need the position embeddings'
             pqk = LinearFn.apply(pos2, None, dict(pack=pk['pqk'], rows=rows), *P)
             pv = LinearFn.apply(a, None, dict(pack=pk['pv'], rows=rows), *P)
-            patt = QKVAttentionFn.apply(pqk, pv, tokens, int(causal), self.H)
+            patt = QKVAttentionFn.apply(pqk, pv, tokens, int(causal), self.H, self._att_drop(2, training, rng))
             a = LinearFn.apply(patt, pos2, dict(pack=pk['po'], p1=self.p, salt1=self._salt_pos, rng=rng, training=training,
                                                 rows=rows), *P)
             a = LayerNormFn.apply(a, ln('ln_po'), *P)
         q = LinearFn.apply(a, None, dict(pack=pk['cq'], rows=rows), *P)
-        catt, p_cross = CrossAttentionFn.apply(q, memory_kv, self.H, Lq, M, vdiv, vmod, want_probs)
+        catt, p_cross = CrossAttentionFn.apply(q, memory_kv, self.H, Lq, M, vdiv, vmod, want_probs, self._att_drop(1, training, rng))
         c = LinearFn.apply(catt, a, dict(pack=pk['co'], p1=self.p, salt1=s[1], rng=rng, training=training, rows=rows), *P)
         c = LayerNormFn.apply(c, ln('ln_co'), *P)
         u = LinearFn.apply(c, None, dict(pack=pk['f1'], act=self.act, rows=rows), *P)
@@ -347,14 +355,14 @@ class BertLayer(nn.Module):
         P, pk, s = self._params, self._pk, self._salts
         common = dict(row_tokens=tok_flat, rng=rng, training=training, rows=rows)
         qkv = LinearFn.apply(x2, None, dict(pack=pk['qkv'], rows=rows), *P)
-        att, p_self = SelfAttentionFn.apply(qkv, tokens, int(causal), self.H, want_probs)
+        att, p_self = SelfAttentionFn.apply(qkv, tokens, int(causal), self.H, want_probs, self._att_drop(0, training, rng))
         a = LinearFn.apply(att, x2 if self.self_residual else None, dict(pack=pk['so'], p1=self.p, salt1=s[0], **common), *P)
         pqk = LinearFn.apply(pos2, None, dict(pack=pk['pqk'], rows=rows), *P)
         pv = LinearFn.apply(a, None, dict(pack=pk['pv'], rows=rows), *P)
-        patt = QKVAttentionFn.apply(pqk, pv, tokens, int(causal), self.H)
+        patt = QKVAttentionFn.apply(pqk, pv, tokens, int(causal), self.H, self._att_drop(2, training, rng))
         a = LinearFn.apply(patt, pos2, dict(pack=pk['po'], p1=self.p, salt1=self._salt_pos, **common), *P)
         q = LinearFn.apply(a, None, dict(pack=pk['cq'], rows=rows), *P)
-        catt, p_cross = CrossAttentionFn.apply(q, memory_kv, self.H, Lq, M, vdiv, vmod, want_probs)
+        catt, p_cross = CrossAttentionFn.apply(q, memory_kv, self.H, Lq, M, vdiv, vmod, want_probs, self._att_drop(1, training, rng))
         c = LinearFn.apply(catt, a, dict(pack=pk['co'], p1=self.p, salt1=s[1], **common), *P)
         u = LinearFn.apply(c, None, dict(pack=pk['f1'], act=self.act, rows=rows), *P)
         y = LinearFn.apply(u, c, dict(pack=pk['f2'], p1=self.p, salt1=s[2], p2=self.p, salt2=s[3], **common), *P)

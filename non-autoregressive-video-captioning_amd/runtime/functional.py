@@ -568,15 +568,15 @@ class SelfAttentionFn(Function):
     (models/bert.py:150-179; masks models/Decoder.py:13-39,105-124)."""
 
     @staticmethod
-    def forward(ctx, qkv, tokens, causal, H, want_probs):
+    def forward(ctx, qkv, tokens, causal, H, want_probs, drop=None):
         R, Lq = tokens.shape
         D = qkv.shape[1] // 3
         dk = D // H
         q, k, v = qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:]
         out = _new((R * Lq, D), qkv)
         probs = _new((H, R, Lq, Lq), qkv) if want_probs else None
-        ops.attention_fwd(q, k, v, out, tokens, causal, probs, R, H, Lq, Lq, dk, 1, R)
-        ctx.qkv, ctx.tokens, ctx.causal, ctx.H = qkv, tokens, causal, H
+        ops.attention_fwd(q, k, v, out, tokens, causal, probs, R, H, Lq, Lq, dk, 1, R, drop=drop)
+        ctx.qkv, ctx.tokens, ctx.causal, ctx.H, ctx.drop = qkv, tokens, causal, H, drop
         if want_probs:
             ctx.mark_non_differentiable(probs)
             return out, probs
@@ -591,9 +591,9 @@ class SelfAttentionFn(Function):
         do = _c2d(do, R * Lq, D)
         dqkv = torch.empty_like(qkv)
         ops.attention_bwd(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], do, dqkv[:, :D], dqkv[:, D:2 * D],
-                          dqkv[:, 2 * D:], tokens, ctx.causal, R, R, ctx.H, Lq, Lq, dk, 1, R)
+                          dqkv[:, 2 * D:], tokens, ctx.causal, R, R, ctx.H, Lq, Lq, dk, 1, R, drop=ctx.drop)
         ctx.qkv = None
-        return dqkv, None, None, None, None
+        return dqkv, None, None, None, None, None
 
 
 class QKVAttentionFn(Function):
@@ -602,13 +602,13 @@ class QKVAttentionFn(Function):
     the hidden states)."""
 
     @staticmethod
-    def forward(ctx, qk, v, tokens, causal, H):
+    def forward(ctx, qk, v, tokens, causal, H, drop=None):
         R, Lq = tokens.shape
         D = v.shape[1]
         dk = D // H
         out = _new((R * Lq, D), v)
-        ops.attention_fwd(qk[:, :D], qk[:, D:], v, out, tokens, causal, None, R, H, Lq, Lq, dk, 1, R)
-        ctx.qk, ctx.v, ctx.tokens, ctx.causal, ctx.H = qk, v, tokens, causal, H
+        ops.attention_fwd(qk[:, :D], qk[:, D:], v, out, tokens, causal, None, R, H, Lq, Lq, dk, 1, R, drop=drop)
+        ctx.qk, ctx.v, ctx.tokens, ctx.causal, ctx.H, ctx.drop = qk, v, tokens, causal, H, drop
         return out
 
     @staticmethod
@@ -620,9 +620,9 @@ class QKVAttentionFn(Function):
         do = _c2d(do, R * Lq, D)
         dqk, dv = torch.empty_like(qk), torch.empty_like(v)
         ops.attention_bwd(qk[:, :D], qk[:, D:], v, do, dqk[:, :D], dqk[:, D:], dv, tokens, ctx.causal, R, R, ctx.H, Lq, Lq,
-                          dk, 1, R)
+                          dk, 1, R, drop=ctx.drop)
         ctx.qk = ctx.v = None
-        return dqk, dv, None, None, None
+        return dqk, dv, None, None, None, None
 
 
 class CrossAttentionFn(Function):
@@ -630,21 +630,21 @@ class CrossAttentionFn(Function):
     memory, computed once per video and shared by every row mapped to it."""
 
     @staticmethod
-    def forward(ctx, q, kv, H, Lq, Lk, kv_div, kv_mod, want_probs):
+    def forward(ctx, q, kv, H, Lq, Lk, kv_div, kv_mod, want_probs, drop=None):
         D = q.shape[1]
         dk = D // H
         R = q.shape[0] // Lq
         k, v = kv[:, :D], kv[:, D:]
         out = _new((R * Lq, D), q)
         probs = _new((H, R, Lq, Lk), q) if want_probs else None
-        if kv_div > 1 and R == kv_div * kv_mod and not want_probs and not any(ctx.needs_input_grad):
+        if kv_div > 1 and R == kv_div * kv_mod and not want_probs and not any(ctx.needs_input_grad) and drop is None:
             # inference with the length beam: the kv_div candidates of a video are consecutive rows and nothing masks a
             # query, so they are ONE sequence of kv_div*Lq queries over that video's memory -- 114 rows in blocks of
             # 32 instead of 6 x (19 padded to 32), and the blocks share the K / V rows they stream
             ops.attention_fwd(q, k, v, out, None, 0, None, kv_mod, H, Lq * kv_div, Lk, dk, 1, kv_mod)
         else:
-            ops.attention_fwd(q, k, v, out, None, 0, probs, R, H, Lq, Lk, dk, kv_div, kv_mod)
-        ctx.q, ctx.kv = q, kv
+            ops.attention_fwd(q, k, v, out, None, 0, probs, R, H, Lq, Lk, dk, kv_div, kv_mod, drop=drop)
+        ctx.q, ctx.kv, ctx.drop = q, kv, drop
         ctx.dims = (R, H, Lq, Lk, dk, kv_div, kv_mod)
         if want_probs:
             ctx.mark_non_differentiable(probs)
@@ -661,9 +661,9 @@ class CrossAttentionFn(Function):
         dq = torch.empty_like(q)
         dkv = torch.empty_like(kv)
         ops.attention_bwd(q, kv[:, :D], kv[:, D:], do, dq, dkv[:, :D], dkv[:, D:], None, 0, R, n_kv, H, Lq, Lk, dk,
-                          kv_div, kv_mod)
+                          kv_div, kv_mod, drop=ctx.drop)
         ctx.q = ctx.kv = None
-        return dq, dkv, None, None, None, None, None, None
+        return dq, dkv, None, None, None, None, None, None, None
 
 
 # ---------------------------------------------------------------- vocabulary

@@ -114,6 +114,9 @@ SIGNATURES = {
     "nacf_attention_fwd": (c_int, [_P, _L, _P, _L, _P, _L, _P, _L, _P, _I, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
     "nacf_attention_bwd": (c_int, [_P, _L, _P, _L, _P, _L, _P, _L, _P, _L, _P, _L, _P, _L, _P, _I,
                                    _I, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "nacf_attention_fwd_dropout": (c_int, [_P, _L, _P, _L, _P, _L, _P, _L, _P, _I, _P, _I, _I, _I, _I, _I, _I, _I, _F, _U, _P, _P]),
+    "nacf_attention_bwd_dropout": (c_int, [_P, _L, _P, _L, _P, _L, _P, _L, _P, _L, _P, _L, _P, _L, _P, _I,
+                                           _I, _I, _I, _I, _I, _I, _I, _I, _F, _U, _P, _P]),
     "nacf_masked_mean_fwd": (c_int, [_P, _P, _P, _I, _I, _I, _P]),
     "nacf_vocab_logsoftmax_fwd": (c_int, [_P, _L, _I, _I, _P, _P, _P, _P, _I, _P]),
     "nacf_nll_reduce": (c_int, [_P, _P, _P, _I, _I, _P, _P]),

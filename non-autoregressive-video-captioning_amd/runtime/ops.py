@@ -873,17 +873,31 @@ def layernorm_bwd(dout, xhat, rstd, ln_w, dx, dln_w, dln_b, seg_in, seg_out, seg
                                    _stream()), "nacf_layernorm_bwd")
 
 
-def attention_fwd(q, k, v, out, key_tokens, causal, probs, R, H, Lq, Lk, dk, kv_div, kv_mod):
-    """q/k/v/out are 2-D column slices (rows = seq*len, cols = H*dk) of packed buffers."""
+def attention_fwd(q, k, v, out, key_tokens, causal, probs, R, H, Lq, Lk, dk, kv_div, kv_mod, drop=None):
+    """q/k/v/out are 2-D column slices (rows = seq*len, cols = H*dk) of packed buffers.
+    drop = (p, salt, RngState): attention_probs_dropout_prob (models/bert.py:135,169)."""
     _chk_f32(q, k, v, out, probs)
+    if drop is not None and drop[0] > 0.0:
+        L.check(L.load().nacf_attention_fwd_dropout(_ptr(q), q.stride(0), _ptr(k), k.stride(0), _ptr(v), v.stride(0),
+                                                    _ptr(out), out.stride(0), _ptr(key_tokens), int(causal), _ptr(probs),
+                                                    R, H, Lq, Lk, dk, kv_div, kv_mod, float(drop[0]), int(drop[1]),
+                                                    _ptr(drop[2].state), _stream()), "nacf_attention_fwd_dropout")
+        return out
     L.check(L.load().nacf_attention_fwd(_ptr(q), q.stride(0), _ptr(k), k.stride(0), _ptr(v), v.stride(0),
                                         _ptr(out), out.stride(0), _ptr(key_tokens), int(causal), _ptr(probs),
                                         R, H, Lq, Lk, dk, kv_div, kv_mod, _stream()), "nacf_attention_fwd")
     return out
 
 
-def attention_bwd(q, k, v, do, dq, dk_, dv, key_tokens, causal, R, n_kv, H, Lq, Lk, dk, kv_div, kv_mod):
+def attention_bwd(q, k, v, do, dq, dk_, dv, key_tokens, causal, R, n_kv, H, Lq, Lk, dk, kv_div, kv_mod, drop=None):
     _chk_f32(q, k, v, do, dq, dk_, dv)
+    if drop is not None and drop[0] > 0.0:
+        L.check(L.load().nacf_attention_bwd_dropout(_ptr(q), q.stride(0), _ptr(k), k.stride(0), _ptr(v), v.stride(0),
+                                                    _ptr(do), do.stride(0), _ptr(dq), dq.stride(0), _ptr(dk_), dk_.stride(0),
+                                                    _ptr(dv), dv.stride(0), _ptr(key_tokens), int(causal), R, n_kv, H, Lq, Lk,
+                                                    dk, kv_div, kv_mod, float(drop[0]), int(drop[1]), _ptr(drop[2].state),
+                                                    _stream()), "nacf_attention_bwd_dropout")
+        return
     L.check(L.load().nacf_attention_bwd(_ptr(q), q.stride(0), _ptr(k), k.stride(0), _ptr(v), v.stride(0),
                                         _ptr(do), do.stride(0), _ptr(dq), dq.stride(0), _ptr(dk_), dk_.stride(0),
                                         _ptr(dv), dv.stride(0), _ptr(key_tokens), int(causal), R, n_kv, H, Lq, Lk,
