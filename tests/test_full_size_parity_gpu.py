@@ -119,6 +119,13 @@ def test_full_size_na_decode_vs_oracle(dev, B, graph):
     assert float(safe_rows.float().mean()) >= 0.99, (float(safe_rows.float().mean()), rec.n_logit, rec.n_conf, int((~beam_safe).sum()))
     assert torch.equal(it_tok.cpu()[safe_rows], o_tok[safe_rows])
     assert maxerr(it_prob.cpu()[safe_rows], o_prob[safe_rows]) < 1e-4
+    # the rows the oracle marks as numerically tied are not bit-exact by construction, but a tie flips one slot of one pass:
+    # they must still agree with the oracle almost everywhere (a kernel that scrambled exactly the tied rows would pass the
+    # assertions above) -- floor on the share of equal token ids over those rows, all passes
+    unsafe_agree = 1.0
+    if int((~safe_rows).sum()) > 0:
+        unsafe_agree = float((it_tok.cpu()[~safe_rows] == o_tok[~safe_rows]).float().mean())
+        assert unsafe_agree >= 0.90, (unsafe_agree, int((~safe_rows).sum()))
     # final choice among the candidates: score = sum log p / len^alpha (na_generate.py:66-77)
     score = o_lp.sum(-1) / (o_beam.float() ** dec["beam_alpha"])
     top2 = score.topk(2, dim=1).values
@@ -129,9 +136,9 @@ def test_full_size_na_decode_vs_oracle(dev, B, graph):
     assert float(safe_vid.float().mean()) >= (0.96 if B >= 128 else 0.93), float(safe_vid.float().mean())
     assert hyp.shape == o_hyp.shape
     assert torch.equal(hyp.cpu()[safe_vid], o_hyp[safe_vid])
-    print("full-size NA decode B=%d graph=%s: %d/%d candidate sequences (%.4f) and %d/%d videos (%.4f) free of numerical ties, all bit-exact"
+    print("full-size NA decode B=%d graph=%s: %d/%d candidate sequences (%.4f) and %d/%d videos (%.4f) free of numerical ties, all bit-exact; token agreement on the %d tied rows %.4f"
           % (B, graph, int(safe_rows.sum()), safe_rows.numel(), float(safe_rows.float().mean()), int(safe_vid.sum()), B,
-             float(safe_vid.float().mean())))
+             float(safe_vid.float().mean()), int((~safe_rows).sum()), unsafe_agree))
 
 
 def test_full_size_ar_beam_vs_oracle(dev):
