@@ -1,0 +1,397 @@
+// The DMA-fed member of the bf16 matrix-core GEMM family for the EXACT mode (three bf16 terms per fp32 operand, six matrix
+// instructions per product block): nn.Linear forward and dX of models/bert.py:139-247, models/Encoder.py:9-66,
+// models/__init__.py:83 and the NA pass decoding/algorithms.py:143-167 -- the launches that round 2's register-staged
+// gemm_bf16_kernel<128 | 64> carried until round 5.
+//
+//   C[m][n] = sum_k Qop[m][k] * Pop[n][k]      Qop: fp32, k-contiguous (activations / dZ), live-row list;  Pop: pre-split image
+//
+// What the round-3 wide kernel (gemm_bf16_wide.hpp) showed to work, rebuilt for TWO workgroups per CU:
+//   * both operands go global -> LDS by DMA (buffer_load_dwordx4 ... lds): no register staging, no LDS stores.  gemm_bf16_kernel
+//     stores three bf16 planes of every activation tile (48 KB per 128 x 128 k-tile) and reads them back as fragments (96 KB) under
+//     two barriers per k-tile; here Qop lands ONCE as raw fp32 (16 KB), Pop as a copy of the k-tile-major planes, and a k-tile
+//     takes one barrier.  The live-row gather and the zero fill past the live rows / the reduce extent sit in the request
+//     (per-lane offsets are k-invariant; the k-tile advances through the request's scalar offset).
+//   * the exact three-way split of Qop happens on the FRAGMENTS, in registers (44 full-rate vector instructions per
+//     32 x 16 fragment), only for the activation side: the weights were split once per step by nacf_wimage_refresh.
+//   * v_mfma_f32_32x32x16_bf16, wave tile (32 MT) x 64: 6 MT + 6 fragment reads (ds_read_b128) and 44 MT split instructions per
+//     12 MT matrix instructions of 32 cycles -- a third of the issue slots, where the 16 x 16 x 32 body of gemm_g256w.hpp needs
+//     all of them.
+//   * one workgroup is 4 waves (one per SIMD), 64 / 80 KB of LDS: TWO workgroups per CU, so the second one's k-loop covers the
+//     first one's prologue (DMA latency), epilogue (bias / activation / Philox dropout / residual: 20-30 k cycles for the FFN
+//     epilogues, which is why they could not move to the one-per-CU wide kernel) and barrier waits.  No hand scheduling: the
+//     partner wave on the SIMD fills what the compiler's order leaves open.
+//   * accumulators per (row block, column block) add their (k-tile, k-step, term) products in the wide kernel's order with the
+//     wide kernel's instruction: the results are the wide kernel's, bit for bit (tests/test_dma128_gpu.py), and the epilogues
+//     are the family's (EpiLinear / EpiStore / EpiArgmax), dropout masks keyed by the element index.
+//
+// Tiles: MT = 2 -> 128 x 128 (LDS 2 x (16 + 24) KB), MT = 1 -> 64 x 128 (2 x (8 + 24) KB) for launches under one round of 128-row
+// tiles.  Reduce extents need not be multiples of 32: the image is zero-padded to whole k-tiles, Qop chunks past the extent are
+// requested out of range (zeros), and a chunk that straddles the extent is cleaned in LDS before the last k-tile is read.
+#pragma once
+#include "gemm_bf16.hpp"
+
+namespace dma128 {
+
+constexpr int BN = 128, BK = 32, NT = 2, WTN = 64;
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __attribute__((address_space(3))) void* lds_ptr;
+
+template <int MT> struct Geo {
+  static constexpr int BM = 64 * MT, WTM = 32 * MT;
+  static constexpr int Q_IMG = BM * 128;                    // [BM rows][32 fp32]
+  static constexpr int P_PLANE = BN * 64;                   // [128 rows][32 bf16]
+  static constexpr int P_IMG = 3 * P_PLANE;
+  static constexpr int STAGE = Q_IMG + P_IMG;               // 40 / 32 KB
+  static constexpr int LDS_BYTES = 2 * STAGE;               // 80 / 64 KB: two workgroups per CU
+  static constexpr int QREQ = 2 * MT;                       // DMA requests (1 KB = 8 rows) per wave for one Qop tile
+  static constexpr int PREQ = 6;                            // ... for the three planes of one Pop tile (24 requests of 16 rows)
+};
+
+// 16-byte chunk swizzle of the fp32 image (128-byte rows, 8 chunks): the two ds_read_b128 of a 32-row fragment (lane = (row & 31,
+// h): chunks 4s + 2h and + 1) are conflict-free under the instruction's lane groups (the wide kernel's fq)
+__device__ __forceinline__ int fq(int row) { return (row >> 1) & 7; }
+
+// per (column tile, row): max logit, its index (smallest on ties), sum exp(l - max) -- argmax_epilogue (gemm_f32.hpp) on the
+// 32 x 32 accumulator map: register r of acc[a][b] is row a*32 + l31, column b*32 + 8*(r >> 2) + 4*lh + (r & 3) of the wave tile
+template <int MT>
+__device__ __forceinline__ void argmax_epilogue(float* smem, const GemmShape& g, const EpiArgmax& epi, f32x16 (&acc)[MT][NT], int m0, int n0,
+                                                int Meff, int tile_n, int wm, int wn, int l31, int lh, int tid) {
+  constexpr int BM = Geo<MT>::BM, WTM = Geo<MT>::WTM, WN = 2;
+  float* redv = smem;                  // [WN][BM]
+  float* reds = smem + WN * BM;        // [WN][BM]
+  int* redi = reinterpret_cast<int*>(smem + 2 * WN * BM);
+  const float NEG = -3.0e38f;
+#pragma unroll
+  for (int a = 0; a < MT; ++a) {
+    float best = NEG;
+    int bidx = 0x7fffffff;
+    const int row = wm * WTM + a * 32 + l31;
+    const int mrow = m0 + row;
+    float* crow = nullptr;
+    if (epi.C && mrow < Meff) crow = epi.C + (int64_t)(g.rows ? g.rows[mrow] : mrow) * epi.ldc;
+#pragma unroll
+    for (int b = 0; b < NT; ++b) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int nb = n0 + wn * WTN + b * 32 + 8 * j + 4 * lh;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int n = nb + e;
+          float v = NEG;
+          if (n < g.N) v = acc[a][b][4 * j + e] + (epi.bias ? epi.bias[n] : 0.f);
+          acc[a][b][4 * j + e] = v;
+          if (v > best) { best = v; bidx = n; }
+        }
+        if (crow) {
+          if (nb + 3 < g.N) *reinterpret_cast<f32x4*>(crow + nb) = f32x4{acc[a][b][4 * j], acc[a][b][4 * j + 1], acc[a][b][4 * j + 2], acc[a][b][4 * j + 3]};
+          else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+              if (nb + e < g.N) crow[nb + e] = acc[a][b][4 * j + e];
+          }
+        }
+      }
+    }
+    {
+      const float ov = __shfl_xor(best, 32, 64);
+      const int oi = __shfl_xor(bidx, 32, 64);
+      if (ov > best || (ov == best && oi < bidx)) { best = ov; bidx = oi; }
+    }
+    if (lh == 0) { redv[wn * BM + row] = best; redi[wn * BM + row] = bidx; }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int a = 0; a < MT; ++a) {
+    const int row = wm * WTM + a * 32 + l31;
+    float tmax = redv[row];
+#pragma unroll
+    for (int w = 1; w < WN; ++w) tmax = fmaxf(tmax, redv[w * BM + row]);
+    float s = 0.f;
+#pragma unroll
+    for (int b = 0; b < NT; ++b)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const float v = acc[a][b][e];
+        s += (v > -1.0e38f) ? (epi.C ? expf(v - tmax) : __expf(v - tmax)) : 0.f;
+      }
+    s += __shfl_xor(s, 32, 64);
+    if (lh == 0) reds[wn * BM + row] = s;
+  }
+  __syncthreads();
+  for (int row = tid; row < BM; row += 256) {
+    const int m = m0 + row;
+    if (m >= Meff) continue;
+    float best = redv[row];
+    int bidx = redi[row];
+    float s = reds[row];
+#pragma unroll
+    for (int w = 1; w < WN; ++w) {
+      const float ov = redv[w * BM + row];
+      const int oi = redi[w * BM + row];
+      if (ov > best || (ov == best && oi < bidx)) { best = ov; bidx = oi; }
+      s += reds[w * BM + row];
+    }
+    const int64_t o = (int64_t)tile_n * g.M + m;
+    epi.pmax[o] = best;
+    epi.psum[o] = s;
+    epi.pidx[o] = bidx;
+  }
+}
+
+#ifdef DMA128_TRACE
+__device__ unsigned long long* g_trace = nullptr;      // tuning builds (tools/probes/dma128_probe.hip): [workgroup][4] shader-clock stamps of wave 0
+#define DMA128_MARK(i) do { if (g_trace && tid == 0) g_trace[(size_t)blockIdx.x * 4 + (i)] = __builtin_readcyclecounter(); } while (0)
+#else
+#define DMA128_MARK(i) do { } while (0)
+#endif
+
+// ABL: tuning builds only: 1 = no DMA inside the k-loop, 2 = no operand split, 4 = no matrix instructions, 8 = no fragment reads, 16 = no phase pinning / priorities
+template <int MT, class Epi, int ABL = 0>
+__global__ __launch_bounds__(256, 2) void gemm_dma128_kernel(GemmShape g, Epi epi) {
+  using G = Geo<MT>;
+  constexpr int BM = G::BM, WTM = G::WTM, QREQ = G::QREQ, PREQ = G::PREQ;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1, l31 = lane & 31, lh = lane >> 5;
+  const int bid = blockIdx.x, z = blockIdx.z;
+  DMA128_MARK(0);
+
+  // ---- live rows, tile of this workgroup (as gemm_bf16_body)
+  int Meff = g.M;
+  if (g.count) Meff = min(Meff, *g.count);
+  const int tiles_m_live = (Meff + BM - 1) / BM;
+  const int nwg = tiles_m_live * g.tiles_n;
+  if (bid >= nwg) {
+    if (g.zero_dead && g.rows && z == 0) {      // workgroups past the live tiles zero-fill the dead rows of the output
+      const int dt = bid - nwg;
+      const int j0 = (dt / g.tiles_n) * BM, c0 = (dt % g.tiles_n) * BN;
+      const int n_dead = g.M - Meff;
+      for (int q = tid; q < BM * (BN / 4); q += 256) {
+        const int j = j0 + q / (BN / 4), n = c0 + (q % (BN / 4)) * 4;
+        if (j < n_dead && n < g.N) epi.zero4(g.rows[Meff + j], n, g.N);
+      }
+    }
+    return;
+  }
+  const int xq = nwg >> 3, xr = nwg & 7, xcd = bid & 7, slot = bid >> 3;
+  const int logical = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + slot;
+  int tile_m = logical / g.tiles_n, tile_n = logical % g.tiles_n;
+  if (g.group_n > 0) {
+    const int per = tiles_m_live * g.group_n;
+    const int grp = logical / per, r = logical - grp * per;
+    const int gn = min(g.group_n, g.tiles_n - grp * g.group_n);
+    tile_m = r / gn;
+    tile_n = grp * g.group_n + (r - tile_m * gn);
+  }
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+  const int kbeg = z * g.k_per_split, kend = min(g.K, kbeg + g.k_per_split);      // (k_per_split is a multiple of 32: the launcher checks)
+  const int klen = kend > kbeg ? kend - kbeg : 0;
+  const int nk = __builtin_amdgcn_readfirstlane((klen + 31) >> 5);
+  const int ktail = klen & 31;                  // != 0: the last k-tile holds only that many reduce indices
+
+  // ---- descriptors and the k-invariant per-lane offsets
+  const uint32_t a_bytes = (uint32_t)min((uint64_t)g.M * (uint64_t)g.ldq * 4u, (uint64_t)0x7ffffff0u);
+  const uint32_t kt_bytes = (uint32_t)(g.ldpi * 2), plane_bytes = (uint32_t)(g.pimg_plane * 2);
+  const uint32_t b_bytes = (uint32_t)((g.K + 31) >> 5) * kt_bytes + 2u * plane_bytes;
+  const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void*)g.Q, 0, a_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc((void*)g.Pimg, 0, b_bytes, 0x00020000);
+  constexpr uint32_t OOB = 0x80000000u;      // past the extent: the request returns zeros
+  // Qop: request j of this wave = rows (wave QREQ + j) 8 .. + 7 of the tile; LDS chunk position lane & 7 of row R receives source
+  // chunk (lane & 7) ^ fq(R).  Rows past the live count are requested out of range.
+  uint32_t voa[4];
+#pragma unroll
+  for (int j = 0; j < QREQ; ++j) {
+    const int R = (wave * QREQ + j) * 8 + (lane >> 3), m = m0 + R;
+    const int ph = m < Meff ? (g.rows ? g.rows[m] : m) : -1;
+    voa[j] = ph >= 0 ? (uint32_t)ph * (uint32_t)(g.ldq * 4) + (uint32_t)(((lane & 7) ^ fq(R)) << 4) : OOB;
+  }
+  // Pop: request i of this wave = number r = wave 6 + i of the tile's 24: plane r >> 3, rows (r & 7) 16 .. + 15; rows past N repeat
+  // row N - 1 (their columns are never stored)
+  uint32_t vob[6];
+#pragma unroll
+  for (int i = 0; i < PREQ; ++i) {
+    const int r = wave * PREQ + i, Rp = (r & 7) * 16 + (lane >> 2);
+    vob[i] = (uint32_t)min(n0 + Rp, g.N - 1) * 64u + (uint32_t)(((lane & 3) ^ lds_sw(Rp)) << 4);
+  }
+  auto issue = [&](const int kt, const int buf) __attribute__((always_inline)) {
+    unsigned char* base = smem + buf * G::STAGE;
+    const uint32_t ka = (uint32_t)(kbeg + 32 * kt) * 4u;
+    const uint32_t kb = (uint32_t)((kbeg >> 5) + kt) * kt_bytes;
+    const bool partial = ktail != 0 && kt == nk - 1;
+#pragma unroll
+    for (int j = 0; j < QREQ; ++j) {
+      uint32_t vo = voa[j];
+      if (partial) {      // chunks that begin at or past the reduce extent arrive as zeros
+        const int R = (wave * QREQ + j) * 8 + (lane >> 3);
+        if ((((lane & 7) ^ fq(R)) << 2) >= ktail) vo = OOB;
+      }
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_ptr)(base + (wave * QREQ + j) * 1024), 16, vo, ka, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < PREQ; ++i) {
+      const int r = wave * PREQ + i;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (lds_ptr)(base + G::Q_IMG + (r >> 3) * G::P_PLANE + (r & 7) * 1024), 16, vob[i],
+                                               kb + (uint32_t)(r >> 3) * plane_bytes, 0, 0);
+    }
+  };
+
+  // ---- fragment addresses (byte offsets inside a stage)
+  //   Pop (a operand, rows n): row wn 64 + b 32 + l31, 16-byte chunk 2s + lh of the plane's 64-byte row
+  //   Qop (b operand, rows m): row wm WTM + a 32 + l31, fp32 chunks 4s + 2lh and + 1 of the 128-byte row
+  const uint32_t p_rd0 = (uint32_t)(G::Q_IMG + (wn * WTN + l31) * 64 + ((lh ^ lds_sw(l31)) << 4));      // s = 0; s = 1: ^ 32
+  const uint32_t q_row = (uint32_t)((wm * WTM + l31) * 128);
+  const uint32_t qch = (uint32_t)((2 * lh) ^ fq(l31));
+
+  f32x16 acc[MT][NT];
+#pragma unroll
+  for (int a = 0; a < MT; ++a)
+#pragma unroll
+    for (int b = 0; b < NT; ++b)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
+
+  constexpr int TP[6] = {2, 0, 1, 1, 0, 0}, TQ[6] = {0, 2, 1, 0, 1, 0};     // six cross terms, smallest first
+  auto compute = [&](const int buf) __attribute__((always_inline)) {
+    const unsigned char* base = smem + buf * G::STAGE;
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      bf16x8_t pf[NT][3], qf[MT][3];
+#pragma unroll
+      for (int b = 0; b < NT; ++b)
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+          if constexpr (ABL & 8) pf[b][p] = __builtin_bit_cast(bf16x8_t, u32x4{p_rd0, qch, (uint32_t)p, (uint32_t)b});
+          else pf[b][p] = *reinterpret_cast<const bf16x8_t*>(base + (p_rd0 ^ (s ? 32u : 0u)) + p * G::P_PLANE + b * 2048);
+        }
+#pragma unroll
+      for (int a = 0; a < MT; ++a) {
+        f32x4 lo, hi;
+        if constexpr (ABL & 8) { lo = f32x4{(float)q_row, 1.f, 2.f, 3.f}; hi = lo; }
+        else {
+          lo = *reinterpret_cast<const f32x4*>(base + q_row + a * 4096 + ((qch ^ (s ? 4u : 0u)) << 4));
+          hi = *reinterpret_cast<const f32x4*>(base + q_row + a * 4096 + ((qch ^ (s ? 5u : 1u)) << 4));
+        }
+        u32x4 pl[3];
+        uint32_t w[3];
+        if constexpr (ABL & 2) {
+          pl[0] = __builtin_bit_cast(u32x4, lo); pl[1] = __builtin_bit_cast(u32x4, hi); pl[2] = pl[0] ^ pl[1];
+        } else {
+        bf16_split2<3>(lo[0], lo[1], w);
+        pl[0][0] = w[0]; pl[1][0] = w[1]; pl[2][0] = w[2];
+        bf16_split2<3>(lo[2], lo[3], w);
+        pl[0][1] = w[0]; pl[1][1] = w[1]; pl[2][1] = w[2];
+        bf16_split2<3>(hi[0], hi[1], w);
+        pl[0][2] = w[0]; pl[1][2] = w[1]; pl[2][2] = w[2];
+        bf16_split2<3>(hi[2], hi[3], w);
+        pl[0][3] = w[0]; pl[1][3] = w[1]; pl[2][3] = w[2];
+        }
+#pragma unroll
+        for (int p = 0; p < 3; ++p) qf[a][p] = __builtin_bit_cast(bf16x8_t, pl[p]);
+      }
+      // two phases per k-step, pinned: (fragment reads + split) at low priority, the 12 MT matrix instructions at high priority --
+      // the partner workgroup's wave on this SIMD is then always allowed to issue its matrix instruction the moment the pipe
+      // is free, and this wave's vector instructions fill the issue slots in between (without the priorities the older wave
+      // wins every arbitration: its split block runs back to back while the other wave's matrix instructions wait)
+      if constexpr (!(ABL & 16)) { __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_setprio(1); }
+#pragma unroll
+      for (int b = 0; b < NT; ++b)
+#pragma unroll
+        for (int t = 0; t < 6; ++t)
+#pragma unroll
+          for (int a = 0; a < MT; ++a) {
+            if constexpr (ABL & 4) asm volatile("" : "+v"(acc[a][b]) : "v"(pf[b][TP[t]]), "v"(qf[a][TQ[t]]));
+            else acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pf[b][TP[t]], qf[a][TQ[t]], acc[a][b], 0, 0, 0);
+          }
+      if constexpr (!(ABL & 16)) { __builtin_amdgcn_s_setprio(0); __builtin_amdgcn_sched_barrier(0); }
+    }
+  };
+
+  // ---- pipeline: the barrier at the top of k-tile t publishes tile t (every wave has waited for its own requests) and frees
+  //      the other image (every wave is done with tile t - 1), which the requests of tile t + 1 then refill
+  if (nk > 0) issue(0, 0);
+#pragma nounroll
+  for (int kt = 0; kt < nk; ++kt) {
+    const int buf = kt & 1;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    if (kt == 0) DMA128_MARK(1);
+    if ((kt + 1 < nk) && !((ABL & 1) && kt >= 1)) issue(kt + 1, buf ^ 1);
+    if ((ktail & 3) != 0 && kt == nk - 1) {
+      // the chunk that straddles the reduce extent carries 1-3 elements of whatever follows in the row: zero them in place
+      if (tid < BM) {
+        const int c = ktail >> 2;
+        float* p = reinterpret_cast<float*>(smem + buf * G::STAGE + tid * 128 + ((c ^ fq(tid)) << 4));
+        for (int e = ktail & 3; e < 4; ++e) p[e] = 0.f;
+      }
+      __syncthreads();
+    }
+    compute(buf);
+  }
+
+  DMA128_MARK(2);
+  // ---- epilogue: register r of acc[a][b] is row (m) a*32 + l31, column (n) b*32 + 8*(r >> 2) + 4*lh + (r & 3) of the wave tile
+  //      (the matrix instruction is issued with a = Pop fragment, b = Qop fragment): 4 float4s per 32 x 32 block and row
+  if constexpr (!Epi::kArgmax) {
+    constexpr int TN = NT * 4;
+    int ncol[TN];
+#pragma unroll
+    for (int b = 0; b < TN; ++b) ncol[b] = n0 + wn * WTN + (b >> 2) * 32 + (b & 3) * 8 + 4 * lh;
+    const bool fast = epi.fast_ok() && m0 + BM <= Meff && n0 + BN <= g.N;
+    // one row block at a time, the block index a COMPILE-TIME constant: inside a run-time loop (hipcc declines to unroll around the
+    // inlined epilogues) the accumulator array is indexed dynamically and lives in scratch for the whole kernel
+    auto rowblock = [&](auto a_c) __attribute__((always_inline)) {
+      constexpr int a = decltype(a_c)::value;
+      f32x4 acc4[1][TN];
+#pragma unroll
+      for (int b = 0; b < TN; ++b)
+        acc4[0][b] = f32x4{acc[a][b >> 2][4 * (b & 3)], acc[a][b >> 2][4 * (b & 3) + 1], acc[a][b >> 2][4 * (b & 3) + 2], acc[a][b >> 2][4 * (b & 3) + 3]};
+      int mlog[1] = {m0 + wm * WTM + a * 32 + l31};
+      int mphys[1] = {(g.rows && mlog[0] < Meff) ? g.rows[mlog[0]] : mlog[0]};
+      if (fast) epi.template tile_fast<1, TN, true>(acc4, mphys, ncol, g.N, z);
+      else epilogue_all<0, 1, TN, true, Epi>(epi, acc4, mlog, mphys, ncol, Meff, g.N, z);
+    };
+    rowblock(std::integral_constant<int, 0>{});
+    if constexpr (MT == 2) rowblock(std::integral_constant<int, 1>{});
+  } else {
+    __syncthreads();      // the last tile's fragments are read: the scratch may reuse the images
+    argmax_epilogue<MT>(reinterpret_cast<float*>(smem), g, epi, acc, m0, n0, Meff, tile_n, wm, wn, l31, lh, tid);
+  }
+#ifdef DMA128_TRACE
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  DMA128_MARK(3);
+#endif
+}
+
+// host side: eligibility and launch
+inline bool eligible(const GemmShape& g, int splits) {
+  if (!g.Pimg) return false;
+  if (splits > 1 && (g.k_per_split & 31) != 0) return false;
+  if ((reinterpret_cast<uintptr_t>(g.Q) & 15) != 0 || (g.ldq & 3) != 0) return false;
+  if ((uint64_t)g.M * (uint64_t)g.ldq * 4u >= 0x7ffffff0ull) return false;                          // 31-bit request offsets
+  const uint64_t bb = (uint64_t)((g.K + 31) >> 5) * (uint64_t)g.ldpi * 2u + 2u * (uint64_t)g.pimg_plane * 2u;
+  return bb < 0x7ffffff0ull && (uint64_t)g.N * 64u < 0x7ffffff0ull;
+}
+template <int MT, class Epi>
+inline void launch(GemmShape g, const Epi& epi, int splits, hipStream_t s) {
+  auto kern = gemm_dma128_kernel<MT, Epi>;
+  constexpr int lds = Geo<MT>::LDS_BYTES;
+  static bool raised = false;
+  if (!raised) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    raised = true;
+  }
+  g.tiles_m = cdiv(g.M, Geo<MT>::BM);
+  g.tiles_n = cdiv(g.N, BN);
+  g.group_n = 0;
+  {
+    // L2-aware order for very wide P (GemmShape::group_n), as the 128 x 128 kernel's launcher
+    static const int group_n = [] { const char* e = getenv("NACF_GEMM_GROUP_N"); return e ? atoi(e) : 6; }();
+    if (group_n > 0 && g.tiles_n >= 32 && splits == 1) g.group_n = group_n;
+  }
+  dim3 grid((g.tiles_m + (g.zero_dead ? 1 : 0)) * g.tiles_n, 1, splits);
+  hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, g, epi);
+}
+
+}  // namespace dma128

@@ -438,7 +438,8 @@ int nacf_linear_fwd(const float* X, int64_t ldx, const float* W, int64_t ldw, fl
   if (mode != NACF_GEMM_F32 && vec) {          // bf16 matrix cores (16-byte addressable operands only)
     find_image(W, ldw, N, K, mode, g);
     const bool heavy_w = heavy || epi.ep.p_drop1 > 0.f || epi.ep.p_drop2 > 0.f;      // nothing overlaps the wide kernel's epilogue
-    if (!(mode == NACF_GEMM_BF16X3 && launch_wide_linear(g, epi, rs != nullptr, heavy_w, as_hip(stream))))
+    if (!(mode == NACF_GEMM_BF16X3 && launch_wide_linear(g, epi, rs != nullptr, heavy_w, as_hip(stream))) &&
+        !(mode == NACF_GEMM_BF16X3 && launch_dma128_linear(g, epi, rs != nullptr, as_hip(stream))))
       launch_bf16_linear(g, epi, pick_tile_bf16(0, M, N, 1, rs != nullptr, mode, heavy), mode, as_hip(stream));
     g_last_was_bf16 = true;
   } else {
@@ -506,7 +507,8 @@ int nacf_linear_bwd_data(const float* dZ, int64_t lddz, const float* W, int64_t 
   }
   if (bf16) {
     find_image_t(W, ldw, N, K, mode, g);       // P = W^T image [K, N] when registered, else the fp32 W read transposed
-    if (!(mode == NACF_GEMM_BF16X3 && launch_wide_dx(g, epi, real_splits, rs != nullptr, s)))
+    if (!(mode == NACF_GEMM_BF16X3 && launch_wide_dx(g, epi, real_splits, rs != nullptr, s)) &&
+        !(mode == NACF_GEMM_BF16X3 && launch_dma128_dx(g, epi, real_splits, rs != nullptr, s)))
       launch_bf16_dx(g, epi, real_splits, pick_tile_bf16(1, M, K, real_splits, rs != nullptr, mode), mode, s);
     g_last_was_bf16 = true;
   } else {
@@ -994,12 +996,6 @@ int nacf_vocab_argmax(const float* hidden, int64_t ldh, const float* W, int64_t 
   NACF_CHECK(!rs || (rs->rows && rs->count), NACF_EINVAL, "nacf_vocab_argmax: incomplete row set");
   const bool bf16_fam = gemm_mode() != NACF_GEMM_F32 && (ldh % 4 == 0) && (ldw % 4 == 0) && aligned16(hidden) && aligned16(W);
   const int tile = bf16_fam ? pick_tile_bf16(0, rows, V, 1, rs != nullptr, gemm_mode()) : pick_tile(rows, V, 1, rs != nullptr);
-  const int tn = cdiv(V, tile == 0 ? 128 : 64);
-  EpiArgmax epi;
-  epi.bias = bias;
-  epi.pmax = reinterpret_cast<float*>(ws);
-  epi.psum = epi.pmax + (size_t)tn * rows;
-  epi.pidx = reinterpret_cast<int*>(epi.psum + (size_t)tn * rows);
   GemmShape g = {};
   g.Q = hidden; g.P = W; g.ldq = ldh; g.ldp = ldw; g.M = rows; g.N = V; g.K = K;
   g.k_per_split = cdiv(K, 32) * 32;
@@ -1007,9 +1003,18 @@ int nacf_vocab_argmax(const float* hidden, int64_t ldh, const float* W, int64_t 
   const bool vec = (ldh % 4 == 0) && (ldw % 4 == 0) && aligned16(hidden) && aligned16(W);
   hipStream_t s = as_hip(stream);
   const int mode = gemm_mode();
+  if (mode != NACF_GEMM_F32 && vec) find_image(W, ldw, V, K, mode, g);
+  // the DMA-fed exact-mode kernel (gemm_dma128.hpp) emits its partials per 128-column tile
+  const int d128 = (mode == NACF_GEMM_BF16X3 && vec) ? dma128_pick(g, 1, rs != nullptr, 3) : 0;
+  const int tn = cdiv(V, (d128 || tile == 0) ? 128 : 64);
+  EpiArgmax epi;
+  epi.bias = bias;
+  epi.pmax = reinterpret_cast<float*>(ws);
+  epi.psum = epi.pmax + (size_t)tn * rows;
+  epi.pidx = reinterpret_cast<int*>(epi.psum + (size_t)tn * rows);
   if (mode != NACF_GEMM_F32 && vec) {
-    find_image(W, ldw, V, K, mode, g);
-    launch_bf16_argmax(g, epi, tile, mode, s);
+    if (d128) launch_dma128_argmax(g, epi, d128, s);
+    else launch_bf16_argmax(g, epi, tile, mode, s);
     g_last_was_bf16 = true;
   } else {
     launch_gemm<true, true, EpiArgmax>(g, epi, 1, tile, vec, s);
@@ -1037,14 +1042,6 @@ int nacf_vocab_lse_fwd(const float* hidden, int64_t ldh, const float* W, int64_t
   NACF_CHECK(!rs || (rs->rows && rs->count), NACF_EINVAL, "nacf_vocab_lse_fwd: incomplete row set");
   const bool bf16_fam = gemm_mode() != NACF_GEMM_F32 && (ldh % 4 == 0) && (ldw % 4 == 0) && aligned16(hidden) && aligned16(W);
   const int tile = bf16_fam ? pick_tile_bf16(0, rows, V, 1, rs != nullptr, gemm_mode()) : pick_tile(rows, V, 1, rs != nullptr);
-  const int tn = cdiv(V, tile == 0 ? 128 : 64);
-  EpiArgmax epi;
-  epi.bias = bias;
-  epi.pmax = reinterpret_cast<float*>(ws);
-  epi.psum = epi.pmax + (size_t)tn * rows;
-  epi.pidx = reinterpret_cast<int*>(epi.psum + (size_t)tn * rows);
-  epi.C = logits;
-  epi.ldc = ldl;
   GemmShape g = {};
   g.Q = hidden; g.P = W; g.ldq = ldh; g.ldp = ldw; g.M = rows; g.N = V; g.K = K;
   g.k_per_split = cdiv(K, 32) * 32;
@@ -1053,9 +1050,19 @@ int nacf_vocab_lse_fwd(const float* hidden, int64_t ldh, const float* W, int64_t
   const bool vec = (ldh % 4 == 0) && (ldw % 4 == 0) && aligned16(hidden) && aligned16(W);
   hipStream_t s = as_hip(stream);
   const int mode = gemm_mode();
+  if (mode != NACF_GEMM_F32 && vec) find_image(W, ldw, V, K, mode, g);
+  const int d128 = (mode == NACF_GEMM_BF16X3 && vec) ? dma128_pick(g, 1, rs != nullptr, 3) : 0;
+  const int tn = cdiv(V, (d128 || tile == 0) ? 128 : 64);
+  EpiArgmax epi;
+  epi.bias = bias;
+  epi.pmax = reinterpret_cast<float*>(ws);
+  epi.psum = epi.pmax + (size_t)tn * rows;
+  epi.pidx = reinterpret_cast<int*>(epi.psum + (size_t)tn * rows);
+  epi.C = logits;
+  epi.ldc = ldl;
   if (mode != NACF_GEMM_F32 && vec) {
-    find_image(W, ldw, V, K, mode, g);
-    launch_bf16_argmax(g, epi, tile, mode, s);
+    if (d128) launch_dma128_argmax(g, epi, d128, s);
+    else launch_bf16_argmax(g, epi, tile, mode, s);
     g_last_was_bf16 = true;
   } else {
     launch_gemm<true, true, EpiArgmax>(g, epi, 1, tile, vec, s);

@@ -71,7 +71,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--only", type=str, default="")
-    ap.add_argument("--tiles", type=str, default="64,128", help="64 | 128 (NACF_GEMM_TILE), wide1 | wide2 (NACF_GEMM_WIDE, exact mode + --images), auto")
+    ap.add_argument("--tiles", type=str, default="64,128", help="64 | 128 (NACF_GEMM_TILE), wide1 | wide2 (NACF_GEMM_WIDE) / dma1 | dma2 (NACF_DMA128) (exact mode + --images), auto")
     ap.add_argument("--shapes", type=str, default="", help="extra shapes 'kind:M:N:K,...' (kind 0 fwd, 1 dX, 2 dW)")
     ap.add_argument("--pad", type=int, default=0, help="extra floats of row pitch on the K-contiguous fwd operands")
     ap.add_argument("--modes", type=str, default="f32", help="NACF_GEMM_MODE values to compare: f32,bf16x3,bf16")
@@ -94,10 +94,15 @@ def main():
             os.environ["NACF_GEMM_MODE"] = mode_
             os.environ.pop("NACF_GEMM_TILE", None)
             os.environ.pop("NACF_GEMM_WIDE", None)
+            os.environ.pop("NACF_DMA128", None)
             if tile_ in ("64", "128"):
-                os.environ["NACF_GEMM_TILE"] = tile_             # (also keeps the wide kernel out)
+                os.environ["NACF_GEMM_TILE"] = tile_             # (also keeps the wide and DMA-fed kernels out)
             elif tile_.startswith("wide"):                       # wide1 / wide2: csrc/gemm_bf16_wide.hpp, 64 / 128-row tiles
                 os.environ["NACF_GEMM_WIDE"] = tile_[4:]
+                os.environ["NACF_DMA128"] = "0"
+            elif tile_.startswith("dma"):                        # dma1 / dma2: csrc/gemm_dma128.hpp, 64 / 128-row tiles
+                os.environ["NACF_GEMM_WIDE"] = "0"
+                os.environ["NACF_DMA128"] = tile_[3:]
             else:
                 assert tile_ == "auto", tile_                    # the production heuristic
             res.append(run(kind, M, N, K, args.iters, dev, args.images))
