@@ -42,8 +42,16 @@ __device__ __forceinline__ uint4 philox4x32_10(uint4 c, uint2 k) {
   const uint32_t W0 = 0x9E3779B9u, W1 = 0xBB67AE85u;
 #pragma unroll
   for (int r = 0; r < 10; ++r) {
-    uint32_t hi0 = __umulhi(M0, c.x), lo0 = M0 * c.x;
-    uint32_t hi1 = __umulhi(M1, c.z), lo1 = M1 * c.z;
+#ifdef NACF_PHILOX_MULHI
+    // (the wide GEMM unit: 64-bit products raise the epilogue's register pressure past what hipcc fits beside the hand-allocated
+    //  accumulators -- it parked spills in a0..a3, tools/check_wide_hazards.py -- so that unit keeps the two-instruction form)
+    const uint32_t hi0 = __umulhi(M0, c.x), lo0 = M0 * c.x, hi1 = __umulhi(M1, c.z), lo1 = M1 * c.z;
+#else
+    // one 32 x 32 -> 64 multiply per product (v_mad_u64_u32) instead of a v_mul_hi_u32 / v_mul_lo_u32 pair: the quarter-rate
+    // multiplies are most of a call, and a GEMM epilogue with dropout makes 16 calls per lane and 128 x 128 tile.  Same bits.
+    const uint64_t p0 = (uint64_t)M0 * (uint64_t)c.x, p1 = (uint64_t)M1 * (uint64_t)c.z;
+    const uint32_t hi0 = (uint32_t)(p0 >> 32), lo0 = (uint32_t)p0, hi1 = (uint32_t)(p1 >> 32), lo1 = (uint32_t)p1;
+#endif
     c = make_uint4(hi1 ^ c.y ^ k.x, lo1, hi0 ^ c.w ^ k.y, lo0);
     k.x += W0;
     k.y += W1;

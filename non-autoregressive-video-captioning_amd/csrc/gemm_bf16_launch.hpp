@@ -21,7 +21,7 @@ bool launch_wide_linear(const GemmShape& g, const EpiLinear& epi, bool has_rows,
 bool launch_wide_dx(const GemmShape& g, const EpiStore& epi, int splits, bool has_rows, hipStream_t s);
 int wide_pick(const GemmShape& g, int splits, bool has_rows, int ns, bool heavy_epilogue);
 // DMA-fed two-per-CU kernels of the exact mode (gemm_dma128.hpp, nacf_gemm_dma128.hip): false / 0 = not eligible, use the others
-int dma128_pick(const GemmShape& g, int splits, bool has_rows, int ns);
+int dma128_pick(const GemmShape& g, int splits, bool has_rows, int ns, int kind);
 bool launch_dma128_linear(const GemmShape& g, const EpiLinear& epi, bool has_rows, hipStream_t s);
 bool launch_dma128_dx(const GemmShape& g, const EpiStore& epi, int splits, bool has_rows, hipStream_t s);
 void launch_dma128_argmax(const GemmShape& g, const EpiArgmax& epi, int mt, hipStream_t s);

@@ -145,7 +145,7 @@ __device__ unsigned long long* g_trace = nullptr;      // tuning builds (tools/p
 #define DMA128_MARK(i) do { } while (0)
 #endif
 
-// ABL: tuning builds only: 1 = no DMA inside the k-loop, 2 = no operand split, 4 = no matrix instructions, 8 = no fragment reads, 16 = no phase pinning / priorities
+// ABL: tuning builds only: 1 = no DMA inside the k-loop, 2 = no operand split, 4 = no matrix instructions, 32 = every tile requested twice, 64 / 128 = nt policy on the Qop / Pop requests
 template <int MT, class Epi, int ABL = 0>
 __global__ __launch_bounds__(256, 2) void gemm_dma128_kernel(GemmShape g, Epi epi) {
   using G = Geo<MT>;
@@ -206,6 +206,14 @@ __global__ __launch_bounds__(256, 2) void gemm_dma128_kernel(GemmShape g, Epi ep
     const int ph = m < Meff ? (g.rows ? g.rows[m] : m) : -1;
     voa[j] = ph >= 0 ? (uint32_t)ph * (uint32_t)(g.ldq * 4) + (uint32_t)(((lane & 7) ^ fq(R)) << 4) : OOB;
   }
+  // the same for a last k-tile that holds only ktail reduce indices: chunks that begin at or past the extent arrive as zeros
+  uint32_t voat[4];
+  const int last_partial = ktail != 0 ? nk - 1 : -1;
+#pragma unroll
+  for (int j = 0; j < QREQ; ++j) {
+    const int R = (wave * QREQ + j) * 8 + (lane >> 3);
+    voat[j] = ((((lane & 7) ^ fq(R)) << 2) >= ktail) ? OOB : voa[j];
+  }
   // Pop: request i of this wave = number r = wave 6 + i of the tile's 24: plane r >> 3, rows (r & 7) 16 .. + 15; rows past N repeat
   // row N - 1 (their columns are never stored)
   uint32_t vob[6];
@@ -214,28 +222,6 @@ __global__ __launch_bounds__(256, 2) void gemm_dma128_kernel(GemmShape g, Epi ep
     const int r = wave * PREQ + i, Rp = (r & 7) * 16 + (lane >> 2);
     vob[i] = (uint32_t)min(n0 + Rp, g.N - 1) * 64u + (uint32_t)(((lane & 3) ^ lds_sw(Rp)) << 4);
   }
-  auto issue = [&](const int kt, const int buf) __attribute__((always_inline)) {
-    unsigned char* base = smem + buf * G::STAGE;
-    const uint32_t ka = (uint32_t)(kbeg + 32 * kt) * 4u;
-    const uint32_t kb = (uint32_t)((kbeg >> 5) + kt) * kt_bytes;
-    const bool partial = ktail != 0 && kt == nk - 1;
-#pragma unroll
-    for (int j = 0; j < QREQ; ++j) {
-      uint32_t vo = voa[j];
-      if (partial) {      // chunks that begin at or past the reduce extent arrive as zeros
-        const int R = (wave * QREQ + j) * 8 + (lane >> 3);
-        if ((((lane & 7) ^ fq(R)) << 2) >= ktail) vo = OOB;
-      }
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_ptr)(base + (wave * QREQ + j) * 1024), 16, vo, ka, 0, 0);
-    }
-#pragma unroll
-    for (int i = 0; i < PREQ; ++i) {
-      const int r = wave * PREQ + i;
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (lds_ptr)(base + G::Q_IMG + (r >> 3) * G::P_PLANE + (r & 7) * 1024), 16, vob[i],
-                                               kb + (uint32_t)(r >> 3) * plane_bytes, 0, 0);
-    }
-  };
-
   // ---- fragment addresses (byte offsets inside a stage)
   //   Pop (a operand, rows n): row wn 64 + b 32 + l31, 16-byte chunk 2s + lh of the plane's 64-byte row
   //   Qop (b operand, rows m): row wm WTM + a 32 + l31, fp32 chunks 4s + 2lh and + 1 of the 128-byte row
@@ -251,83 +237,179 @@ __global__ __launch_bounds__(256, 2) void gemm_dma128_kernel(GemmShape g, Epi ep
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
 
+  // ---- the k-loop: a software pipeline over k-STEPS (16 reduce indices = 12 MT matrix instructions per wave), pinned slot by
+  //      slot.  Measured on the first, compiler-ordered form of this kernel (tools/probes/dma128_probe.hip, 2 workgroups per CU,
+  //      cycles per k-tile and workgroup): matrix instructions alone 3180 (= 2 x 1536 + 3 %), + split 3790, + DMA 4310 -- neither
+  //      the split block nor the burst of 10 DMA requests per wave behind the barrier (the four waves queue up at the address
+  //      unit) overlapped with the partner wave's matrix instructions.  So every other instruction rides in the issue slots
+  //      BEHIND one of this wave's own matrix instructions (32 cycles of pipe time, 4 of issue), as in the wide kernel:
+  //        k-step X runs its 12 MT matrix instructions on fragment set X & 1 while it
+  //          - reads the fragments of k-step X + 1 (2 MT raw fp32 + 6 plane reads, one ds_read_b128 per slot),
+  //          - splits the raw fragments into set (X + 1) & 1 (44 MT vector instructions, 4 per slot),
+  //          - (odd k-steps) requests tile t + 2 into the image tile t has just left (one request per slot).
+  //      Tile t's image is read during k-steps (t - 1, 1) and (t, 0); the barrier between (t, 0) and (t, 1) frees it and
+  //      publishes tile t + 1, requested one k-tile earlier.
   constexpr int TP[6] = {2, 0, 1, 1, 0, 0}, TQ[6] = {0, 2, 1, 0, 1, 0};     // six cross terms, smallest first
-  auto compute = [&](const int buf) __attribute__((always_inline)) {
-    const unsigned char* base = smem + buf * G::STAGE;
-#pragma unroll
-    for (int s = 0; s < 2; ++s) {
-      bf16x8_t pf[NT][3], qf[MT][3];
-#pragma unroll
-      for (int b = 0; b < NT; ++b)
-#pragma unroll
-        for (int p = 0; p < 3; ++p) {
-          if constexpr (ABL & 8) pf[b][p] = __builtin_bit_cast(bf16x8_t, u32x4{p_rd0, qch, (uint32_t)p, (uint32_t)b});
-          else pf[b][p] = *reinterpret_cast<const bf16x8_t*>(base + (p_rd0 ^ (s ? 32u : 0u)) + p * G::P_PLANE + b * 2048);
-        }
-#pragma unroll
-      for (int a = 0; a < MT; ++a) {
-        f32x4 lo, hi;
-        if constexpr (ABL & 8) { lo = f32x4{(float)q_row, 1.f, 2.f, 3.f}; hi = lo; }
-        else {
-          lo = *reinterpret_cast<const f32x4*>(base + q_row + a * 4096 + ((qch ^ (s ? 4u : 0u)) << 4));
-          hi = *reinterpret_cast<const f32x4*>(base + q_row + a * 4096 + ((qch ^ (s ? 5u : 1u)) << 4));
-        }
-        u32x4 pl[3];
-        uint32_t w[3];
-        if constexpr (ABL & 2) {
-          pl[0] = __builtin_bit_cast(u32x4, lo); pl[1] = __builtin_bit_cast(u32x4, hi); pl[2] = pl[0] ^ pl[1];
-        } else {
-        bf16_split2<3>(lo[0], lo[1], w);
-        pl[0][0] = w[0]; pl[1][0] = w[1]; pl[2][0] = w[2];
-        bf16_split2<3>(lo[2], lo[3], w);
-        pl[0][1] = w[0]; pl[1][1] = w[1]; pl[2][1] = w[2];
-        bf16_split2<3>(hi[0], hi[1], w);
-        pl[0][2] = w[0]; pl[1][2] = w[1]; pl[2][2] = w[2];
-        bf16_split2<3>(hi[2], hi[3], w);
-        pl[0][3] = w[0]; pl[1][3] = w[1]; pl[2][3] = w[2];
-        }
-#pragma unroll
-        for (int p = 0; p < 3; ++p) qf[a][p] = __builtin_bit_cast(bf16x8_t, pl[p]);
-      }
-      // two phases per k-step, pinned: (fragment reads + split) at low priority, the 12 MT matrix instructions at high priority --
-      // the partner workgroup's wave on this SIMD is then always allowed to issue its matrix instruction the moment the pipe
-      // is free, and this wave's vector instructions fill the issue slots in between (without the priorities the older wave
-      // wins every arbitration: its split block runs back to back while the other wave's matrix instructions wait)
-      if constexpr (!(ABL & 16)) { __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_setprio(1); }
-#pragma unroll
-      for (int b = 0; b < NT; ++b)
-#pragma unroll
-        for (int t = 0; t < 6; ++t)
-#pragma unroll
-          for (int a = 0; a < MT; ++a) {
-            if constexpr (ABL & 4) asm volatile("" : "+v"(acc[a][b]) : "v"(pf[b][TP[t]]), "v"(qf[a][TQ[t]]));
-            else acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pf[b][TP[t]], qf[a][TQ[t]], acc[a][b], 0, 0, 0);
-          }
-      if constexpr (!(ABL & 16)) { __builtin_amdgcn_s_setprio(0); __builtin_amdgcn_sched_barrier(0); }
+  constexpr int NSLOT = 12 * MT;
+  u32x4 pf[2][NT][3];                 // Pop fragments [set][column block][plane]
+  u32x4 qf[2][MT][3];                 // split Qop fragments [set][row block][plane]
+  f32x4 raw[MT][2];                   // raw fp32 Qop fragment of the NEXT k-step [row block][half]
+  float tmp[4];
+  // vector operation `op` (0..43) of the exact three-way split (bf16_split2<3>) of raw[a] into q[a][.]; the four pairs advance
+  // together so that neighbouring instructions are independent:
+  //   0-3 pack h | 4-19 first residual (and x4, sub x4 for the even elements, then the odd ones) | 20-23 pack m |
+  //   24-39 second residual | 40-43 pack l
+  // (every result goes through an empty volatile asm: without it LLVM sinks the split of a whole k-step to where the next k-step
+  //  uses it -- the scheduling fences below only bind the machine scheduler -- and the vector block runs with no matrix
+  //  instruction to hide behind)
+  auto split_op = [&](u32x4 (&q)[MT][3], const int a, const int op) __attribute__((always_inline)) {
+    auto pack = [&](int plane, int pr) {
+      uint32_t w = bf16_pack_top(raw[a][pr >> 1][(pr & 1) * 2], raw[a][pr >> 1][(pr & 1) * 2 + 1]);
+      asm volatile("" : "+v"(w));
+      q[a][plane][pr] = w;
+    };
+    if (op < 4) pack(0, op);
+    else if (op < 20 || (op >= 24 && op < 40)) {
+      const int o = (op < 20) ? op - 4 : op - 24;       // [element 0 | 1][and | sub][pair]
+      const int el = o >> 3, sub = (o >> 2) & 1, pr = o & 3;
+      const float x = raw[a][pr >> 1][(pr & 1) * 2 + el];
+      if (!sub) { float w = f32_top16(x); asm volatile("" : "+v"(w)); tmp[pr] = w; }
+      else { float w = x - tmp[pr]; asm volatile("" : "+v"(w)); raw[a][pr >> 1][(pr & 1) * 2 + el] = w; }
+    }
+    else if (op < 24) pack(1, op - 20);
+    else pack(2, op - 40);
+  };
+  // fragment read number `i` of k-step s (0 | 1) of the image at `base` into set `SET`: i < 2 MT: raw half (i & 1) of row block i >> 1;
+  // then plane reads (column block, plane)
+  auto frag_read = [&](auto set_c, const unsigned char* base, const int s, const int i) __attribute__((always_inline)) {
+    constexpr int SET = decltype(set_c)::value;
+    if (i < 2 * MT) {
+      const int a = i >> 1, h = i & 1;
+      raw[a][h] = *reinterpret_cast<const f32x4*>(base + q_row + a * 4096 + ((qch ^ (uint32_t)(4 * s + h)) << 4));
+    } else {
+      const int j = i - 2 * MT, b = j / 3, pl = j % 3;
+      pf[SET][b][pl] = *reinterpret_cast<const u32x4*>(base + (p_rd0 ^ (uint32_t)(32 * s)) + pl * G::P_PLANE + b * 2048);
     }
   };
-
-  // ---- pipeline: the barrier at the top of k-tile t publishes tile t (every wave has waited for its own requests) and frees
-  //      the other image (every wave is done with tile t - 1), which the requests of tile t + 1 then refill
-  if (nk > 0) issue(0, 0);
-#pragma nounroll
-  for (int kt = 0; kt < nk; ++kt) {
-    const int buf = kt & 1;
+  // one DMA request (number r of this wave's QREQ + PREQ) of k-tile kt into image `buf`
+  auto issue_one = [&](const int kt, const int buf, const int r) __attribute__((always_inline)) {
+    unsigned char* base = smem + buf * G::STAGE;
+    if (r < QREQ) {
+      const uint32_t vo = (kt == last_partial) ? voat[r] : voa[r];      // (a select, not a branch: the k-step stays one basic block)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_ptr)(base + (wave * QREQ + r) * 1024), 16, vo, (uint32_t)(kbeg + 32 * kt) * 4u, 0, (ABL & 64) ? 2 : 0);
+    } else {
+      const int q = wave * PREQ + (r - QREQ);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (lds_ptr)(base + G::Q_IMG + (q >> 3) * G::P_PLANE + (q & 7) * 1024), 16, vob[r - QREQ],
+                                               (uint32_t)((kbeg >> 5) + kt) * kt_bytes + (uint32_t)(q >> 3) * plane_bytes, 0, (ABL & 128) ? 2 : 0);
+    }
+  };
+  // k-step S of the k-tile in image BUF: matrix instructions on set S, everything of the next k-step behind them.
+  // dma_kt >= 0: request that k-tile into image BUF ^ 1 ... no: into the image the NEXT-next tile owns = BUF (see above)
+  auto kstep = [&](auto buf_c, auto s_c, auto dma_c, const int dma_kt) __attribute__((always_inline)) {
+    constexpr int BUF = decltype(buf_c)::value, S = decltype(s_c)::value;
+    constexpr bool DMA = decltype(dma_c)::value;
+    constexpr int NXT = S ^ 1;                                          // fragment set of the next k-step
+    constexpr int NBUF = S ? (BUF ^ 1) : BUF;                           // its image: (t, 1) lives in tile t's, (t + 1, 0) in the other
+    const unsigned char* nbase = smem + NBUF * G::STAGE;
+    constexpr int NREAD = 2 * MT + 6;
+    constexpr int SPLIT0 = MT == 2 ? 2 : 1;                             // first slot with split operations (4 per slot)
+#pragma unroll
+    for (int gs = 0; gs < NSLOT; ++gs) {
+      const int b = gs / (6 * MT), t = (gs / MT) % 6, a = gs % MT;
+      if constexpr (ABL & 4) asm volatile("" : "+v"(acc[a][b]) : "v"(pf[S][b][TP[t]]), "v"(qf[S][a][TQ[t]]));
+      else acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, pf[S][b][TP[t]]), __builtin_bit_cast(bf16x8_t, qf[S][a][TQ[t]]), acc[a][b], 0, 0, 0);
+      // fragment reads of the next k-step: the raw halves first (their split starts two slots later), then the planes
+      if (MT == 2) { if (gs < NREAD) frag_read(std::integral_constant<int, NXT>{}, nbase, NXT, gs); }
+      else { if (gs == 0) { frag_read(std::integral_constant<int, NXT>{}, nbase, NXT, 0); frag_read(std::integral_constant<int, NXT>{}, nbase, NXT, 1); }
+             else if (gs < NREAD - 1) frag_read(std::integral_constant<int, NXT>{}, nbase, NXT, gs + 1); }
+      if constexpr (!(ABL & 2)) {
+        if (gs >= SPLIT0) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const int o = (gs - SPLIT0) * 4 + i;
+            if (o < 44 * MT) split_op(qf[NXT], o / 44, o % 44);
+          }
+        }
+      } else {
+        if (gs == NSLOT - 1) {
+#pragma unroll
+          for (int a2 = 0; a2 < MT; ++a2) { qf[NXT][a2][0] = __builtin_bit_cast(u32x4, raw[a2][0]); qf[NXT][a2][1] = __builtin_bit_cast(u32x4, raw[a2][1]); qf[NXT][a2][2] = qf[NXT][a2][0] ^ qf[NXT][a2][1]; }
+        }
+      }
+      if constexpr (DMA) {
+        // requests of tile dma_kt, one per slot from the first slot behind the barrier on: they have the rest of this k-step and the
+        // next one to land (one per second slot: the last ones arrived after the barrier that needs them, +250 cycles per k-tile)
+        if (gs < QREQ + PREQ) issue_one(dma_kt, BUF, gs);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+  auto publish = [&]() __attribute__((always_inline)) {      // this wave's requests have landed; every wave's: behind the barrier
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
-    if (kt == 0) DMA128_MARK(1);
-    if ((kt + 1 < nk) && !((ABL & 1) && kt >= 1)) issue(kt + 1, buf ^ 1);
-    if ((ktail & 3) != 0 && kt == nk - 1) {
-      // the chunk that straddles the reduce extent carries 1-3 elements of whatever follows in the row: zero them in place
-      if (tid < BM) {
-        const int c = ktail >> 2;
-        float* p = reinterpret_cast<float*>(smem + buf * G::STAGE + tid * 128 + ((c ^ fq(tid)) << 4));
-        for (int e = ktail & 3; e < 4; ++e) p[e] = 0.f;
-      }
-      __syncthreads();
+  };
+  auto clean_tail = [&](const int buf) __attribute__((always_inline)) {
+    // the chunk that straddles the reduce extent carries 1-3 elements of whatever follows in the row: zero them in place
+    if (tid < BM) {
+      const int c = ktail >> 2;
+      float* p = reinterpret_cast<float*>(smem + buf * G::STAGE + tid * 128 + ((c ^ fq(tid)) << 4));
+      for (int e = ktail & 3; e < 4; ++e) p[e] = 0.f;
     }
-    compute(buf);
+    __syncthreads();
+  };
+  // (DMA is a compile-time flag and the loop below has no run-time choice between k-step variants: where two variants merged,
+  //  hipcc gave the 64 accumulators different registers on the two paths and copied them once per k-tile)
+  auto ktile = [&](auto buf_c, auto dma_c, const int kt) __attribute__((always_inline)) {
+    constexpr int BUF = decltype(buf_c)::value;
+    // (ABL & 32, tuning: the same tile requested a second time from k-step 0 -- twice the bytes in flight; results undefined)
+    kstep(buf_c, std::integral_constant<int, 0>{}, std::integral_constant<bool, (ABL & 32) != 0>{}, kt < nk - 2 ? kt + 2 : kt);
+    publish();                                                   // tile kt + 1 is in image BUF ^ 1; image BUF is free
+    if ((ktail & 3) != 0 && kt + 2 == nk) clean_tail(BUF ^ 1);
+    kstep(buf_c, std::integral_constant<int, 1>{}, dma_c, kt + 2);
+  };
+
+  // ---- prologue: tiles 0 and 1 requested together; the fragments of k-step (0, 0) are read and split with nothing to hide behind
+  if (nk > 0) {
+#pragma unroll
+    for (int r = 0; r < QREQ + PREQ; ++r) issue_one(0, 0, r);
+    if (nk > 1) {
+#pragma unroll
+      for (int r = 0; r < QREQ + PREQ; ++r) issue_one(1, 1, r);
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(QREQ + PREQ) : "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    if ((ktail & 3) != 0 && nk == 1) clean_tail(0);
+#pragma unroll
+    for (int i = 0; i < 2 * MT + 6; ++i) frag_read(std::integral_constant<int, 0>{}, smem, 0, i);
+    if constexpr (!(ABL & 2)) {
+#pragma unroll
+      for (int o = 0; o < 44 * MT; ++o) split_op(qf[0], o / 44, o % 44);
+    } else {
+#pragma unroll
+      for (int a2 = 0; a2 < MT; ++a2) { qf[0][a2][0] = __builtin_bit_cast(u32x4, raw[a2][0]); qf[0][a2][1] = __builtin_bit_cast(u32x4, raw[a2][1]); qf[0][a2][2] = qf[0][a2][0] ^ qf[0][a2][1]; }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    DMA128_MARK(1);
+    using B0 = std::integral_constant<int, 0>;
+    using B1 = std::integral_constant<int, 1>;
+    constexpr bool DMA_ON = !(ABL & 1);
+    using DY = std::integral_constant<bool, DMA_ON>;
+    using DN = std::false_type;
+    int kt = 0;
+    // steady pairs: both tiles have a tile two ahead to request
+#pragma nounroll
+    for (; kt + 3 < nk; kt += 2) {
+      ktile(B0{}, DY{}, kt);
+      ktile(B1{}, DY{}, kt + 1);
+    }
+    // the last one to three tiles, straight line
+    if (kt + 2 < nk) { ktile(B0{}, DY{}, kt); ktile(B1{}, DN{}, kt + 1); ktile(B0{}, DN{}, kt + 2); }
+    else if (kt + 1 < nk) { ktile(B0{}, DN{}, kt); ktile(B1{}, DN{}, kt + 1); }
+    else ktile(B0{}, DN{}, kt);
   }
 
   DMA128_MARK(2);

@@ -1005,7 +1005,7 @@ int nacf_vocab_argmax(const float* hidden, int64_t ldh, const float* W, int64_t 
   const int mode = gemm_mode();
   if (mode != NACF_GEMM_F32 && vec) find_image(W, ldw, V, K, mode, g);
   // the DMA-fed exact-mode kernel (gemm_dma128.hpp) emits its partials per 128-column tile
-  const int d128 = (mode == NACF_GEMM_BF16X3 && vec) ? dma128_pick(g, 1, rs != nullptr, 3) : 0;
+  const int d128 = (mode == NACF_GEMM_BF16X3 && vec) ? dma128_pick(g, 1, rs != nullptr, 3, 2) : 0;
   const int tn = cdiv(V, (d128 || tile == 0) ? 128 : 64);
   EpiArgmax epi;
   epi.bias = bias;
@@ -1051,7 +1051,7 @@ int nacf_vocab_lse_fwd(const float* hidden, int64_t ldh, const float* W, int64_t
   hipStream_t s = as_hip(stream);
   const int mode = gemm_mode();
   if (mode != NACF_GEMM_F32 && vec) find_image(W, ldw, V, K, mode, g);
-  const int d128 = (mode == NACF_GEMM_BF16X3 && vec) ? dma128_pick(g, 1, rs != nullptr, 3) : 0;
+  const int d128 = (mode == NACF_GEMM_BF16X3 && vec) ? dma128_pick(g, 1, rs != nullptr, 3, 2) : 0;
   const int tn = cdiv(V, (d128 || tile == 0) ? 128 : 64);
   EpiArgmax epi;
   epi.bias = bias;

@@ -2,6 +2,7 @@
 // it and the 128x128 / 64x64 kernels, and the grouped launch of independent problems (the two encoder streams).
 #undef NACF_GEMM_TRACE
 #undef NACF_BF16_TRACE
+#define NACF_PHILOX_MULHI 1      // common.hpp: this unit keeps the mul_hi / mul_lo form of the Philox round
 #include <vector>
 #include <mutex>
 #include "gemm_bf16_launch.hpp"

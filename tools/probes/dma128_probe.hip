@@ -117,11 +117,47 @@ int main(int argc, char** argv) {
            name, tt[reps / 2] * 1e3, fl / (tt[reps / 2] * 1e-3) * 1e-12, pro / n, loop / n, loop / n / nk, 768 * DMT, epi / n, (double)(tmax - tmin) / 1000.0);
   };
   variant("dma128", dma128::gemm_dma128_kernel<DMT, EpiStore, 0>);
-  variant("dma128, no phases / priorities", dma128::gemm_dma128_kernel<DMT, EpiStore, 16>);
   variant("dma128, no DMA in loop", dma128::gemm_dma128_kernel<DMT, EpiStore, 1>);
   variant("dma128, no split", dma128::gemm_dma128_kernel<DMT, EpiStore, 2>);
   variant("dma128, no DMA, no split", dma128::gemm_dma128_kernel<DMT, EpiStore, 3>);
   variant("dma128, no MFMA", dma128::gemm_dma128_kernel<DMT, EpiStore, 4>);
-  variant("dma128, DMA + barrier only", dma128::gemm_dma128_kernel<DMT, EpiStore, 14>);
+  variant("dma128, no MFMA, no split", dma128::gemm_dma128_kernel<DMT, EpiStore, 6>);
+  // ---- the FFN1 epilogue (bias, gelu_new, pre-activation store, dropout, residual-free) and the projection epilogue (bias, dropout,
+  //      residual): old kernel vs this one, with the phase stamps
+  {
+    float *bias, *pre, *res; uint64_t* rng;
+    CK(hipMalloc(&bias, N * 4)); CK(hipMalloc(&pre, (size_t)M * ldc * 4)); CK(hipMalloc(&res, (size_t)M * ldc * 4)); CK(hipMalloc(&rng, 16));
+    CK(hipMemset(bias, 0, N * 4)); CK(hipMemset(res, 0, (size_t)M * ldc * 4));
+    uint64_t hr[2] = {1234, 7}; CK(hipMemcpy(rng, hr, 16, hipMemcpyHostToDevice));
+    for (int kind = 0; kind < 2; ++kind) {
+      EpiLinear el; memset(&el, 0, sizeof(el));
+      el.Y = C1; el.ldy = ldc; el.vec_out = 1; el.vec_bias = 1;
+      el.ep.bias = bias; el.ep.rng_state = rng;
+      if (kind == 0) { el.ep.act = NACF_ACT_GELU_NEW; el.ep.preact = pre; el.ep.ld_preact = ldc; el.ep.p_drop1 = 0.5f; el.ep.salt1 = 3; }
+      else { el.ep.act = NACF_ACT_NONE; el.ep.p_drop1 = 0.5f; el.ep.salt1 = 3; el.ep.residual = res; el.ep.ld_residual = ldc; }
+      auto ko = gemm_bf16_kernel<128, 128, SRC_F32_KC, SRC_BF16_KC, 3, 3, EpiLinear>;
+      CK(hipFuncSetAttribute(reinterpret_cast<const void*>(ko), hipFuncAttributeMaxDynamicSharedMemorySize, (int)old_lds));
+      auto ko64 = gemm_bf16_kernel<64, 64, SRC_F32_KC, SRC_BF16_KC, 3, 2, EpiLinear>;
+      constexpr size_t old_lds64 = (size_t)gemm_bf16_lds_chunks<64, 64, 3, 2, false>() * 16;
+      CK(hipFuncSetAttribute(reinterpret_cast<const void*>(ko64), hipFuncAttributeMaxDynamicSharedMemorySize, (int)old_lds64));
+      GemmShape g64 = g; g64.tiles_m = (M + 63) / 64; g64.tiles_n = (N + 63) / 64;
+      auto kn = dma128::gemm_dma128_kernel<DMT, EpiLinear, 0>;
+      CK(hipFuncSetAttribute(reinterpret_cast<const void*>(kn), hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES));
+      std::vector<float> ta, tb, tc;
+      for (int r = 0; r < reps; ++r) {
+        float ms;
+        CK(hipEventRecord(a)); hipLaunchKernelGGL(ko, dim3(g0.tiles_m * g0.tiles_n), dim3(256), old_lds, 0, g0, el); CK(hipEventRecord(b)); CK(hipEventSynchronize(b)); CK(hipEventElapsedTime(&ms, a, b)); ta.push_back(ms);
+        CK(hipEventRecord(a)); hipLaunchKernelGGL(ko64, dim3(g64.tiles_m * g64.tiles_n), dim3(256), old_lds64, 0, g64, el); CK(hipEventRecord(b)); CK(hipEventSynchronize(b)); CK(hipEventElapsedTime(&ms, a, b)); tc.push_back(ms);
+        CK(hipEventRecord(a)); hipLaunchKernelGGL(kn, dim3(nwg1), dim3(256), G::LDS_BYTES, 0, g1, el); CK(hipEventRecord(b)); CK(hipEventSynchronize(b)); CK(hipEventElapsedTime(&ms, a, b)); tb.push_back(ms);
+      }
+      std::sort(ta.begin(), ta.end()); std::sort(tb.begin(), tb.end()); std::sort(tc.begin(), tc.end());
+      std::vector<unsigned long long> h(4 * (size_t)std::min(nwg1, 8192));
+      CK(hipMemcpy(h.data(), tr, h.size() * 8, hipMemcpyDeviceToHost));
+      double pro = 0, loop = 0, epi = 0; const int n = (int)h.size() / 4;
+      for (int i = 0; i < n; ++i) { pro += h[4 * i + 1] - h[4 * i]; loop += h[4 * i + 2] - h[4 * i + 1]; epi += h[4 * i + 3] - h[4 * i + 2]; }
+      printf("  EpiLinear %s: old 128x128 %.1f us, old 64x64 %.1f us, dma128 %.1f us | dma128 per workgroup: prologue %.0f, loop %.0f, epilogue %.0f\n",
+             kind == 0 ? "gelu + preact + dropout" : "dropout + residual", ta[reps / 2] * 1e3, tc[reps / 2] * 1e3, tb[reps / 2] * 1e3, pro / n, loop / n, epi / n);
+    }
+  }
   return 0;
 }
