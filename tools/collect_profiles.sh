@@ -8,12 +8,15 @@ OUT=$ROOT/gpurun_out/profiles_$R
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 # 1. the bench line itself (default flags)
-python $ROOT/bench.py > $OUT/${R}_bench.json 2> $OUT/bench.err
+python $ROOT/bench.py > $OUT/${R}_bench_line.json 2> $OUT/bench.err      # the driver's (compact) line
+cp $ROOT/gpurun_out/bench_full.json $OUT/${R}_bench.json                      # the full record of the same run
 # 2. rocprofv3 kernel stats of the same command
-rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_stats -o b -- python $ROOT/bench.py > $OUT/${R}_bench_under_rocprof.json 2> /dev/null
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_stats -o b -- python $ROOT/bench.py > /dev/null 2> /dev/null
+cp $ROOT/gpurun_out/bench_full.json $OUT/${R}_bench_under_rocprof.json
 cp /tmp/prof_stats/b_kernel_stats.csv $OUT/${R}_bench_kernel_stats.csv
 # 2b. the training leg alone: every launch of a kernel class then has the shapes the bench's roofline object times
-rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_train -o b -- python $ROOT/bench.py --no-decode --no-compare --no-cpu-baseline --no-loader > $OUT/${R}_train_only_bench.json 2> /dev/null
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_train -o b -- python $ROOT/bench.py --no-decode --no-compare --no-cpu-baseline --no-loader > /dev/null 2> /dev/null
+cp $ROOT/gpurun_out/bench_full.json $OUT/${R}_train_only_bench.json
 cp /tmp/prof_train/b_kernel_stats.csv $OUT/${R}_train_only_kernel_stats.csv
 # 3. HBM traffic counters, separate passes (FETCH_SIZE and WRITE_SIZE do not fit one pass)
 for c in FETCH_SIZE WRITE_SIZE; do
