@@ -357,9 +357,13 @@ int nacf_bn_sync_stat(const float* x, int rows, int D, const float* sum_global, 
  * with two nacf_bn_sync_stat calls (the second with its local sum and local row count), the ranks all-GATHER the
  * [2][n_mod][D] vectors, and this merges them exactly about the global mean (parallel-variance formula, ranks in fixed
  * order): out [2][n_mod][D] = (global sum | global squared deviations), the operands of nacf_bn_concat_fwd_sync.
- * gathered: [world][2][n_mod][D]; rows_per_rank: HOST array [n_mod] (every rank holds the same number of rows). */
-int nacf_bn_sync_merge(const float* gathered, int world, int n_mod, int D, const float* rows_per_rank, float* out,
-                       nacf_stream_t stream);
+ * gathered: [world][rank_stride] floats, rank r's [2][n_mod][D] statistics first; rows_per_rank: HOST array [n_mod] (every
+ * rank must hold the same number of rows).  rank_stride >= 2 n_mod D + n_mod: the n_mod floats behind a rank's statistics are
+ * the row counts IT holds (they travel in the same all-gather); a rank whose count differs from rows_per_rank makes the merged
+ * statistics NaN (the step fails on every rank at once, no extra collective, no host read) and sets *ragged_flag (optional
+ * device int32, sticky) for the host to read at its next sync point.  rank_stride == 2 n_mod D: no check. */
+int nacf_bn_sync_merge(const float* gathered, int world, int n_mod, int D, const float* rows_per_rank, int64_t rank_stride, float* out,
+                       int32_t* ragged_flag, nacf_stream_t stream);
 /* The local halves of the data-parallel statistics for every modality at once:
  * nacf_bn_sync_local_multi      loc  [2][n_mod][D] = (sum | squared deviations about this rank's OWN mean) -- gathered by
  *                               the ranks and merged by nacf_bn_sync_merge (3 launches instead of 4 per modality);

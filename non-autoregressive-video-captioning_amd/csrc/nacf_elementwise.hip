@@ -442,21 +442,33 @@ __global__ void bn_fold_multi_kernel(BnFold t, int D, float beta) {
 // data-parallel BatchNorm, forward statistics from ONE exchange: every rank contributes (sum, squared deviations about its
 // OWN mean) of its rows; the parallel-variance merge (Chan et al.) is exact about the global mean:
 //   S = sum_i s_i,  mean = S / N,  Q = sum_i [ q_i + n_i (s_i / n_i - mean)^2 ]        (ranks in fixed order)
-// gathered: [world][2][n_mod][D]; out: [2][n_mod][D] = (S | Q), what nacf_bn_concat_fwd_sync consumes
+// gathered: [world][rank_stride] with rank r's (S_r | Q_r) = [2][n_mod][D] first; out: [2][n_mod][D] = (S | Q), what
+// nacf_bn_concat_fwd_sync consumes.  rank_stride >= 2 n_mod D + n_mod: the n_mod floats behind a rank's statistics are ITS row
+// counts, which travelled in the same all-gather -- every rank must hold rows.n[mod] rows (the merge and the normalisation use
+// n x world).  A rank that does not (a ragged global batch) turns the merged statistics into NaN -- the step's loss is NaN on
+// every rank, at once, with no extra collective and no host read -- and raises *flag (read by the host at its next sync point).
 struct BnMergeN { float n[BN_MAX_MODS]; };
-__global__ void bn_sync_merge_kernel(const float* __restrict__ gathered, int world, int n_mod, int D, BnMergeN rows,
-                                     float* __restrict__ out) {
+__global__ void bn_sync_merge_kernel(const float* __restrict__ gathered, int world, int n_mod, int D, BnMergeN rows, int64_t rank_stride,
+                                     float* __restrict__ out, int* __restrict__ flag) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   const int C = n_mod * D;
   if (c >= C) return;
-  const float n = rows.n[c / D];
+  const int mod = c / D;
+  const float n = rows.n[mod];
+  bool ragged = false;
+  if (rank_stride >= 2 * (int64_t)C + n_mod)
+    for (int r = 0; r < world; ++r) ragged = ragged || gathered[(int64_t)r * rank_stride + 2 * C + mod] != n;
   float S = 0.f;
-  for (int r = 0; r < world; ++r) S += gathered[(int64_t)r * 2 * C + c];
+  for (int r = 0; r < world; ++r) S += gathered[(int64_t)r * rank_stride + c];
   const float mean = S / (n * (float)world);
   float Q = 0.f;
   for (int r = 0; r < world; ++r) {
-    const float dm = gathered[(int64_t)r * 2 * C + c] / n - mean;
-    Q += gathered[(int64_t)r * 2 * C + C + c] + n * dm * dm;
+    const float dm = gathered[(int64_t)r * rank_stride + c] / n - mean;
+    Q += gathered[(int64_t)r * rank_stride + C + c] + n * dm * dm;
+  }
+  if (ragged) {
+    S = Q = __builtin_nanf("");
+    if (flag && c == mod * D) atomicOr(flag, 1);
   }
   out[c] = S;
   out[C + c] = Q;
@@ -1241,8 +1253,8 @@ int nacf_bn_sync_bwd_local_multi(int n_mod, const float* dOut, const float* cons
   return NACF_OK;
 }
 
-int nacf_bn_sync_merge(const float* gathered, int world, int n_mod, int D, const float* rows_per_rank, float* out,
-                       nacf_stream_t stream) {
+int nacf_bn_sync_merge(const float* gathered, int world, int n_mod, int D, const float* rows_per_rank, int64_t rank_stride, float* out,
+                       int32_t* ragged_flag, nacf_stream_t stream) {
   NACF_CHECK(gathered && out && rows_per_rank && world >= 1 && n_mod >= 1 && n_mod <= BN_MAX_MODS && D > 0, NACF_EINVAL,
              "nacf_bn_sync_merge: bad argument");
   BnMergeN rows = {};
@@ -1250,8 +1262,9 @@ int nacf_bn_sync_merge(const float* gathered, int world, int n_mod, int D, const
     NACF_CHECK(rows_per_rank[i] >= 1.f, NACF_EINVAL, "nacf_bn_sync_merge: a modality without rows");
     rows.n[i] = rows_per_rank[i];
   }
+  NACF_CHECK(rank_stride >= 2 * (int64_t)n_mod * D, NACF_EINVAL, "nacf_bn_sync_merge: rank stride shorter than the statistics");
   hipLaunchKernelGGL(bn_sync_merge_kernel, dim3(cdiv(n_mod * D, 256)), dim3(256), 0, as_hip(stream), gathered, world, n_mod, D, rows,
-                     out);
+                     rank_stride, out, ragged_flag);
   NACF_LAUNCH_CHECK("nacf_bn_sync_merge");
   return NACF_OK;
 }

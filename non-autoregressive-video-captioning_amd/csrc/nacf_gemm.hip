@@ -608,7 +608,16 @@ static int dw_items_launch_locked(hipStream_t s) {
   if (n_all == 0) return NACF_OK;
   // (round 3 also had a one-workgroup-per-CU member for this launch, 128 x 256 tiles on the wide kernel's geometry with both
   //  operands through the transposing stager: +23 % on one long problem, +-0 on the step's mix -- DESIGN.md section 4; removed)
-  if (g256_dw_enabled(gemm_mode())) {
+  // the g256 body builds 32-bit request offsets as row * (ld * 4) + column part with a 24-bit multiply (gemm_g256w.hpp: stage): an
+  // operand of 2^24 rows, a row pitch of 2^24 bytes or 4 GiB in all would wrap -- such a group takes the 128 x 128 grouped kernel
+  bool g256_fits = true;
+  for (const DwGemmItem& it : g_dw_items) {
+    const uint64_t ra = (uint64_t)it.lddz * 4u, rb = (uint64_t)it.ldx * 4u;
+    if ((uint64_t)it.M >= (1u << 24) || ra >= (1u << 24) || rb >= (1u << 24) || (uint64_t)it.M * ra >= 0xfffffff0ull ||
+        (uint64_t)it.M * rb >= 0xfffffff0ull)
+      g256_fits = false;
+  }
+  if (g256_fits && g256_dw_enabled(gemm_mode())) {
     // bf16 matrix cores: the 256 x 256 eight-phase body on the fp32 operands, live-row gather in its DMA (nacf_gemm_g256.hip)
     std::vector<G256DwItem> gi(n_all);
     for (int i = 0; i < n_all; ++i) {

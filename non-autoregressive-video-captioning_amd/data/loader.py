@@ -116,6 +116,11 @@ class ShardLoader:
                 self.n_built = 0
                 # whole clips out of pinned memory: "kernel" = kernel-issued PCIe reads, "dma" = one hipMemcpyAsync per clip
                 self.clip_copy = opt.get("loader_clip_copy", os.environ.get("NACF_LOADER_CLIP_COPY", "kernel"))
+                if self.clip_copy not in ("kernel", "dma"):
+                    raise ValueError("loader_clip_copy must be 'kernel' or 'dma', not %r" % (self.clip_copy,))
+                # nacf_gather_clips_zc moves 16-byte packets: a shard whose clips are not a multiple of 16 bytes takes the per-clip DMA
+                if self.clip_copy == "kernel" and any((int(s_.T) * int(s_.D) * 4) % 16 != 0 for s_ in self.shards):
+                    self.clip_copy = "dma"
                 self.clip_copy_wgs = int(opt.get("loader_clip_copy_wgs", os.environ.get("NACF_LOADER_CLIP_COPY_WGS", "24")))
             else:
                 self.pinned = [[torch.empty(self.B, s.T, s.D, dtype=torch.float32).pin_memory() for s in self.shards]

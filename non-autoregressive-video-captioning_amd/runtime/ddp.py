@@ -92,13 +92,31 @@ class DataParallel(object):
         else:                       # gloo (CPU tests)
             dist.all_gather(list(out.unbind(0)), t, group=self.group)
 
+    def ragged_flag(self, device):
+        """device int32[1], sticky: set by nacf_bn_sync_merge when a rank's row count (it travels inside the statistics' own
+        all-gather) differs from this rank's -- the merged statistics of that step are NaN on every rank; read at the sampled
+        host checks below and by raise_if_ragged()"""
+        f = getattr(self, '_ragged_flag', None)
+        if f is None or f.device != device:
+            f = self._ragged_flag = torch.zeros(1, dtype=torch.int32, device=device)
+        return f
+
+    def raise_if_ragged(self):
+        """host read of the sticky flag (a sync point: call it where the host reads the device anyway, e.g. with the meters)"""
+        f = getattr(self, '_ragged_flag', None)
+        if f is not None and int(f.item()) != 0:
+            raise RuntimeError('nacf_amd: SyncBN saw ranks with different row counts (a ragged global batch): the statistics of '
+                               'that step were NaN on every rank; shard the global batch evenly (runtime/ddp.py:shard_range)')
+
     def assert_equal_rows(self, n_rows, what='SyncBN'):
         """SyncBN forms the global statistics as if every rank held `n_rows` rows (runtime/functional.py:BNConcatFn: n_tot =
         rows x world; the reference's single process has one batch): a ragged global batch must fail loudly, not normalise
-        with the wrong count.  The check is a blocking all-reduce plus a host read, so it runs on the first four
-        launch-by-launch calls and on every 64th after that -- a schedule that depends only on the CALL COUNT,
-        which is the same on every rank: ranks that disagree about the rows still all reach the collective.  Never inside a
-        stream capture (a captured step has the shapes of the eager steps before it)."""
+        with the wrong count.  EVERY step is guarded on the device: the row counts travel inside the statistics' all-gather and
+        nacf_bn_sync_merge turns the merged statistics into NaN when they differ (no sampling of the contract).
+        This host-side check only adds the descriptive error: a blocking all-reduce plus a host read, on the first four
+        launch-by-launch calls and on every 64th after that -- a schedule that depends only on the CALL COUNT, which is the same
+        on every rank, so ranks that disagree about the rows still all reach the collective -- and it reads the sticky device
+        flag then.  Never inside a stream capture (a captured step has the shapes of the eager steps before it)."""
         if self.world == 1 or not dist.is_initialized():
             return
         if torch.cuda.is_available() and torch.cuda.is_current_stream_capturing():
@@ -106,6 +124,7 @@ class DataParallel(object):
         self._rows_calls = getattr(self, '_rows_calls', 0) + 1
         if self._rows_calls > 4 and self._rows_calls % 64 != 0:
             return
+        self.raise_if_ragged()
         dev = self.model.flat.data.device if hasattr(self.model, 'flat') else torch.device('cpu')
         t = torch.tensor([n_rows, -n_rows], dtype=torch.int64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)

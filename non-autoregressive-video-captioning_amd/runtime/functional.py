@@ -183,12 +183,21 @@ class BNConcatFn(Function):
         if sync is not None:
             stats = _new((2, n_mod, D), xs[0])
             n_tot = [x.shape[0] * x.shape[1] * sync.world for x in xs]      # every rank holds the same number of rows:
-            if hasattr(sync, "assert_equal_rows"):                          # ... checked on the first calls and periodically (runtime/ddp.py)
-                sync.assert_equal_rows(xs[0].shape[0] * xs[0].shape[1])
+            if hasattr(sync, "assert_equal_rows"):                          # ... a descriptive error on the first calls and periodically
+                sync.assert_equal_rows(xs[0].shape[0] * xs[0].shape[1])     #     (runtime/ddp.py); EVERY step is guarded on the device, below
             if getattr(sync, "all_gather", None) is not None and _SYNC_BN_ONE_EXCHANGE:
-                # one exchange: (sum | squared deviations about the rank's OWN mean) gathered, merged exactly
+                # one exchange: (sum | squared deviations about the rank's OWN mean | this rank's row counts) gathered, merged
+                # exactly.  The counts ride in the same vector: a ragged global batch makes the merged statistics NaN on every
+                # rank in that very step (nacf_bn_sync_merge) -- no extra collective, no host read
                 n_loc = [x.shape[0] * x.shape[1] for x in xs]
-                loc = _new((2, n_mod, D), xs[0])
+                C2 = 2 * n_mod * D
+                key = (tuple(n_loc), D, str(xs[0].device))
+                ext = cfg.setdefault("_sync_loc", {}).get(key)
+                if ext is None:          # persistent: the count tail is written once, the statistics every step (hipGraph-safe)
+                    ext = torch.zeros(C2 + n_mod, dtype=xs[0].dtype, device=xs[0].device)
+                    ext[C2:] = torch.tensor([float(v) for v in n_loc], dtype=xs[0].dtype)
+                    cfg["_sync_loc"][key] = ext
+                loc = ext[:C2].view(2, n_mod, D)
                 if multi:
                     ops.bn_sync_local_multi(xs, loc)
                 else:
@@ -196,9 +205,9 @@ class BNConcatFn(Function):
                         ops.bn_sync_stat(x, None, n_loc[i], loc[0, i])
                     for i, x in enumerate(xs):
                         ops.bn_sync_stat(x, loc[0, i], n_loc[i], loc[1, i])
-                gathered = _new((sync.world, 2, n_mod, D), xs[0])
-                sync.all_gather(gathered, loc)
-                ops.bn_sync_merge(gathered, n_loc, stats)
+                gathered = _new((sync.world, C2 + n_mod), xs[0])
+                sync.all_gather(gathered, ext)
+                ops.bn_sync_merge(gathered, n_loc, stats, getattr(sync, "ragged_flag", lambda d: None)(xs[0].device))
             else:
                 for i, x in enumerate(xs):
                     ops.bn_sync_stat(x, None, n_tot[i], stats[0, i])

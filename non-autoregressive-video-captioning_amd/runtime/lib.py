@@ -89,7 +89,7 @@ SIGNATURES = {
     "nacf_bn_workspace": (_S, [_I, _I]),
     "nacf_bn_concat_fwd": (c_int, [_P, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _I, _F, _F, _P, _S, _P]),
     "nacf_bn_concat_bwd": (c_int, [_P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _F, _P, _S, _P]),
-    "nacf_bn_sync_merge": (c_int, [_P, _I, _I, _I, _P, _P, _P]),
+    "nacf_bn_sync_merge": (c_int, [_P, _I, _I, _I, _P, _L, _P, _P, _P]),
     "nacf_bn_concat_fwd_multi": (c_int, [_I, _P, _P, _I, _P, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _I, _F, _F, _P, _P, _P, _S, _P]),
     "nacf_bn_concat_bwd_multi": (c_int, [_I, _P, _P, _P, _I, _P, _I, _I, _P, _P, _P, _P, _P, _P, _F, _P, _P, _P, _S, _P]),
     "nacf_bn_sync_local_multi": (c_int, [_I, _P, _I, _P, _I, _P, _P, _S, _P]),

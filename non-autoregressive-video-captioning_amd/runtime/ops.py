@@ -734,15 +734,21 @@ def bn_sync_bwd_local_multi(dout, xs, f_offs, save_means, save_invstds, sums, dw
                                              _stream()), "nacf_bn_sync_bwd_local_multi")
 
 
-def bn_sync_merge(gathered, rows_per_rank, out):
-    """gathered [world, 2, n_mod, D] of per-rank (sum | squared deviations about the rank's own mean) -> out [2, n_mod, D]
-    (global sum | squared deviations about the global mean); see nacf_bn_sync_merge"""
+def bn_sync_merge(gathered, rows_per_rank, out, ragged_flag=None):
+    """gathered [world, 2, n_mod, D] (or flat [world, 2*n_mod*D + n_mod]: every rank's row counts behind its statistics) of per-rank
+    (sum | squared deviations about the rank's own mean) -> out [2, n_mod, D] (global sum | squared deviations about the global
+    mean); with the counts, a rank holding another number of rows than rows_per_rank turns `out` into NaN and sets
+    ragged_flag (device int32[1]); see nacf_bn_sync_merge"""
     import ctypes
     _chk_f32(gathered, out)
-    world, two, n_mod, D = gathered.shape
-    assert two == 2 and out.shape == (2, n_mod, D) and gathered.is_contiguous() and out.is_contiguous()
+    two, n_mod, D = out.shape
+    world = gathered.shape[0]
+    assert two == 2 and gathered.is_contiguous() and out.is_contiguous()
+    stride = gathered.numel() // world
+    assert stride in (2 * n_mod * D, 2 * n_mod * D + n_mod), (tuple(gathered.shape), tuple(out.shape))
     rows = (ctypes.c_float * n_mod)(*[float(r) for r in rows_per_rank])
-    L.check(L.load().nacf_bn_sync_merge(_ptr(gathered), world, n_mod, D, rows, _ptr(out), _stream()), "nacf_bn_sync_merge")
+    L.check(L.load().nacf_bn_sync_merge(_ptr(gathered), world, n_mod, D, rows, stride, _ptr(out), _ptr(ragged_flag), _stream()),
+            "nacf_bn_sync_merge")
 
 
 def bn_sync_stat(x, sum_global, n_total, out):

@@ -116,6 +116,7 @@ class FlatParams:
             self.image_epoch += 1
         self.images.refresh()
         self.images_version = self.version
+        self._images_tensor_version = self.data._version
 
     def _retire_images(self) -> None:
         self.images.close()                          # unregister: no new launch finds them
@@ -130,11 +131,16 @@ class FlatParams:
     def ensure_images(self) -> None:
         """entry points that run GEMMs WITHOUT going through Seq2Seq.encode (a direct model.decoder(...) /
         vocab_logprobs / Translator call on cached encoder outputs): rebuild the images if the weights changed since
-        they were built.  Writes that bypass this package (`p.data.mul_(..)`) are not seen: call model.flat.touch()."""
+        they were built (FlatParams.version, or the flat tensor's autograd version for writes made with torch ops)."""
         from . import ops
         if not self.data.is_cuda or torch.cuda.is_current_stream_capturing():
             return
-        stale = self.images is None or self.images.ns != ops.gemm_mode() or self.images_version != self.version
+        # writes that bypass this package (torch.optim on model.parameters(), p.data.copy_, nn.init, an EMA swap, a sub-module
+        # load_state_dict) are seen through the flat tensor's autograd version counter, which every parameter view shares:
+        # an O(1) host check (ADVICE round 5).  The library's own kernels write through raw pointers: those call touch().
+        tv = self.data._version
+        stale = (self.images is None or self.images.ns != ops.gemm_mode() or self.images_version != self.version
+                 or getattr(self, '_images_tensor_version', None) != tv)
         if stale if ops.gemm_mode() != 0 else self.images is not None:      # (fp32 mode: an existing image set is retired, as at a forward entry)
             self.sync_images()
 

@@ -1026,6 +1026,18 @@ def test_sync_bn_kernels_equal_the_global_batch(dev, B, Fr, D, world):
     Q64 = ((x64 - x64.mean(0)) ** 2).sum(0)
     assert err(merged[0, 0], S) <= 2e-6 * float(S.abs().max())
     assert err(merged[1, 0], Q64) <= 3e-6 * float(Q64.max()) and err(Q, Q64) <= 3e-6 * float(Q64.max())
+    # the row counts travel behind every rank's statistics: equal counts merge to the same bits and leave the flag alone; a rank with
+    # another count (a ragged global batch) turns the merged statistics into NaN and raises the sticky flag
+    C2 = 2 * D
+    ext = torch.zeros(world, C2 + 1, device=dev)
+    ext[:, :C2] = gathered.view(world, C2)
+    ext[:, C2] = float(n_loc)
+    merged2, flag = torch.empty(2, 1, D, device=dev), torch.zeros(1, dtype=torch.int32, device=dev)
+    ops.bn_sync_merge(ext, [n_loc], merged2, flag)
+    assert torch.equal(merged2, merged) and int(flag.item()) == 0
+    ext[1, C2] = float(n_loc - 3)
+    ops.bn_sync_merge(ext, [n_loc], merged2, flag)
+    assert bool(torch.isnan(merged2).all()) and int(flag.item()) == 1
     S, Q = merged[0, 0].clone(), merged[1, 0].clone()               # what the ranks apply from here on
     outs, saves, stats = [], [], []
     for r in range(world):
