@@ -52,8 +52,8 @@ LIMITER_128 = ("LDS bandwidth: per 128x128 k-tile a workgroup reads 96 KB of bf1
                "the kernel is priced against, not a saturated unit")
 LIMITER_G256W = ("the operand split: a k-tile of 32 reduce rows is 192 v_mfma_f32_16x16x32_bf16 per wave (3360 cycles at the measured ~17.5 per "
                  "instruction, two waves per SIMD) against ~530 vector instructions per wave that cut the fp32 LDS image into three bf16 planes at "
-                 "fragment time (every wave for its own fragments) plus 4 barriers and 8 DMA requests; SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE x 1024 SIMDs) "
-                 "= 56 % over the whole launch, 3.1 other vector instructions per matrix instruction, no LDS bank conflict (profiles/r05_dw_g256_pmc.txt) "
+                 "fragment time (every wave for its own fragments) plus 4 barriers and 8 DMA requests; SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 XCDs x 1024 SIMDs) "
+                 "= 45 % over the whole launch (49-54 % in-loop), 3.1 other vector instructions per matrix instruction, no LDS bank conflict (profiles/r05_dw_g256_pmc.txt) "
                  "(204-224 TF of 416.7 on a 4096 cube, tools/probes/gemm256w_probe.hip; ablations in profiles/r05_g256w_ablation.txt); a grouped "
                  "launch adds the ragged last round of its 12 problems and the slab combine")
 LIMITER_DMA64 = ("launch latency and fp32 outputs, not the matrix pipe: a launch of <= 768 tiles of 32 x 64 is 2-12 GFLOP (1-5 us of the chip's "

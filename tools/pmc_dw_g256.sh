@@ -24,8 +24,26 @@ for r in csv.DictReader(open(sys.argv[1])):
     if "g256_dw_group_kernel" in r["Kernel_Name"]:
         agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
 for k, v in agg.items():
-    print("  %-28s avg over %d launches  %.4g" % (k, len(v), sum(v) / len(v)))
+    live = [x for x in v if x > 0] or v        # (warm-up launches of an empty set count nothing: not part of the average)
+    print("  %-28s avg over %d launches  %.4g" % (k, len(live), sum(live) / len(live)))
 PY
   done
 done
+# matrix-pipe share of the whole launch, tools/pmc_gemm_summary.py's convention: GRBM_GUI_ACTIVE is summed over the 8 XCDs
+python - $OUT >> $OUT <<'PY'
+import re, sys
+mode, vals = None, {}
+for line in open(sys.argv[1]):
+    m = re.match(r"== mode (\S+)", line)
+    if m:
+        mode = m.group(1); vals[mode] = {}
+        continue
+    m = re.match(r"\s+(\S+)\s+avg over \d+ launches\s+(\S+)", line)
+    if m and mode:
+        vals[mode][m.group(1)] = float(m.group(2))
+for mode, v in vals.items():
+    if "SQ_VALU_MFMA_BUSY_CYCLES" in v and "GRBM_GUI_ACTIVE" in v:
+        print("# %s: matrix pipe busy %.1f %% of the launch = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 x 1024 SIMDs)"
+              % (mode, 100.0 * v["SQ_VALU_MFMA_BUSY_CYCLES"] / (v["GRBM_GUI_ACTIVE"] / 8.0 * 1024.0)))
+PY
 cat $OUT
