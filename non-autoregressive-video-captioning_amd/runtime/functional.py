@@ -192,11 +192,12 @@ class BNConcatFn(Function):
                 n_loc = [x.shape[0] * x.shape[1] for x in xs]
                 C2 = 2 * n_mod * D
                 key = (tuple(n_loc), D, str(xs[0].device))
-                ext = cfg.setdefault("_sync_loc", {}).get(key)
+                cache = sync.__dict__.setdefault("_bn_loc_cache", {})      # (the cfg dict is rebuilt every forward; `sync` lives with the model)
+                ext = cache.get(key)
                 if ext is None:          # persistent: the count tail is written once, the statistics every step (hipGraph-safe)
                     ext = torch.zeros(C2 + n_mod, dtype=xs[0].dtype, device=xs[0].device)
                     ext[C2:] = torch.tensor([float(v) for v in n_loc], dtype=xs[0].dtype)
-                    cfg["_sync_loc"][key] = ext
+                    cache[key] = ext
                 loc = ext[:C2].view(2, n_mod, D)
                 if multi:
                     ops.bn_sync_local_multi(xs, loc)
