@@ -64,7 +64,7 @@ int nacf_version(void);
  * included).  nacf_abi_count() returns the value the LIBRARY was built with; the ctypes loader
  * (runtime/lib.py:load) refuses a library whose count differs from its own signature table, so a stale
  * libnacf_hip.so next to a newer Python package fails at import time, not at the first missing symbol. */
-#define NACF_ABI_COUNT 89
+#define NACF_ABI_COUNT 91
 int nacf_abi_count(void);
 
 /* ---- batch construction (reference: dataloader.py) ----------------------------------------
@@ -523,6 +523,29 @@ int nacf_loss_combine(const float* slab, int n_terms, int stride, const float* c
                       float* meters, nacf_stream_t stream);
 int nacf_loss_combine_bwd(const float* gtotal, const float* coef, int n_terms, int stride, float* gslab,
                           nacf_stream_t stream);
+/* The same tail with its producers folded in: ONE launch forward, ONE backward (misc/crit.py:62-114,214-239 behind the fused
+ * vocabulary loss).  Forward: per pass i < n_pass the five scalars of nacf_nll_reduce over rows[i] rows -> slab[slot[i] * stride ..
+ * + 4]; the legacy KLDivLoss mean of nacf_kldiv_mean over kl_total elements -> slab[kl_slot * stride] (kl_x == NULL: none); then
+ * exactly nacf_loss_combine.  Bit-identical to nacf_nll_reduce(_multi) + nacf_kldiv_mean + nacf_loss_combine.  Backward: gslab as
+ * nacf_loss_combine_bwd, and kl_dx[e] = -kl_t[e] * coef[kl_slot] * gtotal[0] / kl_total (nacf_kldiv_mean's gradient form). */
+typedef struct nacf_crit_tail {
+  int32_t n_pass;                 /* <= 4 */
+  const float* label_logp[4];     /* device, rows[i] entries each */
+  const int64_t* argmax[4];
+  const int64_t* labels[4];
+  int32_t rows[4];
+  int32_t exclude[4];             /* != 0: <mask> labels do not count in the accuracy meter (misc/crit.py:88-90) */
+  int32_t slot[4];                /* term index of pass i in the slab */
+  const float* kl_x;              /* log-probabilities of the length head, or NULL */
+  const float* kl_t;              /* target distribution */
+  int32_t kl_total;               /* elements (the legacy 'mean' divides by all of them) */
+  int32_t kl_slot;
+} nacf_crit_tail;
+int nacf_crit_tail_fwd(const nacf_crit_tail* tail, float* slab, int n_terms, int stride, const float* coef, float* total,
+                       const int32_t* m_dst, const int32_t* m_src, const float* m_scale, int n_meters, float* meters,
+                       nacf_stream_t stream);
+int nacf_crit_tail_bwd(const nacf_crit_tail* tail, const float* gtotal, const float* coef, int n_terms, int stride, float* gslab,
+                       float* kl_dx, nacf_stream_t stream);
 
 /* Reduce per-row results to the scalars the criterion reports:
  * out[0] = -sum_{label!=PAD} logp[label]      (token-SUM NLL, misc/crit.py:82)

@@ -597,6 +597,71 @@ __global__ void loss_combine_bwd_kernel(const float* __restrict__ gtotal, const 
   gslab[i] = (i % stride == 0) ? coef[i / stride] * gtotal[0] : 0.f;
 }
 
+// The whole criterion tail of a step in ONE launch each way (misc/crit.py:62-114,214-239 behind the fused vocabulary loss): per
+// decoding pass the five criterion scalars (nacf_nll_reduce: same thread -> row map and block_sum order, the same bits), the legacy
+// KLDivLoss mean of the length head (nacf_kldiv_mean: 256 threads walk the elements), then the weighted total and the running meters
+// (nacf_loss_combine) -- four single-workgroup launches of 5-10 us each otherwise.
+__global__ __launch_bounds__(1024) void crit_tail_fwd_kernel(nacf_crit_tail t, float* __restrict__ slab, int n_terms, int stride,
+                                                             const float* __restrict__ coef, float* __restrict__ total,
+                                                             const int* __restrict__ m_dst, const int* __restrict__ m_src,
+                                                             const float* __restrict__ m_scale, int n_meters, float* __restrict__ meters) {
+  __shared__ float red[16];
+  for (int pass = 0; pass < t.n_pass; ++pass) {
+    const float* __restrict__ label_logp = t.label_logp[pass];
+    const int64_t* __restrict__ argmax = t.argmax[pass];
+    const int64_t* __restrict__ labels = t.labels[pass];
+    const int exclude_mask = t.exclude[pass];
+    float nll = 0.f, hit = 0.f, cnt = 0.f, sl = 0.f, sc = 0.f;
+    for (int r = threadIdx.x; r < t.rows[pass]; r += blockDim.x) {
+      const int64_t lab = labels[r];
+      if (lab != NACF_PAD) {
+        const float lp = label_logp[r];
+        nll -= lp; sl += lp; sc += 1.f;
+        if (!(exclude_mask && lab == NACF_MASK)) {
+          cnt += 1.f;
+          if (argmax[r] == lab) hit += 1.f;
+        }
+      }
+    }
+    nll = block_sum(nll, red);
+    hit = block_sum(hit, red);
+    cnt = block_sum(cnt, red);
+    sl = block_sum(sl, red);
+    sc = block_sum(sc, red);
+    if (threadIdx.x == 0) {
+      float* out5 = slab + (int64_t)t.slot[pass] * stride;
+      out5[0] = nll; out5[1] = hit; out5[2] = cnt; out5[3] = sl; out5[4] = sc;
+    }
+  }
+  if (t.kl_x) {
+    float acc = 0.f;
+    const float inv = 1.f / (float)t.kl_total;
+    if (threadIdx.x < 256)
+      for (int e = threadIdx.x; e < t.kl_total; e += 256) {
+        const float tt = t.kl_t[e];
+        if (tt > 0.f) acc += tt * (logf(tt) - t.kl_x[e]);
+      }
+    acc = block_sum(acc, red);
+    if (threadIdx.x == 0) slab[(int64_t)t.kl_slot * stride] = acc * inv;
+  }
+  __syncthreads();      // thread 0's slab writes are ITS OWN reads below; the barrier only keeps the phases apart for the reader
+  if (threadIdx.x == 0) {
+    float tot = 0.f;
+    for (int i = 0; i < n_terms; ++i) tot += coef[i] * slab[(int64_t)i * stride];
+    total[0] = tot;
+    for (int j = 0; j < n_meters; ++j) meters[m_dst[j]] += m_scale[j] * slab[m_src[j]];
+  }
+}
+__global__ __launch_bounds__(256) void crit_tail_bwd_kernel(nacf_crit_tail t, const float* __restrict__ gtotal, const float* __restrict__ coef,
+                                                            int n_terms, int stride, float* __restrict__ gslab, float* __restrict__ kl_dx) {
+  for (int i = threadIdx.x; i < n_terms * stride; i += blockDim.x) gslab[i] = (i % stride == 0) ? coef[i / stride] * gtotal[0] : 0.f;
+  if (t.kl_t && kl_dx) {
+    const float inv = 1.f / (float)t.kl_total;
+    const float g = (coef[t.kl_slot] * gtotal[0]) * 1.f;      // (= gscale[0] * scale of nacf_kldiv_mean's backward form)
+    for (int e = threadIdx.x; e < t.kl_total; e += blockDim.x) kl_dx[e] = -t.kl_t[e] * g * inv;
+  }
+}
+
 // ------------------------------------------------------------------ epilogue backward
 // (scalar form for unaligned operands; the same live-row handling as the float4 kernel below: dead rows of dY and of the
 //  pre-activation may be uninitialised under the no-fill policy and must not be read -- ADVICE round 4)
@@ -1415,6 +1480,33 @@ int nacf_loss_combine_bwd(const float* gtotal, const float* coef, int n_terms, i
   hipLaunchKernelGGL(loss_combine_bwd_kernel, dim3(cdiv(n_terms * stride, 64)), dim3(64), 0, as_hip(stream), gtotal, coef,
                      n_terms, stride, gslab);
   NACF_LAUNCH_CHECK("nacf_loss_combine_bwd");
+  return NACF_OK;
+}
+
+int nacf_crit_tail_fwd(const nacf_crit_tail* tail, float* slab, int n_terms, int stride, const float* coef, float* total,
+                       const int32_t* m_dst, const int32_t* m_src, const float* m_scale, int n_meters, float* meters,
+                       nacf_stream_t stream) {
+  NACF_CHECK(tail && slab && coef && total && n_terms > 0 && stride >= 5, NACF_EINVAL, "nacf_crit_tail_fwd: bad argument");
+  NACF_CHECK(n_meters == 0 || (m_dst && m_src && m_scale && meters), NACF_EINVAL, "nacf_crit_tail_fwd: incomplete meter table");
+  NACF_CHECK(tail->n_pass >= 0 && tail->n_pass <= 4, NACF_EINVAL, "nacf_crit_tail_fwd: at most 4 passes");
+  for (int i = 0; i < tail->n_pass; ++i)
+    NACF_CHECK(tail->label_logp[i] && tail->argmax[i] && tail->labels[i] && tail->rows[i] > 0 && tail->slot[i] >= 0 && tail->slot[i] < n_terms,
+               NACF_EINVAL, "nacf_crit_tail_fwd: bad pass %d", i);
+  NACF_CHECK(!tail->kl_x || (tail->kl_t && tail->kl_total > 0 && tail->kl_slot >= 0 && tail->kl_slot < n_terms), NACF_EINVAL,
+             "nacf_crit_tail_fwd: bad length term");
+  hipLaunchKernelGGL(crit_tail_fwd_kernel, dim3(1), dim3(1024), 0, as_hip(stream), *tail, slab, n_terms, stride, coef, total, m_dst,
+                     m_src, m_scale, n_meters, meters);
+  NACF_LAUNCH_CHECK("nacf_crit_tail_fwd");
+  return NACF_OK;
+}
+
+int nacf_crit_tail_bwd(const nacf_crit_tail* tail, const float* gtotal, const float* coef, int n_terms, int stride, float* gslab,
+                       float* kl_dx, nacf_stream_t stream) {
+  NACF_CHECK(tail && gtotal && coef && gslab && n_terms > 0 && stride > 0, NACF_EINVAL, "nacf_crit_tail_bwd: bad argument");
+  NACF_CHECK(!kl_dx || (tail->kl_t && tail->kl_total > 0 && tail->kl_slot >= 0 && tail->kl_slot < n_terms), NACF_EINVAL,
+             "nacf_crit_tail_bwd: bad length term");
+  hipLaunchKernelGGL(crit_tail_bwd_kernel, dim3(1), dim3(256), 0, as_hip(stream), *tail, gtotal, coef, n_terms, stride, gslab, kl_dx);
+  NACF_LAUNCH_CHECK("nacf_crit_tail_bwd");
   return NACF_OK;
 }
 

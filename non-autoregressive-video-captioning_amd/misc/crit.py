@@ -15,6 +15,7 @@ Two input forms:
 Meters accumulate on the device; the host only syncs in get_loss_info().
 """
 import math
+import os
 
 import torch
 
@@ -155,13 +156,16 @@ class Criterion(object):
         S = self._STRIDE
         slab = torch.empty(plan['n_terms'] * S, dtype=torch.float32, device=dev)
         terms = []
+        # the terms' producers leave their reductions to ONE tail launch (nacf_crit_tail_fwd: per-pass criterion scalars + the
+        # length head's KL + the weighted total and the meters; backward: one launch too) -- NACF_CRIT_TAIL=0: a launch each
+        tail = ops.CritTail() if os.environ.get('NACF_CRIT_TAIL', '1') != '0' else None
         both = getattr(hidden, 'both', None)      # the passes are halves of one tensor: project them in one go
         lang_terms = None
         if both is not None and all(labels[i].shape == labels[0].shape for i in range(n_pass)):
             lang_slots = [t for kind, _, t in plan['slots'] if kind == 'lang']
             lab_all = ops.stacked_rows([labels[i].contiguous() for i in range(n_pass)]).reshape(-1)
             lang_terms = FusedVocabXentMultiFn.apply(
-                both.reshape(-1, both.shape[-1]), dict(pack=pack, outs=[slab[t * S:t * S + 5] for t in lang_slots]),
+                both.reshape(-1, both.shape[-1]), dict(pack=pack, outs=[slab[t * S:t * S + 5] for t in lang_slots], tail=tail, slots=lang_slots),
                 lab_all, tuple((i == 0 and self.vw) for i in range(n_pass)), *params)
         for kind, i, t in plan['slots']:
             if kind == 'lang' and lang_terms is not None:
@@ -169,15 +173,15 @@ class Criterion(object):
             elif kind == 'lang':
                 h, lab = hidden[i], labels[i].contiguous()
                 assert h.shape[1] == lab.shape[1]
-                terms.append(FusedVocabXentFn.apply(h.reshape(-1, h.shape[-1]), dict(pack=pack, out=slab[t * S:t * S + 5]),
+                terms.append(FusedVocabXentFn.apply(h.reshape(-1, h.shape[-1]), dict(pack=pack, out=slab[t * S:t * S + 5], tail=tail, slot=t),
                                                     lab, (i == 0 and self.vw), *params))
             else:
                 terms.append(KLDivMeanFn.apply(pred, results[Constants.mapping['length'][1]].to(pred.dtype),
-                                               slab[t * S:t * S + 1]))
+                                               slab[t * S:t * S + 1], tail, t))
         for ci, name in enumerate(self.crit):
             self._loss_cnt[ci] += B if name == 'lang' else pred.shape[0]
         cfg = dict(slab=slab, stride=S, coef=plan['coef'], m_dst=plan['m_dst'], m_src=plan['m_src'],
-                   m_scale=plan['m_scale'], meters=self._meters)
+                   m_scale=plan['m_scale'], meters=self._meters, tail=tail)
         return LossCombineFn.apply(cfg, *terms)
 
     def get_loss(self, results, **kwargs):

@@ -738,7 +738,11 @@ class FusedVocabXentFn(Function):
         stats = cfg.get("out")          # optional slot of the criterion's term slab (LossCombineFn)
         if stats is None:
             stats = _new((5,), h)
-        ops.nll_reduce(label_logp, argmax, labels, exclude_mask, stats)
+        tail = cfg.get("tail")          # ops.CritTail: the reduction runs in the criterion's ONE tail launch, which writes `stats`
+        if tail is not None and cfg.get("out") is not None:
+            tail.add_pass(label_logp, argmax, labels, exclude_mask, cfg["slot"])
+        else:
+            ops.nll_reduce(label_logp, argmax, labels, exclude_mask, stats)
         ctx.cfg, ctx.h, ctx.logp, ctx.labels, ctx.live, ctx.lse = cfg, h, logits, labels, live, lse
         return stats
 
@@ -788,7 +792,12 @@ class FusedVocabXentMultiFn(Function):
         ops.vocab_lse_fwd(h, pk.w, pk.b, logits, labels, lse, argmax, label_logp, live)
         outs = cfg.get("outs")
         stats = [outs[i] if outs is not None else _new((5,), h) for i in range(S)]
-        if 1 < S <= 4:
+        tail = cfg.get("tail")          # ops.CritTail: the reductions run in the criterion's ONE tail launch, which writes `stats`
+        if tail is not None and outs is not None and S <= 4:
+            for i in range(S):
+                sl = slice(i * rp, (i + 1) * rp)
+                tail.add_pass(label_logp[sl], argmax[sl], labels[sl], excludes[i], cfg["slots"][i])
+        elif 1 < S <= 4:
             ops.nll_reduce_multi(label_logp, argmax, labels, excludes, stats)       # every pass in one launch
         else:
             for i in range(S):
@@ -820,19 +829,27 @@ class KLDivMeanFn(Function):
     """legacy nn.KLDivLoss() ('mean' over all elements), misc/crit.py:223."""
 
     @staticmethod
-    def forward(ctx, x, t, out=None):
+    def forward(ctx, x, t, out=None, tail=None, slot=0):
         x, t = x.contiguous(), t.contiguous()
         if out is None:                 # else: a 1-element slot of the criterion's term slab (LossCombineFn)
             out = _new((1,), x)
-        ops.kldiv_mean(x, t, out, None)
-        ctx.x, ctx.t = x, t
+            tail = None
+        if tail is not None:            # ops.CritTail: the criterion's ONE tail launch computes the term (and, backward, dx)
+            tail.kl = (x, t, int(slot))
+        else:
+            ops.kldiv_mean(x, t, out, None)
+        ctx.x, ctx.t, ctx.tail = x, t, tail
         return out.view(())
 
     @staticmethod
     def backward(ctx, dout):
+        pad = (None,) * (len(ctx.needs_input_grad) - 1)
+        if ctx.tail is not None and ctx.tail.kl_dx is not None:
+            dx, ctx.tail.kl_dx = ctx.tail.kl_dx, None          # written by LossCombineFn.backward's tail launch
+            return (dx,) + pad
         dx = torch.empty_like(ctx.x)
         ops.kldiv_mean(ctx.x, ctx.t, None, dx, gscale=dout.reshape(1).contiguous())
-        return dx, None, None
+        return (dx,) + pad
 
 
 class LossCombineFn(Function):
@@ -844,9 +861,15 @@ class LossCombineFn(Function):
     def forward(ctx, cfg, *terms):
         slab, coef = cfg["slab"], cfg["coef"]
         total = _new((1,), slab)
-        ops.loss_combine(slab, len(terms), cfg["stride"], coef, total, cfg.get("m_dst"), cfg.get("m_src"),
-                         cfg.get("m_scale"), cfg.get("meters"))
-        ctx.cfg, ctx.shapes = cfg, [t.shape for t in terms]
+        tail = cfg.get("tail")          # ops.CritTail filled by the terms' producers: their reductions + this combine in ONE launch
+        if tail is not None and (tail.passes or tail.kl is not None):
+            ops.crit_tail_fwd(tail, slab, len(terms), cfg["stride"], coef, total, cfg.get("m_dst"), cfg.get("m_src"),
+                              cfg.get("m_scale"), cfg.get("meters"))
+        else:
+            tail = None
+            ops.loss_combine(slab, len(terms), cfg["stride"], coef, total, cfg.get("m_dst"), cfg.get("m_src"),
+                             cfg.get("m_scale"), cfg.get("meters"))
+        ctx.cfg, ctx.shapes, ctx.tail = cfg, [t.shape for t in terms], tail
         return total.view(())
 
     @staticmethod
@@ -854,7 +877,12 @@ class LossCombineFn(Function):
         cfg, stride = ctx.cfg, ctx.cfg["stride"]
         n = len(ctx.shapes)
         gslab = _new((n * stride,), cfg["slab"])
-        ops.loss_combine_bwd(g.reshape(1).contiguous(), cfg["coef"], n, stride, gslab)
+        if ctx.tail is not None:
+            kl = ctx.tail.kl
+            ctx.tail.kl_dx = torch.empty_like(kl[0]) if kl is not None else None
+            ops.crit_tail_bwd(ctx.tail, g.reshape(1).contiguous(), cfg["coef"], n, stride, gslab, ctx.tail.kl_dx)
+        else:
+            ops.loss_combine_bwd(g.reshape(1).contiguous(), cfg["coef"], n, stride, gslab)
         grads = []
         for t, shp in enumerate(ctx.shapes):
             k = 1

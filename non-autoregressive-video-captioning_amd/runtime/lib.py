@@ -29,6 +29,13 @@ class Epilogue(ctypes.Structure):
     ]
 
 
+class CritTail(ctypes.Structure):
+    """struct nacf_crit_tail."""
+    _fields_ = [("n_pass", c_int32), ("label_logp", c_void_p * 4), ("argmax", c_void_p * 4), ("labels", c_void_p * 4),
+                ("rows", c_int32 * 4), ("exclude", c_int32 * 4), ("slot", c_int32 * 4),
+                ("kl_x", c_void_p), ("kl_t", c_void_p), ("kl_total", c_int32), ("kl_slot", c_int32)]
+
+
 class RowSet(ctypes.Structure):
     """struct nacf_rowset."""
     _fields_ = [("rows", c_void_p), ("count", c_void_p), ("zero_dead", ctypes.c_int32)]
@@ -84,6 +91,8 @@ SIGNATURES = {
                                    _P, _P, _P, _P, _P]),
     "nacf_loss_combine": (c_int, [_P, _I, _I, _P, _P, _P, _P, _P, _I, _P, _P]),
     "nacf_loss_combine_bwd": (c_int, [_P, _P, _I, _I, _P, _P]),
+    "nacf_crit_tail_fwd": (c_int, [POINTER(CritTail), _P, _I, _I, _P, _P, _P, _P, _P, _I, _P, _P]),
+    "nacf_crit_tail_bwd": (c_int, [POINTER(CritTail), _P, _P, _I, _I, _P, _P, _P]),
     "nacf_highway_mix_fwd": (c_int, [_P, _P, _P, _I, _I, _F, _U, _P, _P]),
     "nacf_highway_mix_bwd": (c_int, [_P, _P, _P, _P, _P, _I, _I, _F, _U, _P, _P]),
     "nacf_bn_workspace": (_S, [_I, _I]),

@@ -603,6 +603,48 @@ def loss_combine_bwd(gtotal: Tensor, coef: Tensor, n_terms: int, stride: int, gs
             "nacf_loss_combine_bwd")
 
 
+class CritTail:
+    """What the producers of the criterion's terms leave for the ONE tail launch (nacf_crit_tail_fwd / _bwd) instead of launching
+    their own reductions: per decoding pass (label_logp, argmax, labels, exclude, slot), and the length head's (x, t, slot).
+    kl_dx: the length head's gradient, written by the backward tail launch for KLDivMeanFn.backward to hand on."""
+
+    def __init__(self):
+        self.passes = []
+        self.kl = None
+        self.kl_dx = None
+
+    def add_pass(self, label_logp, argmax, labels, exclude, slot):
+        assert len(self.passes) < 4
+        self.passes.append((label_logp, argmax, labels, bool(exclude), int(slot)))
+
+    def cstruct(self):
+        t = L.CritTail()
+        t.n_pass = len(self.passes)
+        for i, (lp, am, lab, ex, slot) in enumerate(self.passes):
+            assert lp.is_contiguous() and am.is_contiguous() and lab.is_contiguous() and lp.numel() == am.numel() == lab.numel()
+            t.label_logp[i], t.argmax[i], t.labels[i] = lp.data_ptr(), am.data_ptr(), lab.data_ptr()
+            t.rows[i], t.exclude[i], t.slot[i] = lp.numel(), int(ex), slot
+        if self.kl is not None:
+            x, tt, slot = self.kl
+            assert x.is_contiguous() and tt.is_contiguous() and x.numel() == tt.numel()
+            t.kl_x, t.kl_t, t.kl_total, t.kl_slot = x.data_ptr(), tt.data_ptr(), x.numel(), slot
+        return t
+
+
+def crit_tail_fwd(tail: CritTail, slab: Tensor, n_terms: int, stride: int, coef: Tensor, total: Tensor, m_dst: Optional[Tensor],
+                  m_src: Optional[Tensor], m_scale: Optional[Tensor], meters: Optional[Tensor]) -> None:
+    n_m = 0 if m_dst is None else m_dst.numel()
+    t = tail.cstruct()
+    L.check(L.load().nacf_crit_tail_fwd(ctypes.byref(t), _ptr(slab), n_terms, stride, _ptr(coef), _ptr(total), _ptr(m_dst), _ptr(m_src),
+                                        _ptr(m_scale), n_m, _ptr(meters), _stream()), "nacf_crit_tail_fwd")
+
+
+def crit_tail_bwd(tail: CritTail, gtotal: Tensor, coef: Tensor, n_terms: int, stride: int, gslab: Tensor, kl_dx: Optional[Tensor]) -> None:
+    t = tail.cstruct()
+    L.check(L.load().nacf_crit_tail_bwd(ctypes.byref(t), _ptr(gtotal), _ptr(coef), n_terms, stride, _ptr(gslab), _ptr(kl_dx), _stream()),
+            "nacf_crit_tail_bwd")
+
+
 def epilogue_bwd(dy: Tensor, dz: Tensor, dr: Optional[Tensor], epi: Epi, accumulate_dr: bool = False,
                  rows: Optional[RowSet] = None) -> None:
     """rows: the forward GEMM's live-row list -- only those rows of dz are written (its consumers take the same list); the

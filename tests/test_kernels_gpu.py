@@ -1334,3 +1334,42 @@ def test_small_weight_gradient_kernel(dev, monkeypatch, mode):
     dw = torch.full((N, K), 5.0, device=dev)
     ops.linear_bwd_weight(dz, x, dw, None, beta=0.0)
     assert err(dw, dz.double().t() @ x.double()) < 2e-5
+
+
+def test_crit_tail_equals_the_separate_launches(dev):
+    """nacf_crit_tail_fwd / _bwd (the criterion's ONE tail launch each way) against nacf_nll_reduce_multi + nacf_kldiv_mean +
+    nacf_loss_combine and their backward forms: the same bits in the slab, the total, the meters, gslab and the length head's gradient"""
+    from nacf_amd.runtime import ops
+    g = torch.Generator().manual_seed(5)
+    rp, n_pass, S, B, Lm = 700, 2, 8, 16, 20
+    ll = -torch.rand(n_pass * rp, generator=g).to(dev)
+    labels = torch.randint(0, 9, (n_pass * rp,), generator=g).to(dev)          # 0 = <pad>, 4 = <mask> among them
+    am = torch.where(torch.rand(n_pass * rp, generator=g).to(dev) < 0.5, labels, labels + 1)
+    x = torch.log_softmax(torch.randn(B, Lm, generator=g), -1).to(dev)
+    t = torch.softmax(torch.randn(B, Lm, generator=g), -1).to(dev)
+    coef = torch.tensor([0.8 / B, 1.0 / B, 0.3], device=dev)
+    m_dst = torch.tensor([0, 2, 3, 0, 4, 5, 6, 7, 1], dtype=torch.int32, device=dev)
+    m_src = torch.tensor([0, 1, 2, S, S + 1, S + 2, S + 3, S + 4, 2 * S], dtype=torch.int32, device=dev)
+    m_scale = torch.tensor([0.8, 1, 1, 1, 1, 1, 1, 1, float(B * Lm)], device=dev)
+    # separate launches
+    slab0, total0, meters0 = torch.zeros(3 * S, device=dev), torch.zeros(1, device=dev), torch.full((8,), 2.0, device=dev)
+    ops.nll_reduce_multi(ll, am, labels, (True, False), [slab0[0:5], slab0[S:S + 5]])
+    ops.kldiv_mean(x, t, slab0[2 * S:2 * S + 1], None)
+    ops.loss_combine(slab0, 3, S, coef, total0, m_dst, m_src, m_scale, meters0)
+    gt = torch.tensor([1.7], device=dev)
+    gslab0, dx0 = torch.empty(3 * S, device=dev), torch.empty_like(x)
+    ops.loss_combine_bwd(gt, coef, 3, S, gslab0)
+    ops.kldiv_mean(x, t, None, dx0, gscale=gslab0[2 * S:2 * S + 1])
+    # one launch each way
+    tail = ops.CritTail()
+    for i in range(n_pass):
+        sl = slice(i * rp, (i + 1) * rp)
+        tail.add_pass(ll[sl], am[sl], labels[sl], i == 0, i)
+    tail.kl = (x, t, 2)
+    slab1, total1, meters1 = torch.zeros(3 * S, device=dev), torch.zeros(1, device=dev), torch.full((8,), 2.0, device=dev)
+    ops.crit_tail_fwd(tail, slab1, 3, S, coef, total1, m_dst, m_src, m_scale, meters1)
+    gslab1, dx1 = torch.empty(3 * S, device=dev), torch.empty_like(x)
+    ops.crit_tail_bwd(tail, gt, coef, 3, S, gslab1, dx1)
+    assert torch.equal(slab0, slab1) and torch.equal(total0, total1) and torch.equal(meters0, meters1)
+    assert torch.equal(gslab0, gslab1) and torch.equal(dx0, dx1)
+    assert float(total1) != 0.0 and float(slab1[2 * S]) > 0.0
