@@ -740,8 +740,8 @@ def compact_line(out):
         return {k: d[k] for k in keys if isinstance(d, dict) and k in d and d[k] is not None} if isinstance(d, dict) else None
 
     def roof(r):
-        return pick(r, ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "avg_launch_ms", "launches_per_pass",
-                        "all_gemm_tflops", "all_gemm_frac_of_mode_peak"))
+        return pick(r, ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "avg_launch_ms", "all_gemm_tflops",
+                        "all_gemm_frac_of_mode_peak"))
     line = {k: out[k] for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
                                 "vs_baseline", "dtype", "data") if k in out}
     cfg = out.get("config") or {}
@@ -778,12 +778,12 @@ def compact_line(out):
     cpu = out.get("cpu_baseline")
     if cpu:
         line["cpu_baseline"] = pick(cpu, ("value", "unit", "cores", "kind"))
-        line["cpu_baseline"]["sample"] = "oracle NACF train step, 128 videos, 10 timed steps, median"
+        line["cpu_baseline"]["sample"] = "oracle train step, 128 videos, median of 10"
         if isinstance(cpu.get("one_thread"), dict):
             line["cpu_baseline"]["one_thread_value"] = cpu["one_thread"].get("value")
         if isinstance(cpu.get("decode"), dict):
             line["cpu_baseline"]["decode_captions_per_s"] = cpu["decode"].get("value")
-    line["details"] = "full record on stderr; profiles/r06_bench.json"
+    line["details"] = "full record: stderr"
     return line
 
 
