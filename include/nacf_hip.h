@@ -64,7 +64,7 @@ int nacf_version(void);
  * included).  nacf_abi_count() returns the value the LIBRARY was built with; the ctypes loader
  * (runtime/lib.py:load) refuses a library whose count differs from its own signature table, so a stale
  * libnacf_hip.so next to a newer Python package fails at import time, not at the first missing symbol. */
-#define NACF_ABI_COUNT 91
+#define NACF_ABI_COUNT 92
 int nacf_abi_count(void);
 
 /* ---- batch construction (reference: dataloader.py) ----------------------------------------
@@ -692,6 +692,12 @@ int nacf_adam_step(float* param, const float* grad, float* exp_avg, float* exp_a
                    int64_t n, const float* lr, int64_t* step_count,
                    float beta1, float beta2, float eps, float weight_decay,
                    float grad_clip, float grad_scale, nacf_stream_t stream);
+/* torch.optim.RMSprop as misc/optim.py:52-60 constructs it (alpha 0.99, eps 1e-8, momentum 0, not centred, L2 weight decay in the
+ * gradient) over the flat buffers, behind the same elementwise clip (misc/run.py:260) and gradient scale as nacf_adam_step:
+ *   g = clip(grad * grad_scale) + wd * p;  sq = alpha * sq + (1 - alpha) g^2;  p -= lr[0] * g / (sqrt(sq) + eps)
+ * zero_grad != 0 leaves grad zeroed (the step engine's next zero_grad, folded into the walk). */
+int nacf_rmsprop_step(float* param, float* grad, float* square_avg, int64_t n, const float* lr, float alpha, float eps,
+                      float weight_decay, float grad_clip, float grad_scale, int zero_grad, nacf_stream_t stream);
 /* The same update over a PART of the flat buffers (data-parallel training updates the parameters whose gradient
  * bucket has been reduced while the other bucket is still in flight).  `bump` is a bit set: 1 = increment step_count first
  * (exactly one part of a step does), 2 = leave the gradient ZEROED behind (the next step's optimizer.zero_grad() of

@@ -1007,6 +1007,23 @@ __global__ void adam_step_kernel(float* __restrict__ param, float* __restrict__ 
   }
 }
 __global__ void adam_bump_kernel(int64_t* step_p) { step_p[0] += 1; }
+// torch.optim.RMSprop (momentum 0, not centred: what misc/optim.py:52-60 constructs) behind the same clip / scale / zero-fill walk:
+//   g += wd * p;  sq = alpha * sq + (1 - alpha) * g * g;  p -= lr * g / (sqrt(sq) + eps)
+template <bool ZERO>
+__global__ void rmsprop_step_kernel(float* __restrict__ param, float* __restrict__ grad, float* __restrict__ sq, int64_t n,
+                                    const float* __restrict__ lr_p, float alpha, float eps, float wd, float clip, float gscale) {
+  const float lr = lr_p[0];
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    float g = grad[i] * gscale;
+    if (ZERO) grad[i] = 0.f;
+    g = fminf(fmaxf(g, -clip), clip);
+    const float p = param[i];
+    g += wd * p;
+    const float s = alpha * sq[i] + (1.f - alpha) * g * g;
+    sq[i] = s;
+    param[i] = p - lr * (g / (sqrtf(s) + eps));
+  }
+}
 
 inline int grid_for(int64_t total, int block = 256, int cap = 8192) {
   int64_t b = (total + block - 1) / block;
@@ -1624,6 +1641,20 @@ int nacf_adam_step_part(float* param, float* grad, float* exp_avg, float* exp_av
     hipLaunchKernelGGL(adam_step_kernel<false>, dim3(grid_for(n, 256, 4096)), dim3(256), 0, s, param, grad, exp_avg, exp_avg_sq, n,
                        lr, step_count, beta1, beta2, eps, weight_decay, grad_clip, grad_scale);
   NACF_LAUNCH_CHECK("nacf_adam_step");
+  return NACF_OK;
+}
+
+int nacf_rmsprop_step(float* param, float* grad, float* square_avg, int64_t n, const float* lr, float alpha, float eps,
+                      float weight_decay, float grad_clip, float grad_scale, int zero_grad, nacf_stream_t stream) {
+  NACF_CHECK(param && grad && square_avg && lr && n > 0, NACF_EINVAL, "nacf_rmsprop_step: bad argument");
+  hipStream_t s = as_hip(stream);
+  if (zero_grad)
+    hipLaunchKernelGGL(rmsprop_step_kernel<true>, dim3(grid_for(n, 256, 4096)), dim3(256), 0, s, param, grad, square_avg, n, lr, alpha, eps,
+                       weight_decay, grad_clip, grad_scale);
+  else
+    hipLaunchKernelGGL(rmsprop_step_kernel<false>, dim3(grid_for(n, 256, 4096)), dim3(256), 0, s, param, grad, square_avg, n, lr, alpha, eps,
+                       weight_decay, grad_clip, grad_scale);
+  NACF_LAUNCH_CHECK("nacf_rmsprop_step");
   return NACF_OK;
 }
 

@@ -60,6 +60,36 @@ class FusedAdam(object):
                       self.betas[0], self.betas[1], self.eps, self.wd, self.grad_clip, grad_scale, bump=bump, zero_grad=zero_grad)
 
 
+class FusedRMSprop(FusedAdam):
+    """torch.optim.RMSprop as the reference constructs it (misc/optim.py:52-60: defaults alpha 0.99, eps 1e-8, momentum 0, not
+    centred, weight_decay from the options) on the flat buffers: one nacf_rmsprop_step walk per bucket, the same clip / gradient
+    scale / fused zero-grad contract as FusedAdam (the step engine drives both through .step())."""
+
+    def __init__(self, model, weight_decay=5e-4, alpha=0.99, eps=1e-8, grad_clip=5.0):
+        self.alpha = alpha
+        super().__init__(model, weight_decay=weight_decay, eps=eps, grad_clip=grad_clip)
+
+    def _alloc(self):
+        super()._alloc()
+        self.exp_avg = None              # (no first moment: momentum 0)
+
+    def step(self, grad_scale=1.0, lo=None, hi=None, bump=True, zero_grad=False):
+        self.model.flat.touch()
+        if self._flat is not self.model.flat:
+            if torch.cuda.is_current_stream_capturing():
+                raise RuntimeError('nacf_amd: the model was re-homed during a hipGraph capture')
+            old = self.exp_avg_sq
+            self._alloc()
+            if old.numel() == self.exp_avg_sq.numel():
+                self.exp_avg_sq.copy_(old)
+            self.lr_dev.fill_(self.param_groups[0]['lr'])
+            self._lr_on_dev = self.param_groups[0]['lr']
+        f = self._flat
+        sl = slice(lo, hi)
+        ops.rmsprop_step(f.data[sl], f.grad[sl], self.exp_avg_sq[sl], self.lr_dev, self.alpha, self.eps, self.wd, self.grad_clip,
+                         grad_scale, zero_grad=zero_grad)
+
+
 class ScheduledOptim(object):
     def __init__(self, optimizer, learning_rate, minimum_learning_rate, epoch_decay_rate, grad_clip=2,
                  n_warmup_steps=0, summarywriter=None):
@@ -90,9 +120,10 @@ class ScheduledOptim(object):
 
 
 def get_optimizer(opt, model, summarywriter=None):
-    if opt['optim'].lower() != 'adam':
-        raise NotImplementedError('nacf_amd: only adam is built (reference default)')
-    inner = FusedAdam(model, weight_decay=opt['weight_decay'], grad_clip=opt.get('grad_clip', 5.0))
+    kind = opt['optim'].lower()
+    assert kind in ('adam', 'rmsprop'), kind          # misc/optim.py:52-57: the reference's two optimisers
+    cls = FusedAdam if kind == 'adam' else FusedRMSprop
+    inner = cls(model, weight_decay=opt['weight_decay'], grad_clip=opt.get('grad_clip', 5.0))
     return ScheduledOptim(inner, learning_rate=opt['learning_rate'],
                           minimum_learning_rate=opt['minimum_learning_rate'], epoch_decay_rate=opt['decay'],
                           grad_clip=opt.get('grad_clip', 5.0), n_warmup_steps=opt.get('n_warmup_steps', 0))

@@ -153,6 +153,7 @@ SIGNATURES = {
     "nacf_beam_step": (c_int, [_P, _L, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "nacf_adam_step": (c_int, [_P, _P, _P, _P, _L, _P, _P, _F, _F, _F, _F, _F, _F, _P]),
     "nacf_adam_step_part": (c_int, [_P, _P, _P, _P, _L, _P, _P, _F, _F, _F, _F, _F, _F, _I, _P]),
+    "nacf_rmsprop_step": (c_int, [_P, _P, _P, _L, _P, _F, _F, _F, _F, _F, _I, _P]),
 }
 
 _lib = None

@@ -1136,6 +1136,15 @@ def adam_step(param, grad, m, v, lr_dev, step_dev, beta1, beta2, eps, weight_dec
             "nacf_adam_step")
 
 
+def rmsprop_step(param, grad, sq, lr_dev, alpha, eps, weight_decay, grad_clip, grad_scale, zero_grad=False):
+    """torch.optim.RMSprop (momentum 0, not centred) over equal-length slices of the flat buffers (nacf_rmsprop_step)"""
+    _chk_f32(param, grad, sq, lr_dev)
+    assert param.numel() == grad.numel() == sq.numel() and param.is_contiguous()
+    L.check(L.load().nacf_rmsprop_step(_ptr(param), _ptr(grad), _ptr(sq), param.numel(), _ptr(lr_dev), float(alpha), float(eps),
+                                       float(weight_decay), float(grad_clip), float(grad_scale), int(bool(zero_grad)), _stream()),
+            "nacf_rmsprop_step")
+
+
 # ---------------------------------------------------------------- AR beam search
 def beam_step(logp2d, V, t, max_len, want, seqs, scores, fin_scores, fin_len, fin_tokens, fin_count, done, n_active):
     _chk_f32(logp2d, scores, fin_scores)

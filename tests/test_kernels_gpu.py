@@ -1373,3 +1373,35 @@ def test_crit_tail_equals_the_separate_launches(dev):
     assert torch.equal(slab0, slab1) and torch.equal(total0, total1) and torch.equal(meters0, meters1)
     assert torch.equal(gslab0, gslab1) and torch.equal(dx0, dx1)
     assert float(total1) != 0.0 and float(slab1[2 * S]) > 0.0
+
+
+def test_rmsprop_step_equals_torch_rmsprop(dev):
+    """nacf_rmsprop_step against clip_grad_value_ + torch.optim.RMSprop as misc/optim.py:52-60 constructs it (three steps, weight decay),
+    and get_optimizer(opt['optim'] = 'rmsprop') drives it through the step engine's interface"""
+    from nacf_amd.runtime import ops
+    g = torch.Generator().manual_seed(3)
+    n, lr, wd, clip = 5000, 3e-3, 5e-4, 0.5
+    p0 = torch.randn(n, generator=g)
+    grads = [torch.randn(n, generator=g) * 2 for _ in range(3)]
+    ref = torch.nn.Parameter(p0.clone())
+    opt = torch.optim.RMSprop([ref], lr=lr, weight_decay=wd)
+    p, sq, lr_dev = p0.clone().to(dev), torch.zeros(n, device=dev), torch.full((1,), lr, device=dev)
+    for gr in grads:
+        ref.grad = gr.clone()
+        torch.nn.utils.clip_grad_value_([ref], clip)
+        opt.step()
+        gd = gr.clone().to(dev)
+        ops.rmsprop_step(p, gd, sq, lr_dev, 0.99, 1e-8, wd, clip, 1.0, zero_grad=True)
+        assert float(gd.abs().max()) == 0.0
+    assert float((p.cpu() - ref.detach()).abs().max()) < 2e-6
+    import nacf_amd
+    from nacf_amd.misc.optim import get_optimizer, FusedRMSprop
+    o = nacf_amd.opts.make_opt("NAB", "MSRVTT", with_category=True, dim_hidden=64, num_attention_heads=4, intermediate_size=128, dim_i=32,
+                               dim_m=32, max_len=10, vocab_size=101, optim="rmsprop")
+    m = nacf_amd.get_model(o).to(dev)
+    so = get_optimizer(m.opt, m)
+    assert isinstance(so._optimizer, FusedRMSprop)
+    w0 = m.flat.data.clone()
+    m.flat.grad.fill_(0.1)
+    so.step()
+    assert float((m.flat.data - w0).abs().max()) > 0
