@@ -33,8 +33,8 @@ python $ROOT/tools/pmc_traffic.py /tmp/prof_dec_FETCH_SIZE/b_counter_collection.
 # 4. GEMM microbenchmarks (three arithmetic modes, weights from pre-split images as in the model) + attainable MFMA peak
 # (per-launch HIP events, median of 20; one-off stalls the tool saw go to the top of the file as '#' lines)
 python $ROOT/tools/gemm_bench.py --iters 20 --modes f32,bf16x3,bf16 --images > /tmp/mb.txt 2> /tmp/mb.err
-python $ROOT/tools/gemm_bench.py --iters 20 --modes bf16x3 --tiles 128,wide1,wide2,auto --images --only fwd >> /tmp/mb.txt 2>> /tmp/mb.err
-python $ROOT/tools/gemm_bench.py --iters 20 --modes bf16x3 --tiles 128,wide1,wide2,auto --images --only dX >> /tmp/mb.txt 2>> /tmp/mb.err
+python $ROOT/tools/gemm_bench.py --iters 20 --modes bf16x3 --tiles 64,128,wide1,wide2,dma1,dma2,auto --images --only fwd >> /tmp/mb.txt 2>> /tmp/mb.err
+python $ROOT/tools/gemm_bench.py --iters 20 --modes bf16x3 --tiles 64,128,wide1,wide2,dma1,dma2,auto --images --only dX >> /tmp/mb.txt 2>> /tmp/mb.err
 { echo "# per-launch HIP events, MEDIAN of 20 launches (tools/gemm_bench.py)"; grep "^#" /tmp/mb.err; cat /tmp/mb.txt; } > $OUT/${R}_gemm_microbench.txt
 # 4b. the grouped weight-gradient launch per problem and as the step's mix
 python $ROOT/tools/dw_group_bench.py 10 > $OUT/${R}_dw_group_bench.txt 2> /dev/null
@@ -54,6 +54,16 @@ $ROOT/tools/mfma_peak 20000 > $OUT/${R}_mfma_peak.txt 2>&1
 # 5. SQ / GRBM counters of the vocabulary GEMM at K = 512 (the model's shape) and K = 8192, exact and throughput mode
 { for m in bf16x3 bf16; do echo "== mode $m"; $ROOT/tools/pmc_gemm.sh 0:5120:10547:512,0:5120:10547:8192 128 $m --images 2>/dev/null | grep "^pass"; done;
   echo "== mode bf16x3, wide kernel (128 x 256 tiles; csrc/gemm_bf16_wide.hpp)"; $ROOT/tools/pmc_gemm.sh 0:5120:10547:512,0:7680:512:2048,0:15360:1024:512 wide2 bf16x3 --images 2>/dev/null | grep "^pass"; } > $OUT/${R}_gemm_pmc_counters.txt
+# 5a. the same counters on a decoder-layer shape (5120 x 512 x 512) for the 64 x 64 register-staged kernel and the DMA-fed kernels of
+#     gemm_dma128.hpp ("no counter set exists for the 64 x 64 instantiation"), and the vocabulary shape on dma2
+{ for t in 64 128 dma1 dma2; do echo "== mode bf16x3, tile $t, decoder-layer shapes"; $ROOT/tools/pmc_gemm.sh 0:5120:512:512,0:5120:2048:512,1:5120:512:2048 $t bf16x3 --images 2>/dev/null | grep "^pass"; done;
+  echo "== mode bf16x3, tile dma2, vocabulary shape"; $ROOT/tools/pmc_gemm.sh 0:5120:10547:512,1:5120:10547:512 dma2 bf16x3 --images 2>/dev/null | grep "^pass"; } > $OUT/${R}_gemm_pmc_counters_decoder_shapes.txt
+# 5a'. the DMA-fed kernel's phase stamps + ablations (tools/probes/dma128_probe.hip; built by hand, see its header)
+for b in 1 2; do
+  if [ -x $ROOT/tools/probes/dma128_probe_$b ]; then
+    { echo "== dma128, MT=$b (workgroup tile $((64*b)) x 128)"; for shp in "5120 2048 512" "2944 2048 512" "5120 512 2048" "2304 10547 512" "15360 1024 512"; do $ROOT/tools/probes/dma128_probe_$b $shp 10; done; } >> $OUT/${R}_dma128_probe.txt 2>&1
+  fi
+done
 # 5b. the wide kernel's phase stamps + ablations (tools/probes/wide_gemm.hip; built by hand, see its header)
 for b in 1 2; do
   if [ -x $ROOT/tools/probes/wide_gemm$b ]; then
