@@ -135,7 +135,11 @@ class Seq2Seq(nn.Module):
     def encode(self, feats, **kwargs):
         results = LazyResults()
         if self.opt.get('automatic_mask', False):
-            raise NotImplementedError('nacf_amd: automatic_mask is not built')
+            # models/seq2seq.py:37-42: results['attention_mask'] = [feat.sum(-1).eq(0) per modality].  Nothing in the reference reads
+            # the entry (models/Decoder.py builds its masks from the tokens; the cross-attention takes none), so it costs nothing
+            # here either: formed on first access, off the captured path
+            frames = [f for f in feats]
+            results.lazy('attention_mask', lambda: [f.detach().sum(-1).eq(0) for f in frames])
         # bf16 GEMM modes: the weight images follow the fp32 master weights at every training forward entry (one launch, part
         # of a captured step; the forward's and the backward's GEMMs then read images of exactly the weights an fp32 kernel
         # would read).  Inference rebuilds them only when the weights were written since (FlatParams.version: optimiser

@@ -724,3 +724,22 @@ def test_memory_fanout_accumulates_in_place_only_into_a_buffer_it_owns(dev):
             assert torch.equal(res["enc_output"].grad, stash["clone"])          # the retained gradient was not mutated
             assert float(stash["clone"].abs().max()) > 0
     assert torch.equal(grads["plain"], grads["retain"])                         # and the parameters' gradients are the same
+
+
+def test_automatic_mask_yields_the_reference_entry(dev):
+    """opt['automatic_mask'] (models/seq2seq.py:37-42): results['attention_mask'] = [feat.sum(-1).eq(0) per modality]; the rest of the
+    encode is unchanged (nothing reads the entry)"""
+    g = load_gold("tiny_nacf_decode")
+    opt = gold_opt(g)
+    b = gold_batch(g, dev)
+    feats = [f.clone() for f in b["feats"]]
+    feats[0][1, 2:] = 0.0                                                  # zero-padded frames of one clip
+    plain = build(opt, O.init_state_dict(opt, seed=3), dev); plain.eval()
+    masked = build(opt, O.init_state_dict(opt, seed=3), dev, automatic_mask=True); masked.eval()
+    with torch.no_grad():
+        e0, e1 = plain.encode(feats=feats), masked.encode(feats=feats)
+    assert "attention_mask" not in e0 and "attention_mask" in e1
+    am = e1["attention_mask"]
+    assert len(am) == len(feats) and all(torch.equal(a, f.sum(-1).eq(0)) for a, f in zip(am, feats))
+    assert bool(am[0][1, 2:].all()) and not bool(am[0][0].any())
+    assert torch.equal(e0["enc_output"], e1["enc_output"])
