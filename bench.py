@@ -56,6 +56,10 @@ LIMITER_G256W = ("the operand split: a k-tile of 32 reduce rows is 192 v_mfma_f3
                  "= 45 % over the whole launch (49-54 % in-loop), 3.1 other vector instructions per matrix instruction, no LDS bank conflict (profiles/r05_dw_g256_pmc.txt) "
                  "(204-224 TF of 416.7 on a 4096 cube, tools/probes/gemm256w_probe.hip; ablations in profiles/r05_g256w_ablation.txt); a grouped "
                  "launch adds the ragged last round of its 12 problems and the slab combine")
+LIMITER_DMA128 = ("two resources at once: a 128 x 128 exact-mode k-tile moves 40 KB through the CU's L1 / LDS-DMA path (26.7 B/clk/CU at the matrix roof; "
+                  "the path delivers 32-42: a DMA-only loop runs 2350-2600 cycles per k-tile and workgroup) and needs 2 x 1536 matrix cycles per pair of "
+                  "workgroups; measured 3550 with the split hidden to 60 % behind the wave's own matrix instructions (tools/probes/dma128_probe.hip, "
+                  "profiles/r06_dma128_probe.txt); two workgroups per CU cap the tile at 128 x 128 (80 KB LDS, 256 registers)")
 LIMITER_DMA64 = ("launch latency and fp32 outputs, not the matrix pipe: a launch of <= 768 tiles of 32 x 64 is 2-12 GFLOP (1-5 us of the chip's "
                  "bf16 rate) inside a ~4.7 us launch floor, one HBM latency of prologue and an epilogue that writes fp32 (with the pre-activation: "
                  "8 bytes per output against 2 x 512 flops); per launch 7-18 us (profiles/r05_dma64_timeline.txt)")
@@ -202,8 +206,8 @@ def roofline_from(summ, n_prof, mode, prefer_single=True, groups=None, dec_rows=
         cands = cands + list(groups.items())
     name, r = max(cands, key=lambda kv: kv[1]["ms"])
     family = "f32" if name.startswith("gemm_f32") else "bf16"
-    if name.startswith("gemm_wide"):
-        ns = 3                       # the wide kernels exist in the exact mode only
+    if name.startswith("gemm_wide") or name.startswith("gemm_dma128"):
+        ns = 3                       # the wide and the DMA-fed two-per-CU kernels exist in the exact mode only
     else:
         ns = 3 if (family == "bf16" and (", 3, " in name or "<3>" in name)) else 1
     kmode = "f32" if family == "f32" else ("bf16x3" if ns == 3 else "bf16")
@@ -226,11 +230,13 @@ def roofline_from(summ, n_prof, mode, prefer_single=True, groups=None, dec_rows=
           # (the text is ONE top-level entry of the line, `limiters`: repeated per leg it pushed the decode / bf16 legs out of
           #  the tail the driver keeps)
           "limiter": ("limiters.wide" if name.startswith("gemm_wide") else "limiters.g256w" if name.startswith("g256_dw")
-                      else "limiters.dma64" if name.startswith("gemm_dma64") else "limiters.tile128")}
+                      else "limiters.dma64" if name.startswith("gemm_dma64") else "limiters.dma128" if name.startswith("gemm_dma128")
+                      else "limiters.tile128")}
     tab = newest_traffic_table(traffic_leg)
     if tab is not None:
         path, data = tab
-        hits = [e for e in data.get("kernels", []) if name in e["kernel"]]
+        key = name[:-1] if name.endswith(">") else name      # (rocprofv3 prints trailing default template arguments: "<2, EpiArgmax, 0>")
+        hits = [e for e in data.get("kernels", []) if key in e["kernel"]]
         if hits:
             n_l = sum(e["launches_sampled"] for e in hits)
             rl["traffic"] = int(sum(e["hbm_bytes"] * e["launches_sampled"] for e in hits) / n_l)
@@ -705,7 +711,7 @@ def main():
                           "gradient_buckets": (3 if engine.three else 2) if staged else 1},
                "timing": extra_timing, "rank_losses": rank_losses,
                # (bulky / referenced entries first: what reads only the END of this line keeps the legs below)
-               "gemm_kernels": gemm_table, "limiters": {"tile128": LIMITER_128, "wide": LIMITER_WIDE, "g256w": LIMITER_G256W, "dma64": LIMITER_DMA64},
+               "gemm_kernels": gemm_table, "limiters": {"tile128": LIMITER_128, "wide": LIMITER_WIDE, "g256w": LIMITER_G256W, "dma64": LIMITER_DMA64, "dma128": LIMITER_DMA128},
                "loader_fed": loader_leg, "train_L30": l30, "config5_ar_vs_na": compare,
                "nacf_bf16": nacf_bf16, "config1_nab_bf16": nab, "decode": decode,
                "roofline": roofline, "cpu_baseline": cpu, "final_loss": round(final_loss, 4)}
