@@ -47,6 +47,25 @@ template <int MT> struct Geo {
   static constexpr int PREQ = 6;                            // ... for the three planes of one Pop tile (24 requests of 16 rows)
 };
 
+// DMA128_GLOBAL (tuning builds; default 0): 1 = the requests are global_load_lds_dwordx4 (the wide kernel's instruction) instead of
+// buffer_load_dwordx4 ... lds with per-lane offsets.  Tried because the counters of this kernel on the vocabulary shape
+// (tools/pmc_gemm_cache2.sh, profiles/r06_dma128_cache_counters.txt) show TCP_TOTAL_CACHE_ACCESSES 67 M for 956 MB (one look-up per
+// 16-byte lane element) and TA_BUSY 3 x the register-staged kernel's (21 M) and the wide kernel's (18 M for 774 MB): the same k-tile
+// time, bit-identical results (3568 vs 3588 cycles, profiles/r06_dma128_probe_global_vs_buffer.txt) -- the instruction form is not
+// what makes the difference.  The global form has no out-of-range zero fill: rows past the live count repeat the last live row
+// (their outputs are never stored), chunks past the reduce extent are fetched from the k-tile's first chunk and the whole tail is
+// zeroed in LDS.
+#ifndef DMA128_GLOBAL
+#define DMA128_GLOBAL 0
+#endif
+__device__ __forceinline__ void dma16g(uint32_t voff, uint32_t m0, const void* base) {      // LDS destination m0 + lane * 16
+  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %2" : : "v"(voff), "s"(m0), "s"(base) : "memory");
+}
+__device__ __forceinline__ uint64_t uniform64(uint64_t v) {
+  const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+  return ((uint64_t)hi << 32) | lo;
+}
+
 // 16-byte chunk swizzle of the fp32 image (128-byte rows, 8 chunks): the two ds_read_b128 of a 32-row fragment (lane = (row & 31,
 // h): chunks 4s + 2h and + 1) are conflict-free under the instruction's lane groups (the wide kernel's fq)
 __device__ __forceinline__ int fq(int row) { return (row >> 1) & 7; }
@@ -203,16 +222,18 @@ __global__ __launch_bounds__(256, 2) void gemm_dma128_kernel(GemmShape g, Epi ep
 #pragma unroll
   for (int j = 0; j < QREQ; ++j) {
     const int R = (wave * QREQ + j) * 8 + (lane >> 3), m = m0 + R;
-    const int ph = m < Meff ? (g.rows ? g.rows[m] : m) : -1;
+    const int mc = DMA128_GLOBAL ? min(m, Meff - 1) : m;
+    const int ph = mc < Meff ? (g.rows ? g.rows[mc] : mc) : -1;
     voa[j] = ph >= 0 ? (uint32_t)ph * (uint32_t)(g.ldq * 4) + (uint32_t)(((lane & 7) ^ fq(R)) << 4) : OOB;
   }
   // the same for a last k-tile that holds only ktail reduce indices: chunks that begin at or past the extent arrive as zeros
   uint32_t voat[4];
   const int last_partial = ktail != 0 ? nk - 1 : -1;
+  const bool tail_fix = DMA128_GLOBAL ? ktail != 0 : (ktail & 3) != 0;      // the last tile's image needs cleaning in LDS
 #pragma unroll
   for (int j = 0; j < QREQ; ++j) {
     const int R = (wave * QREQ + j) * 8 + (lane >> 3);
-    voat[j] = ((((lane & 7) ^ fq(R)) << 2) >= ktail) ? OOB : voa[j];
+    voat[j] = ((((lane & 7) ^ fq(R)) << 2) >= ktail) ? (DMA128_GLOBAL ? (voa[j] & ~0x70u) : OOB) : voa[j];
   }
   // Pop: request i of this wave = number r = wave 6 + i of the tile's 24: plane r >> 3, rows (r & 7) 16 .. + 15; rows past N repeat
   // row N - 1 (their columns are never stored)
@@ -222,6 +243,11 @@ __global__ __launch_bounds__(256, 2) void gemm_dma128_kernel(GemmShape g, Epi ep
     const int r = wave * PREQ + i, Rp = (r & 7) * 16 + (lane >> 2);
     vob[i] = (uint32_t)min(n0 + Rp, g.N - 1) * 64u + (uint32_t)(((lane & 3) ^ lds_sw(Rp)) << 4);
   }
+  // the global form's sources (wave-uniform, in scalar registers) and the LDS base address
+  const char* const q_src = reinterpret_cast<const char*>(uniform64(reinterpret_cast<uint64_t>(g.Q + kbeg)));
+  const char* const p_src = reinterpret_cast<const char*>(uniform64(reinterpret_cast<uint64_t>(g.Pimg + (int64_t)(kbeg >> 5) * g.ldpi)));
+  const int64_t p_tile_bytes = (int64_t)uniform64((uint64_t)(g.ldpi * 2)), p_plane_bytes = (int64_t)uniform64((uint64_t)(g.pimg_plane * 2));
+  const uint32_t lds0 = (uint32_t)(size_t)(__attribute__((address_space(3))) unsigned char*)smem;
   // ---- fragment addresses (byte offsets inside a stage)
   //   Pop (a operand, rows n): row wn 64 + b 32 + l31, 16-byte chunk 2s + lh of the plane's 64-byte row
   //   Qop (b operand, rows m): row wm WTM + a 32 + l31, fp32 chunks 4s + 2lh and + 1 of the 128-byte row
@@ -296,11 +322,18 @@ __global__ __launch_bounds__(256, 2) void gemm_dma128_kernel(GemmShape g, Epi ep
     unsigned char* base = smem + buf * G::STAGE;
     if (r < QREQ) {
       const uint32_t vo = (kt == last_partial) ? voat[r] : voa[r];      // (a select, not a branch: the k-step stays one basic block)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_ptr)(base + (wave * QREQ + r) * 1024), 16, vo, (uint32_t)(kbeg + 32 * kt) * 4u, 0, (ABL & 64) ? 2 : 0);
+      if constexpr (DMA128_GLOBAL && !(ABL & 192))
+        dma16g(vo, lds0 + buf * G::STAGE + (wave * QREQ + r) * 1024, q_src + (int64_t)kt * 128);
+      else
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_ptr)(base + (wave * QREQ + r) * 1024), 16, vo, (uint32_t)(kbeg + 32 * kt) * 4u, 0, (ABL & 64) ? 2 : 0);
     } else {
       const int q = wave * PREQ + (r - QREQ);
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (lds_ptr)(base + G::Q_IMG + (q >> 3) * G::P_PLANE + (q & 7) * 1024), 16, vob[r - QREQ],
-                                               (uint32_t)((kbeg >> 5) + kt) * kt_bytes + (uint32_t)(q >> 3) * plane_bytes, 0, (ABL & 128) ? 2 : 0);
+      if constexpr (DMA128_GLOBAL && !(ABL & 192))
+        dma16g(vob[r - QREQ], lds0 + buf * G::STAGE + G::Q_IMG + (q >> 3) * G::P_PLANE + (q & 7) * 1024,
+               p_src + (int64_t)kt * p_tile_bytes + (int64_t)(q >> 3) * p_plane_bytes);
+      else
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (lds_ptr)(base + G::Q_IMG + (q >> 3) * G::P_PLANE + (q & 7) * 1024), 16, vob[r - QREQ],
+                                                 (uint32_t)((kbeg >> 5) + kt) * kt_bytes + (uint32_t)(q >> 3) * plane_bytes, 0, (ABL & 128) ? 2 : 0);
     }
   };
   // k-step S of the k-tile in image BUF: matrix instructions on set S, everything of the next k-step behind them.
@@ -352,9 +385,10 @@ __global__ __launch_bounds__(256, 2) void gemm_dma128_kernel(GemmShape g, Epi ep
   auto clean_tail = [&](const int buf) __attribute__((always_inline)) {
     // the chunk that straddles the reduce extent carries 1-3 elements of whatever follows in the row: zero them in place
     if (tid < BM) {
-      const int c = ktail >> 2;
-      float* p = reinterpret_cast<float*>(smem + buf * G::STAGE + tid * 128 + ((c ^ fq(tid)) << 4));
-      for (int e = ktail & 3; e < 4; ++e) p[e] = 0.f;
+      // (global form: every element from the extent on -- the chunks past it hold a copy of the k-tile's first chunk)
+      const int kend_fix = DMA128_GLOBAL ? 32 : ((ktail >> 2) << 2) + 4;
+      for (int k = ktail; k < kend_fix; ++k)
+        reinterpret_cast<float*>(smem + buf * G::STAGE + tid * 128 + (((k >> 2) ^ fq(tid)) << 4))[k & 3] = 0.f;
     }
     __syncthreads();
   };
@@ -365,7 +399,7 @@ __global__ __launch_bounds__(256, 2) void gemm_dma128_kernel(GemmShape g, Epi ep
     // (ABL & 32, tuning: the same tile requested a second time from k-step 0 -- twice the bytes in flight; results undefined)
     kstep(buf_c, std::integral_constant<int, 0>{}, std::integral_constant<bool, (ABL & 32) != 0>{}, kt < nk - 2 ? kt + 2 : kt);
     publish();                                                   // tile kt + 1 is in image BUF ^ 1; image BUF is free
-    if ((ktail & 3) != 0 && kt + 2 == nk) clean_tail(BUF ^ 1);
+    if (tail_fix && kt + 2 == nk) clean_tail(BUF ^ 1);
     kstep(buf_c, std::integral_constant<int, 1>{}, dma_c, kt + 2);
   };
 
@@ -382,7 +416,7 @@ __global__ __launch_bounds__(256, 2) void gemm_dma128_kernel(GemmShape g, Epi ep
     }
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
-    if ((ktail & 3) != 0 && nk == 1) clean_tail(0);
+    if (tail_fix && nk == 1) clean_tail(0);
 #pragma unroll
     for (int i = 0; i < 2 * MT + 6; ++i) frag_read(std::integral_constant<int, 0>{}, smem, 0, i);
     if constexpr (!(ABL & 2)) {
