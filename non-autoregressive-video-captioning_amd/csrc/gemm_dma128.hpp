@@ -17,9 +17,9 @@
 //     12 MT matrix instructions of 32 cycles -- a third of the issue slots, where the 16 x 16 x 32 body of gemm_g256w.hpp needs
 //     all of them.
 //   * one workgroup is 4 waves (one per SIMD), 64 / 80 KB of LDS: TWO workgroups per CU, so the second one's k-loop covers the
-//     first one's prologue (DMA latency), epilogue (bias / activation / Philox dropout / residual: 20-30 k cycles for the FFN
-//     epilogues, which is why they could not move to the one-per-CU wide kernel) and barrier waits.  No hand scheduling: the
-//     partner wave on the SIMD fills what the compiler's order leaves open.
+//     first one's prologue (DMA latency), epilogue and barrier waits.  The k-loop is a software pipeline over k-steps pinned slot
+//     by slot (see "the k-loop" below): the first form left the order to hipcc and to the partner wave on the SIMD, and neither
+//     the split block nor the burst of DMA requests overlapped with the partner's matrix instructions.
 //   * accumulators per (row block, column block) add their (k-tile, k-step, term) products in the wide kernel's order with the
 //     wide kernel's instruction: the results are the wide kernel's, bit for bit (tests/test_dma128_gpu.py), and the epilogues
 //     are the family's (EpiLinear / EpiStore / EpiArgmax), dropout masks keyed by the element index.
@@ -336,8 +336,8 @@ __global__ __launch_bounds__(256, 2) void gemm_dma128_kernel(GemmShape g, Epi ep
                                                  (uint32_t)((kbeg >> 5) + kt) * kt_bytes + (uint32_t)(q >> 3) * plane_bytes, 0, (ABL & 128) ? 2 : 0);
     }
   };
-  // k-step S of the k-tile in image BUF: matrix instructions on set S, everything of the next k-step behind them.
-  // dma_kt >= 0: request that k-tile into image BUF ^ 1 ... no: into the image the NEXT-next tile owns = BUF (see above)
+  // k-step S of the k-tile in image BUF: matrix instructions on fragment set S, everything of the next k-step behind them.
+  // DMA (compile time): also request k-tile dma_kt (= this tile + 2) into image BUF, which this tile has just left
   auto kstep = [&](auto buf_c, auto s_c, auto dma_c, const int dma_kt) __attribute__((always_inline)) {
     constexpr int BUF = decltype(buf_c)::value, S = decltype(s_c)::value;
     constexpr bool DMA = decltype(dma_c)::value;
