@@ -142,11 +142,10 @@ class _Loader(object):
 def get_loader(opt, mode, print_info=False, specific=-1, device=None, **kwargs):
     """DataLoader(VideoDataset(opt, mode), batch_size, shuffle=train) of the reference (run.py:89-96).
     opt['info_corpus'] is the reference's corpus pickle; opt['feats_<m>'] names ONE feature shard per modality
-    (data/shards.py; the reference's per-video HDF5 files are re-packed once with `write_feature_shard`)."""
+    (data/shards.py; the reference's per-video HDF5 files are re-packed once with `write_feature_shard`).
+    specific != -1: only the videos of that category, info['split_category'][mode][specific] (dataloader.py:151-156)."""
     from ..data import CaptionTable, FeatureShard, ShardLoader
     assert mode in ('train', 'validate', 'test')
-    if specific != -1:
-        raise NotImplementedError('nacf_amd: category-specific loaders are not built')
     device = torch.device('cuda') if device is None else torch.device(device)
     with open(opt['info_corpus'], 'rb') as f:
         corpus = pickle.load(f)
@@ -167,9 +166,17 @@ def get_loader(opt, mode, print_info=False, specific=-1, device=None, **kwargs):
     out = _Loader()
     state = {'epoch': 0}
 
+    if specific != -1:
+        by_category = corpus['info'].get('split_category')
+        if by_category is None:
+            raise KeyError("nacf_amd: specific=%d needs info['split_category'] in %s" % (specific, opt['info_corpus']))
+        members = by_category[mode][specific]
+    else:
+        members = corpus['info']['split'][mode]
+
     def build(redraw=False):
         table, vids = CaptionTable.from_corpus(corpus['captions'], corpus.get('pos_tags'), corpus['info'],
-                                               corpus['info']['split'][mode], opt, mode, rng=rs)
+                                               members, opt, mode, rng=rs)
         if redraw:
             state['epoch'] += 1
         out.inner = ShardLoader(shards, table, vids, opt, batch_size=batch_size, device=device, mode=mode,

@@ -212,7 +212,9 @@ def _write_corpus(tmp, n_videos=40, V=60, L=10, T=20, Dm=32, seed=0):
         refs[vid] = [{"image_id": vid, "cap_id": j, "caption": " ".join(itow[w] for w in c[1:-1])} for j, c in enumerate(caps[vid])]
     itop = dict(enumerate(["<pad>", "<unk>", "<bos>", "<eos>", "<mask>", "<vis>", "NOUN", "VERB"]))
     split = {"train": list(range(0, 28)), "validate": list(range(28, 34)), "test": list(range(34, 40))}
-    info = dict(itow=itow, itop=itop, itoc={v: int(cls[v]) for v in range(n_videos)}, length_info=li, split=split)
+    by_cat = {m: {c: [v for v in ix if int(cls[v]) == c] for c in range(n_class)} for m, ix in split.items()}
+    info = dict(itow=itow, itop=itop, itoc={v: int(cls[v]) for v in range(n_videos)}, length_info=li, split=split,
+                split_category=by_cat)
     with open(os.path.join(tmp, "info_corpus.pkl"), "wb") as f:
         pickle.dump({"info": info, "captions": caps, "pos_tags": tags}, f)
     with open(os.path.join(tmp, "refs.pkl"), "wb") as f:
@@ -270,6 +272,32 @@ def test_train_network_all_end_to_end(dev, tmp_path):
     graphed = run_eval(o3, m2, None, get_loader(o3, "validate", device=dev), vl.dataset.get_vocab(), dev)
     assert graphed["CIDEr"] == again["CIDEr"] and graphed["Bleu_4"] == again["Bleu_4"]
     assert any(k[0] != "seen" for k in m2._nacf_decode_graphs)
+
+
+def test_category_specific_loader_serves_only_that_category(dev, tmp_path):
+    """get_loader(..., specific=c): the videos of info['split_category'][mode][c], as dataloader.py:151-156"""
+    from nacf_amd.misc.run import get_loader
+    tmp = str(tmp_path)
+    paths, V = _write_corpus(tmp)
+    opt = _run_opt(tmp, paths, V)
+    corpus = pickle.load(open(opt["info_corpus"], "rb"))
+    whole = get_loader(opt, "test", device=dev)
+    seen_all = sorted(v for b in whole for v in b["video_ids"])
+    assert seen_all == sorted("video%d" % v for v in corpus["info"]["split"]["test"])
+    served = 0
+    for c, members in corpus["info"]["split_category"]["test"].items():
+        if not members:
+            continue
+        part = get_loader(opt, "test", specific=c, device=dev)
+        got = [(v, int(k)) for b in part for v, k in zip(b["video_ids"], b["category"].reshape(-1).tolist())]
+        assert sorted(v for v, _ in got) == sorted("video%d" % v for v in members)
+        assert all(k == c for _, k in got)
+        served += len(got)
+    assert served == len(seen_all)
+    del corpus["info"]["split_category"]
+    pickle.dump(corpus, open(opt["info_corpus"], "wb"))
+    with pytest.raises(KeyError):
+        get_loader(opt, "test", specific=0, device=dev)
 
 
 def test_rank_sharded_loaders_partition_the_global_batch(dev, tmp_path):
