@@ -47,17 +47,43 @@ template <> struct Ld<4> {
   }
 };
 
+// Guarded loads (`row < n ? load : 0`) are basic blocks of their own: the compiler never batches loads across blocks, and each then costs
+// a full L2 latency.  The branch-free forms read the last live row / key instead and replace the value.  Measured per kernel inside the
+// captured step and the decode loop (profiles/r06_attn_branchfree_ab.txt): it pays in the forward kernel's key-token loads (decode:
+// 37.8 -> 35.4 us) and, marginally, in the dK / dV operand loads of the backward; in the row fragments it costs the self-attention
+// backward 2.8 us for 1 us of the forward, and branch-free key-token loads make that backward 8 us slower.  Build switches for the A/B:
+#ifndef NACF_ATTN_BF_ROWFRAG
+#define NACF_ATTN_BF_ROWFRAG 0       // load_row_frag
+#endif
+#ifndef NACF_ATTN_BF_KEYTOK
+#define NACF_ATTN_BF_KEYTOK 1        // softmax_rows<.., FWD = true> (the forward kernels); 2 = the backward too
+#endif
+#ifndef NACF_ATTN_BF_CQ
+#define NACF_ATTN_BF_CQ 1            // contract_q
+#endif
 // row fragments of a [rows, dk] operand for the "reduce over d" contractions:
 // lane (i, g) loads floats [g*dk/4, (g+1)*dk/4) of row (16*t + i); rows >= n_rows read as zero
 template <int DK16>
 __device__ __forceinline__ void load_row_frag(f32x4 (&f)[DK16], const float* __restrict__ base, int64_t ld, int row,
                                               int n_rows, int g) {
   constexpr int DK = 16 * DK16;
+#if NACF_ATTN_BF_ROWFRAG
+  // a guarded load is a basic block of its own, and loads in different blocks are never batched: every fragment then costs one full
+  // L2 latency.  Read the last live row instead (n_rows >= 1) and replace the value by zero.
+  const bool live = row < n_rows;
+  const float* src = base + (int64_t)(live ? row : n_rows - 1) * ld + g * (DK / 4);
+#pragma unroll
+  for (int j = 0; j < DK16; ++j) {
+    const f32x4 v = *reinterpret_cast<const f32x4*>(src + 4 * j);
+    f[j] = live ? v : f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+#else
 #pragma unroll
   for (int j = 0; j < DK16; ++j) {
     f[j] = (row < n_rows) ? *reinterpret_cast<const f32x4*>(base + (int64_t)row * ld + g * (DK / 4) + 4 * j)
                           : f32x4{0.f, 0.f, 0.f, 0.f};
   }
+#endif
 }
 
 // acc[tm][tn] (+)= sum_d  A[16*tn + i][d] * B[16*tm + i][d]   (A: keys side, B: queries side)
@@ -119,7 +145,7 @@ __device__ __forceinline__ void store_rows(const f32x4 (&o)[2][DK16], float* __r
 
 // scores (accumulator layout) -> probabilities, in place.  Mirrors models/bert.py:157-167:
 // divide by sqrt(dk) AFTER the product, masked_fill(-10e6), softmax over keys.
-template <int NKT>
+template <int NKT, bool FWD = false>
 __device__ __forceinline__ void softmax_rows(f32x4 (&s)[2][NKT], float sq, const int64_t* __restrict__ key_tok,
                                              int causal, int Lk, int i, int g) {
   unsigned long long padbits = 0ull;  // bit (tn*4+rr): key is PAD or beyond Lk handled separately
@@ -129,7 +155,12 @@ __device__ __forceinline__ void softmax_rows(f32x4 (&s)[2][NKT], float sq, const
 #pragma unroll
       for (int rr = 0; rr < 4; ++rr) {
         const int key = tn * 16 + g * 4 + rr;
-        if (key < Lk && key_tok[key] == NACF_PAD) padbits |= 1ull << (tn * 4 + rr);
+        if constexpr (NACF_ATTN_BF_KEYTOK > (FWD ? 0 : 1)) {
+          const int64_t tok = key_tok[key < Lk ? key : Lk - 1];     // one batch of loads, not a guarded load (= a latency) per key
+          if (key < Lk && tok == NACF_PAD) padbits |= 1ull << (tn * 4 + rr);
+        } else {
+          if (key < Lk && key_tok[key] == NACF_PAD) padbits |= 1ull << (tn * 4 + rr);
+        }
       }
   }
 #pragma unroll
@@ -198,7 +229,7 @@ __device__ __forceinline__ void fwd_item(const int item, const float* __restrict
 #pragma unroll
     for (int tn = 0; tn < NKT; ++tn) s[tm][tn] = f32x4{0.f, 0.f, 0.f, 0.f};
   contract_d<NKT, DK16>(s, Kb, ldk, Lk, qf, i, g);
-  softmax_rows<NKT>(s, sqrtf((float)DK), key_tokens ? key_tokens + (int64_t)r * Lk : nullptr, causal, Lk, i, g);
+  softmax_rows<NKT, true>(s, sqrtf((float)DK), key_tokens ? key_tokens + (int64_t)r * Lk : nullptr, causal, Lk, i, g);
   if (probs) {
 #pragma unroll
     for (int tm = 0; tm < 2; ++tm) {
@@ -252,9 +283,16 @@ __device__ __forceinline__ void contract_q(const float* T, int pitch, const floa
     for (int st = 0; st < 8; ++st) {
       const int q = st * 4 + g;                 // k-permutation of the reduce index q (Lq padded to 32)
       float af[DK16];
+#if NACF_ATTN_BF_CQ
+      const bool live = q < n_q;
+      Ld<DK16>::ld(A + (int64_t)(live ? q : n_q - 1) * lda + DK16 * i, af);
+#pragma unroll
+      for (int td = 0; td < DK16; ++td) af[td] = live ? af[td] : 0.f;
+#else
 #pragma unroll
       for (int td = 0; td < DK16; ++td) af[td] = 0.f;
       if (q < n_q) Ld<DK16>::ld(A + (int64_t)q * lda + DK16 * i, af);
+#endif
 #pragma unroll
       for (int t = 0; t < TKC; ++t) {
         const float b = T[q * pitch + (tk0 + t) * 16 + i];
@@ -383,6 +421,65 @@ __global__ __launch_bounds__(256) void bwd_kernel(const float* __restrict__ Q, i
   }
 }
 
+// Branch-free forms of the fragment loads (rows past the end: the last live row is read and the value replaced by zero).  A guarded
+// load is a basic block of its own: the compiler cannot batch such loads, and a contraction that takes its operand from global memory
+// step by step then waits out one full L2 latency per step (contract_q_acc: 16 of them per sequence).  n_rows >= 1.
+template <int DK16>
+__device__ __forceinline__ void raw_row_frag(f32x4 (&f)[DK16], const float* __restrict__ base, int64_t ld, int row, int n_rows, int g) {
+  constexpr int DK = 16 * DK16;
+  const float* src = base + (int64_t)(row < n_rows ? row : n_rows - 1) * ld + g * (DK / 4);
+#pragma unroll
+  for (int j = 0; j < DK16; ++j) f[j] = *reinterpret_cast<const f32x4*>(src + 4 * j);
+}
+template <int DK16>
+__device__ __forceinline__ void mask_row_frag(f32x4 (&f)[DK16], bool live) {
+#pragma unroll
+  for (int j = 0; j < DK16; ++j) f[j] = live ? f[j] : f32x4{0.f, 0.f, 0.f, 0.f};
+}
+// acc[tm][tn] += sum_d A[16 tn + i][d] B[16 tm + i][d] with both operands in registers (contract_d's order of operations)
+template <int NKT, int DK16>
+__device__ __forceinline__ void contract_d_regs(f32x4 (&acc)[2][NKT], const f32x4 (&af)[NKT][DK16], const f32x4 (&bf)[2][DK16]) {
+#pragma unroll
+  for (int tn = 0; tn < NKT; ++tn)
+#pragma unroll
+    for (int j = 0; j < DK16; ++j)
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int tm = 0; tm < 2; ++tm)
+          acc[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[tn][j][e], bf[tm][j][e], acc[tm][tn], 0, 0, 0);
+}
+// the A operand of contract_q_acc for all 8 steps, requested in one batch; masked when it is about to be used
+template <int DK16>
+__device__ __forceinline__ void raw_q_cols(float (&af)[8][DK16], const float* __restrict__ A, int64_t lda, int n_q, int i, int g) {
+#pragma unroll
+  for (int st = 0; st < 8; ++st) {
+    const int q = st * 4 + g;
+    Ld<DK16>::ld(A + (int64_t)(q < n_q ? q : n_q - 1) * lda + DK16 * i, af[st]);
+  }
+}
+template <int DK16>
+__device__ __forceinline__ void mask_q_cols(float (&af)[8][DK16], int n_q, int g) {
+#pragma unroll
+  for (int st = 0; st < 8; ++st)
+#pragma unroll
+    for (int td = 0; td < DK16; ++td) af[st][td] = (st * 4 + g < n_q) ? af[st][td] : 0.f;
+}
+template <int DK16>
+__device__ __forceinline__ void contract_q_acc_regs(const float* T, int pitch, const float (&af)[8][DK16],
+                                                    f32x4 (&acc)[DK16][2], int i, int g) {
+#pragma unroll
+  for (int st = 0; st < 8; ++st) {
+    const int q = st * 4 + g;
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const float b = T[q * pitch + t * 16 + i];
+#pragma unroll
+      for (int td = 0; td < DK16; ++td) acc[td][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[st][td], b, acc[td][t], 0, 0, 0);
+    }
+  }
+}
+
 // ---- key-block backward (cross-attention: no key mask, not causal, up to 128 keys) ------------------------------------
 // The kernel above gives one wave a whole (memory row set, head): 1024 waves for B=128 x 8 heads -- one per SIMD, each
 // walking 1280 MFMAs per sequence behind uncovered load latency.  Here the FOUR waves of a workgroup share the item and
@@ -436,7 +533,7 @@ constexpr int KB_WGS = NACF_ATTN_KB_WGS;        // resident workgroups per CU th
                                                 // (measured: 1 -> 121 us, 2 -> 97 us, 3 spills 71 VGPRs -> 145 us)
 constexpr int KB_PITCH = 48;                     // transpose tile [32][48]: 2 key tiles + 16 (rows 16 banks apart)
 constexpr int KB_RED_PITCH = 68;                 // dQ partials [4][32][64 + 4]
-template <int DK16>
+template <int DK16, int NB = 1>      // NB = 0: the guarded loads of the first form (kept for A/B: NACF_ATTN_KB=2)
 __global__ __launch_bounds__(256, KB_WGS) void bwd_kb_kernel(const float* __restrict__ Q, int64_t ldq, const float* __restrict__ K,
                                                       int64_t ldk, const float* __restrict__ V, int64_t ldv,
                                                       const float* __restrict__ dO, int64_t lddo, float* __restrict__ dQ,
@@ -477,17 +574,49 @@ __global__ __launch_bounds__(256, KB_WGS) void bwd_kb_kernel(const float* __rest
       for (int t = 0; t < 2; ++t) { p[tm][t] = f32x4{0.f, 0.f, 0.f, 0.f}; dp[tm][t] = f32x4{0.f, 0.f, 0.f, 0.f}; }
     float bm[2] = {-3.0e38f, -3.0e38f}, bl[2] = {0.f, 0.f};
     if (nk > 0) {
-      {
-        f32x4 qf[2][DK16];
+      if constexpr (NB) {
+        // each contraction's operands are requested as one batch; the zeroing of rows past the end follows the wait.  The scheduling
+        // barriers keep a batch a batch (the scheduler sinks every load to its first use).  All four operands at once would hide the dP
+        // operands under the S contraction, but needs more than the 256 registers two workgroups per CU leave a wave (148 B of spills).
+        {
+          f32x4 qf[2][DK16], kf[2][DK16];
 #pragma unroll
-        for (int tm = 0; tm < 2; ++tm) load_row_frag<DK16>(qf[tm], Qb, ldq, tm * 16 + i, Lq, g);
-        contract_d<2, DK16>(p, Kb, ldk, nk, qf, i, g);            // S block
-      }
-      {
-        f32x4 gf[2][DK16];
+          for (int t = 0; t < 2; ++t) {
+            raw_row_frag<DK16>(qf[t], Qb, ldq, t * 16 + i, Lq, g);
+            raw_row_frag<DK16>(kf[t], Kb, ldk, t * 16 + i, nk, g);
+          }
+          __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int tm = 0; tm < 2; ++tm) load_row_frag<DK16>(gf[tm], dOb, lddo, tm * 16 + i, Lq, g);
-        contract_d<2, DK16>(dp, Vb, ldv, nk, gf, i, g);           // dP block = dO V_blk^T
+          for (int t = 0; t < 2; ++t) { mask_row_frag<DK16>(qf[t], t * 16 + i < Lq); mask_row_frag<DK16>(kf[t], t * 16 + i < nk); }
+          contract_d_regs<2, DK16>(p, kf, qf);                      // S block
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        {
+          f32x4 gf[2][DK16], vf[2][DK16];
+#pragma unroll
+          for (int t = 0; t < 2; ++t) {
+            raw_row_frag<DK16>(gf[t], dOb, lddo, t * 16 + i, Lq, g);
+            raw_row_frag<DK16>(vf[t], Vb, ldv, t * 16 + i, nk, g);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int t = 0; t < 2; ++t) { mask_row_frag<DK16>(gf[t], t * 16 + i < Lq); mask_row_frag<DK16>(vf[t], t * 16 + i < nk); }
+          contract_d_regs<2, DK16>(dp, vf, gf);                     // dP block = dO V_blk^T
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      } else {
+        {
+          f32x4 qf[2][DK16];
+#pragma unroll
+          for (int tm = 0; tm < 2; ++tm) load_row_frag<DK16>(qf[tm], Qb, ldq, tm * 16 + i, Lq, g);
+          contract_d<2, DK16>(p, Kb, ldk, nk, qf, i, g);
+        }
+        {
+          f32x4 gf[2][DK16];
+#pragma unroll
+          for (int tm = 0; tm < 2; ++tm) load_row_frag<DK16>(gf[tm], dOb, lddo, tm * 16 + i, Lq, g);
+          contract_d<2, DK16>(dp, Vb, ldv, nk, gf, i, g);
+        }
       }
 #pragma unroll
       for (int tm = 0; tm < 2; ++tm) {
@@ -601,10 +730,25 @@ __global__ __launch_bounds__(256, KB_WGS) void bwd_kb_kernel(const float* __rest
     }
     __syncthreads();                                            // the transpose tiles alias the dQ partials
     if (nk > 0) {
-      tile_to_lds<2>(T, KB_PITCH, dp, i, g);
-      contract_q_acc<DK16>(T, KB_PITCH, Qb, ldq, Lq, accK, i, g);     // dK_blk += dS_blk^T Q
-      tile_to_lds<2>(T, KB_PITCH, p, i, g);
-      contract_q_acc<DK16>(T, KB_PITCH, dOb, lddo, Lq, accV, i, g);   // dV_blk += P_blk^T dO
+      if constexpr (NB) {
+        // (requested two barriers earlier, ahead of the dQ reduction, these 64 registers spill: 97 -> 114 us; dQ's alone: 102 us)
+        float aq[8][DK16], ao[8][DK16];
+        raw_q_cols<DK16>(aq, Qb, ldq, Lq, i, g);
+        raw_q_cols<DK16>(ao, dOb, lddo, Lq, i, g);
+        __builtin_amdgcn_sched_barrier(0);
+        mask_q_cols<DK16>(aq, Lq, g);
+        tile_to_lds<2>(T, KB_PITCH, dp, i, g);
+        contract_q_acc_regs<DK16>(T, KB_PITCH, aq, accK, i, g);        // dK_blk += dS_blk^T Q
+        __builtin_amdgcn_sched_barrier(0);                             // (dO's wait and zeroing stay behind the dK contraction)
+        mask_q_cols<DK16>(ao, Lq, g);
+        tile_to_lds<2>(T, KB_PITCH, p, i, g);
+        contract_q_acc_regs<DK16>(T, KB_PITCH, ao, accV, i, g);        // dV_blk += P_blk^T dO
+      } else {
+        tile_to_lds<2>(T, KB_PITCH, dp, i, g);
+        contract_q_acc<DK16>(T, KB_PITCH, Qb, ldq, Lq, accK, i, g);
+        tile_to_lds<2>(T, KB_PITCH, p, i, g);
+        contract_q_acc<DK16>(T, KB_PITCH, dOb, lddo, Lq, accV, i, g);
+      }
     }
   }
   if (nk > 0) {

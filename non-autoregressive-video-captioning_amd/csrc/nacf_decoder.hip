@@ -1064,10 +1064,16 @@ int nacf_attention_bwd_dropout(const float* Q, int64_t ldq, const float* K, int6
         if (!set_kb) {
           (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn::bwd_kb_kernel<4>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+          (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn::bwd_kb_kernel<4, 0>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
           set_kb = true;
         }
-        hipLaunchKernelGGL((attn::bwd_kb_kernel<4>), dim3(n_kv * H), dim3(256), lds_kb, as_hip(stream), Q, ldq, K, ldk, V,
-                           ldv, dO, lddo, dQ, lddq, dK, lddk, dV, lddv, R, n_kv, H, Lq, Lk, kv_div, kv_mod, nseq_max);
+        if (e && atoi(e) == 2)
+          hipLaunchKernelGGL((attn::bwd_kb_kernel<4, 0>), dim3(n_kv * H), dim3(256), lds_kb, as_hip(stream), Q, ldq, K, ldk, V,
+                             ldv, dO, lddo, dQ, lddq, dK, lddk, dV, lddv, R, n_kv, H, Lq, Lk, kv_div, kv_mod, nseq_max);
+        else
+          hipLaunchKernelGGL((attn::bwd_kb_kernel<4>), dim3(n_kv * H), dim3(256), lds_kb, as_hip(stream), Q, ldq, K, ldk, V,
+                             ldv, dO, lddo, dQ, lddq, dK, lddk, dV, lddv, R, n_kv, H, Lq, Lk, kv_div, kv_mod, nseq_max);
         NACF_LAUNCH_CHECK("nacf_attention_bwd(mfma, key blocks)");
         return NACF_OK;
       }

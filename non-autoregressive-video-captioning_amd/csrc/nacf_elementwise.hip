@@ -601,55 +601,127 @@ __global__ void loss_combine_bwd_kernel(const float* __restrict__ gtotal, const 
 // decoding pass the five criterion scalars (nacf_nll_reduce: same thread -> row map and block_sum order, the same bits), the legacy
 // KLDivLoss mean of the length head (nacf_kldiv_mean: 256 threads walk the elements), then the weighted total and the running meters
 // (nacf_loss_combine) -- four single-workgroup launches of 5-10 us each otherwise.
+// The scalar tail (total + meters) used to be one lane walking 3 + 9 read-modify-writes behind two dependent loads each (~14 us of the
+// kernel's 24): the index / scale / coefficient / meter loads now go out at the top, one per thread, under the reductions; the slab lives
+// in LDS; the first thread of every meter adds that meter's entries in table order -- the same operations on the same values.
+constexpr int CRIT_TAIL_SLAB = 128, CRIT_TAIL_METERS = 64;
 __global__ __launch_bounds__(1024) void crit_tail_fwd_kernel(nacf_crit_tail t, float* __restrict__ slab, int n_terms, int stride,
                                                              const float* __restrict__ coef, float* __restrict__ total,
                                                              const int* __restrict__ m_dst, const int* __restrict__ m_src,
                                                              const float* __restrict__ m_scale, int n_meters, float* __restrict__ meters) {
-  __shared__ float red[16];
-  for (int pass = 0; pass < t.n_pass; ++pass) {
-    const float* __restrict__ label_logp = t.label_logp[pass];
-    const int64_t* __restrict__ argmax = t.argmax[pass];
-    const int64_t* __restrict__ labels = t.labels[pass];
-    const int exclude_mask = t.exclude[pass];
-    float nll = 0.f, hit = 0.f, cnt = 0.f, sl = 0.f, sc = 0.f;
-    for (int r = threadIdx.x; r < t.rows[pass]; r += blockDim.x) {
-      const int64_t lab = labels[r];
-      if (lab != NACF_PAD) {
-        const float lp = label_logp[r];
-        nll -= lp; sl += lp; sc += 1.f;
-        if (!(exclude_mask && lab == NACF_MASK)) {
-          cnt += 1.f;
-          if (argmax[r] == lab) hit += 1.f;
+  __shared__ float red[16], red5[16 * 5];
+  __shared__ float sslab[CRIT_TAIL_SLAB], scoef[CRIT_TAIL_SLAB], mval[CRIT_TAIL_METERS], mscale[CRIT_TAIL_METERS];
+  __shared__ int mdst[CRIT_TAIL_METERS];
+  const int tid = threadIdx.x;
+  // terms this launch does not produce keep what their producers left in the slab
+  if (tid < n_terms * stride) sslab[tid] = slab[tid];
+  if (tid < n_terms) scoef[tid] = coef[tid];
+  int my_dst = -1, my_src = 0;
+  float my_scale = 0.f, my_meter = 0.f;
+  if (tid < n_meters) {
+    my_dst = m_dst[tid]; my_src = m_src[tid]; my_scale = m_scale[tid];
+    my_meter = meters[my_dst];
+  }
+  __syncthreads();
+  // Every load of the reductions below is issued unconditionally, in batches of four rows / elements per thread, and all of them ahead
+  // of the first block-wide sum (a load behind `if (label != PAD)` is a dependent load: three label -> log p -> argmax chains per pass and
+  // ten t -> x chains of the length term were ~20 L2 latencies in a row).  The five sums of a pass share one pair of barriers.  Every sum
+  // is formed from the same values in the same order as in nacf_nll_reduce / nacf_kldiv_mean.
+  float part[4][5];
+#pragma unroll
+  for (int pass = 0; pass < 4; ++pass) {
+#pragma unroll
+    for (int k = 0; k < 5; ++k) part[pass][k] = 0.f;
+    if (pass < t.n_pass) {
+      const float* __restrict__ label_logp = t.label_logp[pass];
+      const int64_t* __restrict__ argmax = t.argmax[pass];
+      const int64_t* __restrict__ labels = t.labels[pass];
+      const int exclude_mask = t.exclude[pass];
+      const int rows = t.rows[pass];
+      float nll = 0.f, hit = 0.f, cnt = 0.f, sl = 0.f, sc = 0.f;
+      for (int r0 = tid; r0 < rows; r0 += 4 * (int)blockDim.x) {
+        int64_t lab[4], am[4];
+        float lp[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int r = r0 + u * (int)blockDim.x;
+          const int rc = r < rows ? r : rows - 1;
+          lab[u] = labels[rc]; lp[u] = label_logp[rc]; am[u] = argmax[rc];
+          if (r >= rows) lab[u] = NACF_PAD;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          if (lab[u] != NACF_PAD) {
+            nll -= lp[u]; sl += lp[u]; sc += 1.f;
+            if (!(exclude_mask && lab[u] == NACF_MASK)) {
+              cnt += 1.f;
+              if (am[u] == lab[u]) hit += 1.f;
+            }
+          }
         }
       }
+      part[pass][0] = nll; part[pass][1] = hit; part[pass][2] = cnt; part[pass][3] = sl; part[pass][4] = sc;
     }
-    nll = block_sum(nll, red);
-    hit = block_sum(hit, red);
-    cnt = block_sum(cnt, red);
-    sl = block_sum(sl, red);
-    sc = block_sum(sc, red);
-    if (threadIdx.x == 0) {
-      float* out5 = slab + (int64_t)t.slot[pass] * stride;
-      out5[0] = nll; out5[1] = hit; out5[2] = cnt; out5[3] = sl; out5[4] = sc;
+  }
+  float kl_acc = 0.f;
+  if (t.kl_x && tid < 256)
+    for (int e0 = tid; e0 < t.kl_total; e0 += 4 * 256) {
+      float tt[4], xx[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int e = e0 + u * 256;
+        const int ec = e < t.kl_total ? e : t.kl_total - 1;
+        tt[u] = t.kl_t[ec]; xx[u] = t.kl_x[ec];
+        if (e >= t.kl_total) tt[u] = 0.f;
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        if (tt[u] > 0.f) kl_acc += tt[u] * (logf(tt[u]) - xx[u]);
+    }
+  // block-wide sums: wave_sum, then the wave partials in wave order (block_sum's order), five values per barrier pair
+  const int w = tid >> 6, nw = ((int)blockDim.x + 63) >> 6;
+#pragma unroll
+  for (int pass = 0; pass < 4; ++pass) {
+    if (pass < t.n_pass) {
+      float v[5];
+#pragma unroll
+      for (int k = 0; k < 5; ++k) v[k] = wave_sum(part[pass][k]);
+      __syncthreads();
+      if ((tid & 63) == 0) {
+#pragma unroll
+        for (int k = 0; k < 5; ++k) red5[w * 5 + k] = v[k];
+      }
+      __syncthreads();
+      if (tid < 5) {
+        float tot = 0.f;
+        for (int i = 0; i < nw; ++i) tot += red5[i * 5 + tid];
+        slab[(int64_t)t.slot[pass] * stride + tid] = tot;
+        sslab[t.slot[pass] * stride + tid] = tot;
+      }
     }
   }
   if (t.kl_x) {
-    float acc = 0.f;
     const float inv = 1.f / (float)t.kl_total;
-    if (threadIdx.x < 256)
-      for (int e = threadIdx.x; e < t.kl_total; e += 256) {
-        const float tt = t.kl_t[e];
-        if (tt > 0.f) acc += tt * (logf(tt) - t.kl_x[e]);
-      }
-    acc = block_sum(acc, red);
-    if (threadIdx.x == 0) slab[(int64_t)t.kl_slot * stride] = acc * inv;
+    const float acc = block_sum(kl_acc, red);
+    if (tid == 0) { slab[(int64_t)t.kl_slot * stride] = acc * inv; sslab[t.kl_slot * stride] = acc * inv; }
   }
-  __syncthreads();      // thread 0's slab writes are ITS OWN reads below; the barrier only keeps the phases apart for the reader
-  if (threadIdx.x == 0) {
+  __syncthreads();
+  if (tid < n_meters) { mdst[tid] = my_dst; mscale[tid] = my_scale; mval[tid] = sslab[my_src]; }
+  __syncthreads();
+  if (tid == 0) {
     float tot = 0.f;
-    for (int i = 0; i < n_terms; ++i) tot += coef[i] * slab[(int64_t)i * stride];
+    for (int i = 0; i < n_terms; ++i) tot += scoef[i] * sslab[i * stride];
     total[0] = tot;
-    for (int j = 0; j < n_meters; ++j) meters[m_dst[j]] += m_scale[j] * slab[m_src[j]];
+  }
+  if (tid < n_meters) {
+    bool first = true;
+    for (int k = 0; k < tid; ++k) first = first && (mdst[k] != my_dst);
+    if (first) {
+      float m = my_meter;
+      for (int k = tid; k < n_meters; ++k)
+        if (mdst[k] == my_dst) m += mscale[k] * mval[k];
+      meters[my_dst] = m;
+    }
   }
 }
 __global__ __launch_bounds__(256) void crit_tail_bwd_kernel(nacf_crit_tail t, const float* __restrict__ gtotal, const float* __restrict__ coef,
@@ -1506,6 +1578,8 @@ int nacf_crit_tail_fwd(const nacf_crit_tail* tail, float* slab, int n_terms, int
   NACF_CHECK(tail && slab && coef && total && n_terms > 0 && stride >= 5, NACF_EINVAL, "nacf_crit_tail_fwd: bad argument");
   NACF_CHECK(n_meters == 0 || (m_dst && m_src && m_scale && meters), NACF_EINVAL, "nacf_crit_tail_fwd: incomplete meter table");
   NACF_CHECK(tail->n_pass >= 0 && tail->n_pass <= 4, NACF_EINVAL, "nacf_crit_tail_fwd: at most 4 passes");
+  NACF_CHECK(n_terms * stride <= CRIT_TAIL_SLAB && n_meters <= CRIT_TAIL_METERS, NACF_EINVAL,
+             "nacf_crit_tail_fwd: at most %d slab floats and %d meter entries", CRIT_TAIL_SLAB, CRIT_TAIL_METERS);
   for (int i = 0; i < tail->n_pass; ++i)
     NACF_CHECK(tail->label_logp[i] && tail->argmax[i] && tail->labels[i] && tail->rows[i] > 0 && tail->slot[i] >= 0 && tail->slot[i] < n_terms,
                NACF_EINVAL, "nacf_crit_tail_fwd: bad pass %d", i);

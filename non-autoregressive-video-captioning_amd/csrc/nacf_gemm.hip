@@ -286,6 +286,10 @@ __global__ void lse_merge_kernel(const float* __restrict__ pmax, const float* __
   const int lane = threadIdx.x & 63;
   if (row >= rows) return;
   if (count && row >= *count) return;
+  // slot -> label -> that label's logit is a chain of three dependent loads: start it here, under the merge (it used to follow it)
+  const int prow = live ? live[row] : row;     // physical slot
+  const int64_t lab = (label_logp && labels) ? labels[prow] : -1;
+  const float lab_logit = lab >= 0 ? logits[(int64_t)prow * ldl + lab] : 0.f;
   float best = -3.0e38f;
   int bidx = 0x7fffffff;
   for (int t = lane; t < tiles_n; t += 64) {
@@ -303,14 +307,10 @@ __global__ void lse_merge_kernel(const float* __restrict__ pmax, const float* __
   for (int t = lane; t < tiles_n; t += 64) s += psum[(int64_t)t * rows + row] * expf(pmax[(int64_t)t * rows + row] - best);
   s = wave_sum(s);
   if (lane == 0) {
-    const int prow = live ? live[row] : row;     // physical slot
     const float l = best + logf(s);
     if (lse) lse[prow] = l;
     if (argmax) argmax[prow] = bidx;
-    if (label_logp && labels) {
-      const int64_t lab = labels[prow];
-      label_logp[prow] = (lab >= 0) ? logits[(int64_t)prow * ldl + lab] - l : 0.f;
-    }
+    if (label_logp && labels) label_logp[prow] = (lab >= 0) ? lab_logit - l : 0.f;
   }
 }
 

@@ -857,7 +857,25 @@ def test_loss_combine_fwd_bwd(dev):
     assert torch.equal(gslab.cpu(), ref)
 
 
-@pytest.mark.parametrize("kb", ["1", "0"])
+@pytest.mark.parametrize("Lk,Lq", [(120, 20), (120, 32), (70, 7), (33, 1)])
+def test_key_block_backward_batched_loads_change_no_bit(dev, Lk, Lq, monkeypatch):
+    """the key-block kernel with its operand loads issued as branch-free batches (rows past the end read the last live row and are
+    replaced by zero) against its first form with guarded loads (NACF_ATTN_KB=2): the same operations on the same values"""
+    ops, _ = _ops()
+    Bv, k_, H, dk = 6, 2, 8, 64
+    D, R = H * dk, Bv * k_
+    q, kv, do = rnd(R * Lq, D, seed=1).to(dev), rnd(Bv * Lk, 2 * D, seed=2).to(dev), rnd(R * Lq, D, seed=3).to(dev)
+    outs = {}
+    for kb in ("2", "1"):
+        monkeypatch.setenv("NACF_ATTN_KB", kb)
+        dq, dkv = torch.full_like(q, float("nan")), torch.full_like(kv, float("nan"))
+        ops.attention_bwd(q, kv[:, :D], kv[:, D:], do, dq, dkv[:, :D], dkv[:, D:], None, 0, R, Bv, H, Lq, Lk, dk, k_, Bv)
+        outs[kb] = (dq, dkv)
+    assert torch.equal(outs["1"][0], outs["2"][0]) and torch.equal(outs["1"][1], outs["2"][1])
+    assert not bool(torch.isnan(outs["1"][0]).any()) and not bool(torch.isnan(outs["1"][1]).any())
+
+
+@pytest.mark.parametrize("kb", ["1", "0", "2"])
 @pytest.mark.parametrize("mode,Lk", [("mod", 120), ("div", 120), ("mod", 70), ("mod", 33)])
 def test_cross_attention_backward_model_width(dev, mode, Lk, kb, monkeypatch):
     """dk = 64, memory of up to 128 keys: the key-block kernel (four waves split the keys of a (video, head); softmax
