@@ -16,10 +16,10 @@ __global__ void length_beam_kernel(const float* __restrict__ pred_length, int B,
     for (int j = 0; j < lbs; ++j) {
       float best = -3.0e38f;
       int bi = -1;
+#pragma unroll 4      // the load is unconditional: behind `continue` every one of the lbs x max_len loads waited for the one before it
       for (int i = 0; i < max_len; ++i) {
-        if ((taken >> i) & 1ull) continue;
         const float v = p[i];
-        if (bi < 0 || v > best) { best = v; bi = i; }
+        if (!((taken >> i) & 1ull) && (bi < 0 || v > best)) { best = v; bi = i; }
       }
       taken |= 1ull << bi;
       int len = bi + bias;

@@ -604,9 +604,11 @@ __global__ void masked_mean_fwd_kernel(const float* __restrict__ y, const int64_
                                        float* __restrict__ out, int L, int D) {
   const int r = blockIdx.x;
   int cnt = 0;
+#pragma unroll 8
   for (int l = 0; l < L; ++l) cnt += tokens[(int64_t)r * L + l] != NACF_PAD ? 1 : 0;
   for (int d = threadIdx.x; d < D; d += blockDim.x) {
     float acc = 0.f;
+#pragma unroll 8
     for (int l = 0; l < L; ++l) acc += y[((int64_t)r * L + l) * D + d];
     out[(int64_t)r * D + d] = acc / (float)cnt;
   }

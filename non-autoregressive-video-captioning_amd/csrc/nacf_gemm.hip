@@ -238,6 +238,7 @@ __global__ void dw_group_reduce_kernel(DwReduceTable t) {
 }
 
 // merge the per-tile (max, idx, sumexp) partials and apply the decode bookkeeping
+constexpr int MERGE_NPL = 3;      // tile partials per lane held in registers: up to 192 column tiles (V <= 12288 at 64 columns a tile)
 __global__ void argmax_merge_kernel(const float* __restrict__ pmax, const float* __restrict__ psum,
                                     const int* __restrict__ pidx, int tiles_n, int rows,
                                     const int* __restrict__ live, const int* __restrict__ count,
@@ -248,30 +249,58 @@ __global__ void argmax_merge_kernel(const float* __restrict__ pmax, const float*
   const int lane = threadIdx.x & 63;
   if (row >= rows) return;
   if (count && row >= *count) return;
+  // slot -> <pad> / update flags is a chain of dependent loads: start it here, under the merge (it used to follow it); a row whose
+  // token is not to be replaced (mask-predict iterations: every position that is not re-masked) needs no merge at all
+  const int prow = live ? live[row] : row;     // physical slot
+  if (update_mask && !update_mask[prow]) return;
+  const bool is_pad = pad_tokens && pad_tokens[prow] == NACF_PAD;
   float best = -3.0e38f;
   int bidx = 0x7fffffff;
-  for (int t = lane; t < tiles_n; t += 64) {
-    float v = pmax[(int64_t)t * rows + row];
-    int i = pidx[(int64_t)t * rows + row];
-    if (v > best || (v == best && i < bidx)) { best = v; bidx = i; }
-  }
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) {
-    float ov = __shfl_xor(best, o, 64);
-    int oi = __shfl_xor(bidx, o, 64);
-    if (ov > best || (ov == best && oi < bidx)) { best = ov; bidx = oi; }
-  }
   float s = 0.f;
-  for (int t = lane; t < tiles_n; t += 64)
-    s += psum[(int64_t)t * rows + row] * __expf(pmax[(int64_t)t * rows + row] - best);
+  if (tiles_n <= 64 * MERGE_NPL) {
+    // every partial of the row is requested before the first one is used (three chains of loads otherwise: maxima, then sums)
+    float v[MERGE_NPL], e[MERGE_NPL];
+    int ix[MERGE_NPL];
+#pragma unroll
+    for (int u = 0; u < MERGE_NPL; ++u) {
+      const int t = lane + 64 * u;
+      const int64_t at = (int64_t)(t < tiles_n ? t : tiles_n - 1) * rows + row;
+      v[u] = pmax[at]; ix[u] = pidx[at]; e[u] = psum[at];
+    }
+#pragma unroll
+    for (int u = 0; u < MERGE_NPL; ++u)
+      if (lane + 64 * u < tiles_n && (v[u] > best || (v[u] == best && ix[u] < bidx))) { best = v[u]; bidx = ix[u]; }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      float ov = __shfl_xor(best, o, 64);
+      int oi = __shfl_xor(bidx, o, 64);
+      if (ov > best || (ov == best && oi < bidx)) { best = ov; bidx = oi; }
+    }
+#pragma unroll
+    for (int u = 0; u < MERGE_NPL; ++u)
+      if (lane + 64 * u < tiles_n) s += e[u] * __expf(v[u] - best);
+  } else {
+    for (int t = lane; t < tiles_n; t += 64) {
+      float v = pmax[(int64_t)t * rows + row];
+      int i = pidx[(int64_t)t * rows + row];
+      if (v > best || (v == best && i < bidx)) { best = v; bidx = i; }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      float ov = __shfl_xor(best, o, 64);
+      int oi = __shfl_xor(bidx, o, 64);
+      if (ov > best || (ov == best && oi < bidx)) { best = ov; bidx = oi; }
+    }
+    for (int t = lane; t < tiles_n; t += 64)
+      s += psum[(int64_t)t * rows + row] * __expf(pmax[(int64_t)t * rows + row] - best);
+  }
   s = wave_sum(s);
   if (lane == 0) {
-    const int prow = live ? live[row] : row;     // physical slot
     int64_t tok = bidx;
     float p = 1.0f / s;
-    if (pad_tokens && pad_tokens[prow] == NACF_PAD) { tok = NACF_PAD; p = 1.0f; }
+    if (is_pad) { tok = NACF_PAD; p = 1.0f; }
     if (zero_mask_prob && tok == NACF_MASK) p = 0.f;
-    if (!update_mask || update_mask[prow]) { tokens[prow] = tok; probs[prow] = p; }
+    tokens[prow] = tok; probs[prow] = p;
   }
 }
 
@@ -292,19 +321,43 @@ __global__ void lse_merge_kernel(const float* __restrict__ pmax, const float* __
   const float lab_logit = lab >= 0 ? logits[(int64_t)prow * ldl + lab] : 0.f;
   float best = -3.0e38f;
   int bidx = 0x7fffffff;
-  for (int t = lane; t < tiles_n; t += 64) {
-    float v = pmax[(int64_t)t * rows + row];
-    int i = pidx[(int64_t)t * rows + row];
-    if (v > best || (v == best && i < bidx)) { best = v; bidx = i; }
-  }
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) {
-    float ov = __shfl_xor(best, o, 64);
-    int oi = __shfl_xor(bidx, o, 64);
-    if (ov > best || (ov == best && oi < bidx)) { best = ov; bidx = oi; }
-  }
   float s = 0.f;
-  for (int t = lane; t < tiles_n; t += 64) s += psum[(int64_t)t * rows + row] * expf(pmax[(int64_t)t * rows + row] - best);
+  if (tiles_n <= 64 * MERGE_NPL) {
+    // every partial of the row is requested before the first one is used (three chains of loads otherwise: maxima, then sums)
+    float v[MERGE_NPL], e[MERGE_NPL];
+    int ix[MERGE_NPL];
+#pragma unroll
+    for (int u = 0; u < MERGE_NPL; ++u) {
+      const int t = lane + 64 * u;
+      const int64_t at = (int64_t)(t < tiles_n ? t : tiles_n - 1) * rows + row;
+      v[u] = pmax[at]; ix[u] = pidx[at]; e[u] = psum[at];
+    }
+#pragma unroll
+    for (int u = 0; u < MERGE_NPL; ++u)
+      if (lane + 64 * u < tiles_n && (v[u] > best || (v[u] == best && ix[u] < bidx))) { best = v[u]; bidx = ix[u]; }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      float ov = __shfl_xor(best, o, 64);
+      int oi = __shfl_xor(bidx, o, 64);
+      if (ov > best || (ov == best && oi < bidx)) { best = ov; bidx = oi; }
+    }
+#pragma unroll
+    for (int u = 0; u < MERGE_NPL; ++u)
+      if (lane + 64 * u < tiles_n) s += e[u] * expf(v[u] - best);
+  } else {
+    for (int t = lane; t < tiles_n; t += 64) {
+      float v = pmax[(int64_t)t * rows + row];
+      int i = pidx[(int64_t)t * rows + row];
+      if (v > best || (v == best && i < bidx)) { best = v; bidx = i; }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      float ov = __shfl_xor(best, o, 64);
+      int oi = __shfl_xor(bidx, o, 64);
+      if (ov > best || (ov == best && oi < bidx)) { best = ov; bidx = oi; }
+    }
+    for (int t = lane; t < tiles_n; t += 64) s += psum[(int64_t)t * rows + row] * expf(pmax[(int64_t)t * rows + row] - best);
+  }
   s = wave_sum(s);
   if (lane == 0) {
     const float l = best + logf(s);
@@ -317,6 +370,10 @@ __global__ void lse_merge_kernel(const float* __restrict__ pmax, const float* __
 // partition: rows[0..count) = ascending i with (tokens ? tokens[i] != PAD) && (flags ? flags[i] != 0); the other
 // slots fill rows[count..n) from the END (so they come out descending -- their order is irrelevant, the GEMMs only
 // zero-fill them).  One workgroup, ONE sweep, 4 consecutive slots per thread, wave scans by shuffle.
+// EPT consecutive slots per thread and sweep.  (16 -- the decode canvas' 15360 slots in one sweep instead of four -- is slower, 18 us
+// against 11: a lane then reads 128 consecutive bytes and every load instruction touches 64 cache lines.)
+// The token / flag loads are unconditional (past the end: the last slot is read and not used) so that a thread's loads go out together.
+template <int EPT>
 __global__ __launch_bounds__(1024) void rowset_build_kernel(const int64_t* __restrict__ tokens,
                                                              const uint8_t* __restrict__ flags, int n,
                                                              int* __restrict__ rows, int* __restrict__ count) {
@@ -325,17 +382,22 @@ __global__ __launch_bounds__(1024) void rowset_build_kernel(const int64_t* __res
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   if (threadIdx.x == 0) base_s = 0;
   __syncthreads();
-  for (int c0 = 0; c0 < n; c0 += 4096) {
-    const int i0 = c0 + threadIdx.x * 4;
-    bool live[4];
+  for (int c0 = 0; c0 < n; c0 += 1024 * EPT) {
+    const int i0 = c0 + threadIdx.x * EPT;
+    int64_t tok[EPT];
+    uint8_t flg[EPT];
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) {
+      const int ic = i0 + e < n ? i0 + e : n - 1;
+      tok[e] = tokens ? tokens[ic] : 1;
+      flg[e] = flags ? flags[ic] : 1;
+    }
+    unsigned live = 0u;
     int c = 0;
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const int i = i0 + e;
-      bool l = i < n;
-      if (l && tokens) l = tokens[i] != NACF_PAD;
-      if (l && flags) l = flags[i] != 0;
-      live[e] = l;
+    for (int e = 0; e < EPT; ++e) {
+      const bool l = (i0 + e < n) && (!tokens || tok[e] != NACF_PAD) && (!flags || flg[e] != 0);
+      live |= (l ? 1u : 0u) << e;
       c += l ? 1 : 0;
     }
     int incl = c;                       // inclusive scan of the per-thread live counts inside the wave
@@ -350,10 +412,10 @@ __global__ __launch_bounds__(1024) void rowset_build_kernel(const int64_t* __res
     for (int w = 0; w < wave; ++w) off += wsum[w];
     int lpos = off + incl - c;          // live slots before this thread's first element
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
+    for (int e = 0; e < EPT; ++e) {
       const int i = i0 + e;
       if (i < n) {
-        if (live[e]) rows[lpos++] = i;
+        if ((live >> e) & 1u) rows[lpos++] = i;
         else rows[n - 1 - (i - lpos)] = i;     // i - lpos = dead slots before i
       }
     }
@@ -382,7 +444,7 @@ __global__ __launch_bounds__(256) void dw_small_kernel(const float* __restrict__
   const int Mlive = rows ? min(M, *count) : M;
   float acc = 0.f, bsum = 0.f;
   const bool do_b = db && k == 0;
-#pragma unroll 8
+#pragma unroll 32      // (the loads of a body go out together: two latencies -- row index, then operands -- per body, not per row)
   for (int i = 0; i < Mlive; ++i) {
     const int m = rows ? rows[i] : i;
     const float z = dZ[(int64_t)m * lddz + n];
@@ -401,7 +463,7 @@ extern "C" {
 int nacf_rowset_build(const int64_t* tokens, const uint8_t* flags, int64_t n, int32_t* rows, int32_t* count,
                       nacf_stream_t stream) {
   NACF_CHECK((tokens || flags) && rows && count && n > 0 && n < 0x7fffffffLL, NACF_EINVAL, "nacf_rowset_build: bad argument");
-  hipLaunchKernelGGL(rowset_build_kernel, dim3(1), dim3(1024), 0, as_hip(stream), tokens, flags, (int)n, rows, count);
+  hipLaunchKernelGGL(rowset_build_kernel<4>, dim3(1), dim3(1024), 0, as_hip(stream), tokens, flags, (int)n, rows, count);
   NACF_LAUNCH_CHECK("nacf_rowset_build");
   return NACF_OK;
 }
