@@ -601,9 +601,9 @@ __global__ void loss_combine_bwd_kernel(const float* __restrict__ gtotal, const 
 // decoding pass the five criterion scalars (nacf_nll_reduce: same thread -> row map and block_sum order, the same bits), the legacy
 // KLDivLoss mean of the length head (nacf_kldiv_mean: 256 threads walk the elements), then the weighted total and the running meters
 // (nacf_loss_combine) -- four single-workgroup launches of 5-10 us each otherwise.
-// The scalar tail (total + meters) used to be one lane walking 3 + 9 read-modify-writes behind two dependent loads each (~14 us of the
-// kernel's 24): the index / scale / coefficient / meter loads now go out at the top, one per thread, under the reductions; the slab lives
-// in LDS; the first thread of every meter adds that meter's entries in table order -- the same operations on the same values.
+// The scalar tail (total + meters): the index / scale / coefficient / meter loads go out at the top, one per thread, under the
+// reductions; the slab lives in LDS; the first thread of every meter adds that meter's entries in table order -- the same operations
+// on the same values as one lane walking the table (which, measured, cost the same: the kernel's time was in the reductions' loads).
 constexpr int CRIT_TAIL_SLAB = 128, CRIT_TAIL_METERS = 64;
 __global__ __launch_bounds__(1024) void crit_tail_fwd_kernel(nacf_crit_tail t, float* __restrict__ slab, int n_terms, int stride,
                                                              const float* __restrict__ coef, float* __restrict__ total,
