@@ -1,5 +1,5 @@
-// Register-resident multi-head attention on the CDNA4 matrix cores (fp32,
-// v_mfma_f32_16x16x4_f32), forward and backward.  One WAVE owns one
+// Register-resident multi-head attention on the CDNA4 matrix cores (fp32 operands on v_mfma_f32_16x16x4_f32, or -- throughput
+// mode -- bf16 operands on v_mfma_f32_16x16x16_bf16: "PR" below), forward and backward.  One WAVE owns one
 // (sequence, head) pair: Lq <= 32 queries (2 MFMA row tiles), Lk <= 16*NKT keys,
 // dk = 16*DK16.  Nothing is staged through LDS in the forward pass: the MFMA
 // fragment layouts are chosen so that every operand is either a coalesced
@@ -47,6 +47,26 @@ template <> struct Ld<4> {
   }
 };
 
+// Arithmetic of the contractions, template parameter PR of everything below:
+//   PR = 0: fp32 operands, v_mfma_f32_16x16x4_f32 (the exact and the fp32 GEMM modes);
+//   PR = 1: the throughput mode (NACF_GEMM_BF16): operands rounded to bf16 (nearest even) in registers right before the matrix
+//           instruction, v_mfma_f32_16x16x16_bf16 -- ONE instruction where the fp32 form issues four (a lane's four k-steps are the four
+//           bf16 values of its operand: the fragment layouts above are unchanged), 16 against 128 cycles of the matrix pipe.
+//           Soft-max, its statistics, dS and every accumulator stay fp32.
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ s16x4 bf16x4_rne(float a, float b, float c, float d) {
+  typedef float f2 __attribute__((ext_vector_type(2)));
+  typedef __bf16 b2 __attribute__((ext_vector_type(2)));
+  typedef unsigned int u2 __attribute__((ext_vector_type(2)));
+  const u2 w = {__builtin_bit_cast(unsigned int, __builtin_convertvector(f2{a, b}, b2)),
+                __builtin_bit_cast(unsigned int, __builtin_convertvector(f2{c, d}, b2))};
+  return __builtin_bit_cast(s16x4, w);
+}
+__device__ __forceinline__ s16x4 bf16x4_rne(const f32x4& v) { return bf16x4_rne(v[0], v[1], v[2], v[3]); }
+__device__ __forceinline__ f32x4 mfma_bf16(s16x4 a, s16x4 b, f32x4 acc) {
+  return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a, b, acc, 0, 0, 0);
+}
+
 // Guarded loads (`row < n ? load : 0`) are basic blocks of their own: the compiler never batches loads across blocks, and each then costs
 // a full L2 latency.  The branch-free forms read the last live row / key instead and replace the value.  Measured per kernel inside the
 // captured step and the decode loop (profiles/r06_attn_branchfree_ab.txt): it pays in the forward kernel's key-token loads (decode:
@@ -87,27 +107,61 @@ __device__ __forceinline__ void load_row_frag(f32x4 (&f)[DK16], const float* __r
 }
 
 // acc[tm][tn] (+)= sum_d  A[16*tn + i][d] * B[16*tm + i][d]   (A: keys side, B: queries side)
-template <int NKT, int DK16>
+template <int NKT, int DK16, int PR = 0>
 __device__ __forceinline__ void contract_d(f32x4 (&acc)[2][NKT], const float* __restrict__ A, int64_t lda, int n_a,
                                            const f32x4 (&bf)[2][DK16], int i, int g) {
+  s16x4 bp[2][DK16];
+  if constexpr (PR == 1) {
+#pragma unroll
+    for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+      for (int j = 0; j < DK16; ++j) bp[tm][j] = bf16x4_rne(bf[tm][j]);
+  }
 #pragma unroll
   for (int tn = 0; tn < NKT; ++tn) {
     f32x4 af[DK16];
     load_row_frag<DK16>(af, A, lda, tn * 16 + i, n_a, g);
 #pragma unroll
-    for (int j = 0; j < DK16; ++j)
+    for (int j = 0; j < DK16; ++j) {
+      if constexpr (PR == 1) {
+        const s16x4 a = bf16x4_rne(af[j]);
 #pragma unroll
-      for (int e = 0; e < 4; ++e)
+        for (int tm = 0; tm < 2; ++tm) acc[tm][tn] = mfma_bf16(a, bp[tm][j], acc[tm][tn]);
+      } else {
 #pragma unroll
-        for (int tm = 0; tm < 2; ++tm)
-          acc[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[j][e], bf[tm][j][e], acc[tm][tn], 0, 0, 0);
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+          for (int tm = 0; tm < 2; ++tm)
+            acc[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[j][e], bf[tm][j][e], acc[tm][tn], 0, 0, 0);
+      }
+    }
   }
 }
 
 // o[tm][td] = sum_key  P[16*tm + i][key] * A[key][DK16*n + td]   with P in the accumulator layout of contract_d
-template <int NKT, int DK16>
+template <int NKT, int DK16, int PR = 0>
 __device__ __forceinline__ void contract_key(f32x4 (&o)[2][DK16], const f32x4 (&p)[2][NKT],
                                              const float* __restrict__ A, int64_t lda, int n_a, int i, int g) {
+  if constexpr (PR == 1) {
+#pragma unroll
+    for (int tn = 0; tn < NKT; ++tn) {
+      float af[4][DK16];
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr) {
+        int key = tn * 16 + g * 4 + rr;
+        key = key < n_a ? key : n_a - 1;          // P is exactly 0 there; keep the address in range
+        Ld<DK16>::ld(A + (int64_t)key * lda + DK16 * i, af[rr]);
+      }
+      const s16x4 pp[2] = {bf16x4_rne(p[0][tn]), bf16x4_rne(p[1][tn])};
+#pragma unroll
+      for (int td = 0; td < DK16; ++td) {
+        const s16x4 a = bf16x4_rne(af[0][td], af[1][td], af[2][td], af[3][td]);
+#pragma unroll
+        for (int tm = 0; tm < 2; ++tm) o[tm][td] = mfma_bf16(a, pp[tm], o[tm][td]);
+      }
+    }
+    return;
+  }
 #pragma unroll
   for (int tn = 0; tn < NKT; ++tn)
 #pragma unroll
@@ -202,7 +256,7 @@ __device__ __forceinline__ void softmax_rows(f32x4 (&s)[2][NKT], float sq, const
 // One item = (sequence, head, block of 32 queries), the work of one wave; nqb = ceil(Lq / 32) > 1 only without a causal mask.
 // Shared by fwd_kernel (one item per wave of the grid) and by persistent callers (a workgroup's
 // waves walk the items of an attention stage).
-template <int NKT, int DK16>
+template <int NKT, int DK16, int PR = 0>
 __device__ __forceinline__ void fwd_item(const int item, const float* __restrict__ Q, int64_t ldq, const float* __restrict__ K,
                                          int64_t ldk, const float* __restrict__ V, int64_t ldv,
                                          float* __restrict__ O, int64_t ldo,
@@ -228,7 +282,7 @@ __device__ __forceinline__ void fwd_item(const int item, const float* __restrict
   for (int tm = 0; tm < 2; ++tm)
 #pragma unroll
     for (int tn = 0; tn < NKT; ++tn) s[tm][tn] = f32x4{0.f, 0.f, 0.f, 0.f};
-  contract_d<NKT, DK16>(s, Kb, ldk, Lk, qf, i, g);
+  contract_d<NKT, DK16, PR>(s, Kb, ldk, Lk, qf, i, g);
   softmax_rows<NKT, true>(s, sqrtf((float)DK), key_tokens ? key_tokens + (int64_t)r * Lk : nullptr, causal, Lk, i, g);
   if (probs) {
 #pragma unroll
@@ -250,11 +304,11 @@ __device__ __forceinline__ void fwd_item(const int item, const float* __restrict
   for (int tm = 0; tm < 2; ++tm)
 #pragma unroll
     for (int td = 0; td < DK16; ++td) o[tm][td] = f32x4{0.f, 0.f, 0.f, 0.f};
-  contract_key<NKT, DK16>(o, s, Vb, ldv, Lk, i, g);
+  contract_key<NKT, DK16, PR>(o, s, Vb, ldv, Lk, i, g);
   store_rows<DK16>(o, O + ((int64_t)r * Lq + q0) * ldo + h * DK, ldo, nq, i, g);
 }
 
-template <int NKT, int DK16>
+template <int NKT, int DK16, int PR = 0>
 __global__ __launch_bounds__(256) void fwd_kernel(const float* __restrict__ Q, int64_t ldq, const float* __restrict__ K,
                                                    int64_t ldk, const float* __restrict__ V, int64_t ldv,
                                                    float* __restrict__ O, int64_t ldo,
@@ -264,11 +318,11 @@ __global__ __launch_bounds__(256) void fwd_kernel(const float* __restrict__ Q, i
   // The blocks of one (sequence, head) are consecutive items, i.e. waves of ONE workgroup: they walk the same K / V rows together.
   const int item = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (item >= R * H * nqb) return;
-  fwd_item<NKT, DK16>(item, Q, ldq, K, ldk, V, ldv, O, ldo, key_tokens, causal, probs, R, H, Lq, Lk, kv_div, kv_mod, nqb);
+  fwd_item<NKT, DK16, PR>(item, Q, ldq, K, ldk, V, ldv, O, ldo, key_tokens, causal, probs, R, H, Lq, Lk, kv_div, kv_mod, nqb);
 }
 
 // dst[key][d] (+)= sum_q T[q][key] * A[q][d]  for key tiles [tk0, tk0+TKC), T = wave-private LDS tile [32][PITCH]
-template <int NKT, int DK16, int TKC>
+template <int NKT, int DK16, int TKC, int PR = 0>
 __device__ __forceinline__ void contract_q(const float* T, int pitch, const float* __restrict__ A,
                                            int64_t lda, int n_q, float* __restrict__ dst, int64_t ldd, int n_keys,
                                            bool accumulate, int i, int g) {
@@ -279,6 +333,31 @@ __device__ __forceinline__ void contract_q(const float* T, int pitch, const floa
     for (int td = 0; td < DK16; ++td)
 #pragma unroll
       for (int t = 0; t < TKC; ++t) acc[td][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if constexpr (PR == 1) {
+#pragma unroll
+      for (int st0 = 0; st0 < 8; st0 += 4) {       // four k-steps of the fp32 form = one bf16 instruction
+        float af[4][DK16];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int q = (st0 + e) * 4 + g;
+          const bool live = q < n_q;
+          Ld<DK16>::ld(A + (int64_t)(live ? q : n_q - 1) * lda + DK16 * i, af[e]);
+#pragma unroll
+          for (int td = 0; td < DK16; ++td) af[e][td] = live ? af[e][td] : 0.f;
+        }
+        s16x4 a[DK16];
+#pragma unroll
+        for (int td = 0; td < DK16; ++td) a[td] = bf16x4_rne(af[0][td], af[1][td], af[2][td], af[3][td]);
+#pragma unroll
+        for (int t = 0; t < TKC; ++t) {
+          const int c = (tk0 + t) * 16 + i;
+          const s16x4 b = bf16x4_rne(T[(st0 * 4 + g) * pitch + c], T[((st0 + 1) * 4 + g) * pitch + c],
+                                     T[((st0 + 2) * 4 + g) * pitch + c], T[((st0 + 3) * 4 + g) * pitch + c]);
+#pragma unroll
+          for (int td = 0; td < DK16; ++td) acc[td][t] = mfma_bf16(a[td], b, acc[td][t]);
+        }
+      }
+    } else {
 #pragma unroll
     for (int st = 0; st < 8; ++st) {
       const int q = st * 4 + g;                 // k-permutation of the reduce index q (Lq padded to 32)
@@ -300,6 +379,7 @@ __device__ __forceinline__ void contract_q(const float* T, int pitch, const floa
         for (int td = 0; td < DK16; ++td)
           acc[td][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[td], b, acc[td][t], 0, 0, 0);
       }
+    }
     }
 #pragma unroll
     for (int t = 0; t < TKC; ++t) {
@@ -333,7 +413,7 @@ __device__ __forceinline__ void tile_to_lds(float* T, int pitch, const f32x4 (&p
 // takes the sequences k = sub, sub + wpi, ... of the item.  Everything up to dQ runs in parallel; the dK / dV updates
 // (read-modify-write of the same global rows) are then applied one wave at a time in sequence order, separated by
 // workgroup barriers -- deterministic, and with two sequences per video twice the waves are in flight.
-template <int NKT, int DK16>
+template <int NKT, int DK16, int PR = 0>
 __global__ __launch_bounds__(256) void bwd_kernel(const float* __restrict__ Q, int64_t ldq, const float* __restrict__ K,
                                                    int64_t ldk, const float* __restrict__ V, int64_t ldv,
                                                    const float* __restrict__ dO, int64_t lddo, float* __restrict__ dQ,
@@ -373,14 +453,14 @@ __global__ __launch_bounds__(256) void bwd_kernel(const float* __restrict__ Q, i
         f32x4 qf[2][DK16];
 #pragma unroll
         for (int tm = 0; tm < 2; ++tm) load_row_frag<DK16>(qf[tm], Qb, ldq, tm * 16 + i, Lq, g);
-        contract_d<NKT, DK16>(p, Kb, ldk, Lk, qf, i, g);
+        contract_d<NKT, DK16, PR>(p, Kb, ldk, Lk, qf, i, g);
       }
       softmax_rows<NKT>(p, sq, key_tokens ? key_tokens + (int64_t)r * Lk : nullptr, causal, Lk, i, g);
       {
         f32x4 gf[2][DK16];
 #pragma unroll
         for (int tm = 0; tm < 2; ++tm) load_row_frag<DK16>(gf[tm], dOb, lddo, tm * 16 + i, Lq, g);
-        contract_d<NKT, DK16>(dp, Vb, ldv, Lk, gf, i, g);   // dP = dO V^T
+        contract_d<NKT, DK16, PR>(dp, Vb, ldv, Lk, gf, i, g);   // dP = dO V^T
       }
       // dS = P * (dP - rowsum(P * dP)) / sqrt(dk)
 #pragma unroll
@@ -403,7 +483,7 @@ __global__ __launch_bounds__(256) void bwd_kernel(const float* __restrict__ Q, i
         for (int tm = 0; tm < 2; ++tm)
 #pragma unroll
           for (int td = 0; td < DK16; ++td) o[tm][td] = f32x4{0.f, 0.f, 0.f, 0.f};
-        contract_key<NKT, DK16>(o, dp, Kb, ldk, Lk, i, g);   // dQ = dS K
+        contract_key<NKT, DK16, PR>(o, dp, Kb, ldk, Lk, i, g);   // dQ = dS K
         store_rows<DK16>(o, dQ + (int64_t)r * Lq * lddq + h * DK, lddq, Lq, i, g);
       }
     }
@@ -412,9 +492,9 @@ __global__ __launch_bounds__(256) void bwd_kernel(const float* __restrict__ Q, i
       if (has && turn == sub) {
         const bool seen = k > 0;
         tile_to_lds<NKT>(T, PITCH, dp, i, g);
-        contract_q<NKT, DK16, TKC>(T, PITCH, Qb, ldq, Lq, dKb, lddk, Lk, seen, i, g);    // dK (+)= dS^T Q
+        contract_q<NKT, DK16, TKC, PR>(T, PITCH, Qb, ldq, Lq, dKb, lddk, Lk, seen, i, g);    // dK (+)= dS^T Q
         tile_to_lds<NKT>(T, PITCH, p, i, g);
-        contract_q<NKT, DK16, TKC>(T, PITCH, dOb, lddo, Lq, dVb, lddv, Lk, seen, i, g);  // dV (+)= P^T dO
+        contract_q<NKT, DK16, TKC, PR>(T, PITCH, dOb, lddo, Lq, dVb, lddv, Lk, seen, i, g);  // dV (+)= P^T dO
       }
       if (wpi > 1) __syncthreads();
     }
@@ -437,8 +517,24 @@ __device__ __forceinline__ void mask_row_frag(f32x4 (&f)[DK16], bool live) {
   for (int j = 0; j < DK16; ++j) f[j] = live ? f[j] : f32x4{0.f, 0.f, 0.f, 0.f};
 }
 // acc[tm][tn] += sum_d A[16 tn + i][d] B[16 tm + i][d] with both operands in registers (contract_d's order of operations)
-template <int NKT, int DK16>
+template <int NKT, int DK16, int PR = 0>
 __device__ __forceinline__ void contract_d_regs(f32x4 (&acc)[2][NKT], const f32x4 (&af)[NKT][DK16], const f32x4 (&bf)[2][DK16]) {
+  if constexpr (PR == 1) {
+    s16x4 bp[2][DK16];
+#pragma unroll
+    for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+      for (int j = 0; j < DK16; ++j) bp[tm][j] = bf16x4_rne(bf[tm][j]);
+#pragma unroll
+    for (int tn = 0; tn < NKT; ++tn)
+#pragma unroll
+      for (int j = 0; j < DK16; ++j) {
+        const s16x4 a = bf16x4_rne(af[tn][j]);
+#pragma unroll
+        for (int tm = 0; tm < 2; ++tm) acc[tm][tn] = mfma_bf16(a, bp[tm][j], acc[tm][tn]);
+      }
+    return;
+  }
 #pragma unroll
   for (int tn = 0; tn < NKT; ++tn)
 #pragma unroll
@@ -465,9 +561,26 @@ __device__ __forceinline__ void mask_q_cols(float (&af)[8][DK16], int n_q, int g
 #pragma unroll
     for (int td = 0; td < DK16; ++td) af[st][td] = (st * 4 + g < n_q) ? af[st][td] : 0.f;
 }
-template <int DK16>
+template <int DK16, int PR = 0>
 __device__ __forceinline__ void contract_q_acc_regs(const float* T, int pitch, const float (&af)[8][DK16],
                                                     f32x4 (&acc)[DK16][2], int i, int g) {
+  if constexpr (PR == 1) {
+#pragma unroll
+    for (int st0 = 0; st0 < 8; st0 += 4) {
+      s16x4 a[DK16];
+#pragma unroll
+      for (int td = 0; td < DK16; ++td) a[td] = bf16x4_rne(af[st0][td], af[st0 + 1][td], af[st0 + 2][td], af[st0 + 3][td]);
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        const int c = t * 16 + i;
+        const s16x4 b = bf16x4_rne(T[(st0 * 4 + g) * pitch + c], T[((st0 + 1) * 4 + g) * pitch + c],
+                                   T[((st0 + 2) * 4 + g) * pitch + c], T[((st0 + 3) * 4 + g) * pitch + c]);
+#pragma unroll
+        for (int td = 0; td < DK16; ++td) acc[td][t] = mfma_bf16(a[td], b, acc[td][t]);
+      }
+    }
+    return;
+  }
 #pragma unroll
   for (int st = 0; st < 8; ++st) {
     const int q = st * 4 + g;
@@ -533,7 +646,7 @@ constexpr int KB_WGS = NACF_ATTN_KB_WGS;        // resident workgroups per CU th
                                                 // (measured: 1 -> 121 us, 2 -> 97 us, 3 spills 71 VGPRs -> 145 us)
 constexpr int KB_PITCH = 48;                     // transpose tile [32][48]: 2 key tiles + 16 (rows 16 banks apart)
 constexpr int KB_RED_PITCH = 68;                 // dQ partials [4][32][64 + 4]
-template <int DK16, int NB = 1>      // NB = 0: the guarded loads of the first form (kept for A/B: NACF_ATTN_KB=2)
+template <int DK16, int NB = 1, int PR = 0>      // NB = 0: the guarded loads of the first form (kept for A/B: NACF_ATTN_KB=2; fp32 only)
 __global__ __launch_bounds__(256, KB_WGS) void bwd_kb_kernel(const float* __restrict__ Q, int64_t ldq, const float* __restrict__ K,
                                                       int64_t ldk, const float* __restrict__ V, int64_t ldv,
                                                       const float* __restrict__ dO, int64_t lddo, float* __restrict__ dQ,
@@ -542,6 +655,7 @@ __global__ __launch_bounds__(256, KB_WGS) void bwd_kb_kernel(const float* __rest
                                                       int Lk, int kv_div, int kv_mod, int rounds) {
   constexpr int DK = 16 * DK16;
   static_assert(DK <= 64, "dQ reduce buffer is sized for dk <= 64");
+  static_assert(NB == 1 || PR == 0, "the first form is fp32 only");
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   float* ex = smem;                                             // [3][4][32]: block max, block sum, block delta
@@ -588,7 +702,7 @@ __global__ __launch_bounds__(256, KB_WGS) void bwd_kb_kernel(const float* __rest
           __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
           for (int t = 0; t < 2; ++t) { mask_row_frag<DK16>(qf[t], t * 16 + i < Lq); mask_row_frag<DK16>(kf[t], t * 16 + i < nk); }
-          contract_d_regs<2, DK16>(p, kf, qf);                      // S block
+          contract_d_regs<2, DK16, PR>(p, kf, qf);                      // S block
           __builtin_amdgcn_sched_barrier(0);
         }
         {
@@ -601,7 +715,7 @@ __global__ __launch_bounds__(256, KB_WGS) void bwd_kb_kernel(const float* __rest
           __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
           for (int t = 0; t < 2; ++t) { mask_row_frag<DK16>(gf[t], t * 16 + i < Lq); mask_row_frag<DK16>(vf[t], t * 16 + i < nk); }
-          contract_d_regs<2, DK16>(dp, vf, gf);                     // dP block = dO V_blk^T
+          contract_d_regs<2, DK16, PR>(dp, vf, gf);                     // dP block = dO V_blk^T
           __builtin_amdgcn_sched_barrier(0);
         }
       } else {
@@ -698,7 +812,7 @@ __global__ __launch_bounds__(256, KB_WGS) void bwd_kb_kernel(const float* __rest
       for (int tm = 0; tm < 2; ++tm)
 #pragma unroll
         for (int td = 0; td < DK16; ++td) o[tm][td] = f32x4{0.f, 0.f, 0.f, 0.f};
-      if (nk > 0) contract_key<2, DK16>(o, dp, Kb, ldk, nk, i, g);   // dQ partial = dS_blk K_blk
+      if (nk > 0) contract_key<2, DK16, PR>(o, dp, Kb, ldk, nk, i, g);   // dQ partial = dS_blk K_blk
       float* mine = red + wave * 32 * KB_RED_PITCH;
 #pragma unroll
       for (int tm = 0; tm < 2; ++tm)
@@ -738,11 +852,11 @@ __global__ __launch_bounds__(256, KB_WGS) void bwd_kb_kernel(const float* __rest
         __builtin_amdgcn_sched_barrier(0);
         mask_q_cols<DK16>(aq, Lq, g);
         tile_to_lds<2>(T, KB_PITCH, dp, i, g);
-        contract_q_acc_regs<DK16>(T, KB_PITCH, aq, accK, i, g);        // dK_blk += dS_blk^T Q
+        contract_q_acc_regs<DK16, PR>(T, KB_PITCH, aq, accK, i, g);        // dK_blk += dS_blk^T Q
         __builtin_amdgcn_sched_barrier(0);                             // (dO's wait and zeroing stay behind the dK contraction)
         mask_q_cols<DK16>(ao, Lq, g);
         tile_to_lds<2>(T, KB_PITCH, p, i, g);
-        contract_q_acc_regs<DK16>(T, KB_PITCH, ao, accV, i, g);        // dV_blk += P_blk^T dO
+        contract_q_acc_regs<DK16, PR>(T, KB_PITCH, ao, accV, i, g);        // dV_blk += P_blk^T dO
       } else {
         tile_to_lds<2>(T, KB_PITCH, dp, i, g);
         contract_q_acc<DK16>(T, KB_PITCH, Qb, ldq, Lq, accK, i, g);
@@ -768,7 +882,7 @@ __global__ __launch_bounds__(256, KB_WGS) void bwd_kb_kernel(const float* __rest
 constexpr int FL_PITCH = 68;
 // the work of one workgroup for one (memory row set kvr, head h); smem: 2 x 128 x FL_PITCH floats (a caller that walks
 // several items puts a barrier before the next copy).
-template <int DK16>
+template <int DK16, int PR = 0>
 __device__ __forceinline__ void fwd_lds_item(const int item, float* const smem, const float* __restrict__ Q, int64_t ldq,
                                              const float* __restrict__ K, int64_t ldk, const float* __restrict__ V, int64_t ldv,
                                              float* __restrict__ O, int64_t ldo, int R, int H, int Lq, int Lk, int kv_div,
@@ -822,25 +936,25 @@ __device__ __forceinline__ void fwd_lds_item(const int item, float* const smem, 
     for (int tm = 0; tm < 2; ++tm)
 #pragma unroll
       for (int tn = 0; tn < NKT; ++tn) sc[tm][tn] = f32x4{0.f, 0.f, 0.f, 0.f};
-    contract_d<NKT, DK16>(sc, Ks, FL_PITCH, Lk, qf, i, g);
+    contract_d<NKT, DK16, PR>(sc, Ks, FL_PITCH, Lk, qf, i, g);
     softmax_rows<NKT>(sc, sq, nullptr, 0, Lk, i, g);
     f32x4 o[2][DK16];
 #pragma unroll
     for (int tm = 0; tm < 2; ++tm)
 #pragma unroll
       for (int td = 0; td < DK16; ++td) o[tm][td] = f32x4{0.f, 0.f, 0.f, 0.f};
-    contract_key<NKT, DK16>(o, sc, Vs, FL_PITCH, Lk, i, g);
+    contract_key<NKT, DK16, PR>(o, sc, Vs, FL_PITCH, Lk, i, g);
     store_rows<DK16>(o, O + ((int64_t)r * Lq + q0) * ldo + h * DK, ldo, nq, i, g);
   }
 }
 
-template <int DK16>
+template <int DK16, int PR = 0>
 __global__ __launch_bounds__(256, 2) void fwd_lds_kernel(const float* __restrict__ Q, int64_t ldq, const float* __restrict__ K,
                                                           int64_t ldk, const float* __restrict__ V, int64_t ldv,
                                                           float* __restrict__ O, int64_t ldo, int R, int n_kv, int H, int Lq,
                                                           int Lk, int kv_div, int kv_mod, int rounds) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  fwd_lds_item<DK16>((int)blockIdx.x, smem, Q, ldq, K, ldk, V, ldv, O, ldo, R, H, Lq, Lk, kv_div, kv_mod, rounds);
+  fwd_lds_item<DK16, PR>((int)blockIdx.x, smem, Q, ldq, K, ldk, V, ldv, O, ldo, R, H, Lq, Lk, kv_div, kv_mod, rounds);
 }
 
 }  // namespace attn

@@ -18,6 +18,14 @@ inline bool attn_mfma_ok(int Lq, int Lk, int dk) {
   if (e && atoi(e) != 0) return false;
   return Lq <= 32 && Lk <= 128 && (dk == 16 || dk == 64);
 }
+// arithmetic of the matrix-core attention (attn_mfma.hpp "PR"): bf16 operands in the throughput mode of the GEMMs, at the model's
+// head width; NACF_ATTN_BF16=0 | 1 overrides (A/B, tests)
+inline int attn_precision(int dk) {
+  if (dk != 64) return 0;
+  const char* e = getenv("NACF_ATTN_BF16");
+  if (e && *e) return atoi(e) != 0 ? 1 : 0;
+  return nacf_gemm_get_mode() == NACF_GEMM_BF16 ? 1 : 0;
+}
 inline bool attn_aligned(const void* p, int64_t ld) {
   return (reinterpret_cast<uintptr_t>(p) & 15) == 0 && (ld % 4) == 0;
 }
@@ -994,10 +1002,16 @@ int nacf_attention_fwd_dropout(const float* Q, int64_t ldq, const float* K, int6
         if (!set_fl) {
           (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn::fwd_lds_kernel<4>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+          (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn::fwd_lds_kernel<4, 1>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
           set_fl = true;
         }
-        hipLaunchKernelGGL((attn::fwd_lds_kernel<4>), dim3(n_kv * H), dim3(256), lds, as_hip(stream), Q, ldq, K, ldk, V, ldv,
-                           O, ldo, R, n_kv, H, Lq, Lk, kv_div, kv_mod, nseq_max);
+        if (attn_precision(dk))
+          hipLaunchKernelGGL((attn::fwd_lds_kernel<4, 1>), dim3(n_kv * H), dim3(256), lds, as_hip(stream), Q, ldq, K, ldk, V, ldv,
+                             O, ldo, R, n_kv, H, Lq, Lk, kv_div, kv_mod, nseq_max);
+        else
+          hipLaunchKernelGGL((attn::fwd_lds_kernel<4>), dim3(n_kv * H), dim3(256), lds, as_hip(stream), Q, ldq, K, ldk, V, ldv,
+                             O, ldo, R, n_kv, H, Lq, Lk, kv_div, kv_mod, nseq_max);
         NACF_LAUNCH_CHECK("nacf_attention_fwd(mfma, lds)");
         return NACF_OK;
       }
@@ -1006,11 +1020,12 @@ int nacf_attention_fwd_dropout(const float* Q, int64_t ldq, const float* K, int6
     const int nqb = cdiv(Lq, 32);
     const dim3 grid(cdiv(R * H * nqb, 4));
     hipStream_t s = as_hip(stream);
-#define NACF_ATTN_FWD(NKT, DK16)                                                                                      \
-  hipLaunchKernelGGL((attn::fwd_kernel<NKT, DK16>), grid, dim3(256), 0, s, Q, ldq, K, ldk, V, ldv, O, ldo, key_tokens, \
+#define NACF_ATTN_FWD(NKT, DK16, PR)                                                                                      \
+  hipLaunchKernelGGL((attn::fwd_kernel<NKT, DK16, PR>), grid, dim3(256), 0, s, Q, ldq, K, ldk, V, ldv, O, ldo, key_tokens, \
                      causal, probs, R, H, Lq, Lk, kv_div, kv_mod, nqb)
-    if (Lk <= 32) { if (dk == 64) NACF_ATTN_FWD(2, 4); else NACF_ATTN_FWD(2, 1); }
-    else { if (dk == 64) NACF_ATTN_FWD(8, 4); else NACF_ATTN_FWD(8, 1); }
+    const int pr = attn_precision(dk);
+    if (Lk <= 32) { if (dk == 64) { if (pr) NACF_ATTN_FWD(2, 4, 1); else NACF_ATTN_FWD(2, 4, 0); } else NACF_ATTN_FWD(2, 1, 0); }
+    else { if (dk == 64) { if (pr) NACF_ATTN_FWD(8, 4, 1); else NACF_ATTN_FWD(8, 4, 0); } else NACF_ATTN_FWD(8, 1, 0); }
 #undef NACF_ATTN_FWD
     NACF_LAUNCH_CHECK("nacf_attention_fwd(mfma)");
     return NACF_OK;
@@ -1068,10 +1083,15 @@ int nacf_attention_bwd_dropout(const float* Q, int64_t ldq, const float* K, int6
                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
           (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn::bwd_kb_kernel<4, 0>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+          (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn::bwd_kb_kernel<4, 1, 1>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
           set_kb = true;
         }
         if (e && atoi(e) == 2)
           hipLaunchKernelGGL((attn::bwd_kb_kernel<4, 0>), dim3(n_kv * H), dim3(256), lds_kb, as_hip(stream), Q, ldq, K, ldk, V,
+                             ldv, dO, lddo, dQ, lddq, dK, lddk, dV, lddv, R, n_kv, H, Lq, Lk, kv_div, kv_mod, nseq_max);
+        else if (attn_precision(dk))
+          hipLaunchKernelGGL((attn::bwd_kb_kernel<4, 1, 1>), dim3(n_kv * H), dim3(256), lds_kb, as_hip(stream), Q, ldq, K, ldk, V,
                              ldv, dO, lddo, dQ, lddq, dK, lddk, dV, lddv, R, n_kv, H, Lq, Lk, kv_div, kv_mod, nseq_max);
         else
           hipLaunchKernelGGL((attn::bwd_kb_kernel<4>), dim3(n_kv * H), dim3(256), lds_kb, as_hip(stream), Q, ldq, K, ldk, V,
@@ -1089,19 +1109,21 @@ int nacf_attention_bwd_dropout(const float* Q, int64_t ldq, const float* K, int6
     hipStream_t s = as_hip(stream);
     const int nkt = Lk <= 32 ? 2 : 8;
     const size_t lds_m = (size_t)4 * 32 * (nkt * 16 + 16) * sizeof(float);   // one transpose tile per wave
-#define NACF_ATTN_BWD(NKT, DK16)                                                                                       \
+#define NACF_ATTN_BWD(NKT, DK16, PR)                                                                                   \
   do {                                                                                                                \
-    static bool set_##NKT##_##DK16 = false;                                                                           \
-    if (!set_##NKT##_##DK16) {                                                                                        \
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn::bwd_kernel<NKT, DK16>),                           \
+    static bool set_##NKT##_##DK16##_##PR = false;                                                                    \
+    if (!set_##NKT##_##DK16##_##PR) {                                                                                 \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn::bwd_kernel<NKT, DK16, PR>),                       \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                              \
-      set_##NKT##_##DK16 = true;                                                                                      \
+      set_##NKT##_##DK16##_##PR = true;                                                                               \
     }                                                                                                                 \
-    hipLaunchKernelGGL((attn::bwd_kernel<NKT, DK16>), grid, dim3(256), lds_m, s, Q, ldq, K, ldk, V, ldv, dO, lddo, dQ,  \
-                       lddq, dK, lddk, dV, lddv, key_tokens, causal, R, n_kv, H, Lq, Lk, kv_div, kv_mod, wpi, rounds);  \
+    hipLaunchKernelGGL((attn::bwd_kernel<NKT, DK16, PR>), grid, dim3(256), lds_m, s, Q, ldq, K, ldk, V, ldv, dO, lddo, \
+                       dQ, lddq, dK, lddk, dV, lddv, key_tokens, causal, R, n_kv, H, Lq, Lk, kv_div, kv_mod, wpi,      \
+                       rounds);                                                                                       \
   } while (0)
-    if (nkt == 2) { if (dk == 64) NACF_ATTN_BWD(2, 4); else NACF_ATTN_BWD(2, 1); }
-    else { if (dk == 64) NACF_ATTN_BWD(8, 4); else NACF_ATTN_BWD(8, 1); }
+    const int pr = attn_precision(dk);
+    if (nkt == 2) { if (dk == 64) { if (pr) NACF_ATTN_BWD(2, 4, 1); else NACF_ATTN_BWD(2, 4, 0); } else NACF_ATTN_BWD(2, 1, 0); }
+    else { if (dk == 64) { if (pr) NACF_ATTN_BWD(8, 4, 1); else NACF_ATTN_BWD(8, 4, 0); } else NACF_ATTN_BWD(8, 1, 0); }
 #undef NACF_ATTN_BWD
     NACF_LAUNCH_CHECK("nacf_attention_bwd(mfma)");
     return NACF_OK;

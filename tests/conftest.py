@@ -40,7 +40,7 @@ def dev():
 # (restored afterwards).  A leaked value would silently change which kernels every later test exercises -- e.g. the
 # golden train / decode parity of test_model_gpu.py running on forced 128x128 tiles and not on the production
 # heuristic -- so every test starts by asserting that none of them is set.
-TUNING_ENV = ("NACF_DDP_STAGES", "NACF_GEMM_TILE", "NACF_GEMM_SPLITS", "NACF_GEMM_MODE", "NACF_ATTN_VALU", "NACF_ATTN_LDS", "NACF_ATTN_KB",
+TUNING_ENV = ("NACF_DDP_STAGES", "NACF_GEMM_TILE", "NACF_GEMM_SPLITS", "NACF_GEMM_MODE", "NACF_ATTN_VALU", "NACF_ATTN_LDS", "NACF_ATTN_KB", "NACF_ATTN_BF16",
               "NACF_ATTN_WPI", "NACF_HIP_LIB", "NACF_GEMM_GROUP_N", "NACF_DW_GROUP", "NACF_DW_GROUP_WGS", "NACF_GEMM_WIDE",
               "NACF_FUSED_ZERO_GRAD", "NACF_BN_MULTI", "NACF_SYNC_BN_EXCHANGES", "NACF_DDP_GRAPH_COLLECTIVES", "NACF_DW_GROUP_ORDER", "NACF_DEAD_ROWS", "NACF_SELFTEST")
 

@@ -857,6 +857,83 @@ def test_loss_combine_fwd_bwd(dev):
     assert torch.equal(gslab.cpu(), ref)
 
 
+def _bf(x):
+    return x.float().to(torch.bfloat16).double()
+
+
+def _mha_bf16_restatement(q, k, v, do, H, key_pad, causal):
+    """the throughput mode's attention written out in float64: every matrix-instruction operand rounded to bf16 (nearest even), the
+    soft-max, its backward and every sum in full precision -- attn_mfma.hpp "PR = 1".  q [R, Lq, D], k / v [R, Lk, D] (already
+    gathered per sequence); returns o, dq, dk, dv with dk / dv per sequence (the caller sums sequences that share a memory)."""
+    R, Lq, D = q.shape
+    Lk, dk = k.shape[1], D // H
+    sp = lambda x, L: x.view(R, L, H, dk).permute(0, 2, 1, 3)
+    qh, kh, vh, doh = sp(q, Lq), sp(k, Lk), sp(v, Lk), sp(do, Lq)
+    s = _bf(qh) @ _bf(kh).transpose(-1, -2) / math.sqrt(dk)
+    m = torch.zeros(R, 1, Lq, Lk, dtype=torch.bool)
+    if key_pad is not None:
+        m = m | key_pad.view(R, 1, 1, Lk)
+    if causal:
+        m = m | torch.triu(torch.ones(Lq, Lk, dtype=torch.bool), 1).view(1, 1, Lq, Lk)
+    p = torch.softmax(s.masked_fill(m, -10e6), -1)
+    o = _bf(p) @ _bf(vh)
+    dp = _bf(doh) @ _bf(vh).transpose(-1, -2)
+    ds = p * (dp - (p * dp).sum(-1, keepdim=True)) / math.sqrt(dk)
+    dq = _bf(ds) @ _bf(kh)
+    dkk = _bf(ds).transpose(-1, -2) @ _bf(qh)
+    dv = _bf(p).transpose(-1, -2) @ _bf(doh)
+    back = lambda x, L: x.permute(0, 2, 1, 3).reshape(R, L, D)
+    return back(o, Lq), back(dq, Lq), back(dkk, Lk), back(dv, Lk)
+
+
+@pytest.mark.parametrize("kind,Lq,Lk", [("self", 20, 20), ("self_causal", 20, 20), ("cross", 20, 120), ("cross", 32, 70),
+                                        ("cross_beams", 20, 120)])
+def test_attention_with_bf16_operands_equals_its_rounding_restatement(dev, kind, Lq, Lk, monkeypatch):
+    """NACF_ATTN_BF16=1 (the default of the bf16 GEMM mode at dk = 64): v_mfma_f32_16x16x16_bf16 on operands rounded in registers.
+    Every kernel of the family (forward, LDS-staged forward, backward, key-block backward) against the float64 restatement that
+    rounds the same operands; the bar is what one bf16 rounding of a P / dS element that sits on a rounding boundary can move
+    (the kernel's fp32 soft-max and the restatement's differ in the last bits), far below the distance to the unrounded result."""
+    monkeypatch.setenv("NACF_ATTN_BF16", "1")
+    ops, _ = _ops()
+    H, dk = 8, 64
+    D = H * dk
+    if kind.startswith("self"):
+        R, Bv, kv_div, kv_mod = 6, 6, 1, 6
+        causal = kind == "self_causal"
+        tok = torch.randint(1, 9, (R, Lq), generator=torch.Generator().manual_seed(2))
+        tok[0, Lq - 3:] = PAD
+        tok[1, 2] = PAD
+        vid = torch.arange(R)
+    else:
+        k_ = 6 if kind == "cross_beams" else 2            # 6 sequences per memory: the LDS-staged forward
+        Bv = 5
+        R, kv_div, kv_mod, causal, tok = Bv * k_, k_, Bv, False, None
+        vid = torch.arange(R) // k_
+    q, kv, do = rnd(R * Lq, D, seed=1), rnd(Bv * Lk, 2 * D, seed=2), rnd(R * Lq, D, seed=3)
+    kk, vv = kv[:, :D].reshape(Bv, Lk, D)[vid], kv[:, D:].reshape(Bv, Lk, D)[vid]
+    o_ref, dq_ref, dk_seq, dv_seq = _mha_bf16_restatement(q.view(R, Lq, D).double(), kk.double(), vv.double(),
+                                                           do.view(R, Lq, D).double(), H, None if tok is None else tok.eq(PAD), causal)
+    dk_ref = torch.zeros(Bv, Lk, D, dtype=torch.float64).index_add_(0, vid, dk_seq)
+    dv_ref = torch.zeros(Bv, Lk, D, dtype=torch.float64).index_add_(0, vid, dv_seq)
+    o_exact, _ = _mha_ref(q.view(R, Lq, D).double(), kk.double(), vv.double(), H, None if tok is None else tok.eq(PAD), causal)
+    qx, kvx, dox = q.to(dev), kv.to(dev), do.to(dev)
+    tokx = None if tok is None else tok.to(dev)
+    out = torch.full_like(qx, float("nan"))
+    ops.attention_fwd(qx, kvx[:, :D], kvx[:, D:], out, tokx, int(causal), None, R, H, Lq, Lk, dk, kv_div, kv_mod)
+    dq, dkv = torch.full_like(qx, float("nan")), torch.full_like(kvx, float("nan"))
+    ops.attention_bwd(qx, kvx[:, :D], kvx[:, D:], dox, dq, dkv[:, :D], dkv[:, D:], tokx, int(causal), R, Bv, H, Lq, Lk, dk,
+                      kv_div, kv_mod)
+    e_o = err(out.view(R, Lq, D), o_ref)
+    assert e_o < 1e-3, e_o
+    assert err(out.view(R, Lq, D), o_exact) > 4 * e_o            # it IS the bf16 form
+    assert err(dq.view(R, Lq, D), dq_ref) < 2e-3
+    assert err(dkv[:, :D].reshape(Bv, Lk, D), dk_ref) < 4e-3 and err(dkv[:, D:].reshape(Bv, Lk, D), dv_ref) < 4e-3
+    monkeypatch.setenv("NACF_ATTN_BF16", "0")                    # and the switch is per call: fp32 operands again
+    out32 = torch.empty_like(qx)
+    ops.attention_fwd(qx, kvx[:, :D], kvx[:, D:], out32, tokx, int(causal), None, R, H, Lq, Lk, dk, kv_div, kv_mod)
+    assert err(out32.view(R, Lq, D), o_exact) < 2e-5
+
+
 @pytest.mark.parametrize("Lk,Lq", [(120, 20), (120, 32), (70, 7), (33, 1)])
 def test_key_block_backward_batched_loads_change_no_bit(dev, Lk, Lq, monkeypatch):
     """the key-block kernel with its operand loads issued as branch-free batches (rows past the end read the last live row and are

@@ -11,7 +11,7 @@ for envs in "$@"; do
   for leg in step decode; do
     rm -rf /tmp/prof_kb
     if [ $leg = step ]; then cmd="python tools/step_profile.py 60"; else cmd="python tools/decode_profile.py 12"; fi
-    env $envs METHOD=NACF BATCH=128 MODE=bf16x3 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_kb -o b -- $cmd > /tmp/prof_kb.log 2>&1
+    env $envs METHOD=${METHOD:-NACF} BATCH=${BATCH:-128} MODE=${MODE:-bf16x3} rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_kb -o b -- $cmd > /tmp/prof_kb.log 2>&1
     echo "== $envs  [$leg]  $(grep -v rocprofv3 /tmp/prof_kb.log | tail -1)" >> $OUT
     python - <<PY >> $OUT
 import csv, glob
