@@ -501,6 +501,15 @@ __global__ __launch_bounds__(256) void bwd_kernel(const float* __restrict__ Q, i
   }
 }
 
+// ---- key-block backward (cross-attention: no key mask, not causal, up to 128 keys) ------------------------------------
+// The kernel above gives one wave a whole (memory row set, head): 1024 waves for B=128 x 8 heads -- one per SIMD, each
+// walking 1280 MFMAs per sequence behind uncovered load latency.  Here the FOUR waves of a workgroup share the item and
+// split its keys into blocks of 32: a wave computes S, P, dP, dS only for its block, owns the dK / dV rows of that block
+// (accumulated in registers over the item's sequences: no read-modify-write of global rows, no ordering between
+// sequences), and the three quantities that span all keys are combined through LDS in a fixed wave order:
+//   row max / row sum of exp  (softmax statistics, flash-style rescaling),
+//   delta = rowsum(P * dP),
+//   dQ = sum over key blocks of dS_blk K_blk.
 // Branch-free forms of the fragment loads (rows past the end: the last live row is read and the value replaced by zero).  A guarded
 // load is a basic block of its own: the compiler cannot batch such loads, and a contraction that takes its operand from global memory
 // step by step then waits out one full L2 latency per step (contract_q_acc: 16 of them per sequence).  n_rows >= 1.
@@ -593,15 +602,7 @@ __device__ __forceinline__ void contract_q_acc_regs(const float* T, int pitch, c
   }
 }
 
-// ---- key-block backward (cross-attention: no key mask, not causal, up to 128 keys) ------------------------------------
-// The kernel above gives one wave a whole (memory row set, head): 1024 waves for B=128 x 8 heads -- one per SIMD, each
-// walking 1280 MFMAs per sequence behind uncovered load latency.  Here the FOUR waves of a workgroup share the item and
-// split its keys into blocks of 32: a wave computes S, P, dP, dS only for its block, owns the dK / dV rows of that block
-// (accumulated in registers over the item's sequences: no read-modify-write of global rows, no ordering between
-// sequences), and the three quantities that span all keys are combined through LDS in a fixed wave order:
-//   row max / row sum of exp  (softmax statistics, flash-style rescaling),
-//   delta = rowsum(P * dP),
-//   dQ = sum over key blocks of dS_blk K_blk.
+// (first form of the dK / dV contraction: operand loaded inside each step; bwd_kb_kernel<.., NB = 0>)
 template <int DK16>
 __device__ __forceinline__ void contract_q_acc(const float* T, int pitch, const float* __restrict__ A, int64_t lda,
                                                int n_q, f32x4 (&acc)[DK16][2], int i, int g) {
