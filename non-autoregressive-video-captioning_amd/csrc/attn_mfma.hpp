@@ -81,6 +81,9 @@ __device__ __forceinline__ f32x4 mfma_bf16(s16x4 a, s16x4 b, f32x4 acc) {
 #ifndef NACF_ATTN_BF_CQ
 #define NACF_ATTN_BF_CQ 1            // contract_q
 #endif
+#ifndef NACF_ATTN_KEYTOK_BALLOT
+#define NACF_ATTN_KEYTOK_BALLOT 1    // softmax_rows: the key tokens as one load per wave + ballot (supersedes NACF_ATTN_BF_KEYTOK)
+#endif
 // row fragments of a [rows, dk] operand for the "reduce over d" contractions:
 // lane (i, g) loads floats [g*dk/4, (g+1)*dk/4) of row (16*t + i); rows >= n_rows read as zero
 template <int DK16>
@@ -204,6 +207,22 @@ __device__ __forceinline__ void softmax_rows(f32x4 (&s)[2][NKT], float sq, const
                                              int causal, int Lk, int i, int g) {
   unsigned long long padbits = 0ull;  // bit (tn*4+rr): key is PAD or beyond Lk handled separately
   if (key_tok) {
+#if NACF_ATTN_KEYTOK_BALLOT
+    // one token per lane, one load for the whole wave; the <pad> flags travel as a ballot (the 8 or 32 keys of a lane used to be
+    // 8 or 32 guarded loads, each behind the one before it)
+    const int lane = threadIdx.x & 63;
+    const unsigned long long m0 = __ballot(lane < Lk && key_tok[lane < Lk ? lane : 0] == NACF_PAD);
+    unsigned long long m1 = 0ull;
+    if constexpr (NKT > 4) m1 = __ballot(lane + 64 < Lk && key_tok[lane + 64 < Lk ? lane + 64 : 0] == NACF_PAD);
+#pragma unroll
+    for (int tn = 0; tn < NKT; ++tn)
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr) {
+        const int key = tn * 16 + g * 4 + rr;
+        const unsigned long long bit = tn < 4 ? (m0 >> key) & 1ull : (m1 >> (key - 64)) & 1ull;
+        padbits |= bit << (tn * 4 + rr);
+      }
+#else
 #pragma unroll
     for (int tn = 0; tn < NKT; ++tn)
 #pragma unroll
@@ -216,6 +235,7 @@ __device__ __forceinline__ void softmax_rows(f32x4 (&s)[2][NKT], float sq, const
           if (key < Lk && key_tok[key] == NACF_PAD) padbits |= 1ull << (tn * 4 + rr);
         }
       }
+#endif
   }
 #pragma unroll
   for (int tm = 0; tm < 2; ++tm) {
