@@ -527,7 +527,9 @@ int nacf_loss_combine_bwd(const float* gtotal, const float* coef, int n_terms, i
  * vocabulary loss).  Forward: per pass i < n_pass the five scalars of nacf_nll_reduce over rows[i] rows -> slab[slot[i] * stride ..
  * + 4]; the legacy KLDivLoss mean of nacf_kldiv_mean over kl_total elements -> slab[kl_slot * stride] (kl_x == NULL: none); then
  * exactly nacf_loss_combine.  Bit-identical to nacf_nll_reduce(_multi) + nacf_kldiv_mean + nacf_loss_combine.  Backward: gslab as
- * nacf_loss_combine_bwd, and kl_dx[e] = -kl_t[e] * coef[kl_slot] * gtotal[0] / kl_total (nacf_kldiv_mean's gradient form). */
+ * nacf_loss_combine_bwd, and kl_dx[e] = -kl_t[e] * coef[kl_slot] * gtotal[0] / kl_total (nacf_kldiv_mean's gradient form).
+ * Limits of the one-launch form (NACF_EINVAL beyond them; the separate entry points have none): n_terms * stride <= 128 slab floats,
+ * n_meters <= 64. */
 typedef struct nacf_crit_tail {
   int32_t n_pass;                 /* <= 4 */
   const float* label_logp[4];     /* device, rows[i] entries each */
